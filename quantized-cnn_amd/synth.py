@@ -1,0 +1,102 @@
+"""Synthetic Q-CNN parameter sets in the reference's own file layout.
+
+The reference ships AlexNet parameters only (and its fc6 assignment file is missing from the mount,
+SURVEY.md §0 fact 3); the GPU box has no /root/reference at all.  bench.py and the GPU parity tests
+therefore run on parameter sets generated here from a fixed seed: same shapes, same value ranges,
+same files (``<pfx>.biasVec.NN.bin``, ``.ctrdLst.NN.bin``, ``.asmtLst.NN.cbn``; src/CaffePara.cc:262-281)
+as the shipped ones, so that the reference, the oracle and the HIP path all load them through their
+own readers.
+
+Quantisation layout rule (decoded from the shipped headers): conv layers use
+Cs = 8 dims per subspace and K = 128 codewords, M = ceil(Cin_per_group / 8) subspaces (so the first
+conv, Cin = 3, has M = 1 and uses only 3 of the 8 codebook dims, src/CaffeEva.cc:1277); hidden FC
+layers use Cs = 4, K = 32; the classifier FC uses Cs = 1, K = 16.
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, List, Optional
+
+import numpy as np
+
+from . import fileio
+from .topology import CONV, FCNT, fmap_sizes
+
+
+def quant_spec(in_chw, layers, conv_k=128, conv_cs=8, fc_k=32, fc_cs=4, last_k=16, last_cs=1):
+    """Per conv/FC layer: dict(M, K, Cs, Ct, kind, knl, D) following the shipped layout rule."""
+    sizes = fmap_sizes(in_chw, layers)
+    fc_idx = [i for i, ly in enumerate(layers) if ly["type"] == FCNT]
+    spec: Dict[int, dict] = {}
+    for i, ly in enumerate(layers):
+        h, w, c = sizes[i]
+        if ly["type"] == CONV:
+            cg = c // ly["grp"]
+            m = (cg + conv_cs - 1) // conv_cs
+            spec[i] = dict(kind="conv", M=m, K=conv_k, Cs=conv_cs, Ct=ly["cnt"], knl=ly["knl"], D=cg)
+        elif ly["type"] == FCNT:
+            d = h * w * c
+            last = (i == fc_idx[-1]) and len(fc_idx) > 1
+            k, cs = (last_k, last_cs) if last else (fc_k, fc_cs)
+            if d % cs:
+                raise ValueError("FC input %d not divisible by Cs=%d" % (d, cs))
+            spec[i] = dict(kind="fc", M=d // cs, K=k, Cs=cs, Ct=ly["nod"], knl=1, D=d)
+    return spec
+
+
+def make_params(in_chw, layers, seed=0, spec: Optional[Dict[int, dict]] = None):
+    """Random parameters.  Returns {layer_idx: dict(bias[Ct] f32, ctrd[M,K,Cs] f32 (file order),
+    asmt uint8 0-based in file order ([Ct,kh,kw,M] conv / [Ct,M] fc), bits)}."""
+    spec = spec or quant_spec(in_chw, layers)
+    rng = np.random.default_rng(seed)
+    out = {}
+    for i in sorted(spec):
+        s = spec[i]
+        fan_in = s["knl"] * s["knl"] * s["D"]
+        scale = np.float32(np.sqrt(2.0 / fan_in))
+        ctrd = (rng.standard_normal((s["M"], s["K"], s["Cs"])) * scale).astype(np.float32)
+        bias = (rng.standard_normal(s["Ct"]) * 0.1).astype(np.float32)
+        if s["kind"] == "conv":
+            shape = (s["Ct"], s["knl"], s["knl"], s["M"])
+        else:
+            shape = (s["Ct"], s["M"])
+        asmt = rng.integers(0, s["K"], size=shape, dtype=np.uint8)
+        out[i] = dict(bias=bias, ctrd=ctrd, asmt=asmt, bits=fileio.min_bits(np.array([s["K"] - 1])))
+    return out
+
+
+def write_param_dir(dir_path: str, prefix: str, params) -> None:
+    os.makedirs(dir_path, exist_ok=True)
+    for i, p in params.items():
+        fileio.write_bin(fileio.param_path(dir_path, prefix, "biasVec", i + 1, "bin"), p["bias"])
+        fileio.write_bin(fileio.param_path(dir_path, prefix, "ctrdLst", i + 1, "bin"), p["ctrd"])
+        fileio.write_cbn(fileio.param_path(dir_path, prefix, "asmtLst", i + 1, "cbn"), p["asmt"], p["bits"])
+
+
+def load_param_dir(dir_path: str, prefix: str, layers):
+    """Read a parameter directory (shipped or synthetic).  Missing files raise FileNotFoundError."""
+    out = {}
+    for i, ly in enumerate(layers):
+        if ly["type"] not in (CONV, FCNT):
+            continue
+        bias = fileio.read_bin(fileio.param_path(dir_path, prefix, "biasVec", i + 1, "bin"), np.float32)
+        ctrd = fileio.read_bin(fileio.param_path(dir_path, prefix, "ctrdLst", i + 1, "bin"), np.float32)
+        asmt, bits = fileio.read_cbn(fileio.param_path(dir_path, prefix, "asmtLst", i + 1, "cbn"))
+        out[i] = dict(bias=bias.reshape(-1), ctrd=ctrd, asmt=asmt, bits=bits)
+    return out
+
+
+def make_images(n: int, in_chw, seed=1234, mean: Optional[np.ndarray] = None) -> np.ndarray:
+    """Synthetic input batch [n, C, H, W] fp32: uniform 8-bit pixels minus a mean image
+    (the shipped 3x256x256 mean centre-cropped when given, else the ImageNet BGR channel means) —
+    the value range the reference's BmpImgIO produces (src/BmpImgIO.cc:96-98,203-224)."""
+    c, h, w = in_chw
+    rng = np.random.default_rng(seed)
+    px = rng.integers(0, 256, size=(n, c, h, w), dtype=np.uint8).astype(np.float32)
+    if mean is not None:
+        oh, ow = (mean.shape[1] - h) // 2, (mean.shape[2] - w) // 2
+        px -= mean[None, :, oh:oh + h, ow:ow + w]
+    else:
+        ch_mean = np.array([104.0, 117.0, 123.0], dtype=np.float32)[:c]
+        px -= ch_mean[None, :, None, None]
+    return px
