@@ -1,0 +1,117 @@
+/* qcnn_hip.h — C-ABI of the MI355X (gfx950) Quantized-CNN approximate forward pass.
+ *
+ * This is the drop-in boundary: plain C types, caller-owned host/device buffers,
+ * library-owned activations, 0 = OK / non-zero = error + qcnn_last_error().  The host side of this
+ * repository (include/CaffeEva.h, quantized-cnn_amd/host/caffe_eva.cc) binds exactly these entry
+ * points where the reference's CaffeEva calls its CPU routines; INTEGRATION.md shows the same
+ * binding applied to the reference tree.  Built by `hipcc --offload-arch=gfx950` into
+ * quantized-cnn_amd/libqcnn_hip.so.  There is no CPU fallback: without a HIP device every compute
+ * entry point fails with an error string.
+ *
+ * Reference interface each entry point replaces (file:line in CAS-CLab/quantized-cnn):
+ *   qcnn_model_begin            CaffePara::ConfigLayer_* tables            src/CaffePara.cc:20-237
+ *                               + CaffeEva::PrepFeatMap size rule          src/CaffeEva.cc:328-411
+ *   qcnn_model_set_layer_params CaffePara::LoadLayerPara result ->         src/CaffePara.cc:239-306
+ *                               CaffeEva::PrepCtrdBuf / PrepAsmtBuf        src/CaffeEva.cc:534-623
+ *   qcnn_model_commit           CaffeEva::PrepFeatBuf (buffer planning)    src/CaffeEva.cc:413-532
+ *   qcnn_forward[_host]         CaffeEva::ExecForwardPass layer loop       src/CaffeEva.cc:151-261
+ *                               = CalcFeatMap dispatcher                   src/CaffeEva.cc:625-670
+ *                               -> CalcFeatMap_ConvAprx                    src/CaffeEva.cc:760-868
+ *                               -> CalcFeatMap_FCntAprx                    src/CaffeEva.cc:968-1025
+ *                               -> GetInPdMat (look-up-table build)        src/CaffeEva.cc:1261-1296
+ *                               -> _ReLu/_LoRN/_Pool/_Drpt/_SMax           src/CaffeEva.cc:870-921,1027-1116
+ *                               + CvtFeatMapToLablVec (top-5)              src/CaffeEva.cc:1162-1190
+ *   qcnn_run_layer              CaffeEva::CalcFeatMap on one layer         src/CaffeEva.cc:625-670
+ *   qcnn_get_layer_output       featMapLst[l] read-back (parity dumps)     include/CaffeEva.h:109
+ *   qcnn_get_layer_ms           swIndvLayerLst / DispElpsTime              src/CaffeEva.cc:297-326
+ */
+#ifndef QCNN_HIP_H_
+#define QCNN_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QCNN_ABI_VERSION 1
+
+typedef struct QcnnCtx QcnnCtx;
+
+/* layer type codes: the order of ENUM_LyrType (include/CaffePara.h:26) */
+enum { QCNN_CONV = 0, QCNN_POOL = 1, QCNN_FCNT = 2, QCNN_RELU = 3, QCNN_LORN = 4, QCNN_DRPT = 5, QCNN_SMAX = 6 };
+
+/* same fields as the reference's LayerInfo (include/CaffePara.h:28-44) */
+typedef struct {
+  int type;
+  int padSiz, knlSiz, knlCnt, grpCnt, stride, nodCnt, lrnSiz;
+  float lrnAlp, lrnBet, lrnIni, drpRat;
+} QcnnLayerDesc;
+
+/* options for qcnn_set_option */
+enum {
+  QCNN_OPT_LUT_MODE = 0,   /* 0 = exact (VALU mul+add in the reference's order: conv/FC outputs are
+                              bit-identical to the reference's -O2 native build); 1 = MFMA
+                              (v_mfma_f32_16x16x4_f32, fused multiply-add chain; default) */
+  QCNN_OPT_KEEP_ALL = 1,   /* 1 = every layer writes its own feature map (layer-for-layer dumps, default);
+                              0 = fast path: ReLU fused into the producing conv/FC epilogue */
+  QCNN_OPT_PROFILE = 2     /* 1 = bracket every layer with HIP events (qcnn_get_layer_ms) */
+};
+
+/* ---- context ---- */
+/* device_id: HIP device ordinal.  stream: a hipStream_t to enqueue on (e.g. torch's current stream),
+ * or NULL to let the library create its own. */
+int qcnn_ctx_create(int device_id, void* stream, QcnnCtx** out);
+int qcnn_ctx_destroy(QcnnCtx* ctx);
+/* last error of ctx (or of ctx creation when ctx == NULL); never NULL */
+const char* qcnn_last_error(const QcnnCtx* ctx);
+int qcnn_abi_version(void);
+int qcnn_device_count(int* count);
+int qcnn_set_option(QcnnCtx* ctx, int option, int value);
+int qcnn_sync(QcnnCtx* ctx);
+
+/* ---- model ---- */
+int qcnn_model_begin(QcnnCtx* ctx, int layer_cnt, const QcnnLayerDesc* layers, int in_c, int in_h, int in_w);
+/* Declare the quantisation shape of conv/FC layer `layer` (M sub-spaces, K codewords, Cs dims each).
+ * Must precede qcnn_model_commit for every conv/FC layer. */
+int qcnn_model_set_layer_shape(QcnnCtx* ctx, int layer, int M, int K, int Cs);
+/* Size of the packed parameter arena (biases, permuted codebooks, permuted assignments). */
+int qcnn_model_arena_bytes(QcnnCtx* ctx, size_t* bytes);
+/* Plan buffers for up to max_batch images.  dev_arena: caller-owned device memory of
+ * qcnn_model_arena_bytes() bytes (so that a communicator can broadcast it), or NULL to let the
+ * library allocate it. */
+int qcnn_model_commit(QcnnCtx* ctx, int max_batch, void* dev_arena);
+/* Upload one conv/FC layer's parameters from host memory in the reference's FILE layout:
+ * bias [Ct]; ctrd [M][K][Cs]; asmt 0-based uint8, [Ct][kh][kw][M] (conv) or [Ct][M] (FC).
+ * Performs the PrepCtrdBuf / PrepAsmtBuf permutations into the arena.  After commit. */
+int qcnn_model_set_layer_params(QcnnCtx* ctx, int layer, const float* bias, const float* ctrd_file,
+                                const uint8_t* asmt_file);
+/* Declare every conv/FC layer loaded without uploading: the caller filled the arena itself (e.g. the
+ * receiving ranks of an RCCL broadcast of rank 0's arena).  After commit. */
+int qcnn_model_mark_loaded(QcnnCtx* ctx);
+/* (H, W, C) of feature map l in [0, layer_cnt] */
+int qcnn_fm_dims(QcnnCtx* ctx, int l, int* hwc3);
+
+/* ---- forward ---- */
+/* Device-resident forward of n <= max_batch images, asynchronous on the context's stream.
+ * in_nchw_dev [n][C][H][W] fp32; prob_dev [n][classes] fp32 or NULL; top5_dev [n][5] uint16 or NULL. */
+int qcnn_forward(QcnnCtx* ctx, const float* in_nchw_dev, int n, float* prob_dev, uint16_t* top5_dev);
+/* Blocking convenience: host in, host out (H2D + forward + D2H + sync). */
+int qcnn_forward_host(QcnnCtx* ctx, const float* in_nchw_host, int n, float* prob_host, uint16_t* top5_host);
+/* Feature map l of the last forward, images [0, n), NHWC per image, to host (blocking).
+ * Requires QCNN_OPT_KEEP_ALL = 1 for maps that the fast path fuses away. */
+int qcnn_get_layer_output(QcnnCtx* ctx, int l, int n, float* host_out);
+/* Run layer `layer` alone on n images: in_host is fm[layer] NHWC per image (FC layers: the flat
+ * vector in the order the reference consumes it), out_host receives fm[layer+1] (blocking). */
+int qcnn_run_layer(QcnnCtx* ctx, int layer, const float* in_host, int n, float* out_host);
+
+/* ---- timing (QCNN_OPT_PROFILE = 1) ---- */
+/* Mean milliseconds per layer over the forwards recorded since the last reset; ms[layer_cnt]. */
+int qcnn_get_layer_ms(QcnnCtx* ctx, float* ms, int* forwards_recorded);
+int qcnn_reset_layer_ms(QcnnCtx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QCNN_HIP_H_ */

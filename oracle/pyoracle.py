@@ -123,6 +123,23 @@ class COracle:
         return out
 
 
+class _Quiet:
+    """Silence the reference's printf chatter (fd 1) around a call; bench.py prints ONE JSON line."""
+
+    def __enter__(self):
+        import sys
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        self.null = os.open(os.devnull, os.O_WRONLY)
+        os.dup2(self.null, 1)
+
+    def __exit__(self, *a):
+        C.CDLL(None).fflush(None)
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        os.close(self.null)
+
+
 def have_ref() -> bool:
     return os.path.exists(REF_SO)
 
@@ -155,13 +172,15 @@ class RefLib:
 
     def load_bmp(self, mean_path, bmp_path, full=256, crop=227):
         out = np.empty((1, 3, crop, crop), np.float32)
-        rc = self.lib.qref_load_bmp(mean_path.encode(), bmp_path.encode(), full, crop, out)
+        with _Quiet():
+            rc = self.lib.qref_load_bmp(mean_path.encode(), bmp_path.encode(), full, crop, out)
         if rc:
             raise RuntimeError("reference BmpImgIO failed (%d) on %s" % (rc, bmp_path))
         return out
 
     def load_named(self, model, dir_path, prefix):
-        rc = self.lib.qref_load_named(self.h, model.encode(), dir_path.encode(), prefix.encode())
+        with _Quiet():
+            rc = self.lib.qref_load_named(self.h, model.encode(), dir_path.encode(), prefix.encode())
         if rc:
             raise RuntimeError("reference LoadCaffePara failed for %s" % dir_path)
         self.L = self.lib.qref_layer_cnt(self.h)
@@ -175,8 +194,9 @@ class RefLib:
             ip[i] = [l.get("pad", 0), l.get("knl", 0), l.get("cnt", 0), l.get("grp", 0),
                      l.get("stride", 0), l.get("nod", 0), l.get("siz", 0)]
             fp[i] = [l.get("alp", 0.0), l.get("bet", 0.0), l.get("ini", 0.0), l.get("rat", 0.0)]
-        rc = self.lib.qref_load_custom(self.h, dir_path.encode(), prefix.encode(), in_chw[0], in_chw[1],
-                                       in_chw[2], n, types, ip, fp)
+        with _Quiet():
+            rc = self.lib.qref_load_custom(self.h, dir_path.encode(), prefix.encode(), in_chw[0], in_chw[1],
+                                           in_chw[2], n, types, ip, fp)
         if rc:
             raise RuntimeError("reference LoadLayerPara failed for %s" % dir_path)
         self.L = n
@@ -190,7 +210,8 @@ class RefLib:
         img = np.ascontiguousarray(img_nchw, np.float32).reshape(-1)
         n, h, w, c = self.fm_dims(self.L)
         prob = np.empty(n * h * w * c, np.float32)
-        self.lib.qref_forward(self.h, img, prob)
+        with _Quiet():
+            self.lib.qref_forward(self.h, img, prob)
         return prob
 
     def fm(self, l):
@@ -220,5 +241,6 @@ class RefLib:
     def time_forward(self, imgs_nchw):
         imgs = np.ascontiguousarray(imgs_nchw, np.float32)
         cpu = C.c_double(0.0)
-        wall = self.lib.qref_time_forward(self.h, imgs.reshape(-1), imgs.shape[0], C.byref(cpu))
+        with _Quiet():
+            wall = self.lib.qref_time_forward(self.h, imgs.reshape(-1), imgs.shape[0], C.byref(cpu))
         return wall, cpu.value

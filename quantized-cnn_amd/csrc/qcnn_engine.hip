@@ -1,0 +1,554 @@
+// qcnn_engine.hip — the C-ABI of include/qcnn_hip.h: context, model planning, layer loop.
+//
+// Mirrors the control flow of the reference's CaffeEva (src/CaffeEva.cc): LoadCaffePara ->
+// PrepFeatMap/PrepFeatBuf/PrepCtrdBuf/PrepAsmtBuf (:109-149) becomes qcnn_model_begin / commit /
+// set_layer_params; ExecForwardPass's layer loop (:184-205, :232-254) becomes run_layers().
+// Everything the loop touches lives in HBM for the whole batch; the host only enqueues kernels.
+#include <hip/hip_runtime.h>
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/qcnn_hip.h"
+#include "qcnn_kernels.h"
+
+namespace {
+
+std::string g_createError = "";
+
+struct LayerShape {
+  int M = 0, K = 0, Cs = 0;
+  size_t offBias = 0, offCtrd = 0, offAsmt = 0, offDmap = 0;   // byte offsets into the arena
+  size_t asmtBytes = 0;
+  bool hasDmap = false;
+  bool loaded = false;
+};
+
+struct FmDims { int h, w, c; };
+
+constexpr int kProfRing = 128;   // forwards whose per-layer events are kept
+
+}  // namespace
+
+struct QcnnCtx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool ownStream = false;
+  std::string err;
+  int lutMode = 1, keepAll = 1, profile = 0;
+
+  int L = 0, inC = 0, inH = 0, inW = 0;
+  std::vector<QcnnLayerDesc> layers;
+  std::vector<FmDims> dims;          // L + 1
+  std::vector<LayerShape> shapes;    // L
+  int firstFc = -1;
+  bool committed = false;
+  int maxBatch = 0, maxPanels = 0;
+
+  char* arena = nullptr;
+  bool ownArena = false;
+  size_t arenaBytes = 0;
+  std::vector<float*> fmBuf;         // L + 1, own allocations (nullptr where aliased)
+  float* stageIn = nullptr;          // [maxBatch][maxE] linear staging for host <-> device conversions
+  float* stageOut = nullptr;
+  size_t stageElems = 0;
+  uint16_t* stageTop5 = nullptr;
+  int lastN = 0;
+  std::vector<float*> lastFm;        // pointer table of the last forward
+
+  std::vector<hipEvent_t> ev;        // kProfRing * L * 2
+  int profCount = 0;
+  std::vector<double> profSum;
+  int profForwards = 0;
+};
+
+namespace {
+
+int fail(QcnnCtx* c, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (c) c->err = buf; else g_createError = buf;
+  return 1;
+}
+
+#define HIP_TRY(c, call)                                                                  \
+  do {                                                                                    \
+    hipError_t e_ = (call);                                                               \
+    if (e_ != hipSuccess) return fail((c), "%s -> %s", #call, hipGetErrorString(e_));     \
+  } while (0)
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+int conv_out(int in, int knl, int stride, int pad) { return (in + 2 * pad - knl) / stride + 1; }
+int pool_out(int in, int knl, int stride, int pad) {          // ceil mode, src/CaffeEva.cc:367-370
+  const int num = in + 2 * pad - knl;
+  return (num + stride - 1) / stride + 1;
+}
+
+size_t fm_elems(const QcnnCtx* c, int l) { return (size_t)c->dims[l].h * c->dims[l].w * c->dims[l].c; }
+
+int plan_arena(QcnnCtx* c) {
+  size_t off = 0;
+  for (int l = 0; l < c->L; ++l) {
+    const QcnnLayerDesc& d = c->layers[l];
+    if (d.type != QCNN_CONV && d.type != QCNN_FCNT) continue;
+    LayerShape& s = c->shapes[l];
+    if (s.K <= 0) return fail(c, "layer %d: quantisation shape not declared (qcnn_model_set_layer_shape)", l);
+    const int Ct = c->dims[l + 1].c;
+    s.offBias = off; off = align_up(off + sizeof(float) * Ct, 256);
+    s.offCtrd = off; off = align_up(off + sizeof(float) * (size_t)s.M * s.Cs * s.K, 256);
+    s.asmtBytes = (d.type == QCNN_CONV) ? (size_t)d.knlSiz * d.knlSiz * s.M * Ct : (size_t)s.M * Ct;
+    s.offAsmt = off; off = align_up(off + s.asmtBytes + QCNN_ASMT_PAD, 256);
+    s.hasDmap = (d.type == QCNN_FCNT && l == c->firstFc && c->dims[l].h * c->dims[l].w > 1);
+    if (s.hasDmap) { s.offDmap = off; off = align_up(off + sizeof(int) * fm_elems(c, l), 256); }
+  }
+  c->arenaBytes = off ? off : 256;
+  return 0;
+}
+
+void free_model(QcnnCtx* c) {
+  for (float* p : c->fmBuf) if (p) (void)hipFree(p);
+  c->fmBuf.clear();
+  if (c->ownArena && c->arena) (void)hipFree(c->arena);
+  c->arena = nullptr; c->ownArena = false;
+  if (c->stageIn) (void)hipFree(c->stageIn);
+  if (c->stageOut) (void)hipFree(c->stageOut);
+  if (c->stageTop5) (void)hipFree(c->stageTop5);
+  c->stageIn = c->stageOut = nullptr; c->stageTop5 = nullptr; c->stageElems = 0;
+  for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
+  c->ev.clear();
+  c->committed = false;
+}
+
+int ensure_stage(QcnnCtx* c) {
+  if (c->stageIn) return 0;
+  size_t maxE = 0;
+  for (int l = 0; l <= c->L; ++l) maxE = fm_elems(c, l) > maxE ? fm_elems(c, l) : maxE;
+  c->stageElems = maxE * c->maxBatch;
+  HIP_TRY(c, hipMalloc(&c->stageIn, c->stageElems * sizeof(float)));
+  HIP_TRY(c, hipMalloc(&c->stageOut, c->stageElems * sizeof(float)));
+  HIP_TRY(c, hipMalloc(&c->stageTop5, (size_t)c->maxBatch * 5 * sizeof(uint16_t)));
+  return 0;
+}
+
+// One layer on `panels` panels: src/dst in panel layout.  flatFcInput: the FC input rows are already
+// in consumption order (qcnn_run_layer), so the NCHW-flatten map is not applied.
+int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bool fuseRelu, bool flatFcInput) {
+  const QcnnLayerDesc& d = c->layers[l];
+  const FmDims& a = c->dims[l];
+  const FmDims& b = c->dims[l + 1];
+  const LayerShape& s = c->shapes[l];
+  hipError_t e = hipSuccess;
+  switch (d.type) {
+    case QCNN_CONV: {
+      if (!s.loaded) return fail(c, "layer %d: parameters not uploaded", l);
+      ConvParams p;
+      p.src = src; p.dst = dst;
+      p.bias = reinterpret_cast<const float*>(c->arena + s.offBias);
+      p.ctrd = reinterpret_cast<const float*>(c->arena + s.offCtrd);
+      p.asmt = reinterpret_cast<const uint8_t*>(c->arena + s.offAsmt);
+      p.H = a.h; p.W = a.w; p.Cin = a.c; p.Ho = b.h; p.Wo = b.w; p.Ct = b.c;
+      p.knl = d.knlSiz; p.stride = d.stride; p.pad = d.padSiz; p.grp = d.grpCnt;
+      p.M = s.M; p.Cs = s.Cs; p.K = s.K; p.relu = fuseRelu ? 1 : 0; p.panels = panels;
+      e = qk_conv_aprx(p, c->lutMode, c->stream);
+      break;
+    }
+    case QCNN_FCNT: {
+      if (!s.loaded) return fail(c, "layer %d: parameters not uploaded", l);
+      FcParams p;
+      p.src = src; p.dst = dst;
+      p.bias = reinterpret_cast<const float*>(c->arena + s.offBias);
+      p.ctrd = reinterpret_cast<const float*>(c->arena + s.offCtrd);
+      p.asmt = reinterpret_cast<const uint8_t*>(c->arena + s.offAsmt);
+      p.dmap = (s.hasDmap && !flatFcInput) ? reinterpret_cast<const int*>(c->arena + s.offDmap) : nullptr;
+      p.D = a.h * a.w * a.c; p.Ct = b.c; p.M = s.M; p.Cs = s.Cs; p.K = s.K;
+      p.relu = fuseRelu ? 1 : 0; p.panels = panels;
+      e = qk_fc_aprx(p, c->lutMode, c->stream);
+      break;
+    }
+    case QCNN_POOL:
+      e = qk_pool(src, dst, panels, a.h, a.w, a.c, b.h, b.w, d.knlSiz, d.stride, d.padSiz, c->stream);
+      break;
+    case QCNN_RELU:
+      e = qk_relu(src, dst, (size_t)panels * fm_elems(c, l) * QCNN_PANEL, c->stream);
+      break;
+    case QCNN_LORN:
+      e = qk_lrn(src, dst, panels, a.h * a.w, a.c, d.lrnSiz, d.lrnAlp, d.lrnBet, d.lrnIni, c->stream);
+      break;
+    case QCNN_DRPT:   // test-time dropout is a copy (src/CaffeEva.cc:1091-1096); only reached by qcnn_run_layer
+      e = hipMemcpyAsync(dst, src, (size_t)panels * fm_elems(c, l) * QCNN_PANEL * sizeof(float),
+                         hipMemcpyDeviceToDevice, c->stream);
+      break;
+    case QCNN_SMAX:
+      e = qk_softmax(src, dst, panels, a.h * a.w * a.c, c->stream);
+      break;
+    default:
+      return fail(c, "layer %d: invalid layer type %d", l, d.type);
+  }
+  if (e != hipSuccess) return fail(c, "layer %d (type %d) launch failed: %s", l, d.type, hipGetErrorString(e));
+  return 0;
+}
+
+int run_layers(QcnnCtx* c, int n) {
+  const int panels = (n + QCNN_PANEL - 1) / QCNN_PANEL;
+  const bool prof = c->profile && c->profCount < kProfRing;
+  c->lastFm.assign(c->L + 1, nullptr);
+  c->lastFm[0] = c->fmBuf[0];
+  for (int l = 0; l < c->L; ++l) {
+    const int type = c->layers[l].type;
+    const float* src = c->lastFm[l];
+    float* dst = c->fmBuf[l + 1];
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (prof) {
+      e0 = c->ev[((size_t)c->profCount * c->L + l) * 2];
+      e1 = c->ev[((size_t)c->profCount * c->L + l) * 2 + 1];
+      HIP_TRY(c, hipEventRecord(e0, c->stream));
+    }
+    const bool prevFused = l > 0 && !c->keepAll && type == QCNN_RELU &&
+                           (c->layers[l - 1].type == QCNN_CONV || c->layers[l - 1].type == QCNN_FCNT);
+    if (type == QCNN_DRPT || prevFused) {
+      c->lastFm[l + 1] = const_cast<float*>(src);          // alias: copy semantics, no traffic
+    } else {
+      const bool fuse = !c->keepAll && (type == QCNN_CONV || type == QCNN_FCNT) && l + 1 < c->L &&
+                        c->layers[l + 1].type == QCNN_RELU;
+      if (launch_layer(c, l, src, dst, panels, fuse, false)) return 1;
+      c->lastFm[l + 1] = dst;
+    }
+    if (prof) HIP_TRY(c, hipEventRecord(e1, c->stream));
+  }
+  if (prof) c->profCount++;
+  c->lastN = n;
+  return 0;
+}
+
+int drain_profile(QcnnCtx* c) {
+  if (!c->profCount) return 0;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  for (int f = 0; f < c->profCount; ++f)
+    for (int l = 0; l < c->L; ++l) {
+      float ms = 0.0f;
+      HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[((size_t)f * c->L + l) * 2], c->ev[((size_t)f * c->L + l) * 2 + 1]));
+      c->profSum[l] += ms;
+    }
+  c->profForwards += c->profCount;
+  c->profCount = 0;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int qcnn_abi_version(void) { return QCNN_ABI_VERSION; }
+
+int qcnn_device_count(int* count) {
+  hipError_t e = hipGetDeviceCount(count);
+  if (e != hipSuccess) { *count = 0; return fail(nullptr, "hipGetDeviceCount -> %s", hipGetErrorString(e)); }
+  return 0;
+}
+
+const char* qcnn_last_error(const QcnnCtx* ctx) { return ctx ? ctx->err.c_str() : g_createError.c_str(); }
+
+int qcnn_ctx_create(int device_id, void* stream, QcnnCtx** out) {
+  if (!out) return fail(nullptr, "qcnn_ctx_create: out == NULL");
+  *out = nullptr;
+  int cnt = 0;
+  hipError_t e = hipGetDeviceCount(&cnt);
+  if (e != hipSuccess || cnt <= 0)
+    return fail(nullptr, "no HIP device available (%s); this library has no CPU path",
+                e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+  if (device_id < 0 || device_id >= cnt) return fail(nullptr, "device %d out of range [0, %d)", device_id, cnt);
+  e = hipSetDevice(device_id);
+  if (e != hipSuccess) return fail(nullptr, "hipSetDevice(%d) -> %s", device_id, hipGetErrorString(e));
+  hipDeviceProp_t prop;
+  e = hipGetDeviceProperties(&prop, device_id);
+  if (e != hipSuccess) return fail(nullptr, "hipGetDeviceProperties -> %s", hipGetErrorString(e));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(nullptr, "device %d is %s; this library is built for gfx950 only", device_id, prop.gcnArchName);
+  QcnnCtx* c = new QcnnCtx;
+  c->device = device_id;
+  if (stream) {
+    c->stream = static_cast<hipStream_t>(stream);
+  } else {
+    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete c; return fail(nullptr, "hipStreamCreate -> %s", hipGetErrorString(e)); }
+    c->ownStream = true;
+  }
+  *out = c;
+  return 0;
+}
+
+int qcnn_ctx_destroy(QcnnCtx* c) {
+  if (!c) return 0;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  free_model(c);
+  if (c->ownStream) (void)hipStreamDestroy(c->stream);
+  delete c;
+  return 0;
+}
+
+int qcnn_set_option(QcnnCtx* c, int option, int value) {
+  switch (option) {
+    case QCNN_OPT_LUT_MODE: if (value != 0 && value != 1) return fail(c, "LUT mode must be 0 or 1"); c->lutMode = value; return 0;
+    case QCNN_OPT_KEEP_ALL: c->keepAll = value ? 1 : 0; return 0;
+    case QCNN_OPT_PROFILE: c->profile = value ? 1 : 0; return 0;
+    default: return fail(c, "unknown option %d", option);
+  }
+}
+
+int qcnn_sync(QcnnCtx* c) {
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int qcnn_model_begin(QcnnCtx* c, int layer_cnt, const QcnnLayerDesc* layers, int in_c, int in_h, int in_w) {
+  HIP_TRY(c, hipSetDevice(c->device));
+  free_model(c);
+  if (layer_cnt <= 0 || !layers) return fail(c, "qcnn_model_begin: empty layer table");
+  c->L = layer_cnt; c->inC = in_c; c->inH = in_h; c->inW = in_w;
+  c->layers.assign(layers, layers + layer_cnt);
+  c->shapes.assign(layer_cnt, LayerShape());
+  c->dims.assign(layer_cnt + 1, FmDims{0, 0, 0});
+  c->firstFc = -1;
+  int h = in_h, w = in_w, ch = in_c;
+  c->dims[0] = FmDims{h, w, ch};
+  for (int l = 0; l < layer_cnt; ++l) {           // feature-map size rule, src/CaffeEva.cc:357-391
+    const QcnnLayerDesc& d = layers[l];
+    switch (d.type) {
+      case QCNN_CONV:
+        if (d.grpCnt <= 0 || d.stride <= 0 || d.knlSiz <= 0 || ch % d.grpCnt || d.knlCnt % d.grpCnt)
+          return fail(c, "layer %d: bad conv geometry", l);
+        h = conv_out(h, d.knlSiz, d.stride, d.padSiz); w = conv_out(w, d.knlSiz, d.stride, d.padSiz); ch = d.knlCnt;
+        break;
+      case QCNN_POOL:
+        if (d.stride <= 0 || d.knlSiz <= 0) return fail(c, "layer %d: bad pool geometry", l);
+        h = pool_out(h, d.knlSiz, d.stride, d.padSiz); w = pool_out(w, d.knlSiz, d.stride, d.padSiz);
+        break;
+      case QCNN_FCNT:
+        if (c->firstFc < 0) c->firstFc = l;
+        h = 1; w = 1; ch = d.nodCnt;
+        break;
+      case QCNN_RELU: case QCNN_LORN: case QCNN_DRPT: case QCNN_SMAX: break;
+      default: return fail(c, "layer %d: invalid layer type %d", l, d.type);
+    }
+    if (h <= 0 || w <= 0 || ch <= 0) return fail(c, "layer %d: empty feature map", l);
+    c->dims[l + 1] = FmDims{h, w, ch};
+  }
+  return 0;
+}
+
+int qcnn_model_set_layer_shape(QcnnCtx* c, int layer, int M, int K, int Cs) {
+  if (layer < 0 || layer >= c->L) return fail(c, "layer %d out of range", layer);
+  const QcnnLayerDesc& d = c->layers[layer];
+  if (d.type != QCNN_CONV && d.type != QCNN_FCNT) return fail(c, "layer %d carries no parameters", layer);
+  if (M <= 0 || K <= 0 || K > 256 || Cs <= 0 || Cs > QCNN_MAX_CS)
+    return fail(c, "layer %d: unsupported quantisation shape M=%d K=%d Cs=%d (K <= 256, Cs <= %d)", layer, M, K, Cs, QCNN_MAX_CS);
+  const int D = (d.type == QCNN_CONV) ? c->dims[layer].c / d.grpCnt : (int)fm_elems(c, layer);
+  if ((size_t)M * Cs < (size_t)D) return fail(c, "layer %d: M*Cs = %d does not cover %d input dims", layer, M * Cs, D);
+  if ((M - 1) * Cs >= D) return fail(c, "layer %d: sub-space %d starts beyond the %d input dims", layer, M - 1, D);
+  const int Ct = c->dims[layer + 1].c;
+  const int Ctg = (d.type == QCNN_CONV) ? Ct / d.grpCnt : Ct;
+  if (Ctg % 4) return fail(c, "layer %d: %d output channels per group is not a multiple of 4", layer, Ctg);
+  c->shapes[layer].M = M; c->shapes[layer].K = K; c->shapes[layer].Cs = Cs;
+  return 0;
+}
+
+int qcnn_model_arena_bytes(QcnnCtx* c, size_t* bytes) {
+  if (plan_arena(c)) return 1;
+  *bytes = c->arenaBytes;
+  return 0;
+}
+
+int qcnn_model_commit(QcnnCtx* c, int max_batch, void* dev_arena) {
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (c->committed) return fail(c, "model already committed");
+  if (max_batch <= 0) return fail(c, "max_batch must be positive");
+  if (plan_arena(c)) return 1;
+  c->maxBatch = max_batch;
+  c->maxPanels = (max_batch + QCNN_PANEL - 1) / QCNN_PANEL;
+  if (dev_arena) {
+    c->arena = static_cast<char*>(dev_arena);
+    c->ownArena = false;
+  } else {
+    HIP_TRY(c, hipMalloc(&c->arena, c->arenaBytes));
+    c->ownArena = true;
+    HIP_TRY(c, hipMemsetAsync(c->arena, 0, c->arenaBytes, c->stream));
+  }
+  c->fmBuf.assign(c->L + 1, nullptr);
+  for (int l = 0; l <= c->L; ++l) {
+    if (l > 0 && c->layers[l - 1].type == QCNN_DRPT) continue;   // always an alias of its input
+    const size_t bytes = (size_t)c->maxPanels * fm_elems(c, l) * QCNN_PANEL * sizeof(float);
+    HIP_TRY(c, hipMalloc(&c->fmBuf[l], bytes));
+  }
+  c->ev.resize((size_t)kProfRing * c->L * 2);
+  for (hipEvent_t& e : c->ev) HIP_TRY(c, hipEventCreate(&e));
+  c->profSum.assign(c->L, 0.0);
+  c->profCount = 0; c->profForwards = 0;
+  // first-FC flatten map: consumption index d = (ch*H + y)*W + x  ->  NHWC row (y*W + x)*C + ch  (src/CaffeEva.cc:187-189)
+  for (int l = 0; l < c->L; ++l) {
+    const LayerShape& s = c->shapes[l];
+    if (!s.hasDmap) continue;
+    const FmDims& a = c->dims[l];
+    std::vector<int> map(fm_elems(c, l));
+    for (int ch = 0; ch < a.c; ++ch)
+      for (int y = 0; y < a.h; ++y)
+        for (int x = 0; x < a.w; ++x) map[((size_t)ch * a.h + y) * a.w + x] = (y * a.w + x) * a.c + ch;
+    HIP_TRY(c, hipMemcpyAsync(c->arena + s.offDmap, map.data(), map.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+  }
+  c->committed = true;
+  return 0;
+}
+
+int qcnn_model_set_layer_params(QcnnCtx* c, int layer, const float* bias, const float* ctrd_file,
+                                const uint8_t* asmt_file) {
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (!c->committed) return fail(c, "qcnn_model_commit must precede qcnn_model_set_layer_params");
+  if (layer < 0 || layer >= c->L) return fail(c, "layer %d out of range", layer);
+  const QcnnLayerDesc& d = c->layers[layer];
+  LayerShape& s = c->shapes[layer];
+  if (s.K <= 0) return fail(c, "layer %d carries no parameters", layer);
+  const int Ct = c->dims[layer + 1].c;
+  const int M = s.M, K = s.K, Cs = s.Cs;
+  // PrepCtrdBuf: [M][K][Cs] -> [M][Cs][K]  (src/CaffeEva.cc:556-557)
+  std::vector<float> ctrd((size_t)M * Cs * K);
+  for (int m = 0; m < M; ++m)
+    for (int k = 0; k < K; ++k)
+      for (int dd = 0; dd < Cs; ++dd) ctrd[((size_t)m * Cs + dd) * K + k] = ctrd_file[((size_t)m * K + k) * Cs + dd];
+  // PrepAsmtBuf: conv [Ct][kh][kw][M] -> [kh][kw][M][Ct] (:585-586); FC [Ct][M] -> [M][Ct] (:610-611)
+  std::vector<uint8_t> asmt(s.asmtBytes + QCNN_ASMT_PAD, 0);
+  const size_t taps = (d.type == QCNN_CONV) ? (size_t)d.knlSiz * d.knlSiz : 1;
+  for (int ch = 0; ch < Ct; ++ch)
+    for (size_t t = 0; t < taps; ++t)
+      for (int m = 0; m < M; ++m) {
+        const uint8_t v = asmt_file[((size_t)ch * taps + t) * M + m];
+        if (v >= K) return fail(c, "layer %d: assignment %u >= K = %d", layer, (unsigned)v, K);
+        asmt[(t * M + m) * Ct + ch] = v;
+      }
+  HIP_TRY(c, hipMemcpyAsync(c->arena + s.offBias, bias, sizeof(float) * Ct, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->arena + s.offCtrd, ctrd.data(), sizeof(float) * ctrd.size(), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->arena + s.offAsmt, asmt.data(), asmt.size(), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  s.loaded = true;
+  return 0;
+}
+
+/* Mark every conv/FC layer as loaded without uploading: the arena was filled by a broadcast. */
+int qcnn_model_mark_loaded(QcnnCtx* c) {
+  if (!c->committed) return fail(c, "model not committed");
+  for (int l = 0; l < c->L; ++l)
+    if (c->shapes[l].K > 0) c->shapes[l].loaded = true;
+  return 0;
+}
+
+int qcnn_fm_dims(QcnnCtx* c, int l, int* hwc3) {
+  if (l < 0 || l > c->L) return fail(c, "feature map %d out of range", l);
+  hwc3[0] = c->dims[l].h; hwc3[1] = c->dims[l].w; hwc3[2] = c->dims[l].c;
+  return 0;
+}
+
+int qcnn_forward(QcnnCtx* c, const float* in_nchw_dev, int n, float* prob_dev, uint16_t* top5_dev) {
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (!c->committed) return fail(c, "model not committed");
+  if (n <= 0 || n > c->maxBatch) return fail(c, "batch %d outside (0, %d]", n, c->maxBatch);
+  hipError_t e = qk_pack_nchw(in_nchw_dev, c->fmBuf[0], n, c->inC, c->inH, c->inW, c->stream);
+  if (e != hipSuccess) return fail(c, "input pack launch failed: %s", hipGetErrorString(e));
+  if (run_layers(c, n)) return 1;
+  const int classes = (int)fm_elems(c, c->L);
+  if (prob_dev) {
+    e = qk_unpack_rows(c->lastFm[c->L], prob_dev, n, classes, c->stream);
+    if (e != hipSuccess) return fail(c, "output unpack launch failed: %s", hipGetErrorString(e));
+  }
+  if (top5_dev) {
+    e = qk_top5(c->lastFm[c->L], top5_dev, n, classes, c->stream);
+    if (e != hipSuccess) return fail(c, "top-5 launch failed: %s", hipGetErrorString(e));
+  }
+  return 0;
+}
+
+int qcnn_forward_host(QcnnCtx* c, const float* in_nchw_host, int n, float* prob_host, uint16_t* top5_host) {
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (!c->committed) return fail(c, "model not committed");
+  if (n <= 0 || n > c->maxBatch) return fail(c, "batch %d outside (0, %d]", n, c->maxBatch);
+  if (ensure_stage(c)) return 1;
+  const size_t inElems = fm_elems(c, 0) * n;
+  const int classes = (int)fm_elems(c, c->L);
+  HIP_TRY(c, hipMemcpyAsync(c->stageIn, in_nchw_host, inElems * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  if (qcnn_forward(c, c->stageIn, n, prob_host ? c->stageOut : nullptr, top5_host ? c->stageTop5 : nullptr)) return 1;
+  if (prob_host)
+    HIP_TRY(c, hipMemcpyAsync(prob_host, c->stageOut, (size_t)n * classes * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  if (top5_host)
+    HIP_TRY(c, hipMemcpyAsync(top5_host, c->stageTop5, (size_t)n * 5 * sizeof(uint16_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int qcnn_get_layer_output(QcnnCtx* c, int l, int n, float* host_out) {
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (l < 0 || l > c->L) return fail(c, "feature map %d out of range", l);
+  if (n <= 0 || n > c->lastN) return fail(c, "n = %d exceeds the last forward's batch %d", n, c->lastN);
+  if ((int)c->lastFm.size() != c->L + 1 || !c->lastFm[l]) return fail(c, "feature map %d is not available", l);
+  if (!c->keepAll && l > 0 && (c->layers[l - 1].type == QCNN_CONV || c->layers[l - 1].type == QCNN_FCNT) &&
+      l < c->L && c->layers[l].type == QCNN_RELU)
+    return fail(c, "feature map %d was fused away (QCNN_OPT_KEEP_ALL = 0)", l);
+  if (ensure_stage(c)) return 1;
+  const int E = (int)fm_elems(c, l);
+  hipError_t e = qk_unpack_rows(c->lastFm[l], c->stageOut, n, E, c->stream);
+  if (e != hipSuccess) return fail(c, "unpack launch failed: %s", hipGetErrorString(e));
+  HIP_TRY(c, hipMemcpyAsync(host_out, c->stageOut, (size_t)n * E * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int qcnn_run_layer(QcnnCtx* c, int layer, const float* in_host, int n, float* out_host) {
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (!c->committed) return fail(c, "model not committed");
+  if (layer < 0 || layer >= c->L) return fail(c, "layer %d out of range", layer);
+  if (n <= 0 || n > c->maxBatch) return fail(c, "batch %d outside (0, %d]", n, c->maxBatch);
+  if (ensure_stage(c)) return 1;
+  const int Ein = (int)fm_elems(c, layer), Eout = (int)fm_elems(c, layer + 1);
+  const int panels = (n + QCNN_PANEL - 1) / QCNN_PANEL;
+  // scratch: reuse the layer's own input/output maps (sized for maxBatch)
+  float* src = c->fmBuf[layer] ? c->fmBuf[layer] : c->fmBuf[layer - 1];
+  float* dst = c->fmBuf[layer + 1] ? c->fmBuf[layer + 1] : c->stageOut;
+  if (c->layers[layer].type == QCNN_DRPT && !c->fmBuf[layer + 1]) {
+    // aliased output map: stage through the linear buffer instead
+    memcpy(out_host, in_host, (size_t)n * Ein * sizeof(float));
+    return 0;
+  }
+  HIP_TRY(c, hipMemcpyAsync(c->stageIn, in_host, (size_t)n * Ein * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  hipError_t e = qk_pack_rows(c->stageIn, src, n, Ein, c->stream);
+  if (e != hipSuccess) return fail(c, "pack launch failed: %s", hipGetErrorString(e));
+  if (launch_layer(c, layer, src, dst, panels, false, true)) return 1;
+  e = qk_unpack_rows(dst, c->stageOut, n, Eout, c->stream);
+  if (e != hipSuccess) return fail(c, "unpack launch failed: %s", hipGetErrorString(e));
+  HIP_TRY(c, hipMemcpyAsync(out_host, c->stageOut, (size_t)n * Eout * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int qcnn_get_layer_ms(QcnnCtx* c, float* ms, int* forwards_recorded) {
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (drain_profile(c)) return 1;
+  for (int l = 0; l < c->L; ++l) ms[l] = c->profForwards ? (float)(c->profSum[l] / c->profForwards) : 0.0f;
+  if (forwards_recorded) *forwards_recorded = c->profForwards;
+  return 0;
+}
+
+int qcnn_reset_layer_ms(QcnnCtx* c) {
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (drain_profile(c)) return 1;
+  c->profSum.assign(c->L, 0.0);
+  c->profForwards = 0;
+  return 0;
+}
+
+}  // extern "C"

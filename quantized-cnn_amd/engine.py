@@ -1,0 +1,139 @@
+"""CaffeEva-shaped Python driver over the C-ABI (used by bench.py, the tests and smoke()).
+
+Same life-cycle as the reference's CaffeEva (include/CaffeEva.h:64-85): configure the layer table,
+load the per-layer parameters, run forward passes, read per-layer timings — but for a whole batch of
+images resident on one MI355X.  All arithmetic happens in libqcnn_hip.so; this file only moves
+pointers.  The C++ host mirror (include/CaffeEva.h of this repo) is the same thing for C++ callers.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .topology import CONV, FCNT
+
+
+class QcnnError(RuntimeError):
+    pass
+
+
+class QcnnEngine:
+    def __init__(self, device: int = 0, stream: int | None = None):
+        self.lib = capi.load()
+        h = C.c_void_p()
+        rc = self.lib.qcnn_ctx_create(device, C.c_void_p(stream) if stream else None, C.byref(h))
+        if rc:
+            raise QcnnError(self.lib.qcnn_last_error(None).decode())
+        self.h = h
+        self.layers = None
+        self.L = 0
+        self.max_batch = 0
+
+    # -- plumbing -------------------------------------------------------------------------------
+    def _chk(self, rc):
+        if rc:
+            raise QcnnError(self.lib.qcnn_last_error(self.h).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.qcnn_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_option(self, opt: int, value: int):
+        self._chk(self.lib.qcnn_set_option(self.h, opt, value))
+
+    def sync(self):
+        self._chk(self.lib.qcnn_sync(self.h))
+
+    # -- model ----------------------------------------------------------------------------------
+    def configure(self, in_chw, layers, shapes):
+        """shapes: {layer_idx: (M, K, Cs)} for every conv/FC layer."""
+        arr = (capi.QcnnLayerDesc * len(layers))(*[capi.layer_desc(l) for l in layers])
+        self._chk(self.lib.qcnn_model_begin(self.h, len(layers), arr, in_chw[0], in_chw[1], in_chw[2]))
+        for i, (m, k, cs) in shapes.items():
+            self._chk(self.lib.qcnn_model_set_layer_shape(self.h, i, m, k, cs))
+        self.layers, self.L, self.in_chw = layers, len(layers), tuple(in_chw)
+
+    def arena_bytes(self) -> int:
+        n = C.c_size_t(0)
+        self._chk(self.lib.qcnn_model_arena_bytes(self.h, C.byref(n)))
+        return n.value
+
+    def commit(self, max_batch: int, arena_ptr: int | None = None):
+        self._chk(self.lib.qcnn_model_commit(self.h, max_batch, C.c_void_p(arena_ptr) if arena_ptr else None))
+        self.max_batch = max_batch
+
+    def upload(self, params):
+        for i, p in params.items():
+            bias = np.ascontiguousarray(p["bias"], np.float32)
+            ctrd = np.ascontiguousarray(p["ctrd"], np.float32)
+            asmt = np.ascontiguousarray(p["asmt"], np.uint8)
+            self._chk(self.lib.qcnn_model_set_layer_params(self.h, i, bias.ctypes.data, ctrd.ctypes.data,
+                                                           asmt.ctypes.data))
+
+    def mark_loaded(self):
+        self._chk(self.lib.qcnn_model_mark_loaded(self.h))
+
+    def load_model(self, in_chw, layers, params, max_batch, arena_ptr=None, upload=True):
+        shapes = {i: tuple(int(x) for x in p["ctrd"].shape) for i, p in params.items()}   # (M, K, Cs)
+        for i, ly in enumerate(layers):
+            if ly["type"] in (CONV, FCNT) and i not in shapes:
+                raise QcnnError("layer %d has no parameters" % i)
+        self.configure(in_chw, layers, shapes)
+        self.commit(max_batch, arena_ptr)
+        if upload:
+            self.upload(params)
+
+    def fm_dims(self, l):
+        d = (C.c_int * 3)()
+        self._chk(self.lib.qcnn_fm_dims(self.h, l, d))
+        return int(d[0]), int(d[1]), int(d[2])
+
+    # -- forward --------------------------------------------------------------------------------
+    def forward_dev(self, in_ptr: int, n: int, prob_ptr: int | None = None, top5_ptr: int | None = None):
+        """Asynchronous, device pointers (e.g. torch tensors' data_ptr())."""
+        self._chk(self.lib.qcnn_forward(self.h, C.c_void_p(in_ptr), n,
+                                        C.c_void_p(prob_ptr) if prob_ptr else None,
+                                        C.c_void_p(top5_ptr) if top5_ptr else None))
+
+    def forward_host(self, imgs_nchw, want_prob=True, want_top5=True):
+        imgs = np.ascontiguousarray(imgs_nchw, np.float32)
+        n = imgs.shape[0]
+        h, w, c = self.fm_dims(self.L)
+        prob = np.empty((n, h * w * c), np.float32) if want_prob else None
+        top5 = np.empty((n, 5), np.uint16) if want_top5 else None
+        self._chk(self.lib.qcnn_forward_host(self.h, imgs.ctypes.data, n,
+                                             prob.ctypes.data if want_prob else None,
+                                             top5.ctypes.data if want_top5 else None))
+        return prob, top5
+
+    def layer_output(self, l: int, n: int):
+        h, w, c = self.fm_dims(l)
+        out = np.empty((n, h, w, c), np.float32)
+        self._chk(self.lib.qcnn_get_layer_output(self.h, l, n, out.ctypes.data))
+        return out
+
+    def run_layer(self, l: int, x, n: int):
+        x = np.ascontiguousarray(x, np.float32)
+        h, w, c = self.fm_dims(l + 1)
+        out = np.empty((n, h, w, c), np.float32)
+        self._chk(self.lib.qcnn_run_layer(self.h, l, x.ctypes.data, n, out.ctypes.data))
+        return out
+
+    # -- timing ---------------------------------------------------------------------------------
+    def layer_ms(self):
+        ms = (C.c_float * self.L)()
+        cnt = C.c_int(0)
+        self._chk(self.lib.qcnn_get_layer_ms(self.h, ms, C.byref(cnt)))
+        return np.array(ms[:], np.float64), cnt.value
+
+    def reset_layer_ms(self):
+        self._chk(self.lib.qcnn_reset_layer_ms(self.h))

@@ -50,10 +50,14 @@ def make_params(in_chw, layers, seed=0, spec: Optional[Dict[int, dict]] = None):
     spec = spec or quant_spec(in_chw, layers)
     rng = np.random.default_rng(seed)
     out = {}
+    first = min(spec) if spec else -1
     for i in sorted(spec):
         s = spec[i]
         fan_in = s["knl"] * s["knl"] * s["D"]
-        scale = np.float32(np.sqrt(2.0 / fan_in))
+        # He-style scale keeps the activation variance layer to layer; the first layer also brings the
+        # +-128 pixel range down to O(1) so that the reference's un-shifted softmax (expf, no max
+        # subtraction, src/CaffeEva.cc:1107-1114) stays finite.
+        scale = np.float32(np.sqrt(2.0 / fan_in) * (1.0 / 64.0 if i == first else 1.0))
         ctrd = (rng.standard_normal((s["M"], s["K"], s["Cs"])) * scale).astype(np.float32)
         bias = (rng.standard_normal(s["Ct"]) * 0.1).astype(np.float32)
         if s["kind"] == "conv":

@@ -1,0 +1,234 @@
+"""GPU parity tests: the HIP path, called through the C-ABI (include/qcnn_hip.h), against the oracle and
+the reference-generated golden vectors.
+
+Bars (north_star): conv / FC / ReLU / pool / dropout are integer-indexed fp32 adds in a fixed order —
+with the "exact" LUT builder they must be BIT-IDENTICAL to the reference.  LRN and softmax call
+expf/logf (device libm vs glibc): <= 1e-6 relative.  MFMA LUT builder (fused multiply-add chain) and
+whole-network runs: <= 1e-4 relative, max-norm and l2 (TOL), per feature map.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import pyoracle as po
+from conftest import fingerprint, pkg, rel_err, tiny_params_from_golden
+
+pytestmark = pytest.mark.gpu
+
+topo = pkg("topology")
+synth = pkg("synth")
+capi = pkg("capi")
+TOL = 1e-4          # north_star: "within 1e-4 relative"
+TOL_LIBM = 1e-6     # expf/logf differences only
+SAMPLE_STRIDE = 97
+BITWISE_TYPES = (topo.CONV, topo.FCNT, topo.RELU, topo.POOL, topo.DRPT)
+
+
+def make_engine(in_chw, layers, params, max_batch, lut=capi.LUT_EXACT, keep_all=1):
+    eng = pkg("engine").QcnnEngine(0)
+    eng.set_option(capi.OPT_LUT_MODE, lut)
+    eng.set_option(capi.OPT_KEEP_ALL, keep_all)
+    eng.load_model(in_chw, layers, params, max_batch)
+    return eng
+
+
+def first_fc(layers):
+    return [i for i, l in enumerate(layers) if l["type"] == topo.FCNT][0]
+
+
+def consumption_order(layers, l, x):
+    """fm[l] NHWC -> what layer l consumes (NCHW flatten for the first FC, src/CaffeEva.cc:187-189)."""
+    if l == first_fc(layers):
+        return np.ascontiguousarray(x.transpose(0, 3, 1, 2))
+    return x
+
+
+# ---------------------------------------------------------------- tiny network, full tensors ----
+def test_tiny_layers_in_isolation_exact(golden_tiny):
+    z = golden_tiny
+    in_chw, layers = topo.tiny_model()
+    eng = make_engine(in_chw, layers, tiny_params_from_golden(z, layers), 8)
+    B = z["imgs"].shape[0]
+    for l, ly in enumerate(layers):
+        y = eng.run_layer(l, consumption_order(layers, l, z["fm_%02d" % l]), B)
+        ref = z["fm_%02d" % (l + 1)]
+        if ly["type"] in BITWISE_TYPES:
+            assert np.array_equal(y, ref), "layer %d (%s) not bit-identical" % (l, topo.TYPE_NAMES[ly["type"]])
+        else:
+            e_inf, e_l2 = rel_err(y, ref)
+            assert e_inf <= TOL_LIBM and e_l2 <= TOL_LIBM, "layer %d: %g %g" % (l, e_inf, e_l2)
+
+
+@pytest.mark.parametrize("lut", [capi.LUT_EXACT, capi.LUT_MFMA])
+def test_tiny_end_to_end(golden_tiny, lut):
+    z = golden_tiny
+    in_chw, layers = topo.tiny_model()
+    eng = make_engine(in_chw, layers, tiny_params_from_golden(z, layers), 8, lut=lut)
+    prob, top5 = eng.forward_host(z["imgs"])
+    B = z["imgs"].shape[0]
+    for l in range(len(layers) + 1):
+        e_inf, e_l2 = rel_err(eng.layer_output(l, B), z["fm_%02d" % l])
+        assert e_inf <= TOL and e_l2 <= TOL, "fm[%d]: %g %g" % (l, e_inf, e_l2)
+    assert np.array_equal(top5, z["top5"])
+    assert np.allclose(prob, z["fm_%02d" % len(layers)].reshape(B, -1), rtol=TOL, atol=1e-9)
+    if lut == capi.LUT_EXACT:      # up to the first libm layer everything is bit-identical
+        assert np.array_equal(eng.layer_output(1, B), z["fm_01"])
+        assert np.array_equal(eng.layer_output(2, B), z["fm_02"])
+
+
+def test_tiny_ragged_multi_panel_batch(golden_tiny):
+    """130 images = 2 full panels + 2 images: every image must equal its own single-image result."""
+    z = golden_tiny
+    in_chw, layers = topo.tiny_model()
+    params = tiny_params_from_golden(z, layers)
+    imgs = synth.make_images(130, in_chw, seed=31)
+    imgs[:3] = z["imgs"]
+    eng = make_engine(in_chw, layers, params, 130)
+    prob, top5 = eng.forward_host(imgs)
+    orc = po.COracle(in_chw, layers)
+    orc.set_params(params)
+    orc.forward(imgs)
+    L = len(layers)
+    for l in (1, 4, 5, 7, 8, 11):
+        e_inf, e_l2 = rel_err(eng.layer_output(l, 130), orc.fm(l))
+        assert e_inf <= TOL and e_l2 <= TOL, "fm[%d]: %g %g" % (l, e_inf, e_l2)
+    assert np.array_equal(eng.layer_output(1, 130), orc.fm(1))           # conv1, exact builder
+    tops = np.stack([orc.top5(orc.fm(L)[i]) for i in range(130)])
+    assert np.array_equal(top5, tops)
+    assert np.array_equal(top5[:3], z["top5"])
+    # batch of 1 and of 64 give the same bits as the batch of 130
+    p1, _ = eng.forward_host(imgs[129:130])
+    assert np.array_equal(p1[0], prob[129])
+    p64, _ = eng.forward_host(imgs[:64])
+    assert np.array_equal(p64, prob[:64])
+
+
+def test_fast_path_equals_layer_for_layer_path(golden_tiny):
+    z = golden_tiny
+    in_chw, layers = topo.tiny_model()
+    params = tiny_params_from_golden(z, layers)
+    a = make_engine(in_chw, layers, params, 8, lut=capi.LUT_MFMA, keep_all=1)
+    b = make_engine(in_chw, layers, params, 8, lut=capi.LUT_MFMA, keep_all=0)
+    pa, ta = a.forward_host(z["imgs"])
+    pb, tb = b.forward_host(z["imgs"])
+    assert np.array_equal(pa, pb) and np.array_equal(ta, tb)
+    assert np.array_equal(a.layer_output(2, 3), b.layer_output(2, 3))    # post-ReLU map exists in both
+    with pytest.raises(pkg("engine").QcnnError):
+        b.layer_output(1, 3)                                             # pre-ReLU map was fused away
+
+
+def test_error_paths(golden_tiny):
+    z = golden_tiny
+    in_chw, layers = topo.tiny_model()
+    eng = make_engine(in_chw, layers, tiny_params_from_golden(z, layers), 4)
+    with pytest.raises(pkg("engine").QcnnError):
+        eng.forward_host(synth.make_images(5, in_chw))                   # batch > max_batch
+    bad = tiny_params_from_golden(z, layers)
+    bad[0] = dict(bad[0], asmt=np.full_like(bad[0]["asmt"], 200))        # index >= K
+    eng2 = pkg("engine").QcnnEngine(0)
+    with pytest.raises(pkg("engine").QcnnError):
+        eng2.load_model(in_chw, layers, bad, 4)
+
+
+# ---------------------------------------------------------------- AlexNet ----
+def test_alexnet_conv1_real_parameters_bitwise(golden_alex_real):
+    z = golden_alex_real
+    in_chw, layers, _, _ = topo.MODELS["AlexNet"]
+    params = synth.make_params(in_chw, layers, seed=7)
+    params[0] = dict(bias=z["conv1_bias"], ctrd=z["conv1_ctrd"], asmt=z["conv1_asmt"])
+    eng = make_engine(in_chw, layers, params, 4)
+    y = eng.run_layer(0, z["conv1_in"][None], 1)
+    assert np.array_equal(y[0], z["conv1_out"])
+    eng.set_option(capi.OPT_LUT_MODE, capi.LUT_MFMA)
+    e_inf, e_l2 = rel_err(eng.run_layer(0, z["conv1_in"][None], 1)[0], z["conv1_out"])
+    assert e_inf <= TOL and e_l2 <= TOL
+
+
+@pytest.mark.parametrize("lut", [capi.LUT_EXACT, capi.LUT_MFMA])
+def test_alexnet_synthetic_vs_reference_golden(golden_alex_syn, lut):
+    z = golden_alex_syn
+    in_chw, layers, _, _ = topo.MODELS["AlexNet"]
+    params = synth.make_params(in_chw, layers, seed=7)
+    imgs = synth.make_images(2, in_chw, seed=8)
+    eng = make_engine(in_chw, layers, params, 2, lut=lut)
+    prob, top5 = eng.forward_host(imgs)
+    worst = 0.0
+    for l in range(len(layers) + 1):
+        fm = eng.layer_output(l, 2)
+        smp = fm.reshape(2, -1)[:, ::SAMPLE_STRIDE]
+        scale = max(abs(z["fp_%02d" % l][:, 3]).max(), abs(z["fp_%02d" % l][:, 4]).max())
+        err = np.abs(smp.astype(np.float64) - z["smp_%02d" % l]).max() / scale
+        worst = max(worst, err)
+        assert err <= TOL, "fm[%d] samples: %g" % (l, err)
+        for i in range(2):
+            fp, gp = fingerprint(fm[i]), z["fp_%02d" % l][i]
+            assert abs(fp[2] - gp[2]) <= TOL * gp[2], "fm[%d] l2" % l
+    assert np.array_equal(top5, z["top5"])
+    print("alexnet synthetic lut=%d worst sample error %.3g" % (lut, worst))
+
+
+def test_alexnet_layers_in_isolation_bitwise():
+    """Every conv/FC layer of AlexNet on the oracle's own activations, exact builder: bit-identical."""
+    in_chw, layers, _, _ = topo.MODELS["AlexNet"]
+    params = synth.make_params(in_chw, layers, seed=7)
+    imgs = synth.make_images(3, in_chw, seed=9)
+    orc = po.COracle(in_chw, layers)
+    orc.set_params(params)
+    orc.forward(imgs)
+    eng = make_engine(in_chw, layers, params, 3)
+    for l, ly in enumerate(layers):
+        x = consumption_order(layers, l, orc.fm(l))
+        y = eng.run_layer(l, x, 3)
+        if ly["type"] in BITWISE_TYPES:
+            assert np.array_equal(y, orc.fm(l + 1)), "layer %d (%s)" % (l, topo.TYPE_NAMES[ly["type"]])
+        else:
+            e_inf, e_l2 = rel_err(y, orc.fm(l + 1))
+            assert e_inf <= TOL_LIBM and e_l2 <= TOL_LIBM, "layer %d: %g %g" % (l, e_inf, e_l2)
+
+
+@pytest.mark.skipif(not os.path.isdir(po.REF_DATA), reason="shipped parameters not staged (oracle/_ref/data)")
+def test_alexnet_real_parameters_all_feature_maps(golden_alex_real):
+    z = golden_alex_real
+    in_chw, layers, sub, pfx = topo.MODELS["AlexNet"]
+    params = synth.load_param_dir(os.path.join(po.REF_DATA, sub), pfx, layers)
+    img = np.ascontiguousarray(z["conv1_in"].transpose(2, 0, 1))[None]
+    for lut in (capi.LUT_EXACT, capi.LUT_MFMA):
+        eng = make_engine(in_chw, layers, params, 1, lut=lut)
+        prob, top5 = eng.forward_host(img)
+        for l in range(len(layers) + 1):
+            fm = eng.layer_output(l, 1)
+            scale = max(abs(z["fp_%02d" % l][0, 3]), abs(z["fp_%02d" % l][0, 4]), 1e-30)
+            err = np.abs(fm.reshape(1, -1)[:, ::SAMPLE_STRIDE].astype(np.float64) - z["smp_%02d" % l]).max() / scale
+            assert err <= TOL, "lut %d fm[%d]: %g" % (lut, l, err)
+            assert abs(fingerprint(fm)[2] - z["fp_%02d" % l][0, 2]) <= TOL * max(z["fp_%02d" % l][0, 2], 1e-30)
+        assert np.array_equal(top5[0], z["top5"][0])
+        if lut == capi.LUT_EXACT:
+            assert np.array_equal(eng.layer_output(1, 1)[0], z["conv1_out"])
+
+
+def test_alexnet_full_batch_properties():
+    """BASELINE.json configs[1] size (1000 images): size-independent properties instead of a 90 s oracle run:
+    batch invariance (bit-identical to the same image in a 64-image batch), permutation equivariance,
+    softmax rows sum to 1, and the oracle on a handful of sampled images."""
+    in_chw, layers, _, _ = topo.MODELS["AlexNet"]
+    params = synth.make_params(in_chw, layers, seed=7)
+    imgs = synth.make_images(1000, in_chw, seed=10)
+    eng = make_engine(in_chw, layers, params, 1000, lut=capi.LUT_MFMA, keep_all=0)
+    prob, top5 = eng.forward_host(imgs)
+    assert prob.shape == (1000, 1000) and np.isfinite(prob).all()
+    assert np.abs(prob.sum(axis=1) - 1.0).max() < 1e-4
+    p64, t64 = eng.forward_host(imgs[936:1000])
+    assert np.array_equal(p64, prob[936:1000]) and np.array_equal(t64, top5[936:1000])
+    perm = np.random.default_rng(3).permutation(1000)
+    pp, tp = eng.forward_host(imgs[perm])
+    assert np.array_equal(pp, prob[perm]) and np.array_equal(tp, top5[perm])
+    orc = po.COracle(in_chw, layers)
+    orc.set_params(params)
+    pick = [0, 63, 64, 511, 999]
+    orc.forward(imgs[pick])
+    ref = orc.fm(len(layers)).reshape(len(pick), -1)
+    for j, i in enumerate(pick):
+        e_inf, e_l2 = rel_err(prob[i], ref[j])
+        assert e_inf <= TOL and e_l2 <= TOL, "image %d: %g %g" % (i, e_inf, e_l2)
+        assert np.array_equal(top5[i], orc.top5(ref[j]))

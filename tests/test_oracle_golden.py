@@ -1,0 +1,102 @@
+"""The oracle (oracle/qcnn_oracle.c) against golden vectors produced by the COMPILED REFERENCE
+(oracle/make_golden.py).  CPU only; runs wherever the repo goes (no /root/reference needed)."""
+import os
+
+import numpy as np
+import pytest
+
+import pyoracle as po
+from conftest import fingerprint, pkg, tiny_params_from_golden
+
+topo = pkg("topology")
+synth = pkg("synth")
+SAMPLE_STRIDE = 97
+
+
+def test_tiny_all_layers_bit_exact(golden_tiny):
+    z = golden_tiny
+    in_chw, layers = topo.tiny_model()
+    orc = po.COracle(in_chw, layers)
+    orc.set_params(tiny_params_from_golden(z, layers))
+    orc.forward(z["imgs"])
+    for l in range(len(layers) + 1):
+        assert np.array_equal(orc.fm(l), z["fm_%02d" % l]), "fm[%d] differs from the reference" % l
+    for i in range(z["imgs"].shape[0]):
+        assert np.array_equal(orc.top5(orc.fm(len(layers))[i]), z["top5"][i])
+
+
+def test_tiny_batch_equals_single(golden_tiny):
+    """The reference is batch-1; the oracle's batch loop must not couple images."""
+    z = golden_tiny
+    in_chw, layers = topo.tiny_model()
+    orc = po.COracle(in_chw, layers)
+    orc.set_params(tiny_params_from_golden(z, layers))
+    orc.forward(z["imgs"][1:2])
+    one = orc.fm(len(layers))
+    assert np.array_equal(one[0], z["fm_%02d" % len(layers)][1])
+
+
+def test_tiny_layer_isolation(golden_tiny):
+    z = golden_tiny
+    in_chw, layers = topo.tiny_model()
+    orc = po.COracle(in_chw, layers)
+    orc.set_params(tiny_params_from_golden(z, layers))
+    first_fc = [i for i, l in enumerate(layers) if l["type"] == topo.FCNT][0]
+    B = z["imgs"].shape[0]
+    for l in range(len(layers)):
+        x = z["fm_%02d" % l]
+        if l == first_fc:
+            x = np.ascontiguousarray(x.transpose(0, 3, 1, 2))          # NCHW flatten, src/CaffeEva.cc:187-189
+        y = orc.run_layer(l, x, B)
+        assert np.array_equal(y, z["fm_%02d" % (l + 1)]), "layer %d" % l
+
+
+def test_alexnet_conv1_real_parameters(golden_alex_real):
+    """conv1 with the SHIPPED codebook/assignments on a real image (stored in full in the fixture)."""
+    z = golden_alex_real
+    in_chw, layers, _, _ = topo.MODELS["AlexNet"]
+    orc = po.COracle(in_chw, layers)
+    orc.set_params({0: dict(bias=z["conv1_bias"], ctrd=z["conv1_ctrd"], asmt=z["conv1_asmt"])})
+    y = orc.run_layer(0, z["conv1_in"][None], 1)
+    assert np.array_equal(y[0], z["conv1_out"])
+    # SURVEY.md §8c fingerprint of fm[1]
+    fp = fingerprint(y)
+    assert abs(fp[0] - 8.476510e+05) < 1.0 and abs(fp[3] + 2214.58594) < 1e-3 and abs(fp[4] - 2282.12915) < 1e-3
+
+
+def test_alexnet_synthetic_fingerprints(golden_alex_syn):
+    z = golden_alex_syn
+    in_chw, layers, _, _ = topo.MODELS["AlexNet"]
+    params = synth.make_params(in_chw, layers, seed=7)
+    imgs = synth.make_images(2, in_chw, seed=8)
+    orc = po.COracle(in_chw, layers)
+    orc.set_params(params)
+    orc.forward(imgs)
+    for l in range(len(layers) + 1):
+        fm = orc.fm(l)
+        smp = fm.reshape(2, -1)[:, ::SAMPLE_STRIDE]
+        assert np.array_equal(smp, z["smp_%02d" % l]), "fm[%d] samples" % l
+        for i in range(2):
+            assert np.allclose(fingerprint(fm[i]), z["fp_%02d" % l][i], rtol=1e-12, atol=0), "fm[%d] fingerprint" % l
+    for i in range(2):
+        assert np.array_equal(orc.top5(orc.fm(len(layers))[i]), z["top5"][i])
+
+
+@pytest.mark.skipif(not os.path.isdir(po.REF_DATA), reason="shipped parameters not staged (oracle/_ref/data)")
+def test_alexnet_real_fingerprints(golden_alex_real):
+    z = golden_alex_real
+    in_chw, layers, sub, pfx = topo.MODELS["AlexNet"]
+    params = synth.load_param_dir(os.path.join(po.REF_DATA, sub), pfx, layers)
+    orc = po.COracle(in_chw, layers)
+    orc.set_params(params)
+    img = np.ascontiguousarray(z["conv1_in"].transpose(2, 0, 1))[None]     # back to NCHW
+    orc.forward(img)
+    for l in range(len(layers) + 1):
+        fm = orc.fm(l)
+        assert np.array_equal(fm.reshape(1, -1)[:, ::SAMPLE_STRIDE], z["smp_%02d" % l]), "fm[%d]" % l
+        assert np.allclose(fingerprint(fm), z["fp_%02d" % l][0], rtol=1e-12, atol=0)
+    assert np.array_equal(orc.top5(orc.fm(len(layers))[0]), z["top5"][0])
+    # SURVEY.md §8c fingerprints
+    assert abs(fingerprint(orc.fm(5))[0] + 1.106604e+07) < 10.0
+    assert abs(fingerprint(orc.fm(15))[0] - 3.416127e+04) < 0.1
+    assert abs(fingerprint(orc.fm(16))[0] - 1.858081e+04) < 0.1
