@@ -82,6 +82,8 @@ def build_reference_driver(ref: str = "/root/reference", force: bool = False):
     (SURVEY.md §0 fact 9): stage copies under build/stage/src beside build/stage/include -> include/."""
     if not os.path.isdir(os.path.join(ref, "src")) or not os.path.exists(HOST_SO):
         return None
+    if not os.path.exists(os.path.join(HOST, "caffe_eva_wrapper.cc")):
+        return None     # host mirror incomplete: nothing to link the reference drivers against
     stage = os.path.join(ROOT, "build", "stage")
     os.makedirs(os.path.join(stage, "src"), exist_ok=True)
     inc_link = os.path.join(stage, "include")

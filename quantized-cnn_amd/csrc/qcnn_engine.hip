@@ -104,8 +104,8 @@ int plan_arena(QcnnCtx* c) {
     const int Ct = c->dims[l + 1].c;
     s.offBias = off; off = align_up(off + sizeof(float) * Ct, 256);
     s.offCtrd = off; off = align_up(off + sizeof(float) * (size_t)s.M * s.Cs * s.K, 256);
-    s.asmtBytes = (d.type == QCNN_CONV) ? (size_t)d.knlSiz * d.knlSiz * s.M * Ct : (size_t)s.M * Ct;
-    s.offAsmt = off; off = align_up(off + s.asmtBytes + QCNN_ASMT_PAD, 256);
+    s.asmtBytes = (d.type == QCNN_CONV) ? (size_t)d.knlSiz * d.knlSiz * s.M * Ct : (size_t)s.M * Ct;   // entries
+    s.offAsmt = off; off = align_up(off + (s.asmtBytes + QCNN_OFFS_PAD) * sizeof(uint32_t), 256);
     s.hasDmap = (d.type == QCNN_FCNT && l == c->firstFc && c->dims[l].h * c->dims[l].w > 1);
     if (s.hasDmap) { s.offDmap = off; off = align_up(off + sizeof(int) * fm_elems(c, l), 256); }
   }
@@ -153,7 +153,7 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
       p.src = src; p.dst = dst;
       p.bias = reinterpret_cast<const float*>(c->arena + s.offBias);
       p.ctrd = reinterpret_cast<const float*>(c->arena + s.offCtrd);
-      p.asmt = reinterpret_cast<const uint8_t*>(c->arena + s.offAsmt);
+      p.offs = reinterpret_cast<const uint32_t*>(c->arena + s.offAsmt);
       p.H = a.h; p.W = a.w; p.Cin = a.c; p.Ho = b.h; p.Wo = b.w; p.Ct = b.c;
       p.knl = d.knlSiz; p.stride = d.stride; p.pad = d.padSiz; p.grp = d.grpCnt;
       p.M = s.M; p.Cs = s.Cs; p.K = s.K; p.relu = fuseRelu ? 1 : 0; p.panels = panels;
@@ -166,7 +166,7 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
       p.src = src; p.dst = dst;
       p.bias = reinterpret_cast<const float*>(c->arena + s.offBias);
       p.ctrd = reinterpret_cast<const float*>(c->arena + s.offCtrd);
-      p.asmt = reinterpret_cast<const uint8_t*>(c->arena + s.offAsmt);
+      p.offs = reinterpret_cast<const uint32_t*>(c->arena + s.offAsmt);
       p.dmap = (s.hasDmap && !flatFcInput) ? reinterpret_cast<const int*>(c->arena + s.offDmap) : nullptr;
       p.D = a.h * a.w * a.c; p.Ct = b.c; p.M = s.M; p.Cs = s.Cs; p.K = s.K;
       p.relu = fuseRelu ? 1 : 0; p.panels = panels;
@@ -423,19 +423,20 @@ int qcnn_model_set_layer_params(QcnnCtx* c, int layer, const float* bias, const 
   for (int m = 0; m < M; ++m)
     for (int k = 0; k < K; ++k)
       for (int dd = 0; dd < Cs; ++dd) ctrd[((size_t)m * Cs + dd) * K + k] = ctrd_file[((size_t)m * K + k) * Cs + dd];
-  // PrepAsmtBuf: conv [Ct][kh][kw][M] -> [kh][kw][M][Ct] (:585-586); FC [Ct][M] -> [M][Ct] (:610-611)
-  std::vector<uint8_t> asmt(s.asmtBytes + QCNN_ASMT_PAD, 0);
+  // PrepAsmtBuf: conv [Ct][kh][kw][M] -> [kh][kw][M][Ct] (:585-586); FC [Ct][M] -> [M][Ct] (:610-611);
+  // stored as the byte offset of the code-word row inside a LUT slot (index * 128 images * 4 B)
+  std::vector<uint32_t> asmt(s.asmtBytes + QCNN_OFFS_PAD, 0);
   const size_t taps = (d.type == QCNN_CONV) ? (size_t)d.knlSiz * d.knlSiz : 1;
   for (int ch = 0; ch < Ct; ++ch)
     for (size_t t = 0; t < taps; ++t)
       for (int m = 0; m < M; ++m) {
         const uint8_t v = asmt_file[((size_t)ch * taps + t) * M + m];
         if (v >= K) return fail(c, "layer %d: assignment %u >= K = %d", layer, (unsigned)v, K);
-        asmt[(t * M + m) * Ct + ch] = v;
+        asmt[(t * M + m) * Ct + ch] = (uint32_t)v * (QCNN_PANEL * (uint32_t)sizeof(float));
       }
   HIP_TRY(c, hipMemcpyAsync(c->arena + s.offBias, bias, sizeof(float) * Ct, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipMemcpyAsync(c->arena + s.offCtrd, ctrd.data(), sizeof(float) * ctrd.size(), hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(c->arena + s.offAsmt, asmt.data(), asmt.size(), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->arena + s.offAsmt, asmt.data(), asmt.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   s.loaded = true;
   return 0;

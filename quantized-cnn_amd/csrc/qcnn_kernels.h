@@ -1,27 +1,30 @@
 // qcnn_kernels.h — launch wrappers of the gfx950 kernels (internal; the public surface is include/qcnn_hip.h).
 //
-// Activation layout in HBM ("image-minor panels"): a batch is cut into panels of QCNN_PANEL = 64
-// images; feature map l of one panel is a row-major matrix [E_l][64] with E_l = H*W*C elements in the
-// reference's NHWC order and the 64 images of the panel innermost.  One wavefront lane = one image:
-// every load/store of a wave is a full 256-byte row, and the code-word index of the approximate
-// layers is wave-uniform (it depends on the layer's assignment table only), so table look-ups become
-// conflict-free LDS row reads instead of random gathers.
+// Activation layout in HBM ("image-minor panels"): a batch is cut into panels of QCNN_PANEL = 128
+// images; feature map l of one panel is a row-major matrix [E_l][128] with E_l = H*W*C elements in the
+// reference's NHWC order and the 128 images of the panel innermost.  One wavefront lane carries an
+// image PAIR (images 2*lane, 2*lane+1 of the panel): every load/store of a wave is a full 512-byte row,
+// a table look-up is one conflict-free ds_read_b64 and the accumulation one v_pk_add_f32.  The
+// code-word index of the approximate layers is wave-uniform (it depends on the layer's assignment table
+// only) and arrives through scalar loads.
 #ifndef QCNN_KERNELS_H_
 #define QCNN_KERNELS_H_
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define QCNN_PANEL 64
+#define QCNN_PANEL 128
 #define QCNN_MAX_CS 8          // dims per sub-space supported by the LUT builders
-#define QCNN_ASMT_PAD 64       // bytes of slack after every assignment table (vector over-read)
+#define QCNN_OFFS_PAD 64       // uint32 entries of slack after every offset table (vector over-read)
 
+// Assignment tables are stored on the device as uint32 BYTE OFFSETS of the code-word row inside a
+// LUT slot: offs = index * QCNN_PANEL * sizeof(float).
 struct ConvParams {
-  const float* src;      // [panels][H*W*Cin][64]
-  float* dst;            // [panels][Ho*Wo*Ct][64]
+  const float* src;      // [panels][H*W*Cin][128]
+  float* dst;            // [panels][Ho*Wo*Ct][128]
   const float* bias;     // [Ct]
   const float* ctrd;     // [M][Cs][K]      (PrepCtrdBuf layout, src/CaffeEva.cc:556-557)
-  const uint8_t* asmt;   // [kh][kw][M][Ct] (PrepAsmtBuf layout, src/CaffeEva.cc:585-586)
+  const uint32_t* offs;  // [kh][kw][M][Ct] (PrepAsmtBuf layout, src/CaffeEva.cc:585-586), pre-scaled
   int H, W, Cin, Ho, Wo, Ct;
   int knl, stride, pad, grp;
   int M, Cs, K;
@@ -30,11 +33,11 @@ struct ConvParams {
 };
 
 struct FcParams {
-  const float* src;      // [panels][D][64]
-  float* dst;            // [panels][Ct][64]
+  const float* src;      // [panels][D][128]
+  float* dst;            // [panels][Ct][128]
   const float* bias;
   const float* ctrd;     // [M][Cs][K]
-  const uint8_t* asmt;   // [M][Ct]         (src/CaffeEva.cc:610-611)
+  const uint32_t* offs;  // [M][Ct]         (src/CaffeEva.cc:610-611), pre-scaled
   const int* dmap;       // [D] row of input element d in src (NCHW-flatten of the first FC), or NULL
   int D, Ct, M, Cs, K;
   int relu;
@@ -53,11 +56,11 @@ hipError_t qk_pool(const float* src, float* dst, int panels, int H, int W, int C
 hipError_t qk_softmax(const float* src, float* dst, int panels, int C, hipStream_t st);
 hipError_t qk_top5(const float* prob, uint16_t* out, int n, int C, hipStream_t st);   // prob panel layout -> [n][5]
 
-// [n][C][H][W] -> panels [H*W*C][64] (lanes >= n zero-filled)
+// [n][C][H][W] -> panels [H*W*C][128] (lanes >= n zero-filled)
 hipError_t qk_pack_nchw(const float* in, float* dst, int n, int C, int H, int W, hipStream_t st);
-// [n][E] (already in NHWC / flat order) -> panels [E][64]
+// [n][E] (already in NHWC / flat order) -> panels [E][128]
 hipError_t qk_pack_rows(const float* in, float* dst, int n, int E, hipStream_t st);
-// panels [E][64] -> [n][E]
+// panels [E][128] -> [n][E]
 hipError_t qk_unpack_rows(const float* src, float* out, int n, int E, hipStream_t st);
 
 #endif  // QCNN_KERNELS_H_
