@@ -10,6 +10,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -57,6 +58,9 @@ struct QcnnCtx {
   float* stageOut = nullptr;
   size_t stageElems = 0;
   uint16_t* stageTop5 = nullptr;
+  float* fcFlat = nullptr;           // first FC layer's input in consumption order
+  float* fcPartial = nullptr;        // split-M partial sums of the FC layers
+  size_t fcPartialElems = 0;
   int lastN = 0;
   std::vector<float*> lastFm;        // pointer table of the last forward
 
@@ -121,7 +125,11 @@ void free_model(QcnnCtx* c) {
   if (c->stageIn) (void)hipFree(c->stageIn);
   if (c->stageOut) (void)hipFree(c->stageOut);
   if (c->stageTop5) (void)hipFree(c->stageTop5);
+  if (c->fcPartial) (void)hipFree(c->fcPartial);
+  if (c->fcFlat) (void)hipFree(c->fcFlat);
+  c->fcFlat = nullptr;
   c->stageIn = c->stageOut = nullptr; c->stageTop5 = nullptr; c->stageElems = 0;
+  c->fcPartial = nullptr; c->fcPartialElems = 0;
   for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
   c->ev.clear();
   c->committed = false;
@@ -167,10 +175,33 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
       p.bias = reinterpret_cast<const float*>(c->arena + s.offBias);
       p.ctrd = reinterpret_cast<const float*>(c->arena + s.offCtrd);
       p.offs = reinterpret_cast<const uint32_t*>(c->arena + s.offAsmt);
-      p.dmap = (s.hasDmap && !flatFcInput) ? reinterpret_cast<const int*>(c->arena + s.offDmap) : nullptr;
+      if (s.hasDmap && !flatFcInput) {   // NHWC -> consumption order (NCHW flatten) into the scratch map
+        e = qk_permute_rows(src, c->fcFlat, reinterpret_cast<const int*>(c->arena + s.offDmap), a.h * a.w * a.c,
+                            panels, c->stream);
+        if (e != hipSuccess) break;
+        p.src = c->fcFlat;
+      }
       p.D = a.h * a.w * a.c; p.Ct = b.c; p.M = s.M; p.Cs = s.Cs; p.K = s.K;
       p.relu = fuseRelu ? 1 : 0; p.panels = panels;
+      // Split the sub-space axis over workgroups when the (channel chunk x panel) grid cannot fill the
+      // chip; the exact builder keeps one pass so that the summation order stays the reference's.
+      p.msplit = 1; p.partial = nullptr;
+      if (c->lutMode == 1) {
+        const int G = qcnn_stage_group(s.K);
+        const int stages = (s.M + G - 1) / G;
+        const int cpw = p.Ct >= 2048 ? 64 : (p.Ct >= 512 ? 32 : (p.Ct >= 64 ? 8 : 4));
+        // batch-independent choice (a given image must produce the same bits in any batch):
+        // aim at >= 64 workgroups per panel, keep >= 16 stages per workgroup, at most 16 splits
+        const int chunks = (p.Ct + 8 * cpw - 1) / (8 * cpw);
+        int ms = (64 + chunks - 1) / chunks;
+        if (ms > 16) ms = 16;
+        while (ms > 1 && stages / ms < 16) --ms;
+        const size_t need = (size_t)ms * panels * p.Ct * QCNN_PANEL;
+        if (ms > 1 && need <= c->fcPartialElems) { p.msplit = ms; p.partial = c->fcPartial; }
+      }
       e = qk_fc_aprx(p, c->lutMode, c->stream);
+      if (e == hipSuccess && p.msplit > 1)
+        e = qk_sum_partials(p.partial, dst, p.msplit, (size_t)panels * p.Ct * QCNN_PANEL, p.relu, c->stream);
       break;
     }
     case QCNN_POOL:
@@ -349,8 +380,9 @@ int qcnn_model_set_layer_shape(QcnnCtx* c, int layer, int M, int K, int Cs) {
   if (layer < 0 || layer >= c->L) return fail(c, "layer %d out of range", layer);
   const QcnnLayerDesc& d = c->layers[layer];
   if (d.type != QCNN_CONV && d.type != QCNN_FCNT) return fail(c, "layer %d carries no parameters", layer);
-  if (M <= 0 || K <= 0 || K > 256 || Cs <= 0 || Cs > QCNN_MAX_CS)
-    return fail(c, "layer %d: unsupported quantisation shape M=%d K=%d Cs=%d (K <= 256, Cs <= %d)", layer, M, K, Cs, QCNN_MAX_CS);
+  if (M <= 0 || K <= 0 || K > QCNN_MAX_K || Cs <= 0 || Cs > QCNN_MAX_CS)
+    return fail(c, "layer %d: unsupported quantisation shape M=%d K=%d Cs=%d (K <= %d, Cs <= %d)", layer, M, K, Cs,
+                QCNN_MAX_K, QCNN_MAX_CS);
   const int D = (d.type == QCNN_CONV) ? c->dims[layer].c / d.grpCnt : (int)fm_elems(c, layer);
   if ((size_t)M * Cs < (size_t)D) return fail(c, "layer %d: M*Cs = %d does not cover %d input dims", layer, M * Cs, D);
   if ((M - 1) * Cs >= D) return fail(c, "layer %d: sub-space %d starts beyond the %d input dims", layer, M - 1, D);
@@ -388,6 +420,15 @@ int qcnn_model_commit(QcnnCtx* c, int max_batch, void* dev_arena) {
     const size_t bytes = (size_t)c->maxPanels * fm_elems(c, l) * QCNN_PANEL * sizeof(float);
     HIP_TRY(c, hipMalloc(&c->fmBuf[l], bytes));
   }
+  {
+    size_t maxCt = 0;
+    for (int l = 0; l < c->L; ++l)
+      if (c->layers[l].type == QCNN_FCNT) maxCt = std::max<size_t>(maxCt, c->dims[l + 1].c);
+    c->fcPartialElems = (size_t)16 * c->maxPanels * maxCt * QCNN_PANEL;
+    if (c->fcPartialElems) HIP_TRY(c, hipMalloc(&c->fcPartial, c->fcPartialElems * sizeof(float)));
+    if (c->firstFc >= 0 && c->shapes[c->firstFc].hasDmap)
+      HIP_TRY(c, hipMalloc(&c->fcFlat, (size_t)c->maxPanels * fm_elems(c, c->firstFc) * QCNN_PANEL * sizeof(float)));
+  }
   c->ev.resize((size_t)kProfRing * c->L * 2);
   for (hipEvent_t& e : c->ev) HIP_TRY(c, hipEventCreate(&e));
   c->profSum.assign(c->L, 0.0);
@@ -424,15 +465,16 @@ int qcnn_model_set_layer_params(QcnnCtx* c, int layer, const float* bias, const 
     for (int k = 0; k < K; ++k)
       for (int dd = 0; dd < Cs; ++dd) ctrd[((size_t)m * Cs + dd) * K + k] = ctrd_file[((size_t)m * K + k) * Cs + dd];
   // PrepAsmtBuf: conv [Ct][kh][kw][M] -> [kh][kw][M][Ct] (:585-586); FC [Ct][M] -> [M][Ct] (:610-611);
-  // stored as the byte offset of the code-word row inside a LUT slot (index * 128 images * 4 B)
+  // stored as the byte offset of the code-word row inside a LUT stage: ((m % G) * K + index) * row bytes
   std::vector<uint32_t> asmt(s.asmtBytes + QCNN_OFFS_PAD, 0);
+  const int G = qcnn_stage_group(K);
   const size_t taps = (d.type == QCNN_CONV) ? (size_t)d.knlSiz * d.knlSiz : 1;
   for (int ch = 0; ch < Ct; ++ch)
     for (size_t t = 0; t < taps; ++t)
       for (int m = 0; m < M; ++m) {
         const uint8_t v = asmt_file[((size_t)ch * taps + t) * M + m];
         if (v >= K) return fail(c, "layer %d: assignment %u >= K = %d", layer, (unsigned)v, K);
-        asmt[(t * M + m) * Ct + ch] = (uint32_t)v * (QCNN_PANEL * (uint32_t)sizeof(float));
+        asmt[(t * M + m) * Ct + ch] = (uint32_t)((m % G) * K + v) * (uint32_t)QCNN_ROW_BYTES;
       }
   HIP_TRY(c, hipMemcpyAsync(c->arena + s.offBias, bias, sizeof(float) * Ct, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipMemcpyAsync(c->arena + s.offCtrd, ctrd.data(), sizeof(float) * ctrd.size(), hipMemcpyHostToDevice, c->stream));

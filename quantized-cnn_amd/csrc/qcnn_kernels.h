@@ -15,10 +15,15 @@
 
 #define QCNN_PANEL 128
 #define QCNN_MAX_CS 8          // dims per sub-space supported by the LUT builders
+#define QCNN_MAX_K 128         // code words per sub-space supported (a LUT stage holds 128 rows)
 #define QCNN_OFFS_PAD 64       // uint32 entries of slack after every offset table (vector over-read)
+#define QCNN_STAGE_ROWS 128    // code-word rows of one LUT stage in LDS
+#define QCNN_ROW_BYTES 528     // LDS row stride: 128 images * 4 B + 16 B pad (conflict-free MFMA tile writes)
 
-// Assignment tables are stored on the device as uint32 BYTE OFFSETS of the code-word row inside a
-// LUT slot: offs = index * QCNN_PANEL * sizeof(float).
+// A LUT stage holds G = qcnn_stage_group(K) consecutive sub-spaces of one source pixel (conv) / of the
+// input vector (FC): G * K <= 128 rows.  Assignment tables are stored on the device as uint32 BYTE
+// OFFSETS of the code-word row inside a stage:  offs = ((m % G) * K + index) * QCNN_ROW_BYTES.
+static inline int qcnn_stage_group(int K) { return K <= 64 ? QCNN_STAGE_ROWS / K : 1; }
 struct ConvParams {
   const float* src;      // [panels][H*W*Cin][128]
   float* dst;            // [panels][Ho*Wo*Ct][128]
@@ -33,12 +38,13 @@ struct ConvParams {
 };
 
 struct FcParams {
+  float* partial;        // [msplit][panels][Ct][128] scratch for split-M partial sums (msplit > 1)
+  int msplit;            // blocks along the sub-space axis (1 = single pass, bit-exact summation order)
   const float* src;      // [panels][D][128]
   float* dst;            // [panels][Ct][128]
   const float* bias;
   const float* ctrd;     // [M][Cs][K]
   const uint32_t* offs;  // [M][Ct]         (src/CaffeEva.cc:610-611), pre-scaled
-  const int* dmap;       // [D] row of input element d in src (NCHW-flatten of the first FC), or NULL
   int D, Ct, M, Cs, K;
   int relu;
   int panels;
@@ -47,6 +53,12 @@ struct FcParams {
 // lutMode: 0 exact VALU, 1 MFMA.  Return hipError_t of the launch.
 hipError_t qk_conv_aprx(const ConvParams& p, int lutMode, hipStream_t st);
 hipError_t qk_fc_aprx(const FcParams& p, int lutMode, hipStream_t st);
+
+// dst row e = src row map[e], rows of 128 images ([panels][D][128]); the first FC layer consumes its input
+// NCHW-flattened (src/CaffeEva.cc:187-189)
+hipError_t qk_permute_rows(const float* src, float* dst, const int* map, int D, int panels, hipStream_t st);
+// dst[e] = sum_z partial[z][e] (z ascending), optional ReLU; n floats per partial slab
+hipError_t qk_sum_partials(const float* partial, float* dst, int msplit, size_t n, int relu, hipStream_t st);
 
 hipError_t qk_relu(const float* src, float* dst, size_t n, hipStream_t st);
 hipError_t qk_lrn(const float* src, float* dst, int panels, int HW, int C, int lrnSiz, float alp, float bet,

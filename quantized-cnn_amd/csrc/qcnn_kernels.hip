@@ -6,30 +6,35 @@
 // Glue kernels (row a9): ReLU :1027, LRN :1038, max-pool :870, softmax :1098, top-5 :1162,
 // NCHW<->panel conversions (:1146-1160, :187-189).
 //
-// Mapping (see qcnn_kernels.h for the HBM layout): a lane carries an image pair.  A workgroup owns one
-// 128-image panel, one tile of output positions and one slice of output channels; every wave keeps
-// (positions x channels-per-wave) float2 accumulators in VGPRs.  The look-up table is never
-// materialised in HBM: it is produced one "slot" at a time in LDS — slot(p, m) = the K inner products of
-// sub-space m of source pixel p for the 128 images, laid out [K][128] so that a code-word row is 512
-// contiguous bytes = one conflict-free ds_read_b64 per wave — double buffered, built by all waves
-// (v_mfma_f32_16x16x4_f32 with operands prefetched one slot ahead, or ordered VALU mul+add in "exact"
-// mode), then consumed by every (position, channel) of the tile whose receptive field contains p.
-// Slots are visited in (pixel row-major, m ascending) order, which for any one output is exactly the
-// reference's (kh, kw, m) summation order (:840-863), so with the exact builder conv/FC outputs are
-// bit-identical to the reference.  Code-word offsets are wave-uniform and come in through scalar loads.
+// Mapping (see qcnn_kernels.h for the HBM layout): a lane carries an image pair.  A workgroup (8 waves)
+// owns one 128-image panel, one tile of output positions and one slice of output channels; every wave
+// keeps (positions x channels-per-wave) float2 accumulators in VGPRs.  The look-up table is never
+// materialised in HBM: it is produced one STAGE at a time in LDS — a stage = 128 code-word rows =
+// G = 128/K consecutive sub-spaces of one source pixel (conv) or of the input vector (FC) for the 128
+// images; a row is 512 contiguous bytes (+16 B pad) = one conflict-free ds_read_b64 per wave.  Stages
+// are double buffered: while the waves gather from stage s, the MFMA operands of stage s+1 are already
+// in flight and its tiles (v_mfma_f32_16x16x4_f32, or ordered VALU mul+add in "exact" mode) are written
+// to the other buffer; one s_barrier per stage.  Stages are visited in (pixel row-major, sub-space
+// ascending) order, which for any one output is exactly the reference's (kh, kw, m) summation order
+// (:840-863), so with the exact builder conv/FC outputs are bit-identical to the reference.  Code-word
+// offsets are wave-uniform and arrive through scalar loads.
 #include "qcnn_kernels.h"
 
 #include <float.h>
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int PANEL = QCNN_PANEL;          // images per panel
-constexpr int ROWB = PANEL * 4;            // bytes of one code-word row of a slot
-
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+constexpr int PANEL = QCNN_PANEL;              // images per panel
+constexpr int NW = 8;                          // waves per workgroup of the two hot kernels
+constexpr int ROWB = QCNN_ROW_BYTES;           // LDS bytes per code-word row
+constexpr int ROWF = ROWB / 4;                 // ... in floats
+constexpr int STAGE_ROWS = QCNN_STAGE_ROWS;
+constexpr int STAGE_BYTES = STAGE_ROWS * ROWB;  // 67 584 B; two stages = 132 KB of the 160 KB LDS
+constexpr int XROWB = PANEL * 4;               // bytes of one activation row in HBM
 
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
@@ -37,7 +42,7 @@ __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlan
 // time through s_load_dwordx4 (the tables are 16-byte aligned: Ct and the wave's first channel are
 // multiples of 4); each look-up is one ds_read_b64 of the image pair + one v_pk_add_f32.
 template <int CPW>
-__device__ __forceinline__ void gather_row(f32x2 (&acc)[CPW], const uint32_t* __restrict__ ap, const char* slot) {
+__device__ __forceinline__ void gather_row(f32x2 (&acc)[CPW], const uint32_t* __restrict__ ap, const char* stage) {
   static_assert(CPW % 4 == 0, "offsets are fetched as 4 x uint32");
   constexpr int G = (CPW % 24 == 0) ? 24 : ((CPW % 16 == 0) ? 16 : ((CPW % 12 == 0) ? 12 : ((CPW % 8 == 0) ? 8 : 4)));
   const u32x4* __restrict__ ap4 = reinterpret_cast<const u32x4*>(__builtin_assume_aligned(ap, 16));
@@ -53,10 +58,10 @@ __device__ __forceinline__ void gather_row(f32x2 (&acc)[CPW], const uint32_t* __
     f32x2 v[G];
 #pragma unroll
     for (int j = 0; j < G / 4; ++j) {
-      v[4 * j + 0] = *reinterpret_cast<const f32x2*>(slot + o[j].x);
-      v[4 * j + 1] = *reinterpret_cast<const f32x2*>(slot + o[j].y);
-      v[4 * j + 2] = *reinterpret_cast<const f32x2*>(slot + o[j].z);
-      v[4 * j + 3] = *reinterpret_cast<const f32x2*>(slot + o[j].w);
+      v[4 * j + 0] = *reinterpret_cast<const f32x2*>(stage + o[j].x);
+      v[4 * j + 1] = *reinterpret_cast<const f32x2*>(stage + o[j].y);
+      v[4 * j + 2] = *reinterpret_cast<const f32x2*>(stage + o[j].z);
+      v[4 * j + 3] = *reinterpret_cast<const f32x2*>(stage + o[j].w);
     }
 #pragma unroll
     for (int j = 0; j < G; ++j) acc[g0 + j] += v[j];
@@ -65,101 +70,117 @@ __device__ __forceinline__ void gather_row(f32x2 (&acc)[CPW], const uint32_t* __
 }
 
 // ------------------------------------------------------------------------------------------------
-// LUT slot builders.  slot: LDS [K][128] floats.  xrow(d): global pointer to the 128-image row of
-// input dim d of this sub-space.  ctrdM: code book of sub-space m, [Cs][K].  dsel = dims that exist.
+// LUT stage builders.  A stage covers sub-spaces m0 .. m0+G-1 (those < mEnd), K rows each.
+// xoff(m, d): byte offset (from xbase) of the 128-image activation row of dim d of sub-space m.
 // ------------------------------------------------------------------------------------------------
 
 // exact: y = ((0 + x0*c0) + x1*c1) + ...  with separately rounded product and sum, the order of the
-// reference's saxpy chain (src/CaffeEva.cc:1284-1289, include/BlasWrapper.h:164-184).
-template <int NW, typename RowFn>
-__device__ __forceinline__ void build_slot_exact(float* slot, const float* __restrict__ ctrdM, int K, int dsel,
-                                                 int wave, int lane, RowFn xrow) {
-  f32x2 xv[QCNN_MAX_CS];
-#pragma unroll
-  for (int d = 0; d < QCNN_MAX_CS; ++d) {
-    xv[d] = f32x2{0.0f, 0.0f};
-    if (d < dsel) xv[d] = *reinterpret_cast<const f32x2*>(xrow(d) + 2 * lane);
-  }
+// reference's saxpy chain (src/CaffeEva.cc:1284-1289, include/BlasWrapper.h:164-184).  Any K <= 128.
+template <typename OffFn>
+__device__ __forceinline__ void build_stage_exact(char* stage, const char* __restrict__ xbase,
+                                                  const float* __restrict__ ctrd, int K, int Cs, int D, int G, int m0,
+                                                  int mEnd, int wave, int lane, OffFn xoff) {
   const int kpw = (K + NW - 1) / NW;
   const int k0 = wave * kpw;
   const int k1 = min(K, k0 + kpw);
-  for (int k = k0; k < k1; ++k) {
-    float v0 = 0.0f, v1 = 0.0f;
+  for (int g = 0; g < G; ++g) {
+    const int m = m0 + g;
+    if (m >= mEnd) break;
+    const int dsel = min(D - m * Cs, Cs);
+    f32x2 xv[QCNN_MAX_CS];
 #pragma unroll
     for (int d = 0; d < QCNN_MAX_CS; ++d) {
-      if (d < dsel) {
-        const float c = ctrdM[d * K + k];
-        v0 = __fadd_rn(v0, __fmul_rn(xv[d].x, c));
-        v1 = __fadd_rn(v1, __fmul_rn(xv[d].y, c));
-      }
+      xv[d] = f32x2{0.0f, 0.0f};
+      if (d < dsel) xv[d] = *reinterpret_cast<const f32x2*>(xbase + xoff(m, d) + lane * 8);
     }
-    *reinterpret_cast<f32x2*>(slot + k * PANEL + 2 * lane) = f32x2{v0, v1};
+    const float* __restrict__ cm = ctrd + (size_t)m * Cs * K;
+    for (int k = k0; k < k1; ++k) {
+      float v0 = 0.0f, v1 = 0.0f;
+#pragma unroll
+      for (int d = 0; d < QCNN_MAX_CS; ++d) {
+        if (d < dsel) {
+          const float c = cm[d * K + k];
+          v0 = __fadd_rn(v0, __fmul_rn(xv[d].x, c));
+          v1 = __fadd_rn(v1, __fmul_rn(xv[d].y, c));
+        }
+      }
+      *reinterpret_cast<f32x2*>(stage + (g * K + k) * ROWB + lane * 8) = f32x2{v0, v1};
+    }
   }
 }
 
-// MFMA: D[16 code words][16 images] += A[16 code words x 4 dims] * B[4 dims x 16 images]
-// (v_mfma_f32_16x16x4_f32).  Lane l holds A[l&15][l>>4], B[l>>4][l&15], D[(l>>4)*4 + r][l&15].
-// A slot is KT x 8 tiles (KT = K/16 code-word tiles, 8 image tiles); wave w owns tiles w, w+NW, ...
-// Operands are fetched into registers (mfma_load) well before they are consumed (mfma_store).
-template <int KT, int NW>
+// MFMA: D[16 rows][16 images] += A[16 rows x 4 dims] * B[4 dims x 16 images] (v_mfma_f32_16x16x4_f32).
+// Lane l holds A[l&15][l>>4], B[l>>4][l&15], D[(l>>4)*4 + r][l&15].  A stage is 8 row tiles x 8 image
+// tiles; wave w owns image tile w and all 8 row tiles.  Row tile i belongs to sub-space m0 + (16 i)/K
+// and starts at code word (16 i) % K  (KT = K/16 in {1, 2, 4, 8}).  Operands are fetched into registers
+// (mfma_load) one stage ahead of their use (mfma_store).
+template <int KT>
 struct MfmaOps {
-  static constexpr int TPW = (KT * 8 + NW - 1) / NW;      // tiles per wave
-  static constexpr int XT = (NW % 8 == 0) ? 1 : TPW;      // with NW % 8 == 0 a wave keeps one image tile
-  float a[TPW][2];   // code-book operand per tile and k-step
-  float b[XT][2];    // input operand per image tile and k-step
+  static constexpr int NB = (KT == 8) ? 1 : 8;   // K = 128: one sub-space per stage, one activation operand
+  float a[8][2];    // code-book operand per row tile and k-step
+  float b[NB][2];   // activation operand per row tile (sub-space) and k-step
 };
 
-template <int KT, int NW, typename RowFn>
-__device__ __forceinline__ void mfma_load(MfmaOps<KT, NW>& o, const float* __restrict__ ctrdM, int dsel, int wave,
-                                          int lane, RowFn xrow) {
+template <int KT, typename OffFn>
+__device__ __forceinline__ void mfma_load(MfmaOps<KT>& o, const char* __restrict__ xbase,
+                                          const float* __restrict__ ctrd, int Cs, int D, int m0, int mEnd, int wave,
+                                          int lane, OffFn xoff) {
   constexpr int K = KT * 16;
-  using Ops = MfmaOps<KT, NW>;
   const int li = lane & 15, lk = lane >> 4;
 #pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
-    const int d = ks * 4 + lk;
-    const bool dv = d < dsel;
+  for (int i = 0; i < 8; ++i) {
+    const int m = m0 + (i * 16) / K;          // compile-time offset from m0
+    const int kk = (i * 16) % K;
+    const int dsel = min(D - m * Cs, Cs);
 #pragma unroll
-    for (int i = 0; i < Ops::XT; ++i) {
-      const int it = (wave + NW * i) & 7;
-      o.b[i][ks] = dv ? xrow(d)[it * 16 + li] : 0.0f;
-    }
-#pragma unroll
-    for (int i = 0; i < Ops::TPW; ++i) {
-      const int q = wave + NW * i;
-      o.a[i][ks] = (dv && q < KT * 8) ? ctrdM[d * K + (q >> 3) * 16 + li] : 0.0f;
+    for (int ks = 0; ks < 2; ++ks) {
+      const int d = ks * 4 + lk;
+      const bool ok = m < mEnd && d < dsel;
+      o.a[i][ks] = ok ? ctrd[((size_t)m * Cs + d) * K + kk + li] : 0.0f;
+      if (i < MfmaOps<KT>::NB)
+        o.b[i][ks] = ok ? *reinterpret_cast<const float*>(xbase + xoff(m, d) + (wave * 16 + li) * 4) : 0.0f;
     }
   }
 }
 
-template <int KT, int NW>
-__device__ __forceinline__ void mfma_store(const MfmaOps<KT, NW>& o, float* slot, int dsel, int wave, int lane) {
-  using Ops = MfmaOps<KT, NW>;
+template <int KT>
+__device__ __forceinline__ void mfma_store(const MfmaOps<KT>& o, char* stage, int Cs, int wave, int lane) {
+  constexpr int NB = MfmaOps<KT>::NB;
   const int li = lane & 15, lk = lane >> 4;
+  char* w0 = stage + (lk * 4) * ROWB + (wave * 16 + li) * 4;
+  const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-  for (int i = 0; i < Ops::TPW; ++i) {
-    const int q = wave + NW * i;
-    if (q < KT * 8) {
-      const int kt = q >> 3, it = q & 7;
-      const int xi = (Ops::XT == 1) ? 0 : i;
-      f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a[i][0], o.b[xi][0], acc, 0, 0, 0);
-      if (dsel > 4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a[i][1], o.b[xi][1], acc, 0, 0, 0);
-      float* w = slot + (kt * 16 + lk * 4) * PANEL + it * 16 + li;
-      w[0] = acc[0];
-      w[PANEL] = acc[1];
-      w[2 * PANEL] = acc[2];
-      w[3 * PANEL] = acc[3];
+  for (int h = 0; h < 2; ++h) {             // two batches of four independent tiles
+    f32x4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int i = 4 * h + j;
+      acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a[i][0], o.b[NB == 1 ? 0 : i][0], zero, 0, 0, 0);
+    }
+    if (Cs > 4) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int i = 4 * h + j;
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a[i][1], o.b[NB == 1 ? 0 : i][1], acc[j], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      char* w = w0 + (4 * h + j) * 16 * ROWB;
+      *reinterpret_cast<float*>(w) = acc[j][0];
+      *reinterpret_cast<float*>(w + ROWB) = acc[j][1];
+      *reinterpret_cast<float*>(w + 2 * ROWB) = acc[j][2];
+      *reinterpret_cast<float*>(w + 3 * ROWB) = acc[j][3];
     }
   }
 }
 
 // ------------------------------------------------------------------------------------------------
-// conv: TH x TW output positions, NW waves, CPW channels per wave; KT = K/16 for the MFMA builder,
-// KT = 0 selects the exact builder (any K).
+// conv: TH x TW output positions, 8 waves, CPW channels per wave; KT = K/16 for the MFMA builder,
+// KT = 0 selects the exact builder (any K <= 128).
 // ------------------------------------------------------------------------------------------------
-template <int TH, int TW, int CPW, int NW, int KT>
-__global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX, int chunksPerGrp) {
+template <int TH, int TW, int CPW, int KT>
+__global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX, int chunksPerGrp, int G) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   constexpr int NT = TH * TW;
   constexpr int KTT = KT > 0 ? KT : 1;
@@ -170,20 +191,21 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
   const int panel = blockIdx.z;
   const int Cg = p.Cin / p.grp, Ctg = p.Ct / p.grp;
   const int cw0 = chunk * (NW * CPW) + wave * CPW;   // first channel of this wave inside the group
-  const int ccnt = min(CPW, Ctg - cw0);              // <= 0: the wave only helps building slots
+  const int ccnt = min(CPW, Ctg - cw0);              // <= 0: the wave only helps building stages
   const int c0 = g * Ctg + cw0;
   const int K = p.K, M = p.M, Cs = p.Cs;
-  const int slotBytes = K * ROWB;
+  const int MG = (M + G - 1) / G;                    // stages per source pixel
+  const int MCt = M * p.Ct;
 
-  const float* __restrict__ src = p.src + (size_t)panel * p.H * p.W * p.Cin * PANEL;
-  const int chanBase = g * Cg;
+  const char* __restrict__ xbase =
+      reinterpret_cast<const char*>(p.src + ((size_t)panel * p.H * p.W * p.Cin + (size_t)g * Cg) * PANEL);
 
   f32x2 acc[NT][CPW];
   {
-    const float* __restrict__ bp = p.bias + c0;
+    const float* __restrict__ bp = p.bias + c0;   // reads past the last channel stay inside the arena
 #pragma unroll
     for (int c = 0; c < CPW; ++c) {
-      const float b = (c < ccnt) ? bp[c] : 0.0f;
+      const float b = bp[c];
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[t][c] = f32x2{b, b};
     }
@@ -193,62 +215,55 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
   const int hoL = min(ho0 + TH, p.Ho) - 1, woL = min(wo0 + TW, p.Wo) - 1;   // last real position of the tile
   const int hiL = max(0, ho0 * p.stride - p.pad), hiU = min(p.H - 1, hoL * p.stride - p.pad + p.knl - 1);
   const int wiL = max(0, wo0 * p.stride - p.pad), wiU = min(p.W - 1, woL * p.stride - p.pad + p.knl - 1);
-  const int S = (hiU - hiL + 1) * (wiU - wiL + 1) * M;
+  const int S = (hiU - hiL + 1) * (wiU - wiL + 1) * MG;
 
-  // first source row / column of every position of the tile; positions outside the map get a start
-  // that can never match a tap
+  // first source row / column of every position of the tile; positions outside the map get a start that
+  // can never match a tap
   int rowStart[TH], colStart[TW];
 #pragma unroll
   for (int dy = 0; dy < TH; ++dy) rowStart[dy] = (ho0 + dy < p.Ho) ? (ho0 + dy) * p.stride - p.pad : -(1 << 28);
 #pragma unroll
   for (int dx = 0; dx < TW; ++dx) colStart[dx] = (wo0 + dx < p.Wo) ? (wo0 + dx) * p.stride - p.pad : -(1 << 28);
 
-  auto xptr = [&](int hi, int wi, int m) {
-    return src + ((size_t)(hi * p.W + wi) * p.Cin + chanBase + m * Cs) * PANEL;
-  };
-
-  MfmaOps<KTT, NW> ops;
-  int hi = hiL, wi = wiL, m = 0;
+  MfmaOps<KTT> ops;
+  int hi = hiL, wi = wiL, mg = 0;
   {
-    const float* __restrict__ xp = xptr(hi, wi, m);
-    const float* __restrict__ cm = p.ctrd + (size_t)m * Cs * K;
-    const int dsel = min(Cg - m * Cs, Cs);
-    auto xrow = [&](int d) { return xp + d * PANEL; };
+    const uint32_t pix = (uint32_t)(hi * p.W + wi) * p.Cin;
+    auto xoff = [&](int m, int d) { return (pix + m * Cs + d) * (uint32_t)XROWB; };
     if (KT > 0) {
-      mfma_load<KTT, NW>(ops, cm, dsel, wave, lane, xrow);
-      mfma_store<KTT, NW>(ops, reinterpret_cast<float*>(lds), dsel, wave, lane);
+      mfma_load<KTT>(ops, xbase, p.ctrd, Cs, Cg, 0, M, wave, lane, xoff);
+      mfma_store<KTT>(ops, lds, Cs, wave, lane);
     } else {
-      build_slot_exact<NW>(reinterpret_cast<float*>(lds), cm, K, dsel, wave, lane, xrow);
+      build_stage_exact(lds, xbase, p.ctrd, K, Cs, Cg, G, 0, M, wave, lane, xoff);
     }
   }
   __syncthreads();
 
   for (int s = 0; s < S; ++s) {
-    int mn = m + 1, wn = wi, hn = hi;
-    if (mn == M) {
-      mn = 0;
+    int mgn = mg + 1, wn = wi, hn = hi;
+    if (mgn == MG) {
+      mgn = 0;
       if (++wn > wiU) { wn = wiL; ++hn; }
     }
     const bool more = s + 1 < S;
-    const int dselN = min(Cg - mn * Cs, Cs);
-    const float* __restrict__ xpN = xptr(more ? hn : hi, more ? wn : wi, more ? mn : m);
-    const float* __restrict__ cmN = p.ctrd + (size_t)mn * Cs * K;
-    auto xrowN = [&](int d) { return xpN + d * PANEL; };
-    if (KT > 0 && more) mfma_load<KTT, NW>(ops, cmN, dselN, wave, lane, xrowN);
+    const uint32_t pixN = (uint32_t)((more ? hn : hi) * p.W + (more ? wn : wi)) * p.Cin;
+    auto xoffN = [&](int m, int d) { return (pixN + m * Cs + d) * (uint32_t)XROWB; };
+    if (KT > 0 && more) mfma_load<KTT>(ops, xbase, p.ctrd, Cs, Cg, mgn * G, M, wave, lane, xoffN);
 
     if (ccnt > 0) {
-      const char* slot = lds + (s & 1) * slotBytes + lane * 8;
-      const uint32_t* __restrict__ tapBase = p.offs + (size_t)m * p.Ct + c0;
+      const char* stage = lds + (s & 1) * STAGE_BYTES + lane * 8;
+      const int mLast = min(M, (mg + 1) * G);
+      for (int m = mg * G; m < mLast; ++m) {
+        const uint32_t* __restrict__ tapBase = p.offs + m * p.Ct + c0;
 #pragma unroll
-      for (int dy = 0; dy < TH; ++dy) {
-        const int kh = hi - rowStart[dy];
-        if ((unsigned)kh < (unsigned)p.knl) {
+        for (int dy = 0; dy < TH; ++dy) {
+          const int kh = hi - rowStart[dy];
+          if ((unsigned)kh < (unsigned)p.knl) {
 #pragma unroll
-          for (int dx = 0; dx < TW; ++dx) {
-            const int kw = wi - colStart[dx];
-            if ((unsigned)kw < (unsigned)p.knl) {
-              const uint32_t* __restrict__ ap = tapBase + (size_t)(kh * p.knl + kw) * M * p.Ct;
-              gather_row<CPW>(acc[dy * TW + dx], ap, slot);
+            for (int dx = 0; dx < TW; ++dx) {
+              const int kw = wi - colStart[dx];
+              if ((unsigned)kw < (unsigned)p.knl)
+                gather_row<CPW>(acc[dy * TW + dx], tapBase + (kh * p.knl + kw) * MCt, stage);
             }
           }
         }
@@ -256,12 +271,12 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
     }
 
     if (more) {
-      float* nslot = reinterpret_cast<float*>(lds + ((s + 1) & 1) * slotBytes);
-      if (KT > 0) mfma_store<KTT, NW>(ops, nslot, dselN, wave, lane);
-      else build_slot_exact<NW>(nslot, cmN, K, dselN, wave, lane, xrowN);
+      char* nstage = lds + ((s + 1) & 1) * STAGE_BYTES;
+      if (KT > 0) mfma_store<KTT>(ops, nstage, Cs, wave, lane);
+      else build_stage_exact(nstage, xbase, p.ctrd, K, Cs, Cg, G, mgn * G, M, wave, lane, xoffN);
     }
     __syncthreads();
-    hi = hn; wi = wn; m = mn;
+    hi = hn; wi = wn; mg = mgn;
   }
 
   if (ccnt > 0) {
@@ -288,84 +303,110 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
 }
 
 // ------------------------------------------------------------------------------------------------
-// fully connected: slot(m) for the panel, CPW channels per wave
+// fully connected: stages of G sub-spaces, CPW channels per wave, optional split over the sub-space
+// axis (blockIdx.z): partial sums go to p.partial and are reduced by k_sum_partials.
 // ------------------------------------------------------------------------------------------------
-template <int CPW, int NW, int KT>
-__global__ __launch_bounds__(NW * 64) void k_fc_aprx(FcParams p) {
+template <int CPW, int KT>
+__global__ __launch_bounds__(NW * 64) void k_fc_aprx(FcParams p, int G, int stagesPerSplit) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   constexpr int KTT = KT > 0 ? KT : 1;
   const int lane = threadIdx.x & 63;
   const int wave = uni(threadIdx.x >> 6);
   const int panel = blockIdx.y;
+  const int split = blockIdx.z;
   const int cw0 = blockIdx.x * (NW * CPW) + wave * CPW;
   const int ccnt = min(CPW, p.Ct - cw0);
   const int K = p.K, M = p.M, Cs = p.Cs;
-  const int slotBytes = K * ROWB;
-  const float* __restrict__ src = p.src + (size_t)panel * p.D * PANEL;
-  const int* __restrict__ dmap = p.dmap;
+  const int mBeg = split * stagesPerSplit * G;
+  const int mEnd = min(M, mBeg + stagesPerSplit * G);
+  const int S = (mEnd - mBeg + G - 1) / G;
+  const char* __restrict__ xbase = reinterpret_cast<const char*>(p.src + (size_t)panel * p.D * PANEL);
+  auto xoff = [&](int m, int d) { return (uint32_t)(m * Cs + d) * (uint32_t)XROWB; };
 
   f32x2 acc[CPW];
 #pragma unroll
   for (int c = 0; c < CPW; ++c) {
-    const float b = (c < ccnt) ? p.bias[cw0 + c] : 0.0f;
+    const float b = (split == 0) ? p.bias[cw0 + c] : 0.0f;   // over-read stays inside the arena
     acc[c] = f32x2{b, b};
   }
 
-  MfmaOps<KTT, NW> ops;
-  auto xrow_of = [&](int m) {
-    return [=](int d) {
-      const int e = m * Cs + d;
-      const int row = dmap ? dmap[e] : e;
-      return src + (size_t)row * PANEL;
-    };
-  };
-  {
-    const int dsel = min(p.D, Cs);
-    auto xrow = xrow_of(0);
+  MfmaOps<KTT> ops;
+  if (S > 0) {
     if (KT > 0) {
-      mfma_load<KTT, NW>(ops, p.ctrd, dsel, wave, lane, xrow);
-      mfma_store<KTT, NW>(ops, reinterpret_cast<float*>(lds), dsel, wave, lane);
+      mfma_load<KTT>(ops, xbase, p.ctrd, Cs, p.D, mBeg, mEnd, wave, lane, xoff);
+      mfma_store<KTT>(ops, lds, Cs, wave, lane);
     } else {
-      build_slot_exact<NW>(reinterpret_cast<float*>(lds), p.ctrd, K, dsel, wave, lane, xrow);
+      build_stage_exact(lds, xbase, p.ctrd, K, Cs, p.D, G, mBeg, mEnd, wave, lane, xoff);
     }
   }
   __syncthreads();
 
-  for (int m = 0; m < M; ++m) {
-    const bool more = m + 1 < M;
-    const int mn = more ? m + 1 : m;
-    const int dselN = min(p.D - mn * Cs, Cs);
-    const float* __restrict__ cmN = p.ctrd + (size_t)mn * Cs * K;
-    auto xrowN = xrow_of(mn);
-    if (KT > 0 && more) mfma_load<KTT, NW>(ops, cmN, dselN, wave, lane, xrowN);
+  for (int s = 0; s < S; ++s) {
+    const int m0 = mBeg + s * G;
+    const bool more = s + 1 < S;
+    if (KT > 0 && more) mfma_load<KTT>(ops, xbase, p.ctrd, Cs, p.D, m0 + G, mEnd, wave, lane, xoff);
 
     if (ccnt > 0) {
-      const char* slot = lds + (m & 1) * slotBytes + lane * 8;
-      const uint32_t* __restrict__ ap = p.offs + (size_t)m * p.Ct + cw0;
-      gather_row<CPW>(acc, ap, slot);
+      const char* stage = lds + (s & 1) * STAGE_BYTES + lane * 8;
+      const int mLast = min(mEnd, m0 + G);
+      for (int m = m0; m < mLast; ++m) gather_row<CPW>(acc, p.offs + (size_t)m * p.Ct + cw0, stage);
     }
 
     if (more) {
-      float* nslot = reinterpret_cast<float*>(lds + ((m + 1) & 1) * slotBytes);
-      if (KT > 0) mfma_store<KTT, NW>(ops, nslot, dselN, wave, lane);
-      else build_slot_exact<NW>(nslot, cmN, K, dselN, wave, lane, xrowN);
+      char* nstage = lds + ((s + 1) & 1) * STAGE_BYTES;
+      if (KT > 0) mfma_store<KTT>(ops, nstage, Cs, wave, lane);
+      else build_stage_exact(nstage, xbase, p.ctrd, K, Cs, p.D, G, m0 + G, mEnd, wave, lane, xoff);
     }
     __syncthreads();
   }
 
   if (ccnt > 0) {
-    float* o = p.dst + ((size_t)panel * p.Ct + cw0) * PANEL + 2 * lane;
+    float* base = (p.msplit > 1) ? p.partial + (size_t)split * p.panels * p.Ct * PANEL : p.dst;
+    float* o = base + ((size_t)panel * p.Ct + cw0) * PANEL + 2 * lane;
 #pragma unroll
     for (int c = 0; c < CPW; ++c) {
       if (c < ccnt) {
         f32x2 v = acc[c];
-        if (p.relu) {
+        if (p.relu && p.msplit == 1) {
           v.x = (0.0f < v.x) ? v.x : 0.0f;
           v.y = (0.0f < v.y) ? v.y : 0.0f;
         }
         *reinterpret_cast<f32x2*>(o + c * PANEL) = v;
       }
     }
+  }
+}
+
+// dst row e = src row map[e] (the NHWC -> NCHW flatten in front of the first FC layer, src/CaffeEva.cc:187-189)
+__global__ void k_permute_rows(const float* __restrict__ src, float* __restrict__ dst, const int* __restrict__ map,
+                               int D, int panels) {
+  const int lane = threadIdx.x & 63;
+  const size_t rows = (size_t)panels * D;
+  for (size_t r = blockIdx.x * (size_t)(blockDim.x >> 6) + (threadIdx.x >> 6); r < rows;
+       r += (size_t)gridDim.x * (blockDim.x >> 6)) {
+    const size_t panel = r / D;
+    const int e = (int)(r % D);
+    *reinterpret_cast<f32x2*>(dst + r * PANEL + 2 * lane) =
+        *reinterpret_cast<const f32x2*>(src + (panel * D + map[e]) * PANEL + 2 * lane);
+  }
+}
+
+// dst = partial[0] + partial[1] + ... (fixed order), optional ReLU
+__global__ void k_sum_partials(const float4* __restrict__ partial, float4* __restrict__ dst, int msplit, size_t n4,
+                               int relu) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    float4 v = partial[i];
+    for (int z = 1; z < msplit; ++z) {
+      const float4 w = partial[(size_t)z * n4 + i];
+      v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+    }
+    if (relu) {
+      v.x = (0.0f < v.x) ? v.x : 0.0f;
+      v.y = (0.0f < v.y) ? v.y : 0.0f;
+      v.z = (0.0f < v.z) ? v.z : 0.0f;
+      v.w = (0.0f < v.w) ? v.w : 0.0f;
+    }
+    dst[i] = v;
   }
 }
 
@@ -533,60 +574,85 @@ __global__ __launch_bounds__(256) void k_unpack(const float* __restrict__ src, f
 
 inline int panels_of(int n) { return (n + PANEL - 1) / PANEL; }
 
-template <int TH, int TW, int CPW, int NW>
+template <int TH, int TW, int CPW>
 hipError_t launch_conv(const ConvParams& p, int lutMode, hipStream_t st) {
   const int Ctg = p.Ct / p.grp;
   const int tilesX = (p.Wo + TW - 1) / TW, tilesY = (p.Ho + TH - 1) / TH;
   const int chunksPerGrp = (Ctg + NW * CPW - 1) / (NW * CPW);
   const dim3 grid(tilesX * tilesY, chunksPerGrp * p.grp, p.panels);
-  const size_t shm = (size_t)2 * p.K * ROWB;
-  auto kern = (lutMode == 1 && p.K == 128) ? k_conv_aprx<TH, TW, CPW, NW, 8> : k_conv_aprx<TH, TW, CPW, NW, 0>;
+  const size_t shm = (size_t)2 * STAGE_BYTES;
+  const int G = qcnn_stage_group(p.K);
+  auto kern = k_conv_aprx<TH, TW, CPW, 0>;
+  if (lutMode == 1 && p.K == 128) kern = k_conv_aprx<TH, TW, CPW, 8>;
+  if (lutMode == 1 && p.K == 64) kern = k_conv_aprx<TH, TW, CPW, 4>;
+  if (lutMode == 1 && p.K == 32) kern = k_conv_aprx<TH, TW, CPW, 2>;
+  if (lutMode == 1 && p.K == 16) kern = k_conv_aprx<TH, TW, CPW, 1>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)shm);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, grid, dim3(NW * 64), shm, st, p, tilesX, chunksPerGrp);
+  hipLaunchKernelGGL(kern, grid, dim3(NW * 64), shm, st, p, tilesX, chunksPerGrp, G);
   return hipGetLastError();
 }
 
-template <int CPW, int NW>
+template <int CPW>
 hipError_t launch_fc(const FcParams& p, int lutMode, hipStream_t st) {
-  const dim3 grid((p.Ct + NW * CPW - 1) / (NW * CPW), p.panels);
-  const size_t shm = (size_t)2 * p.K * ROWB;
-  auto kern = k_fc_aprx<CPW, NW, 0>;
-  if (lutMode == 1 && p.K == 32) kern = k_fc_aprx<CPW, NW, 2>;
-  if (lutMode == 1 && p.K == 16) kern = k_fc_aprx<CPW, NW, 1>;
-  if (lutMode == 1 && p.K == 128) kern = k_fc_aprx<CPW, NW, 8>;
+  const int G = qcnn_stage_group(p.K);
+  const int stages = (p.M + G - 1) / G;
+  const int stagesPerSplit = (stages + p.msplit - 1) / p.msplit;
+  const dim3 grid((p.Ct + NW * CPW - 1) / (NW * CPW), p.panels, p.msplit);
+  const size_t shm = (size_t)2 * STAGE_BYTES;
+  auto kern = k_fc_aprx<CPW, 0>;
+  if (lutMode == 1 && p.K == 128) kern = k_fc_aprx<CPW, 8>;
+  if (lutMode == 1 && p.K == 64) kern = k_fc_aprx<CPW, 4>;
+  if (lutMode == 1 && p.K == 32) kern = k_fc_aprx<CPW, 2>;
+  if (lutMode == 1 && p.K == 16) kern = k_fc_aprx<CPW, 1>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)shm);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, grid, dim3(NW * 64), shm, st, p);
+  hipLaunchKernelGGL(kern, grid, dim3(NW * 64), shm, st, p, G, stagesPerSplit);
   return hipGetLastError();
 }
 
 }  // namespace
 
 // Tile selection: 8 waves; channels-per-wave from the group's channel count; the position tile is as
-// large as ~72 float2 accumulators per lane allow (more starve the LDS-read pipeline of registers) (more positions per tile = more reuse of a LUT slot).
-// The MFMA builder is instantiated for K = 128 (conv) and K = 16 / 32 / 128 (FC); any other K runs
-// the exact builder.
+// large as ~72 float2 accumulators per lane allow (more starve the LDS-read pipeline of registers).
+// The MFMA builder is instantiated for K in {16, 32, 64, 128}; any other K <= 128 runs the exact builder.
 hipError_t qk_conv_aprx(const ConvParams& p, int lutMode, hipStream_t st) {
   const int Ctg = p.Ct / p.grp;
-  if (Ctg % 4 || p.Cs > QCNN_MAX_CS || p.K > 256 || (size_t)2 * p.K * ROWB > 160 * 1024) return hipErrorInvalidValue;
-  if (Ctg % 384 == 0) return launch_conv<1, 1, 48, 8>(p, lutMode, st);
-  if (Ctg % 256 == 0) return launch_conv<1, 2, 32, 8>(p, lutMode, st);
-  if (Ctg % 192 == 0) return launch_conv<1, 3, 24, 8>(p, lutMode, st);
-  if (Ctg % 128 == 0) return launch_conv<2, 2, 16, 8>(p, lutMode, st);
-  if (Ctg % 96 == 0) return launch_conv<2, 3, 12, 8>(p, lutMode, st);
-  if (Ctg % 64 == 0) return launch_conv<2, 4, 8, 8>(p, lutMode, st);
-  if (Ctg > 64) return launch_conv<2, 2, 16, 8>(p, lutMode, st);
-  return launch_conv<3, 4, 4, 8>(p, lutMode, st);
+  if (Ctg % 4 || p.Cs > QCNN_MAX_CS || p.K > QCNN_MAX_K) return hipErrorInvalidValue;
+  if (Ctg % 384 == 0) return launch_conv<1, 1, 48>(p, lutMode, st);
+  if (Ctg % 256 == 0) return launch_conv<1, 2, 32>(p, lutMode, st);
+  if (Ctg % 192 == 0) return launch_conv<1, 3, 24>(p, lutMode, st);
+  if (Ctg % 128 == 0) return launch_conv<2, 2, 16>(p, lutMode, st);
+  if (Ctg % 96 == 0) return launch_conv<2, 3, 12>(p, lutMode, st);
+  if (Ctg % 64 == 0) return launch_conv<2, 4, 8>(p, lutMode, st);
+  if (Ctg > 64) return launch_conv<2, 2, 16>(p, lutMode, st);
+  return launch_conv<3, 4, 4>(p, lutMode, st);
 }
 
+// p.msplit is chosen by the caller (engine): 1 keeps the reference's summation order.
 hipError_t qk_fc_aprx(const FcParams& p, int lutMode, hipStream_t st) {
-  if (p.Ct % 4 || p.Cs > QCNN_MAX_CS || p.K > 256 || (size_t)2 * p.K * ROWB > 160 * 1024) return hipErrorInvalidValue;
-  if (p.Ct >= 2048) return launch_fc<32, 4>(p, lutMode, st);
-  if (p.Ct >= 256) return launch_fc<16, 4>(p, lutMode, st);
-  return launch_fc<4, 4>(p, lutMode, st);
+  if (p.Ct % 4 || p.Cs > QCNN_MAX_CS || p.K > QCNN_MAX_K || p.msplit < 1) return hipErrorInvalidValue;
+  if (p.Ct >= 2048) return launch_fc<64>(p, lutMode, st);
+  if (p.Ct >= 512) return launch_fc<32>(p, lutMode, st);
+  if (p.Ct >= 64) return launch_fc<8>(p, lutMode, st);
+  return launch_fc<4>(p, lutMode, st);
+}
+
+hipError_t qk_sum_partials(const float* partial, float* dst, int msplit, size_t n, int relu, hipStream_t st) {
+  const size_t n4 = n / 4;
+  const int blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+  hipLaunchKernelGGL(k_sum_partials, dim3(blocks ? blocks : 1), dim3(256), 0, st,
+                     reinterpret_cast<const float4*>(partial), reinterpret_cast<float4*>(dst), msplit, n4, relu);
+  return hipGetLastError();
+}
+
+hipError_t qk_permute_rows(const float* src, float* dst, const int* map, int D, int panels, hipStream_t st) {
+  const size_t rows = (size_t)panels * D;
+  const int blocks = (int)((rows + 3) / 4 < 8192 ? (rows + 3) / 4 : 8192);
+  hipLaunchKernelGGL(k_permute_rows, dim3(blocks ? blocks : 1), dim3(256), 0, st, src, dst, map, D, panels);
+  return hipGetLastError();
 }
 
 hipError_t qk_relu(const float* src, float* dst, size_t n, hipStream_t st) {
