@@ -32,6 +32,8 @@ struct LayerShape {
 struct FmDims { int h, w, c; };
 
 constexpr int kProfRing = 128;   // forwards whose per-layer events are kept
+constexpr size_t kSlack = 64 * 1024;   // bytes of slack behind every device buffer: the MFMA operand loads are
+                                        // unconditional and may read a few rows past the last dim / sub-space
 
 }  // namespace
 
@@ -113,7 +115,7 @@ int plan_arena(QcnnCtx* c) {
     s.hasDmap = (d.type == QCNN_FCNT && l == c->firstFc && c->dims[l].h * c->dims[l].w > 1);
     if (s.hasDmap) { s.offDmap = off; off = align_up(off + sizeof(int) * fm_elems(c, l), 256); }
   }
-  c->arenaBytes = off ? off : 256;
+  c->arenaBytes = off + kSlack;
   return 0;
 }
 
@@ -410,14 +412,14 @@ int qcnn_model_commit(QcnnCtx* c, int max_batch, void* dev_arena) {
     c->arena = static_cast<char*>(dev_arena);
     c->ownArena = false;
   } else {
-    HIP_TRY(c, hipMalloc(&c->arena, c->arenaBytes));
+    HIP_TRY(c, hipMalloc(&c->arena, c->arenaBytes));   // arenaBytes already includes the slack
     c->ownArena = true;
     HIP_TRY(c, hipMemsetAsync(c->arena, 0, c->arenaBytes, c->stream));
   }
   c->fmBuf.assign(c->L + 1, nullptr);
   for (int l = 0; l <= c->L; ++l) {
     if (l > 0 && c->layers[l - 1].type == QCNN_DRPT) continue;   // always an alias of its input
-    const size_t bytes = (size_t)c->maxPanels * fm_elems(c, l) * QCNN_PANEL * sizeof(float);
+    const size_t bytes = (size_t)c->maxPanels * fm_elems(c, l) * QCNN_PANEL * sizeof(float) + kSlack;
     HIP_TRY(c, hipMalloc(&c->fmBuf[l], bytes));
   }
   {
@@ -427,7 +429,7 @@ int qcnn_model_commit(QcnnCtx* c, int max_batch, void* dev_arena) {
     c->fcPartialElems = (size_t)16 * c->maxPanels * maxCt * QCNN_PANEL;
     if (c->fcPartialElems) HIP_TRY(c, hipMalloc(&c->fcPartial, c->fcPartialElems * sizeof(float)));
     if (c->firstFc >= 0 && c->shapes[c->firstFc].hasDmap)
-      HIP_TRY(c, hipMalloc(&c->fcFlat, (size_t)c->maxPanels * fm_elems(c, c->firstFc) * QCNN_PANEL * sizeof(float)));
+      HIP_TRY(c, hipMalloc(&c->fcFlat, (size_t)c->maxPanels * fm_elems(c, c->firstFc) * QCNN_PANEL * sizeof(float) + kSlack));
   }
   c->ev.resize((size_t)kProfRing * c->L * 2);
   for (hipEvent_t& e : c->ev) HIP_TRY(c, hipEventCreate(&e));

@@ -31,7 +31,6 @@ namespace {
 constexpr int PANEL = QCNN_PANEL;              // images per panel
 constexpr int NW = 8;                          // waves per workgroup of the two hot kernels
 constexpr int ROWB = QCNN_ROW_BYTES;           // LDS bytes per code-word row
-constexpr int ROWF = ROWB / 4;                 // ... in floats
 constexpr int STAGE_ROWS = QCNN_STAGE_ROWS;
 constexpr int STAGE_BYTES = STAGE_ROWS * ROWB;  // 67 584 B; two stages = 132 KB of the 160 KB LDS
 constexpr int XROWB = PANEL * 4;               // bytes of one activation row in HBM
@@ -70,16 +69,15 @@ __device__ __forceinline__ void gather_row(f32x2 (&acc)[CPW], const uint32_t* __
 }
 
 // ------------------------------------------------------------------------------------------------
-// LUT stage builders.  A stage covers sub-spaces m0 .. m0+G-1 (those < mEnd), K rows each.
-// xoff(m, d): byte offset (from xbase) of the 128-image activation row of dim d of sub-space m.
+// LUT stage builders.  A stage covers sub-spaces m0 .. m0+G-1 (those < mEnd), K rows each.  The
+// 128-image activation row of dim d of sub-space m starts at xbase + xoff0 + (m*Cs + d) * 512 bytes.
 // ------------------------------------------------------------------------------------------------
 
 // exact: y = ((0 + x0*c0) + x1*c1) + ...  with separately rounded product and sum, the order of the
 // reference's saxpy chain (src/CaffeEva.cc:1284-1289, include/BlasWrapper.h:164-184).  Any K <= 128.
-template <typename OffFn>
-__device__ __forceinline__ void build_stage_exact(char* stage, const char* __restrict__ xbase,
+__device__ __forceinline__ void build_stage_exact(char* stage, const char* __restrict__ xbase, uint32_t xoff0,
                                                   const float* __restrict__ ctrd, int K, int Cs, int D, int G, int m0,
-                                                  int mEnd, int wave, int lane, OffFn xoff) {
+                                                  int mEnd, int wave, int lane) {
   const int kpw = (K + NW - 1) / NW;
   const int k0 = wave * kpw;
   const int k1 = min(K, k0 + kpw);
@@ -87,11 +85,12 @@ __device__ __forceinline__ void build_stage_exact(char* stage, const char* __res
     const int m = m0 + g;
     if (m >= mEnd) break;
     const int dsel = min(D - m * Cs, Cs);
+    const char* __restrict__ xm = xbase + xoff0 + (uint32_t)(m * Cs) * (uint32_t)XROWB + lane * 8;
     f32x2 xv[QCNN_MAX_CS];
 #pragma unroll
     for (int d = 0; d < QCNN_MAX_CS; ++d) {
       xv[d] = f32x2{0.0f, 0.0f};
-      if (d < dsel) xv[d] = *reinterpret_cast<const f32x2*>(xbase + xoff(m, d) + lane * 8);
+      if (d < dsel) xv[d] = *reinterpret_cast<const f32x2*>(xm + d * XROWB);
     }
     const float* __restrict__ cm = ctrd + (size_t)m * Cs * K;
     for (int k = k0; k < k1; ++k) {
@@ -113,7 +112,9 @@ __device__ __forceinline__ void build_stage_exact(char* stage, const char* __res
 // Lane l holds A[l&15][l>>4], B[l>>4][l&15], D[(l>>4)*4 + r][l&15].  A stage is 8 row tiles x 8 image
 // tiles; wave w owns image tile w and all 8 row tiles.  Row tile i belongs to sub-space m0 + (16 i)/K
 // and starts at code word (16 i) % K  (KT = K/16 in {1, 2, 4, 8}).  Operands are fetched into registers
-// (mfma_load) one stage ahead of their use (mfma_store).
+// (mfma_load) one stage ahead of their use (mfma_store).  All operand loads are UNCONDITIONAL, at
+// wave-uniform base + per-lane constant + immediate (device buffers carry slack for the over-read of
+// dims / sub-spaces that do not exist); what must not contribute is zeroed by a select.
 template <int KT>
 struct MfmaOps {
   static constexpr int NB = (KT == 8) ? 1 : 8;   // K = 128: one sub-space per stage, one activation operand
@@ -121,32 +122,54 @@ struct MfmaOps {
   float b[NB][2];   // activation operand per row tile (sub-space) and k-step
 };
 
-template <int KT, typename OffFn>
-__device__ __forceinline__ void mfma_load(MfmaOps<KT>& o, const char* __restrict__ xbase,
+template <int KT>
+__device__ __forceinline__ void mfma_load(MfmaOps<KT>& o, const char* __restrict__ xbase, uint32_t xoff0,
                                           const float* __restrict__ ctrd, int Cs, int D, int m0, int mEnd, int wave,
-                                          int lane, OffFn xoff) {
+                                          int lane) {
   constexpr int K = KT * 16;
+  constexpr int NB = MfmaOps<KT>::NB;
+  constexpr int SUBS = 128 / K;                               // sub-spaces per stage
   const int li = lane & 15, lk = lane >> 4;
+  const float* __restrict__ cb = ctrd + (size_t)m0 * Cs * K + (lk * K + li);                          // + uniform
+  const char* __restrict__ xb = xbase + xoff0 + (uint32_t)(m0 * Cs) * (uint32_t)XROWB + (lk * XROWB + (wave * 16 + li) * 4);
+  const int ksteps = (min(D, Cs) > 4) ? 2 : 1;
+  (void)mEnd; (void)SUBS;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int m = m0 + (i * 16) / K;          // compile-time offset from m0
-    const int kk = (i * 16) % K;
-    const int dsel = min(D - m * Cs, Cs);
+  for (int ks = 0; ks < 2; ++ks) {
+    if (ks < ksteps) {
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int d = ks * 4 + lk;
-      const bool ok = m < mEnd && d < dsel;
-      o.a[i][ks] = ok ? ctrd[((size_t)m * Cs + d) * K + kk + li] : 0.0f;
-      if (i < MfmaOps<KT>::NB)
-        o.b[i][ks] = ok ? *reinterpret_cast<const float*>(xbase + xoff(m, d) + (wave * 16 + li) * 4) : 0.0f;
+      for (int i = 0; i < 8; ++i) {
+        const int mi = (i * 16) / K, kk = (i * 16) % K;       // compile-time
+        o.a[i][ks] = cb[(mi * Cs + ks * 4) * K + kk];
+        if (i < NB) o.b[i][ks] = *reinterpret_cast<const float*>(xb + (mi * Cs + ks * 4) * XROWB);
+      }
     }
   }
 }
 
+// The stage described by (m0, mEnd, D, Cs) is the one `o` was loaded for: operands of dims / sub-spaces
+// that do not exist are zeroed here (at use, so that the loads stay in flight during the gather).
 template <int KT>
-__device__ __forceinline__ void mfma_store(const MfmaOps<KT>& o, char* stage, int Cs, int wave, int lane) {
+__device__ __forceinline__ void mfma_store(MfmaOps<KT>& o, char* stage, int ksteps, int Cs, int D, int m0, int mEnd,
+                                           int wave, int lane) {
+  constexpr int K = KT * 16;
   constexpr int NB = MfmaOps<KT>::NB;
+  constexpr int SUBS = 128 / K;
   const int li = lane & 15, lk = lane >> 4;
+  // plain: every sub-space of the stage exists and has all Cs (4 or 8) dims -> nothing to zero
+  const bool plain = (m0 + SUBS <= mEnd) && (D - (m0 + SUBS - 1) * Cs >= Cs) && (Cs == 4 || Cs == 8);
+  if (!plain) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int mi = (i * 16) / K;
+        const bool ok = (ks < ksteps) && (m0 + mi < mEnd) && (ks * 4 + lk < min(D - (m0 + mi) * Cs, Cs));
+        o.a[i][ks] = ok ? o.a[i][ks] : 0.0f;
+        if (i < NB) o.b[i][ks] = ok ? o.b[i][ks] : 0.0f;
+      }
+    }
+  }
   char* w0 = stage + (lk * 4) * ROWB + (wave * 16 + li) * 4;
   const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
@@ -157,7 +180,7 @@ __device__ __forceinline__ void mfma_store(const MfmaOps<KT>& o, char* stage, in
       const int i = 4 * h + j;
       acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a[i][0], o.b[NB == 1 ? 0 : i][0], zero, 0, 0, 0);
     }
-    if (Cs > 4) {
+    if (ksteps > 1) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int i = 4 * h + j;
@@ -196,6 +219,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
   const int K = p.K, M = p.M, Cs = p.Cs;
   const int MG = (M + G - 1) / G;                    // stages per source pixel
   const int MCt = M * p.Ct;
+  const int ksteps = (min(Cg, Cs) > 4) ? 2 : 1;      // MFMA k-steps (4 dims each) that carry data
 
   const char* __restrict__ xbase =
       reinterpret_cast<const char*>(p.src + ((size_t)panel * p.H * p.W * p.Cin + (size_t)g * Cg) * PANEL);
@@ -228,13 +252,12 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
   MfmaOps<KTT> ops;
   int hi = hiL, wi = wiL, mg = 0;
   {
-    const uint32_t pix = (uint32_t)(hi * p.W + wi) * p.Cin;
-    auto xoff = [&](int m, int d) { return (pix + m * Cs + d) * (uint32_t)XROWB; };
+    const uint32_t xoff0 = (uint32_t)(hi * p.W + wi) * p.Cin * (uint32_t)XROWB;
     if (KT > 0) {
-      mfma_load<KTT>(ops, xbase, p.ctrd, Cs, Cg, 0, M, wave, lane, xoff);
-      mfma_store<KTT>(ops, lds, Cs, wave, lane);
+      mfma_load<KTT>(ops, xbase, xoff0, p.ctrd, Cs, Cg, 0, M, wave, lane);
+      mfma_store<KTT>(ops, lds, ksteps, Cs, Cg, 0, M, wave, lane);
     } else {
-      build_stage_exact(lds, xbase, p.ctrd, K, Cs, Cg, G, 0, M, wave, lane, xoff);
+      build_stage_exact(lds, xbase, xoff0, p.ctrd, K, Cs, Cg, G, 0, M, wave, lane);
     }
   }
   __syncthreads();
@@ -246,9 +269,8 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
       if (++wn > wiU) { wn = wiL; ++hn; }
     }
     const bool more = s + 1 < S;
-    const uint32_t pixN = (uint32_t)((more ? hn : hi) * p.W + (more ? wn : wi)) * p.Cin;
-    auto xoffN = [&](int m, int d) { return (pixN + m * Cs + d) * (uint32_t)XROWB; };
-    if (KT > 0 && more) mfma_load<KTT>(ops, xbase, p.ctrd, Cs, Cg, mgn * G, M, wave, lane, xoffN);
+    const uint32_t xoffN = (uint32_t)((more ? hn : hi) * p.W + (more ? wn : wi)) * p.Cin * (uint32_t)XROWB;
+    if (KT > 0 && more) mfma_load<KTT>(ops, xbase, xoffN, p.ctrd, Cs, Cg, mgn * G, M, wave, lane);
 
     if (ccnt > 0) {
       const char* stage = lds + (s & 1) * STAGE_BYTES + lane * 8;
@@ -272,8 +294,8 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
 
     if (more) {
       char* nstage = lds + ((s + 1) & 1) * STAGE_BYTES;
-      if (KT > 0) mfma_store<KTT>(ops, nstage, Cs, wave, lane);
-      else build_stage_exact(nstage, xbase, p.ctrd, K, Cs, Cg, G, mgn * G, M, wave, lane, xoffN);
+      if (KT > 0) mfma_store<KTT>(ops, nstage, ksteps, Cs, Cg, mgn * G, M, wave, lane);
+      else build_stage_exact(nstage, xbase, xoffN, p.ctrd, K, Cs, Cg, G, mgn * G, M, wave, lane);
     }
     __syncthreads();
     hi = hn; wi = wn; mg = mgn;
@@ -321,7 +343,7 @@ __global__ __launch_bounds__(NW * 64) void k_fc_aprx(FcParams p, int G, int stag
   const int mEnd = min(M, mBeg + stagesPerSplit * G);
   const int S = (mEnd - mBeg + G - 1) / G;
   const char* __restrict__ xbase = reinterpret_cast<const char*>(p.src + (size_t)panel * p.D * PANEL);
-  auto xoff = [&](int m, int d) { return (uint32_t)(m * Cs + d) * (uint32_t)XROWB; };
+  const int ksteps = (min(p.D, Cs) > 4) ? 2 : 1;
 
   f32x2 acc[CPW];
 #pragma unroll
@@ -333,10 +355,10 @@ __global__ __launch_bounds__(NW * 64) void k_fc_aprx(FcParams p, int G, int stag
   MfmaOps<KTT> ops;
   if (S > 0) {
     if (KT > 0) {
-      mfma_load<KTT>(ops, xbase, p.ctrd, Cs, p.D, mBeg, mEnd, wave, lane, xoff);
-      mfma_store<KTT>(ops, lds, Cs, wave, lane);
+      mfma_load<KTT>(ops, xbase, 0u, p.ctrd, Cs, p.D, mBeg, mEnd, wave, lane);
+      mfma_store<KTT>(ops, lds, ksteps, Cs, p.D, mBeg, mEnd, wave, lane);
     } else {
-      build_stage_exact(lds, xbase, p.ctrd, K, Cs, p.D, G, mBeg, mEnd, wave, lane, xoff);
+      build_stage_exact(lds, xbase, 0u, p.ctrd, K, Cs, p.D, G, mBeg, mEnd, wave, lane);
     }
   }
   __syncthreads();
@@ -344,7 +366,7 @@ __global__ __launch_bounds__(NW * 64) void k_fc_aprx(FcParams p, int G, int stag
   for (int s = 0; s < S; ++s) {
     const int m0 = mBeg + s * G;
     const bool more = s + 1 < S;
-    if (KT > 0 && more) mfma_load<KTT>(ops, xbase, p.ctrd, Cs, p.D, m0 + G, mEnd, wave, lane, xoff);
+    if (KT > 0 && more) mfma_load<KTT>(ops, xbase, 0u, p.ctrd, Cs, p.D, m0 + G, mEnd, wave, lane);
 
     if (ccnt > 0) {
       const char* stage = lds + (s & 1) * STAGE_BYTES + lane * 8;
@@ -354,8 +376,8 @@ __global__ __launch_bounds__(NW * 64) void k_fc_aprx(FcParams p, int G, int stag
 
     if (more) {
       char* nstage = lds + ((s + 1) & 1) * STAGE_BYTES;
-      if (KT > 0) mfma_store<KTT>(ops, nstage, Cs, wave, lane);
-      else build_stage_exact(nstage, xbase, p.ctrd, K, Cs, p.D, G, m0 + G, mEnd, wave, lane, xoff);
+      if (KT > 0) mfma_store<KTT>(ops, nstage, ksteps, Cs, p.D, m0 + G, mEnd, wave, lane);
+      else build_stage_exact(nstage, xbase, 0u, p.ctrd, K, Cs, p.D, G, m0 + G, mEnd, wave, lane);
     }
     __syncthreads();
   }
