@@ -1,0 +1,82 @@
+// CaffeEva.h — the inference engine behind the reference's public interface (include/CaffeEva.h:64-85),
+// re-implemented for MI355X: the ten public methods keep their names, arguments and return
+// conventions (bool success / printf("[ERROR] ...")), so src/Main.cc + src/UnitTest.cc of the reference
+// drive it unchanged.  Everything private is different: there are no host feature maps or buffers —
+// the object owns one device context (include/qcnn_hip.h) and all arithmetic of the approximate
+// forward pass runs there.
+//
+// Behavioural notes
+//  * Only the approximate path exists (Init(true)).  Init(false) makes LoadCaffePara() fail with an
+//    [ERROR] line: the exact im2col+sgemm path needs convKnl/fcntWei files the reference never shipped
+//     and is out of this repository's scope.
+//  * The reference hard-codes 1 image per batch and 100 batches (src/CaffeEva.cc:23-24).  Here they are
+//    the DEFAULTS of two environment variables read at LoadCaffePara():
+//        QCNN_BATCH    images per forward pass       (default 1)
+//        QCNN_BATCHES  forward passes to run         (default 100)
+//        QCNN_DEVICE   HIP device ordinal            (default 0)
+//        QCNN_LUT      "mfma" (default) | "exact"    look-up-table builder (exact = bit-identical conv/FC)
+//  * DispElpsTime() prints the reference's stop-watch names; the values are HIP-event times of the
+//    layers (LUT build and look-up are one fused kernel, so swCompLkupTbl* report 0 and swEstiInPdVal*
+//    carry the fused time).
+#ifndef QCNN_HOST_CAFFEEVA_H_
+#define QCNN_HOST_CAFFEEVA_H_
+
+#include <string>
+#include <vector>
+
+#include "../include/Common.h"
+#include "../include/BlasWrapper.h"
+#include "../include/CaffePara.h"
+#include "../include/Matrix.h"
+#include "../include/StopWatch.h"
+
+struct QcnnCtx;   // include/qcnn_hip.h
+
+class CaffeEva {
+ public:
+  CaffeEva(void);
+  ~CaffeEva(void);
+
+ public:
+  void Init(const bool enblAprxSrc);
+  void SetModelName(const std::string& modelNameSrc);
+  void SetModelPath(const std::string& dirPathMainSrc, const std::string& fileNamePfxSrc);
+  bool LoadDataset(const std::string& dirPathData);
+  bool LoadCaffePara(void);
+  // classify QCNN_BATCHES x QCNN_BATCH images of the loaded dataset
+  void ExecForwardPass(void);
+  // one image [1, C, H, W] in, class probabilities out
+  void ExecForwardPass(const Matrix<float>& imgDataIn, Matrix<float>* pProbVecOut);
+  void CalcPredAccu(void);
+  float DispElpsTime(void);
+
+  // extensions (not in the reference): feature map l of the last forward pass, NHWC per image
+  bool GetFeatMap(const int layerInd, const int dataCnt, Matrix<float>* pFeatMap);
+  std::string GetErrorMsg(void) const { return lastError_; }
+
+ private:
+  CaffeEva(const CaffeEva&);
+  CaffeEva& operator=(const CaffeEva&);
+
+  bool enblAprx;
+  std::string modelName;
+  std::string dirPathMain;
+  std::string fileNamePfx;
+  CaffePara caffeParaObj;
+  Matrix<float> dataLst;            // [N, C, H, W]
+  Matrix<uint16_t> lablVecGrth;     // ground truth, 0-based
+  Matrix<uint16_t> lablVecPred;     // [N, 5]
+
+  QcnnCtx* ctx_;                    // device context; owns every activation / parameter buffer
+  bool modelReady_;
+  int batchSize_;                   // QCNN_BATCH
+  int batchCnt_;                    // QCNN_BATCHES
+  int imagesDone_;                  // images classified by the last ExecForwardPass(void)
+  std::string lastError_;
+  StopWatch swWall_;                // wall clock around the forward passes (host view)
+
+  bool fail(const std::string& what);
+  bool buildDeviceModel(void);
+};
+
+#endif  // QCNN_HOST_CAFFEEVA_H_

@@ -1,0 +1,244 @@
+// caffe_eva.cc — host side of CaffeEva: parameter hand-over to the device and the batch loop.
+// Mirrors the control flow of the reference's src/CaffeEva.cc (LoadCaffePara :109-149, ExecForwardPass
+// :151-261, CalcPredAccu :263-295, DispElpsTime :297-326); the per-layer work is the C-ABI of
+// include/qcnn_hip.h.
+#include "../../include/CaffeEva.h"
+
+#include "../../include/FileIO.h"
+#include "../../include/qcnn_hip.h"
+
+namespace {
+
+const int kLablCntPerData = 5;   // top-5, as src/CaffeEva.cc:25
+
+int envInt(const char* name, int dflt) {
+  const char* v = getenv(name);
+  if (v == nullptr || *v == '\0') return dflt;
+  const int x = atoi(v);
+  return x > 0 ? x : dflt;
+}
+
+QcnnLayerDesc toDesc(const LayerInfo& li) {
+  QcnnLayerDesc d;
+  d.type = static_cast<int>(li.type);
+  d.padSiz = li.padSiz; d.knlSiz = li.knlSiz; d.knlCnt = li.knlCnt; d.grpCnt = li.grpCnt;
+  d.stride = li.stride; d.nodCnt = li.nodCnt; d.lrnSiz = li.lrnSiz;
+  d.lrnAlp = li.lrnAlp; d.lrnBet = li.lrnBet; d.lrnIni = li.lrnIni; d.drpRat = li.drpRat;
+  return d;
+}
+
+}  // namespace
+
+CaffeEva::CaffeEva(void)
+    : enblAprx(true), ctx_(nullptr), modelReady_(false), batchSize_(1), batchCnt_(100), imagesDone_(0) {}
+
+CaffeEva::~CaffeEva(void) {
+  if (ctx_ != nullptr) qcnn_ctx_destroy(ctx_);
+}
+
+bool CaffeEva::fail(const std::string& what) {
+  lastError_ = what;
+  if (ctx_ != nullptr && *qcnn_last_error(ctx_)) lastError_ += std::string(": ") + qcnn_last_error(ctx_);
+  printf("[ERROR] %s\n", lastError_.c_str());
+  return false;
+}
+
+void CaffeEva::Init(const bool enblAprxSrc) {
+  enblAprx = enblAprxSrc;
+  swWall_.Reset();
+  if (ctx_ != nullptr && modelReady_) qcnn_reset_layer_ms(ctx_);
+}
+
+void CaffeEva::SetModelName(const std::string& modelNameSrc) {
+  printf("[CHECK-POINT] entering CaffeEva::SetModelName()\n");
+  modelName = modelNameSrc;
+}
+
+void CaffeEva::SetModelPath(const std::string& dirPathMainSrc, const std::string& fileNamePfxSrc) {
+  printf("[CHECK-POINT] entering CaffeEva::SetModelPath()\n");
+  dirPathMain = dirPathMainSrc;
+  fileNamePfx = fileNamePfxSrc;
+}
+
+bool CaffeEva::LoadDataset(const std::string& dirPathData) {
+  printf("[CHECK-POINT] entering CaffeEva::LoadDataset()\n");
+  if (!FileIO::ReadBinFile(dirPathData + "/dataMatTst.single.bin", &dataLst)) return false;
+  if (!FileIO::ReadBinFile(dirPathData + "/lablVecTst.uint16.bin", &lablVecGrth)) return false;
+  return true;
+}
+
+bool CaffeEva::LoadCaffePara(void) {
+  printf("[CHECK-POINT] entering CaffeEva::LoadCaffePara()\n");
+  modelReady_ = false;
+  if (!enblAprx)
+    return fail("the precise (im2col + sgemm) path is not part of this library; call Init(true)");
+
+  caffeParaObj.Init(dirPathMain, fileNamePfx);
+  if (modelName == "AlexNet") caffeParaObj.ConfigLayer_AlexNet();
+  else if (modelName == "CaffeNet") caffeParaObj.ConfigLayer_CaffeNet();
+  else if (modelName == "VggCnnS") caffeParaObj.ConfigLayer_VggCnnS();
+  else if (modelName == "VGG16") caffeParaObj.ConfigLayer_VGG16();
+  else if (modelName == "CaffeNetFGB") caffeParaObj.ConfigLayer_CaffeNetFGB();
+  else if (modelName == "CaffeNetFGD") caffeParaObj.ConfigLayer_CaffeNetFGD();
+  else {
+    printf("[ERROR] unrecognized caffe model name: %s\n", modelName.c_str());
+    return false;
+  }
+  if (!caffeParaObj.LoadLayerPara(enblAprx, ENUM_AsmtEnc::Compact)) return false;
+
+  batchSize_ = envInt("QCNN_BATCH", 1);
+  batchCnt_ = envInt("QCNN_BATCHES", 100);
+  return buildDeviceModel();
+}
+
+// PrepFeatMap / PrepFeatBuf / PrepCtrdBuf / PrepAsmtBuf of the reference (src/CaffeEva.cc:328-623) happen
+// on the device side of the C-ABI; here the loaded tensors are only handed over.
+bool CaffeEva::buildDeviceModel(void) {
+  if (ctx_ == nullptr) {
+    const char* dev = getenv("QCNN_DEVICE");
+    if (qcnn_ctx_create(dev ? atoi(dev) : 0, nullptr, &ctx_) != 0)
+      return fail(std::string("cannot create the device context: ") + qcnn_last_error(nullptr));
+  }
+  const char* lut = getenv("QCNN_LUT");
+  qcnn_set_option(ctx_, QCNN_OPT_LUT_MODE, (lut && std::string(lut) == "exact") ? 0 : 1);
+  qcnn_set_option(ctx_, QCNN_OPT_KEEP_ALL, 1);
+  qcnn_set_option(ctx_, QCNN_OPT_PROFILE, 1);
+
+  const int L = caffeParaObj.layerCnt;
+  std::vector<QcnnLayerDesc> descs(L);
+  for (int l = 0; l < L; ++l) descs[l] = toDesc(caffeParaObj.layerInfoLst[l]);
+  if (qcnn_model_begin(ctx_, L, descs.data(), caffeParaObj.imgChnIn, caffeParaObj.imgHeiIn, caffeParaObj.imgWidIn))
+    return fail("qcnn_model_begin");
+  for (int l = 0; l < L; ++l) {
+    const ENUM_LyrType t = caffeParaObj.layerInfoLst[l].type;
+    if (t != ENUM_LyrType::Conv && t != ENUM_LyrType::FCnt) continue;
+    const Matrix<float>& ctrd = caffeParaObj.layerParaLst[l].ctrdLst;   // [M][K][Cs]
+    if (ctrd.GetDimCnt() != 3) return fail("layer without a 3-D ctrdLst");
+    if (qcnn_model_set_layer_shape(ctx_, l, ctrd.GetDimLen(0), ctrd.GetDimLen(1), ctrd.GetDimLen(2)))
+      return fail("qcnn_model_set_layer_shape");
+  }
+  if (qcnn_model_commit(ctx_, batchSize_, nullptr)) return fail("qcnn_model_commit");
+  for (int l = 0; l < L; ++l) {
+    const ENUM_LyrType t = caffeParaObj.layerInfoLst[l].type;
+    if (t != ENUM_LyrType::Conv && t != ENUM_LyrType::FCnt) continue;
+    const LayerPara& lp = caffeParaObj.layerParaLst[l];
+    if (qcnn_model_set_layer_params(ctx_, l, lp.biasVec.GetDataPtr(), lp.ctrdLst.GetDataPtr(), lp.asmtLst.GetDataPtr()))
+      return fail("qcnn_model_set_layer_params");
+  }
+  // the reference prints the feature-map sizes here (src/CaffeEva.cc:403-410)
+  for (int l = 0; l <= L; ++l) {
+    int hwc[3];
+    qcnn_fm_dims(ctx_, l, hwc);
+    printf("layer #%2d: %4d x %4d x %4d x %4d (%6.2f MB)\n", l, batchSize_, hwc[0], hwc[1], hwc[2],
+           batchSize_ * hwc[0] * hwc[1] * hwc[2] * 4 / 1024.0 / 1024.0);
+  }
+  modelReady_ = true;
+  return true;
+}
+
+void CaffeEva::ExecForwardPass(void) {
+  printf("[CHECK-POINT] entering CaffeEva::ExecForwardPass()\n");
+  imagesDone_ = 0;
+  if (!modelReady_) { fail("ExecForwardPass() before a successful LoadCaffePara()"); return; }
+  if (dataLst.GetDimCnt() != 4) { fail("ExecForwardPass() before a successful LoadDataset()"); return; }
+  const int dataCnt = dataLst.GetDimLen(0);
+  const int perImg = dataLst.GetDimStp(0);
+  if (dataCnt < batchSize_) { fail("dataset smaller than one batch"); return; }
+  lablVecPred.Create(dataCnt, kLablCntPerData, 1, 1);
+  memset(lablVecPred.GetDataPtr(), 0, sizeof(uint16_t) * lablVecPred.GetEleCnt());
+  std::vector<uint16_t> top5(static_cast<size_t>(batchSize_) * kLablCntPerData);
+  const int batchesInData = (dataCnt + batchSize_ - 1) / batchSize_;
+  swWall_.Resume();
+  for (int b = 0; b < batchCnt_; ++b) {
+    printf("processing the %d-th batch\n", b + 1);
+    // same window rule as the reference (src/CaffeEva.cc:170-177): the last window is right-aligned
+    int first = batchSize_ * b;
+    if (b >= batchesInData - 1) first = dataCnt - batchSize_;
+    if (first < 0 || first + batchSize_ > dataCnt) first = dataCnt - batchSize_;
+    if (qcnn_forward_host(ctx_, dataLst.GetDataPtr() + static_cast<size_t>(first) * perImg, batchSize_, nullptr,
+                          top5.data()) != 0) {
+      fail("qcnn_forward_host");
+      break;
+    }
+    for (int i = 0; i < batchSize_; ++i)
+      for (int r = 0; r < kLablCntPerData; ++r) lablVecPred.SetEleAt(top5[i * kLablCntPerData + r], first + i, r, 0, 0);
+    imagesDone_ += batchSize_;
+  }
+  swWall_.Pause();
+}
+
+void CaffeEva::ExecForwardPass(const Matrix<float>& imgDataIn, Matrix<float>* pProbVecOut) {
+  printf("[CHECK-POINT] entering CaffeEva::ExecForwardPass()\n");
+  if (!modelReady_) { fail("ExecForwardPass() before a successful LoadCaffePara()"); return; }
+  int hwc[3];
+  qcnn_fm_dims(ctx_, caffeParaObj.layerCnt, hwc);
+  pProbVecOut->Resize(hwc[0] * hwc[1] * hwc[2]);
+  swWall_.Resume();
+  if (qcnn_forward_host(ctx_, imgDataIn.GetDataPtr(), 1, pProbVecOut->GetDataPtr(), nullptr) != 0)
+    fail("qcnn_forward_host");
+  swWall_.Pause();
+}
+
+bool CaffeEva::GetFeatMap(const int layerInd, const int dataCnt, Matrix<float>* pFeatMap) {
+  if (!modelReady_) return fail("GetFeatMap() before a successful LoadCaffePara()");
+  int hwc[3];
+  if (qcnn_fm_dims(ctx_, layerInd, hwc)) return fail("qcnn_fm_dims");
+  pFeatMap->Create(dataCnt, hwc[0], hwc[1], hwc[2]);
+  if (qcnn_get_layer_output(ctx_, layerInd, dataCnt, pFeatMap->GetDataPtr())) return fail("qcnn_get_layer_output");
+  return true;
+}
+
+void CaffeEva::CalcPredAccu(void) {
+  printf("[CHECK-POINT] entering CaffeEva::CalcPredAccu()\n");
+  const int dataCnt = imagesDone_;
+  if (dataCnt <= 0 || lablVecGrth.GetEleCnt() < dataCnt) {
+    printf("[ERROR] no predictions to score\n");
+    return;
+  }
+  // cumulative top-k hits over the images that were classified (src/CaffeEva.cc:274-294 scores the first
+  // kDataCntInBatch * kBatchCntProc entries; with the defaults that is the same 100 images)
+  unsigned hits[kLablCntPerData] = {0, 0, 0, 0, 0};
+  const uint16_t* truth = lablVecGrth.GetDataPtr();
+  for (int i = 0; i < dataCnt; ++i)
+    for (int r = 0; r < kLablCntPerData; ++r)
+      if (lablVecPred.GetEleAt(i, r, 0, 0) == truth[i]) hits[r]++;
+  unsigned acc = 0;
+  for (int r = 0; r < kLablCntPerData; ++r) {
+    acc += hits[r];
+    printf("ACCURACY@%d: %d, %.2f%%\n", r + 1, acc, 100.0 * acc / dataCnt);
+  }
+}
+
+float CaffeEva::DispElpsTime(void) {
+  const int L = caffeParaObj.layerCnt;
+  std::vector<float> ms(L > 0 ? L : 1, 0.0f);
+  int forwards = 0;
+  if (modelReady_) qcnn_get_layer_ms(ctx_, ms.data(), &forwards);
+  double byType[7] = {0, 0, 0, 0, 0, 0, 0};
+  double convK = 0.0, fcK = 0.0, total = 0.0;
+  for (int l = 0; l < L; ++l) {
+    const double s = ms[l] * 1e-3 * forwards;          // seconds over all recorded forward passes
+    const int t = static_cast<int>(caffeParaObj.layerInfoLst[l].type);
+    byType[t] += s;
+    total += s;
+    if (t == static_cast<int>(ENUM_LyrType::Conv)) convK += s;
+    if (t == static_cast<int>(ENUM_LyrType::FCnt)) fcK += s;
+  }
+  printf("swAllLayers: %.4f (s)\n", total);
+  printf("swConvLayer: %.4f (s)\n", byType[static_cast<int>(ENUM_LyrType::Conv)]);
+  printf("swPoolLayer: %.4f (s)\n", byType[static_cast<int>(ENUM_LyrType::Pool)]);
+  printf("swFCntLayer: %.4f (s)\n", byType[static_cast<int>(ENUM_LyrType::FCnt)]);
+  printf("swReLuLayer: %.4f (s)\n", byType[static_cast<int>(ENUM_LyrType::ReLU)]);
+  printf("swLoRNLayer: %.4f (s)\n", byType[static_cast<int>(ENUM_LyrType::LoRN)]);
+  printf("swDrptLayer: %.4f (s)\n", byType[static_cast<int>(ENUM_LyrType::Drpt)]);
+  printf("swSMaxLayer: %.4f (s)\n", byType[static_cast<int>(ENUM_LyrType::SMax)]);
+  printf("swCompLkupTblConv: %.4f (s)\n", 0.0);        // fused into the look-up kernel
+  printf("swEstiInPdValConv: %.4f (s)\n", convK);
+  printf("swCompLkupTblFCnt: %.4f (s)\n", 0.0);
+  printf("swEstiInPdValFCnt: %.4f (s)\n", fcK);
+  printf("swDebugTimePri: %.4f (s)\n", static_cast<double>(swWall_.GetTime()));   // host wall clock incl. H2D/D2H
+  printf("swDebugTimeSec: %.4f (s)\n", 0.0);
+  for (int l = 0; l < L; ++l) printf("swIndvLayerLst #%2d: %.4f (s)\n", l + 1, ms[l] * 1e-3 * forwards);
+  Init(enblAprx);
+  return static_cast<float>(total);
+}

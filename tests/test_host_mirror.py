@@ -1,0 +1,161 @@
+"""The C++ host mirror of the reference interface (include/*.h + quantized-cnn_amd/host/*.cc).
+
+CPU tier: Matrix / FileIO / CaffePara / BmpImgIO against numpy and against the compiled reference.
+GPU tier: the reference's UNMODIFIED Main.cc + UnitTest.cc (build/bin/QuanCNN_hip, staged copies linked
+against the mirror) drive the HIP path and print the same ACCURACY@k lines as the reference binary."""
+import ctypes as C
+import os
+import re
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+import pyoracle as po
+from conftest import ROOT, pkg
+
+topo = pkg("topology")
+synth = pkg("synth")
+fileio = pkg("fileio")
+HOST_SO = os.path.join(ROOT, "quantized-cnn_amd", "libqcnn_host.so")
+pytestmark = pytest.mark.skipif(not os.path.exists(HOST_SO), reason="libqcnn_host.so not built")
+
+
+def host():
+    lib = C.CDLL(HOST_SO)
+    f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+    i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+    f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+    lib.qh_bmp_load.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, f32p]
+    lib.qh_para_load.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_int), i32p, f64p]
+    lib.qh_para_convert.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
+    lib.qh_cbn_rewrite.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
+    return lib
+
+
+def test_matrix_semantics():
+    assert host().qh_matrix_selftest() == 0
+
+
+@pytest.mark.parametrize("model", ["AlexNet", "CaffeNet", "VggCnnS", "VGG16", "CaffeNetFGB", "CaffeNetFGD"])
+def test_topology_tables_match_python_mirror(model):
+    lib = host()
+    n = C.c_int(0)
+    dims = np.zeros((64, 8), np.int32)
+    sums = np.zeros((64, 3), np.float64)
+    with po._Quiet():
+        rc = lib.qh_para_load(model.encode(), b"", b"", 0, C.byref(n), dims, sums)
+    assert rc == 0
+    _, layers, _, _ = topo.MODELS[model]
+    assert n.value == len(layers)
+    for l, ly in enumerate(layers):
+        want = [ly["type"], ly.get("pad", 0), ly.get("knl", 0), ly.get("cnt", 0), ly.get("grp", 0),
+                ly.get("stride", 0), ly.get("nod", 0), ly.get("siz", 0)]
+        assert list(dims[l]) == want, "%s layer %d" % (model, l)
+
+
+def test_parameter_loading_and_encoding_conversion(tmp_path):
+    """LoadLayerPara (0-based after load), CvtAsmtEnc Compact -> Raw -> Compact, against the numpy reader."""
+    lib = host()
+    in_chw, layers, _, _ = topo.MODELS["AlexNet"]
+    spec = synth.quant_spec(in_chw, layers)
+    for i in (15, 18, 21):      # keep the test small: shrink the FC layers' tables
+        spec[i] = dict(spec[i])
+    params = synth.make_params(in_chw, layers, seed=5, spec=spec)
+    d = str(tmp_path)
+    synth.write_param_dir(d, "p", params)
+    n = C.c_int(0)
+    dims = np.zeros((64, 8), np.int32)
+    sums = np.zeros((64, 3), np.float64)
+    with po._Quiet():
+        assert lib.qh_para_load(b"AlexNet", d.encode(), b"p", 0, C.byref(n), dims, sums) == 0
+    for i, p in params.items():
+        assert abs(sums[i, 0] - p["bias"].astype(np.float64).sum()) < 1e-6
+        assert abs(sums[i, 1] - p["ctrd"].astype(np.float64).sum()) < 1e-3
+        assert sums[i, 2] == p["asmt"].astype(np.float64).sum()          # 0-based after LoadLayerPara
+    with po._Quiet():
+        assert lib.qh_para_convert(d.encode(), b"p", 0) == 0             # Compact -> Raw (.bin, 1-based bytes)
+    raw = fileio.read_bin(fileio.param_path(d, "p", "asmtLst", 1, "bin"), np.uint8)
+    assert np.array_equal(raw, params[0]["asmt"] + 1)
+    for i in params:
+        os.rename(fileio.param_path(d, "p", "asmtLst", i + 1, "cbn"), fileio.param_path(d, "p", "asmtLst", i + 1, "cbn") + ".orig")
+    with po._Quiet():
+        assert lib.qh_para_convert(d.encode(), b"p", 1) == 0             # Raw -> Compact
+    for i in params:
+        a = open(fileio.param_path(d, "p", "asmtLst", i + 1, "cbn"), "rb").read()
+        b = open(fileio.param_path(d, "p", "asmtLst", i + 1, "cbn") + ".orig", "rb").read()
+        assert a == b, "layer %d: re-encoded .cbn differs from the numpy writer's" % i
+    with po._Quiet():
+        assert lib.qh_para_load(b"AlexNet", d.encode(), b"p", 1, C.byref(n), dims, sums) == 0   # Raw load
+    assert sums[0, 2] == params[0]["asmt"].astype(np.float64).sum()
+
+
+@pytest.mark.skipif(not (po.have_ref() and os.path.isdir(po.REF_DATA)), reason="needs oracle/_ref (+ data)")
+def test_bmp_preprocessing_matches_reference_bitwise():
+    lib = host()
+    ref = po.RefLib()
+    mean = os.path.join(po.REF_DATA, "AlexNet/imagenet_mean.single.bin")
+    for i in (1, 2, 5, 7):     # 500x375, 375x500-ish mixes
+        bmp = os.path.join(po.REF_DATA, "Bmp.Files/ILSVRC2012_val_%08d.BMP" % i)
+        want = ref.load_bmp(mean, bmp)
+        got = np.empty((1, 3, 227, 227), np.float32)
+        with po._Quiet():
+            assert lib.qh_bmp_load(mean.encode(), bmp.encode(), 256, 227, 0, got) == 0
+        assert np.array_equal(got, want), bmp
+
+
+@pytest.mark.skipif(not (po.have_ref() and os.path.isdir(po.REF_DATA)), reason="needs oracle/_ref (+ data)")
+def test_shipped_cbn_files_reencode_identically(tmp_path):
+    """Read a SHIPPED .cbn with this repo's FileIO and write it back: byte-identical file."""
+    lib = host()
+    for nn, bits in ((1, 7), (19, 5), (22, 4)):
+        src = os.path.join(po.REF_DATA, "AlexNet/Bin.Files/bvlc_alexnet_aCaF.asmtLst.%02d.cbn" % nn)
+        dst = str(tmp_path / ("a%02d.cbn" % nn))
+        with po._Quiet():
+            assert lib.qh_cbn_rewrite(src.encode(), dst.encode(), bits) == 0
+        assert open(src, "rb").read() == open(dst, "rb").read()
+
+
+def _make_data_root(tmp_path, n_images=100):
+    root = str(tmp_path / "root")
+    os.makedirs(os.path.join(root, "ILSVRC12.227x227.IMG"))
+    for rel in ("AlexNet", "Cls.Names", "Bmp.Files"):
+        os.symlink(os.path.join(po.REF_DATA, rel), os.path.join(root, rel))
+    shutil.copyfile(os.path.join(po.REF_DATA, "ILSVRC12.227x227.IMG/lablVecTst.uint16.bin"),
+                    os.path.join(root, "ILSVRC12.227x227.IMG/lablVecTst.uint16.bin"))
+    mean = fileio.read_bin(os.path.join(po.REF_DATA, "AlexNet/imagenet_mean.single.bin"), np.float32)
+    imgs = synth.make_images(n_images, (3, 227, 227), seed=1234, mean=mean)
+    fileio.write_bin(os.path.join(root, "ILSVRC12.227x227.IMG/dataMatTst.single.bin"), imgs)
+    return root
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.isdir(po.REF_DATA), reason="needs the staged shipped parameters")
+def test_reference_main_drives_the_hip_path(tmp_path):
+    """src/Main.cc + src/UnitTest.cc of the reference, byte-identical, linked against the mirror."""
+    exe = os.path.join(ROOT, "build", "bin", "QuanCNN_hip")
+    if not os.path.exists(exe):
+        pytest.skip("build/bin/QuanCNN_hip not built (needs /root/reference at build time)")
+    root = _make_data_root(tmp_path)
+    out = subprocess.run([exe], cwd=root, capture_output=True, text=True, timeout=600).stdout
+    acc = re.findall(r"ACCURACY@(\d): (\d+), ([0-9.]+)%", out)
+    assert [a[0] for a in acc] == ["1", "2", "3", "4", "5"], out[-2000:]
+    assert re.search(r"swAllLayers: [0-9.]+ \(s\)", out) and "elapsed time" in out
+    ref_exe = os.path.join(po.REF_DIR, "QuanCNN")
+    if os.path.exists(ref_exe):      # the reference binary itself, same data root: identical accuracy lines
+        ref_out = subprocess.run([ref_exe], cwd=root, capture_output=True, text=True, timeout=900).stdout
+        assert re.findall(r"ACCURACY@(\d): (\d+), ([0-9.]+)%", ref_out) == acc
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.isdir(po.REF_DATA), reason="needs the staged shipped parameters")
+def test_single_image_mode_matches_golden_top5(golden_alex_real):
+    exe = os.path.join(ROOT, "build", "bin", "qcnn_main")
+    if not os.path.exists(exe):
+        pytest.skip("build/bin/qcnn_main not built")
+    bmp = os.path.join(po.REF_DATA, "Bmp.Files/ILSVRC2012_val_00000002.BMP")
+    out = subprocess.run([exe, "image", bmp, po.REF_DATA], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, QCNN_LUT="exact")).stdout
+    got = [int(m) for m in re.findall(r"No\. \d: .* \((\d+) / [0-9.]+\)", out)]
+    assert got == [int(x) for x in golden_alex_real["top5"][0]], out[-1500:]
