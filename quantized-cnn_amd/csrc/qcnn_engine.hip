@@ -111,7 +111,7 @@ int plan_arena(QcnnCtx* c) {
     s.offBias = off; off = align_up(off + sizeof(float) * Ct, 256);
     s.offCtrd = off; off = align_up(off + sizeof(float) * (size_t)s.M * s.Cs * s.K, 256);
     s.asmtBytes = (d.type == QCNN_CONV) ? (size_t)d.knlSiz * d.knlSiz * s.M * Ct : (size_t)s.M * Ct;   // entries
-    s.offAsmt = off; off = align_up(off + (s.asmtBytes + QCNN_OFFS_PAD) * sizeof(uint32_t), 256);
+    s.offAsmt = off; off = align_up(off + s.asmtBytes + QCNN_ROWS_PAD, 256);
     s.hasDmap = (d.type == QCNN_FCNT && l == c->firstFc && c->dims[l].h * c->dims[l].w > 1);
     if (s.hasDmap) { s.offDmap = off; off = align_up(off + sizeof(int) * fm_elems(c, l), 256); }
   }
@@ -163,7 +163,7 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
       p.src = src; p.dst = dst;
       p.bias = reinterpret_cast<const float*>(c->arena + s.offBias);
       p.ctrd = reinterpret_cast<const float*>(c->arena + s.offCtrd);
-      p.offs = reinterpret_cast<const uint32_t*>(c->arena + s.offAsmt);
+      p.rows = reinterpret_cast<const uint8_t*>(c->arena + s.offAsmt);
       p.H = a.h; p.W = a.w; p.Cin = a.c; p.Ho = b.h; p.Wo = b.w; p.Ct = b.c;
       p.knl = d.knlSiz; p.stride = d.stride; p.pad = d.padSiz; p.grp = d.grpCnt;
       p.M = s.M; p.Cs = s.Cs; p.K = s.K; p.relu = fuseRelu ? 1 : 0; p.panels = panels;
@@ -176,7 +176,7 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
       p.src = src; p.dst = dst;
       p.bias = reinterpret_cast<const float*>(c->arena + s.offBias);
       p.ctrd = reinterpret_cast<const float*>(c->arena + s.offCtrd);
-      p.offs = reinterpret_cast<const uint32_t*>(c->arena + s.offAsmt);
+      p.rows = reinterpret_cast<const uint8_t*>(c->arena + s.offAsmt);
       if (s.hasDmap && !flatFcInput) {   // NHWC -> consumption order (NCHW flatten) into the scratch map
         e = qk_permute_rows(src, c->fcFlat, reinterpret_cast<const int*>(c->arena + s.offDmap), a.h * a.w * a.c,
                             panels, c->stream);
@@ -191,10 +191,10 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
       if (c->lutMode == 1) {
         const int G = qcnn_stage_group(s.K);
         const int stages = (s.M + G - 1) / G;
-        const int cpw = p.Ct >= 2048 ? 64 : (p.Ct >= 512 ? 32 : (p.Ct >= 64 ? 8 : 4));
         // batch-independent choice (a given image must produce the same bits in any batch):
         // aim at >= 64 workgroups per panel, keep >= 16 stages per workgroup, at most 16 splits
-        const int chunks = (p.Ct + 8 * cpw - 1) / (8 * cpw);
+        const int cpb = qk_fc_channels_per_block(p.Ct);
+        const int chunks = (p.Ct + cpb - 1) / cpb;
         int ms = (64 + chunks - 1) / chunks;
         if (ms > 16) ms = 16;
         while (ms > 1 && stages / ms < 16) --ms;
@@ -467,8 +467,8 @@ int qcnn_model_set_layer_params(QcnnCtx* c, int layer, const float* bias, const 
     for (int k = 0; k < K; ++k)
       for (int dd = 0; dd < Cs; ++dd) ctrd[((size_t)m * Cs + dd) * K + k] = ctrd_file[((size_t)m * K + k) * Cs + dd];
   // PrepAsmtBuf: conv [Ct][kh][kw][M] -> [kh][kw][M][Ct] (:585-586); FC [Ct][M] -> [M][Ct] (:610-611);
-  // stored as the byte offset of the code-word row inside a LUT stage: ((m % G) * K + index) * row bytes
-  std::vector<uint32_t> asmt(s.asmtBytes + QCNN_OFFS_PAD, 0);
+  // stored as the row index of the code word inside a LUT stage: (m % G) * K + index  (< 128)
+  std::vector<uint8_t> asmt(s.asmtBytes + QCNN_ROWS_PAD, 0);
   const int G = qcnn_stage_group(K);
   const size_t taps = (d.type == QCNN_CONV) ? (size_t)d.knlSiz * d.knlSiz : 1;
   for (int ch = 0; ch < Ct; ++ch)
@@ -476,11 +476,11 @@ int qcnn_model_set_layer_params(QcnnCtx* c, int layer, const float* bias, const 
       for (int m = 0; m < M; ++m) {
         const uint8_t v = asmt_file[((size_t)ch * taps + t) * M + m];
         if (v >= K) return fail(c, "layer %d: assignment %u >= K = %d", layer, (unsigned)v, K);
-        asmt[(t * M + m) * Ct + ch] = (uint32_t)((m % G) * K + v) * (uint32_t)QCNN_ROW_BYTES;
+        asmt[(t * M + m) * Ct + ch] = (uint8_t)((m % G) * K + v);
       }
   HIP_TRY(c, hipMemcpyAsync(c->arena + s.offBias, bias, sizeof(float) * Ct, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipMemcpyAsync(c->arena + s.offCtrd, ctrd.data(), sizeof(float) * ctrd.size(), hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(c->arena + s.offAsmt, asmt.data(), asmt.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->arena + s.offAsmt, asmt.data(), asmt.size(), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   s.loaded = true;
   return 0;

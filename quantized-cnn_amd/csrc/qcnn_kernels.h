@@ -6,7 +6,7 @@
 // image PAIR (images 2*lane, 2*lane+1 of the panel): every load/store of a wave is a full 512-byte row,
 // a table look-up is one conflict-free ds_read_b64 and the accumulation one v_pk_add_f32.  The
 // code-word index of the approximate layers is wave-uniform (it depends on the layer's assignment table
-// only) and arrives through scalar loads.
+// only): it is fetched as packed uint8 and broadcast into SGPRs.
 #ifndef QCNN_KERNELS_H_
 #define QCNN_KERNELS_H_
 
@@ -16,20 +16,20 @@
 #define QCNN_PANEL 128
 #define QCNN_MAX_CS 8          // dims per sub-space supported by the LUT builders
 #define QCNN_MAX_K 128         // code words per sub-space supported (a LUT stage holds 128 rows)
-#define QCNN_OFFS_PAD 64       // uint32 entries of slack after every offset table (vector over-read)
+#define QCNN_ROWS_PAD 256      // bytes of slack after every row-index table (over-read of the last groups)
 #define QCNN_STAGE_ROWS 128    // code-word rows of one LUT stage in LDS
 #define QCNN_ROW_BYTES 528     // LDS row stride: 128 images * 4 B + 16 B pad (conflict-free MFMA tile writes)
 
 // A LUT stage holds G = qcnn_stage_group(K) consecutive sub-spaces of one source pixel (conv) / of the
-// input vector (FC): G * K <= 128 rows.  Assignment tables are stored on the device as uint32 BYTE
-// OFFSETS of the code-word row inside a stage:  offs = ((m % G) * K + index) * QCNN_ROW_BYTES.
+// input vector (FC): G * K <= 128 rows.  Assignment tables are stored on the device as uint8 ROW INDICES
+// of the code word inside a stage:  row = (m % G) * K + assignment  (< 128).
 static inline int qcnn_stage_group(int K) { return K <= 64 ? QCNN_STAGE_ROWS / K : 1; }
 struct ConvParams {
   const float* src;      // [panels][H*W*Cin][128]
   float* dst;            // [panels][Ho*Wo*Ct][128]
   const float* bias;     // [Ct]
   const float* ctrd;     // [M][Cs][K]      (PrepCtrdBuf layout, src/CaffeEva.cc:556-557)
-  const uint32_t* offs;  // [kh][kw][M][Ct] (PrepAsmtBuf layout, src/CaffeEva.cc:585-586), pre-scaled
+  const uint8_t* rows;   // [kh][kw][M][Ct] (PrepAsmtBuf layout, src/CaffeEva.cc:585-586), stage row indices
   int H, W, Cin, Ho, Wo, Ct;
   int knl, stride, pad, grp;
   int M, Cs, K;
@@ -44,7 +44,7 @@ struct FcParams {
   float* dst;            // [panels][Ct][128]
   const float* bias;
   const float* ctrd;     // [M][Cs][K]
-  const uint32_t* offs;  // [M][Ct]         (src/CaffeEva.cc:610-611), pre-scaled
+  const uint8_t* rows;   // [M][Ct]         (src/CaffeEva.cc:610-611), stage row indices
   int D, Ct, M, Cs, K;
   int relu;
   int panels;
@@ -53,6 +53,7 @@ struct FcParams {
 // lutMode: 0 exact VALU, 1 MFMA.  Return hipError_t of the launch.
 hipError_t qk_conv_aprx(const ConvParams& p, int lutMode, hipStream_t st);
 hipError_t qk_fc_aprx(const FcParams& p, int lutMode, hipStream_t st);
+int qk_fc_channels_per_block(int Ct);   // output channels one k_fc_aprx workgroup covers
 
 // dst row e = src row map[e], rows of 128 images ([panels][D][128]); the first FC layer consumes its input
 // NCHW-flattened (src/CaffeEva.cc:187-189)

@@ -29,7 +29,9 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 namespace {
 
 constexpr int PANEL = QCNN_PANEL;              // images per panel
-constexpr int NW = 8;                          // waves per workgroup of the two hot kernels
+constexpr int NW = 16;                         // waves per workgroup of the two hot kernels (4 per SIMD)
+constexpr int NBW = 4;                         // builder waves (waves 0..3: one per SIMD) — MFMA + LDS writes
+constexpr int NGW = NW - NBW;                  // gather waves (waves 4..15) — LDS reads + packed adds
 constexpr int ROWB = QCNN_ROW_BYTES;           // LDS bytes per code-word row
 constexpr int STAGE_ROWS = QCNN_STAGE_ROWS;
 constexpr int STAGE_BYTES = STAGE_ROWS * ROWB;  // 67 584 B; two stages = 132 KB of the 160 KB LDS
@@ -37,49 +39,123 @@ constexpr int XROWB = PANEL * 4;               // bytes of one activation row in
 
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
-// CPW look-ups of one (position, sub-space): the code-word offsets are wave-uniform and arrive four at a
-// time through s_load_dwordx4 (the tables are 16-byte aligned: Ct and the wave's first channel are
-// multiples of 4); each look-up is one ds_read_b64 of the image pair + one v_pk_add_f32.
+// Workgroup barrier WITHOUT the implicit "wait for everything" of __syncthreads(): the builder waves
+// wait for their LDS writes only (their operand prefetch of the stage after next stays in flight), the
+// gather waves wait for nothing (their look-ups were consumed by the adds; their index prefetch stays
+// in flight).  The "memory" clobber keeps the compiler from moving LDS accesses across it.
+__device__ __forceinline__ void barrier_after_lds_writes() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void barrier_plain() { asm volatile("s_barrier" ::: "memory"); }
+
+// ------------------------------------------------------------------------------------------------
+// Gather (gather waves).  The code-word ROW INDICES (uint8, 0..127: (m mod G)*K + assignment) of
+// CPW consecutive output channels are wave-uniform.  They are prefetched one group ahead as packed
+// dwords through the VECTOR memory path (every lane loads the same address; tracked by vmcnt, so the
+// prefetch never blocks an lgkmcnt wait of the LDS look-ups) and broadcast into SGPRs with
+// v_readfirstlane when the group starts.  Every look-up is then s_bfe_u32 + s_mul (row byte offset),
+// v_add_u32 (+ lane*8), ds_read_b64 (image pair), v_pk_add_f32.
+// ------------------------------------------------------------------------------------------------
+template <int N4>
+struct Idx {
+  uint32_t w[N4];
+};
+
+// per-lane (vector) load of N4 dwords at base + vzero (vzero: a VGPR holding 0 the compiler cannot see through)
+template <int N4>
+__device__ __forceinline__ void vload_idx(Idx<N4>& o, const uint8_t* __restrict__ ap, uint32_t vzero) {
+  const uint32_t* __restrict__ ap4 = reinterpret_cast<const uint32_t*>(__builtin_assume_aligned(ap + vzero, 4));
+#pragma unroll
+  for (int j = 0; j < N4; ++j) o.w[j] = ap4[j];
+}
+template <int N4>
+__device__ __forceinline__ void bcast_idx(Idx<N4>& s, const Idx<N4>& v) {
+#pragma unroll
+  for (int j = 0; j < N4; ++j) s.w[j] = (uint32_t)__builtin_amdgcn_readfirstlane((int)v.w[j]);
+}
+// immediate load (fallback for groups that were not prefetched); the result is forced into SGPRs
+template <int N4>
+__device__ __forceinline__ void sload_idx(Idx<N4>& o, const uint8_t* __restrict__ ap) {
+  const uint32_t* __restrict__ ap4 = reinterpret_cast<const uint32_t*>(__builtin_assume_aligned(ap, 4));
+#pragma unroll
+  for (int j = 0; j < N4; ++j) o.w[j] = (uint32_t)__builtin_amdgcn_readfirstlane((int)ap4[j]);
+}
+
+// One hand-scheduled block of 4 (gather4) or 8 (gather8) look-ups: row byte offsets on the scalar unit
+// (s_and/s_bfe/s_lshr + s_mulk 528), v_add_u32 with the lane's stage address, all ds_read_b64 issued
+// back to back, then counted s_waitcnt + v_pk_add_f32 IN PLACE (tied operands: an accumulator never
+// changes register).  The counted waits stay correct with other lgkm operations outstanding at entry:
+// LDS returns in order, so "at most N outstanding" implies the first 8-N reads of the block are back.
+// `valid` (wave-uniform) = 0 skips the block with a branch INSIDE the asm text, so that the compiler
+// sees straight-line code and keeps every accumulator in one register for the whole kernel.
+#define QCNN_LK(ext, w, a, v)                                                                      \
+  ext " %[t], %[" w "]\n\ts_mulk_i32 %[t], 0x210\n\tv_add_u32 %[" a "], %[t], %[b]\n\tds_read_b64 %[" v "], %[" a "]\n\t"
+#define QCNN_LK4(w, v0, v1, v2, v3)                                                               \
+  "s_and_b32 %[t], %[" w "], 0xff\n\ts_mulk_i32 %[t], 0x210\n\tv_add_u32 %[a0], %[t], %[b]\n\tds_read_b64 %[" v0 "], %[a0]\n\t" \
+  "s_bfe_u32 %[t], %[" w "], 0x80008\n\ts_mulk_i32 %[t], 0x210\n\tv_add_u32 %[a1], %[t], %[b]\n\tds_read_b64 %[" v1 "], %[a1]\n\t" \
+  "s_bfe_u32 %[t], %[" w "], 0x80010\n\ts_mulk_i32 %[t], 0x210\n\tv_add_u32 %[a0], %[t], %[b]\n\tds_read_b64 %[" v2 "], %[a0]\n\t" \
+  "s_lshr_b32 %[t], %[" w "], 24\n\ts_mulk_i32 %[t], 0x210\n\tv_add_u32 %[a1], %[t], %[b]\n\tds_read_b64 %[" v3 "], %[a1]\n\t"
+static_assert(QCNN_ROW_BYTES == 0x210, "the look-up blocks multiply by the literal row stride");
+
+__device__ __forceinline__ void gather8(f32x2* acc, uint32_t w0, uint32_t w1, uint32_t base, int valid) {
+  f32x2 v0, v1, v2, v3, v4, v5, v6, v7;
+  uint32_t a0, a1, t;
+  asm volatile("s_cmp_eq_u32 %[ok], 0\n\ts_cbranch_scc1 .Lqskip%=\n\t"
+               QCNN_LK4("w0", "v0", "v1", "v2", "v3") QCNN_LK4("w1", "v4", "v5", "v6", "v7")
+               "s_waitcnt lgkmcnt(7)\n\tv_pk_add_f32 %[c0], %[v0], %[c0]\n\t"
+               "s_waitcnt lgkmcnt(6)\n\tv_pk_add_f32 %[c1], %[v1], %[c1]\n\t"
+               "s_waitcnt lgkmcnt(5)\n\tv_pk_add_f32 %[c2], %[v2], %[c2]\n\t"
+               "s_waitcnt lgkmcnt(4)\n\tv_pk_add_f32 %[c3], %[v3], %[c3]\n\t"
+               "s_waitcnt lgkmcnt(3)\n\tv_pk_add_f32 %[c4], %[v4], %[c4]\n\t"
+               "s_waitcnt lgkmcnt(2)\n\tv_pk_add_f32 %[c5], %[v5], %[c5]\n\t"
+               "s_waitcnt lgkmcnt(1)\n\tv_pk_add_f32 %[c6], %[v6], %[c6]\n\t"
+               "s_waitcnt lgkmcnt(0)\n\tv_pk_add_f32 %[c7], %[v7], %[c7]\n"
+               ".Lqskip%=:"
+               : [c0] "+v"(acc[0]), [c1] "+v"(acc[1]), [c2] "+v"(acc[2]), [c3] "+v"(acc[3]), [c4] "+v"(acc[4]),
+                 [c5] "+v"(acc[5]), [c6] "+v"(acc[6]), [c7] "+v"(acc[7]), [v0] "=&v"(v0), [v1] "=&v"(v1),
+                 [v2] "=&v"(v2), [v3] "=&v"(v3), [v4] "=&v"(v4), [v5] "=&v"(v5), [v6] "=&v"(v6), [v7] "=&v"(v7),
+                 [a0] "=&v"(a0), [a1] "=&v"(a1), [t] "=&s"(t)
+               : [w0] "s"(w0), [w1] "s"(w1), [b] "v"(base), [ok] "s"(valid)
+               : "scc");
+}
+
+__device__ __forceinline__ void gather4(f32x2* acc, uint32_t w0, uint32_t base, int valid) {
+  f32x2 v0, v1, v2, v3;
+  uint32_t a0, a1, t;
+  asm volatile("s_cmp_eq_u32 %[ok], 0\n\ts_cbranch_scc1 .Lqskip%=\n\t"
+               QCNN_LK4("w0", "v0", "v1", "v2", "v3")
+               "s_waitcnt lgkmcnt(3)\n\tv_pk_add_f32 %[c0], %[v0], %[c0]\n\t"
+               "s_waitcnt lgkmcnt(2)\n\tv_pk_add_f32 %[c1], %[v1], %[c1]\n\t"
+               "s_waitcnt lgkmcnt(1)\n\tv_pk_add_f32 %[c2], %[v2], %[c2]\n\t"
+               "s_waitcnt lgkmcnt(0)\n\tv_pk_add_f32 %[c3], %[v3], %[c3]\n"
+               ".Lqskip%=:"
+               : [c0] "+v"(acc[0]), [c1] "+v"(acc[1]), [c2] "+v"(acc[2]), [c3] "+v"(acc[3]), [v0] "=&v"(v0),
+                 [v1] "=&v"(v1), [v2] "=&v"(v2), [v3] "=&v"(v3), [a0] "=&v"(a0), [a1] "=&v"(a1), [t] "=&s"(t)
+               : [w0] "s"(w0), [b] "v"(base), [ok] "s"(valid)
+               : "scc");
+}
+
+// CPW look-ups of one group; `stage` = LDS byte address of the lane's image pair in row 0 of the stage
 template <int CPW>
-__device__ __forceinline__ void gather_row(f32x2 (&acc)[CPW], const uint32_t* __restrict__ ap, const char* stage) {
-  static_assert(CPW % 4 == 0, "offsets are fetched as 4 x uint32");
-  constexpr int G = (CPW % 24 == 0) ? 24 : ((CPW % 16 == 0) ? 16 : ((CPW % 12 == 0) ? 12 : ((CPW % 8 == 0) ? 8 : 4)));
-  const u32x4* __restrict__ ap4 = reinterpret_cast<const u32x4*>(__builtin_assume_aligned(ap, 16));
+__device__ __forceinline__ void gather_apply(f32x2 (&acc)[CPW], const Idx<CPW / 4>& o, uint32_t stage, int valid) {
+  static_assert(CPW % 4 == 0, "indices are fetched as packed dwords");
 #pragma unroll
-  for (int g0 = 0; g0 < CPW; g0 += G) {
-    // phase 1: all scalar loads of the group (SMEM returns out of order, so LDS reads may only be
-    // counted with s_waitcnt lgkmcnt(N > 0) once no scalar load is in flight)
-    u32x4 o[G / 4];
-#pragma unroll
-    for (int j = 0; j < G / 4; ++j) o[j] = ap4[g0 / 4 + j];
-    __builtin_amdgcn_sched_barrier(0);
-    // phase 2: G back-to-back ds_read_b64, then the packed adds as the reads return
-    f32x2 v[G];
-#pragma unroll
-    for (int j = 0; j < G / 4; ++j) {
-      v[4 * j + 0] = *reinterpret_cast<const f32x2*>(stage + o[j].x);
-      v[4 * j + 1] = *reinterpret_cast<const f32x2*>(stage + o[j].y);
-      v[4 * j + 2] = *reinterpret_cast<const f32x2*>(stage + o[j].z);
-      v[4 * j + 3] = *reinterpret_cast<const f32x2*>(stage + o[j].w);
-    }
-#pragma unroll
-    for (int j = 0; j < G; ++j) acc[g0 + j] += v[j];
-    __builtin_amdgcn_sched_barrier(0);
-  }
+  for (int j = 0; j + 1 < CPW / 4; j += 2) gather8(&acc[4 * j], o.w[j], o.w[j + 1], stage, valid);
+  if ((CPW / 4) % 2) gather4(&acc[CPW - 4], o.w[CPW / 4 - 1], stage, valid);
 }
 
 // ------------------------------------------------------------------------------------------------
-// LUT stage builders.  A stage covers sub-spaces m0 .. m0+G-1 (those < mEnd), K rows each.  The
-// 128-image activation row of dim d of sub-space m starts at xbase + xoff0 + (m*Cs + d) * 512 bytes.
+// LUT stage builders (builder waves).  A stage covers sub-spaces m0 .. m0+G-1 (those < mEnd), K rows
+// each.  The 128-image activation row of dim d of sub-space m starts at
+// xbase + xoff0 + (m*Cs + d) * 512 bytes.
 // ------------------------------------------------------------------------------------------------
 
 // exact: y = ((0 + x0*c0) + x1*c1) + ...  with separately rounded product and sum, the order of the
 // reference's saxpy chain (src/CaffeEva.cc:1284-1289, include/BlasWrapper.h:164-184).  Any K <= 128.
+// Builder wave bw computes rows bw*ceil(K/4) .. of every sub-space; a lane carries an image pair.
 __device__ __forceinline__ void build_stage_exact(char* stage, const char* __restrict__ xbase, uint32_t xoff0,
                                                   const float* __restrict__ ctrd, int K, int Cs, int D, int G, int m0,
-                                                  int mEnd, int wave, int lane) {
-  const int kpw = (K + NW - 1) / NW;
-  const int k0 = wave * kpw;
+                                                  int mEnd, int bw, int lane) {
+  const int kpw = (K + NBW - 1) / NBW;
+  const int k0 = bw * kpw;
   const int k1 = min(K, k0 + kpw);
   for (int g = 0; g < G; ++g) {
     const int m = m0 + g;
@@ -110,51 +186,51 @@ __device__ __forceinline__ void build_stage_exact(char* stage, const char* __res
 
 // MFMA: D[16 rows][16 images] += A[16 rows x 4 dims] * B[4 dims x 16 images] (v_mfma_f32_16x16x4_f32).
 // Lane l holds A[l&15][l>>4], B[l>>4][l&15], D[(l>>4)*4 + r][l&15].  A stage is 8 row tiles x 8 image
-// tiles; wave w owns image tile w and all 8 row tiles.  Row tile i belongs to sub-space m0 + (16 i)/K
-// and starts at code word (16 i) % K  (KT = K/16 in {1, 2, 4, 8}).  Operands are fetched into registers
-// (mfma_load) one stage ahead of their use (mfma_store).  All operand loads are UNCONDITIONAL, at
-// wave-uniform base + per-lane constant + immediate (device buffers carry slack for the over-read of
-// dims / sub-spaces that do not exist); what must not contribute is zeroed by a select.
+// tiles; builder wave bw owns image tiles 2*bw, 2*bw+1 and all 8 row tiles.  Row tile i belongs to
+// sub-space m0 + i/KT and starts at code word (i % KT)*16  (KT = K/16 in {1, 2, 4, 8}).  Operands are
+// fetched into registers (mfma_load) a whole stage period ahead of their use (mfma_store).  All operand
+// loads are UNCONDITIONAL, at wave-uniform base + per-lane constant + immediate (device buffers carry
+// slack for the over-read of dims / sub-spaces that do not exist); what must not contribute is zeroed
+// by a select at use.
 template <int KT>
 struct MfmaOps {
-  static constexpr int NB = (KT == 8) ? 1 : 8;   // K = 128: one sub-space per stage, one activation operand
-  float a[8][2];    // code-book operand per row tile and k-step
-  float b[NB][2];   // activation operand per row tile (sub-space) and k-step
+  static constexpr int SUBS = 8 / KT;   // sub-spaces per stage
+  float a[8][2];          // code-book operand per row tile and k-step
+  float b[2][SUBS][2];    // activation operand per image tile, sub-space and k-step
 };
 
 template <int KT>
 __device__ __forceinline__ void mfma_load(MfmaOps<KT>& o, const char* __restrict__ xbase, uint32_t xoff0,
-                                          const float* __restrict__ ctrd, int Cs, int D, int m0, int mEnd, int wave,
+                                          const float* __restrict__ ctrd, int Cs, int ksteps, int m0, int bw,
                                           int lane) {
   constexpr int K = KT * 16;
-  constexpr int NB = MfmaOps<KT>::NB;
-  constexpr int SUBS = 128 / K;                               // sub-spaces per stage
+  constexpr int SUBS = MfmaOps<KT>::SUBS;
   const int li = lane & 15, lk = lane >> 4;
-  const float* __restrict__ cb = ctrd + (size_t)m0 * Cs * K + (lk * K + li);                          // + uniform
-  const char* __restrict__ xb = xbase + xoff0 + (uint32_t)(m0 * Cs) * (uint32_t)XROWB + (lk * XROWB + (wave * 16 + li) * 4);
-  const int ksteps = (min(D, Cs) > 4) ? 2 : 1;
-  (void)mEnd; (void)SUBS;
+  const float* __restrict__ cb = ctrd + (size_t)m0 * Cs * K + (lk * K + li);
+  const char* __restrict__ xb =
+      xbase + xoff0 + (uint32_t)(m0 * Cs) * (uint32_t)XROWB + (lk * XROWB + (bw * 32 + li) * 4);
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
     if (ks < ksteps) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const int mi = (i * 16) / K, kk = (i * 16) % K;       // compile-time
+        const int mi = i / KT, kk = (i % KT) * 16;             // compile-time
         o.a[i][ks] = cb[(mi * Cs + ks * 4) * K + kk];
-        if (i < NB) o.b[i][ks] = *reinterpret_cast<const float*>(xb + (mi * Cs + ks * 4) * XROWB);
       }
+#pragma unroll
+      for (int it = 0; it < 2; ++it)
+#pragma unroll
+        for (int sub = 0; sub < SUBS; ++sub)
+          o.b[it][sub][ks] = *reinterpret_cast<const float*>(xb + (sub * Cs + ks * 4) * XROWB + it * 64);
     }
   }
 }
 
-// The stage described by (m0, mEnd, D, Cs) is the one `o` was loaded for: operands of dims / sub-spaces
-// that do not exist are zeroed here (at use, so that the loads stay in flight during the gather).
+// The stage described by (m0, mEnd, D, Cs) is the one `o` was loaded for.
 template <int KT>
 __device__ __forceinline__ void mfma_store(MfmaOps<KT>& o, char* stage, int ksteps, int Cs, int D, int m0, int mEnd,
-                                           int wave, int lane) {
-  constexpr int K = KT * 16;
-  constexpr int NB = MfmaOps<KT>::NB;
-  constexpr int SUBS = 128 / K;
+                                           int bw, int lane) {
+  constexpr int SUBS = MfmaOps<KT>::SUBS;
   const int li = lane & 15, lk = lane >> 4;
   // plain: every sub-space of the stage exists and has all Cs (4 or 8) dims -> nothing to zero
   const bool plain = (m0 + SUBS <= mEnd) && (D - (m0 + SUBS - 1) * Cs >= Cs) && (Cs == 4 || Cs == 8);
@@ -162,156 +238,237 @@ __device__ __forceinline__ void mfma_store(MfmaOps<KT>& o, char* stage, int kste
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int mi = (i * 16) / K;
-        const bool ok = (ks < ksteps) && (m0 + mi < mEnd) && (ks * 4 + lk < min(D - (m0 + mi) * Cs, Cs));
-        o.a[i][ks] = ok ? o.a[i][ks] : 0.0f;
-        if (i < NB) o.b[i][ks] = ok ? o.b[i][ks] : 0.0f;
+      for (int sub = 0; sub < SUBS; ++sub) {
+        const bool ok = (ks < ksteps) && (m0 + sub < mEnd) && (ks * 4 + lk < min(D - (m0 + sub) * Cs, Cs));
+#pragma unroll
+        for (int it = 0; it < 2; ++it) o.b[it][sub][ks] = ok ? o.b[it][sub][ks] : 0.0f;
+#pragma unroll
+        for (int i = sub * KT; i < (sub + 1) * KT; ++i) o.a[i][ks] = ok ? o.a[i][ks] : 0.0f;
       }
     }
   }
-  char* w0 = stage + (lk * 4) * ROWB + (wave * 16 + li) * 4;
   const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {             // two batches of four independent tiles
-    f32x4 acc[4];
+  for (int it = 0; it < 2; ++it) {
+    char* w0 = stage + (lk * 4) * ROWB + (bw * 32 + it * 16 + li) * 4;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int i = 4 * h + j;
-      acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a[i][0], o.b[NB == 1 ? 0 : i][0], zero, 0, 0, 0);
-    }
-    if (ksteps > 1) {
+    for (int h = 0; h < 2; ++h) {            // batches of four independent tiles
+      f32x4 acc[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int i = 4 * h + j;
-        acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a[i][1], o.b[NB == 1 ? 0 : i][1], acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a[i][0], o.b[it][i / KT][0], zero, 0, 0, 0);
       }
-    }
+      if (ksteps > 1) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      char* w = w0 + (4 * h + j) * 16 * ROWB;
-      *reinterpret_cast<float*>(w) = acc[j][0];
-      *reinterpret_cast<float*>(w + ROWB) = acc[j][1];
-      *reinterpret_cast<float*>(w + 2 * ROWB) = acc[j][2];
-      *reinterpret_cast<float*>(w + 3 * ROWB) = acc[j][3];
+        for (int j = 0; j < 4; ++j) {
+          const int i = 4 * h + j;
+          acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a[i][1], o.b[it][i / KT][1], acc[j], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        char* w = w0 + (4 * h + j) * 16 * ROWB;
+        *reinterpret_cast<float*>(w) = acc[j][0];
+        *reinterpret_cast<float*>(w + ROWB) = acc[j][1];
+        *reinterpret_cast<float*>(w + 2 * ROWB) = acc[j][2];
+        *reinterpret_cast<float*>(w + 3 * ROWB) = acc[j][3];
+      }
     }
   }
 }
 
 // ------------------------------------------------------------------------------------------------
-// conv: TH x TW output positions, 8 waves, CPW channels per wave; KT = K/16 for the MFMA builder,
-// KT = 0 selects the exact builder (any K <= 128).
+// conv.  Workgroup = 16 waves = one 128-image panel x a TH x TW tile of output positions x NC*CPW
+// output channels of one group.  Stages (source pixel row-major, sub-space group ascending) are double
+// buffered in LDS, one s_barrier per stage.  The waves are SPECIALISED, so that the chain "MFMA -> LDS
+// write" of stage s+1 and the chain "LDS read -> add" of stage s run concurrently instead of one after
+// the other in every wave:
+//   builder waves 0..3 (one per SIMD):  [build stage s+1 from operands in registers] [fetch operands s+2]
+//   gather waves 4..15:                 [broadcast indices of stage s] [prefetch indices s+1] [gather stage s]
+// The tile is cut into 1 x SW strips; gather wave gw owns strip gw / NC and channels (gw % NC)*CPW ..
+// +CPW-1 and keeps SW x CPW float2 accumulators.  KT = K/16 selects the MFMA builder, KT = 0 the exact
+// builder (any K <= 128).
 // ------------------------------------------------------------------------------------------------
-template <int TH, int TW, int CPW, int KT>
+struct ConvGeom {
+  int W, Cin, knl, M, Ct, MG, G, wiL, wiU;
+};
+struct StagePos {
+  int hi, wi, mg;
+};
+__device__ __forceinline__ StagePos next_pos(const StagePos& c, const ConvGeom& g) {
+  StagePos n = c;
+  if (++n.mg == g.MG) {
+    n.mg = 0;
+    if (++n.wi > g.wiU) { n.wi = g.wiL; ++n.hi; }
+  }
+  return n;
+}
+__device__ __forceinline__ uint32_t pixel_off(const StagePos& c, const ConvGeom& g) {
+  return (uint32_t)(c.hi * g.W + c.wi) * (uint32_t)g.Cin * (uint32_t)XROWB;
+}
+
+// indices of the first sub-space of stage c for every position of the wave's strip (taps that do not
+// exist are clamped to an existing one: the load is harmless, the gather skips them)
+template <int SW, int CPW>
+__device__ __forceinline__ void conv_prefetch_idx(Idx<CPW / 4> (&v)[SW], const StagePos& c, const ConvGeom& g,
+                                                  const uint8_t* __restrict__ rowsC, int rowStart,
+                                                  const int (&colStart)[SW], uint32_t vzero) {
+  const int kh = min(max(c.hi - rowStart, 0), g.knl - 1);
+#pragma unroll
+  for (int dx = 0; dx < SW; ++dx) {
+    const int kw = min(max(c.wi - colStart[dx], 0), g.knl - 1);
+    vload_idx(v[dx], rowsC + (size_t)((kh * g.knl + kw) * g.M + c.mg * g.G) * g.Ct, vzero);
+  }
+}
+
+template <int SW, int CPW, bool ONE>
+__device__ __forceinline__ void conv_gather(f32x2 (&acc)[SW][CPW], const Idx<CPW / 4> (&first)[SW], const StagePos& c,
+                                            const ConvGeom& g, const uint8_t* __restrict__ rowsC, int rowStart,
+                                            const int (&colStart)[SW], uint32_t stage) {
+  const int kh = c.hi - rowStart;
+  const bool rowOk = (unsigned)kh < (unsigned)g.knl;
+#pragma unroll
+  for (int dx = 0; dx < SW; ++dx) {
+    const int kw = c.wi - colStart[dx];
+    const int valid = uni((rowOk && (unsigned)kw < (unsigned)g.knl) ? 1 : 0);
+    gather_apply<CPW>(acc[dx], first[dx], stage, valid);
+    if (!ONE) {                              // further sub-spaces of the stage (K <= 64 only)
+      const int m0 = c.mg * g.G;
+      const int n = valid ? min(g.M, m0 + g.G) - m0 : 0;
+      for (int i = 1; i < n; ++i) {
+        Idx<CPW / 4> more;
+        sload_idx(more, rowsC + (size_t)((kh * g.knl + kw) * g.M + m0 + i) * g.Ct);
+        gather_apply<CPW>(acc[dx], more, stage, 1);
+      }
+    }
+  }
+}
+
+template <int TH, int TW, int SW, int CPW, int KT>
 __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX, int chunksPerGrp, int G) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  constexpr int NT = TH * TW;
+  static_assert(TW % SW == 0, "strips tile the row");
+  constexpr int SPR = TW / SW;            // strips per tile row
+  constexpr int NSTRIP = TH * SPR;
+  static_assert(NGW % NSTRIP == 0, "gather waves split evenly over strips");
+  constexpr int NC = NGW / NSTRIP;        // channel chunks (of CPW) inside the workgroup
   constexpr int KTT = KT > 0 ? KT : 1;
   const int lane = threadIdx.x & 63;
   const int wave = uni(threadIdx.x >> 6);
   const int ty = blockIdx.x / tilesX, tx = blockIdx.x % tilesX;
-  const int g = blockIdx.y / chunksPerGrp, chunk = blockIdx.y % chunksPerGrp;
+  const int grp = blockIdx.y / chunksPerGrp, chunk = blockIdx.y % chunksPerGrp;
   const int panel = blockIdx.z;
   const int Cg = p.Cin / p.grp, Ctg = p.Ct / p.grp;
-  const int cw0 = chunk * (NW * CPW) + wave * CPW;   // first channel of this wave inside the group
-  const int ccnt = min(CPW, Ctg - cw0);              // <= 0: the wave only helps building stages
-  const int c0 = g * Ctg + cw0;
-  const int K = p.K, M = p.M, Cs = p.Cs;
-  const int MG = (M + G - 1) / G;                    // stages per source pixel
-  const int MCt = M * p.Ct;
-  const int ksteps = (min(Cg, Cs) > 4) ? 2 : 1;      // MFMA k-steps (4 dims each) that carry data
-
-  const char* __restrict__ xbase =
-      reinterpret_cast<const char*>(p.src + ((size_t)panel * p.H * p.W * p.Cin + (size_t)g * Cg) * PANEL);
-
-  f32x2 acc[NT][CPW];
-  {
-    const float* __restrict__ bp = p.bias + c0;   // reads past the last channel stay inside the arena
-#pragma unroll
-    for (int c = 0; c < CPW; ++c) {
-      const float b = bp[c];
-#pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t][c] = f32x2{b, b};
-    }
-  }
+  const int M = p.M;
 
   const int ho0 = ty * TH, wo0 = tx * TW;
   const int hoL = min(ho0 + TH, p.Ho) - 1, woL = min(wo0 + TW, p.Wo) - 1;   // last real position of the tile
   const int hiL = max(0, ho0 * p.stride - p.pad), hiU = min(p.H - 1, hoL * p.stride - p.pad + p.knl - 1);
-  const int wiL = max(0, wo0 * p.stride - p.pad), wiU = min(p.W - 1, woL * p.stride - p.pad + p.knl - 1);
-  const int S = (hiU - hiL + 1) * (wiU - wiL + 1) * MG;
+  ConvGeom g;
+  g.W = p.W; g.Cin = p.Cin; g.knl = p.knl; g.M = M; g.Ct = p.Ct; g.G = G;
+  g.MG = (M + G - 1) / G;                           // stages per source pixel
+  g.wiL = max(0, wo0 * p.stride - p.pad);
+  g.wiU = min(p.W - 1, woL * p.stride - p.pad + p.knl - 1);
+  const int S = (hiU - hiL + 1) * (g.wiU - g.wiL + 1) * g.MG;
+  const StagePos first = {hiL, g.wiL, 0};
 
-  // first source row / column of every position of the tile; positions outside the map get a start that
-  // can never match a tap
-  int rowStart[TH], colStart[TW];
-#pragma unroll
-  for (int dy = 0; dy < TH; ++dy) rowStart[dy] = (ho0 + dy < p.Ho) ? (ho0 + dy) * p.stride - p.pad : -(1 << 28);
-#pragma unroll
-  for (int dx = 0; dx < TW; ++dx) colStart[dx] = (wo0 + dx < p.Wo) ? (wo0 + dx) * p.stride - p.pad : -(1 << 28);
-
-  MfmaOps<KTT> ops;
-  int hi = hiL, wi = wiL, mg = 0;
-  {
-    const uint32_t xoff0 = (uint32_t)(hi * p.W + wi) * p.Cin * (uint32_t)XROWB;
+  if (wave < NBW) {
+    // ---------------------------------------------------------------- builder wave ----
+    const int bw = wave;
+    const int K = p.K, Cs = p.Cs;
+    const int ksteps = (min(Cg, Cs) > 4) ? 2 : 1;      // MFMA k-steps (4 dims each) that carry data
+    const char* __restrict__ xbase =
+        reinterpret_cast<const char*>(p.src + ((size_t)panel * p.H * p.W * p.Cin + (size_t)grp * Cg) * PANEL);
+    MfmaOps<KTT> ops;
+    StagePos c1 = next_pos(first, g);
+    StagePos c2 = next_pos(c1, g);
     if (KT > 0) {
-      mfma_load<KTT>(ops, xbase, xoff0, p.ctrd, Cs, Cg, 0, M, wave, lane);
-      mfma_store<KTT>(ops, lds, ksteps, Cs, Cg, 0, M, wave, lane);
+      mfma_load<KTT>(ops, xbase, pixel_off(first, g), p.ctrd, Cs, ksteps, 0, bw, lane);
+      mfma_store<KTT>(ops, lds, ksteps, Cs, Cg, 0, M, bw, lane);
+      if (S > 1) mfma_load<KTT>(ops, xbase, pixel_off(c1, g), p.ctrd, Cs, ksteps, c1.mg * G, bw, lane);
     } else {
-      build_stage_exact(lds, xbase, xoff0, p.ctrd, K, Cs, Cg, G, 0, M, wave, lane);
+      build_stage_exact(lds, xbase, pixel_off(first, g), p.ctrd, K, Cs, Cg, G, 0, M, bw, lane);
     }
-  }
-  __syncthreads();
-
-  for (int s = 0; s < S; ++s) {
-    int mgn = mg + 1, wn = wi, hn = hi;
-    if (mgn == MG) {
-      mgn = 0;
-      if (++wn > wiU) { wn = wiL; ++hn; }
-    }
-    const bool more = s + 1 < S;
-    const uint32_t xoffN = (uint32_t)((more ? hn : hi) * p.W + (more ? wn : wi)) * p.Cin * (uint32_t)XROWB;
-    if (KT > 0 && more) mfma_load<KTT>(ops, xbase, xoffN, p.ctrd, Cs, Cg, mgn * G, M, wave, lane);
-
-    if (ccnt > 0) {
-      const char* stage = lds + (s & 1) * STAGE_BYTES + lane * 8;
-      const int mLast = min(M, (mg + 1) * G);
-      for (int m = mg * G; m < mLast; ++m) {
-        const uint32_t* __restrict__ tapBase = p.offs + m * p.Ct + c0;
-#pragma unroll
-        for (int dy = 0; dy < TH; ++dy) {
-          const int kh = hi - rowStart[dy];
-          if ((unsigned)kh < (unsigned)p.knl) {
-#pragma unroll
-            for (int dx = 0; dx < TW; ++dx) {
-              const int kw = wi - colStart[dx];
-              if ((unsigned)kw < (unsigned)p.knl)
-                gather_row<CPW>(acc[dy * TW + dx], tapBase + (kh * p.knl + kw) * MCt, stage);
-            }
-          }
-        }
+    barrier_after_lds_writes();
+    for (int s = 0; s < S; ++s) {
+      if (s + 1 < S) {
+        char* nstage = lds + ((s + 1) & 1) * STAGE_BYTES;
+        if (KT > 0) mfma_store<KTT>(ops, nstage, ksteps, Cs, Cg, c1.mg * G, M, bw, lane);
+        else build_stage_exact(nstage, xbase, pixel_off(c1, g), p.ctrd, K, Cs, Cg, G, c1.mg * G, M, bw, lane);
       }
+      if (KT > 0 && s + 2 < S) mfma_load<KTT>(ops, xbase, pixel_off(c2, g), p.ctrd, Cs, ksteps, c2.mg * G, bw, lane);
+      barrier_after_lds_writes();
+      c1 = c2; c2 = next_pos(c2, g);
     }
-
-    if (more) {
-      char* nstage = lds + ((s + 1) & 1) * STAGE_BYTES;
-      if (KT > 0) mfma_store<KTT>(ops, nstage, ksteps, Cs, Cg, mgn * G, M, wave, lane);
-      else build_stage_exact(nstage, xbase, xoffN, p.ctrd, K, Cs, Cg, G, mgn * G, M, wave, lane);
-    }
-    __syncthreads();
-    hi = hn; wi = wn; mg = mgn;
+    return;
   }
 
-  if (ccnt > 0) {
+  // ------------------------------------------------------------------ gather wave ----
+  const int gw = wave - NBW;
+  const int strip = gw / NC, cc = gw % NC;
+  const int sdy = strip / SPR, sdx0 = (strip % SPR) * SW;
+  const int cw0 = chunk * (NC * CPW) + cc * CPW;     // first channel of this wave inside the group
+  const int ccnt = min(CPW, Ctg - cw0);
+  const int ho = ho0 + sdy;
+  const bool active = ccnt > 0 && ho < p.Ho;         // waves without channels / outside the map only keep the barriers
+  const int c0 = grp * Ctg + (active ? cw0 : 0);
+  const uint8_t* __restrict__ rowsC = p.rows + c0;
+  uint32_t vzero;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
+  const uint32_t ldsBase = (uint32_t)(uintptr_t)lds;   // LDS byte address of the dynamic segment
+
+  f32x2 acc[SW][CPW];
+  {
+    const float* __restrict__ bp = p.bias + c0;   // reads past the last channel stay inside the arena
+#pragma unroll
+    for (int cb = 0; cb < CPW; cb += 4) {         // four at a time: few bias temporaries alive
+      float b[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = bp[cb + j];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int dx = 0; dx < SW; ++dx) acc[dx][cb + j] = f32x2{b[j], b[j]};
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // first source row / column of the strip's positions; positions outside the map get a start that can
+  // never match a tap
+  const int rowStart = active ? ho * p.stride - p.pad : -(1 << 28);
+  int colStart[SW];
+#pragma unroll
+  for (int dx = 0; dx < SW; ++dx) {
+    const int wo = wo0 + sdx0 + dx;
+    colStart[dx] = (wo < p.Wo) ? wo * p.stride - p.pad : -(1 << 28);
+  }
+
+  Idx<CPW / 4> vidx[SW], sidx[SW];
+  StagePos c0p = first;
+  StagePos c1p = next_pos(c0p, g);
+  conv_prefetch_idx<SW, CPW>(vidx, c0p, g, rowsC, rowStart, colStart, vzero);
+  barrier_plain();
+  for (int s = 0; s < S; ++s) {
+#pragma unroll
+    for (int dx = 0; dx < SW; ++dx) bcast_idx(sidx[dx], vidx[dx]);
+    conv_prefetch_idx<SW, CPW>(vidx, c1p, g, rowsC, rowStart, colStart, vzero);   // past the last stage: clamped, unused
+    conv_gather<SW, CPW, KT == 8>(acc, sidx, c0p, g, rowsC, rowStart, colStart,
+                                  ldsBase + (uint32_t)((s & 1) * STAGE_BYTES + lane * 8));
+    barrier_plain();
+    c0p = c1p; c1p = next_pos(c1p, g);
+  }
+
+  if (active) {
     float* __restrict__ dst = p.dst + (size_t)panel * p.Ho * p.Wo * p.Ct * PANEL;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const int ho = ho0 + t / TW, wo = wo0 + t % TW;
-      if (ho < p.Ho && wo < p.Wo) {
+    for (int dx = 0; dx < SW; ++dx) {
+      const int wo = wo0 + sdx0 + dx;
+      if (wo < p.Wo) {
         float* o = dst + ((size_t)(ho * p.Wo + wo) * p.Ct + c0) * PANEL + 2 * lane;
 #pragma unroll
         for (int c = 0; c < CPW; ++c) {
           if (c < ccnt) {
-            f32x2 v = acc[t][c];
+            f32x2 v = acc[dx][c];
             if (p.relu) {
               v.x = (0.0f < v.x) ? v.x : 0.0f;
               v.y = (0.0f < v.y) ? v.y : 0.0f;
@@ -325,8 +482,10 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
 }
 
 // ------------------------------------------------------------------------------------------------
-// fully connected: stages of G sub-spaces, CPW channels per wave, optional split over the sub-space
-// axis (blockIdx.z): partial sums go to p.partial and are reduced by k_sum_partials.
+// fully connected: stages of G sub-spaces; 4 builder waves + 12 gather waves x CPW channels, as in the
+// conv kernel; the gather waves walk a stream of groups (one sub-space each) with the indices of the
+// next group always in flight.  Optional split over the sub-space axis (blockIdx.z): partial sums go
+// to p.partial and are reduced by k_sum_partials.
 // ------------------------------------------------------------------------------------------------
 template <int CPW, int KT>
 __global__ __launch_bounds__(NW * 64) void k_fc_aprx(FcParams p, int G, int stagesPerSplit) {
@@ -336,53 +495,84 @@ __global__ __launch_bounds__(NW * 64) void k_fc_aprx(FcParams p, int G, int stag
   const int wave = uni(threadIdx.x >> 6);
   const int panel = blockIdx.y;
   const int split = blockIdx.z;
-  const int cw0 = blockIdx.x * (NW * CPW) + wave * CPW;
-  const int ccnt = min(CPW, p.Ct - cw0);
-  const int K = p.K, M = p.M, Cs = p.Cs;
+  const int M = p.M;
   const int mBeg = split * stagesPerSplit * G;
   const int mEnd = min(M, mBeg + stagesPerSplit * G);
   const int S = (mEnd - mBeg + G - 1) / G;
-  const char* __restrict__ xbase = reinterpret_cast<const char*>(p.src + (size_t)panel * p.D * PANEL);
-  const int ksteps = (min(p.D, Cs) > 4) ? 2 : 1;
+
+  if (wave < NBW) {
+    const int bw = wave;
+    const int K = p.K, Cs = p.Cs;
+    const char* __restrict__ xbase = reinterpret_cast<const char*>(p.src + (size_t)panel * p.D * PANEL);
+    const int ksteps = (min(p.D, Cs) > 4) ? 2 : 1;
+    MfmaOps<KTT> ops;
+    if (S > 0) {
+      if (KT > 0) {
+        mfma_load<KTT>(ops, xbase, 0u, p.ctrd, Cs, ksteps, mBeg, bw, lane);
+        mfma_store<KTT>(ops, lds, ksteps, Cs, p.D, mBeg, mEnd, bw, lane);
+        if (S > 1) mfma_load<KTT>(ops, xbase, 0u, p.ctrd, Cs, ksteps, mBeg + G, bw, lane);
+      } else {
+        build_stage_exact(lds, xbase, 0u, p.ctrd, K, Cs, p.D, G, mBeg, mEnd, bw, lane);
+      }
+    }
+    barrier_after_lds_writes();
+    for (int s = 0; s < S; ++s) {
+      const int m0 = mBeg + s * G;
+      if (s + 1 < S) {
+        char* nstage = lds + ((s + 1) & 1) * STAGE_BYTES;
+        if (KT > 0) mfma_store<KTT>(ops, nstage, ksteps, Cs, p.D, m0 + G, mEnd, bw, lane);
+        else build_stage_exact(nstage, xbase, 0u, p.ctrd, K, Cs, p.D, G, m0 + G, mEnd, bw, lane);
+      }
+      if (KT > 0 && s + 2 < S) mfma_load<KTT>(ops, xbase, 0u, p.ctrd, Cs, ksteps, m0 + 2 * G, bw, lane);
+      barrier_after_lds_writes();
+    }
+    return;
+  }
+
+  const int gw = wave - NBW;
+  const int cw0r = blockIdx.x * (NGW * CPW) + gw * CPW;
+  const int ccnt = min(CPW, p.Ct - cw0r);
+  const bool active = ccnt > 0;
+  const int cw0 = active ? cw0r : 0;
+  const uint8_t* __restrict__ rowsC = p.rows + cw0;
+  uint32_t vzero;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
+  const uint32_t ldsBase = (uint32_t)(uintptr_t)lds;   // LDS byte address of the dynamic segment
 
   f32x2 acc[CPW];
 #pragma unroll
-  for (int c = 0; c < CPW; ++c) {
-    const float b = (split == 0) ? p.bias[cw0 + c] : 0.0f;   // over-read stays inside the arena
-    acc[c] = f32x2{b, b};
-  }
-
-  MfmaOps<KTT> ops;
-  if (S > 0) {
-    if (KT > 0) {
-      mfma_load<KTT>(ops, xbase, 0u, p.ctrd, Cs, p.D, mBeg, mEnd, wave, lane);
-      mfma_store<KTT>(ops, lds, ksteps, Cs, p.D, mBeg, mEnd, wave, lane);
-    } else {
-      build_stage_exact(lds, xbase, 0u, p.ctrd, K, Cs, p.D, G, mBeg, mEnd, wave, lane);
+  for (int c = 0; c < CPW; ++c) acc[c] = f32x2{0.0f, 0.0f};
+  if (split == 0) {
+    const float* __restrict__ bp = p.bias + cw0;   // over-read stays inside the arena
+#pragma unroll
+    for (int cb = 0; cb < CPW; cb += 4) {
+      float b[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = bp[cb + j];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[cb + j] = f32x2{b[j], b[j]};
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
-  __syncthreads();
 
+  Idx<CPW / 4> vidx, sidx;
+  if (S > 0) vload_idx(vidx, rowsC + (size_t)mBeg * p.Ct, vzero);
+  barrier_plain();
   for (int s = 0; s < S; ++s) {
     const int m0 = mBeg + s * G;
-    const bool more = s + 1 < S;
-    if (KT > 0 && more) mfma_load<KTT>(ops, xbase, 0u, p.ctrd, Cs, p.D, m0 + G, mEnd, wave, lane);
-
-    if (ccnt > 0) {
-      const char* stage = lds + (s & 1) * STAGE_BYTES + lane * 8;
-      const int mLast = min(mEnd, m0 + G);
-      for (int m = m0; m < mLast; ++m) gather_row<CPW>(acc, p.offs + (size_t)m * p.Ct + cw0, stage);
+    const int mLast = min(mEnd, m0 + G);
+    const uint32_t stage = ldsBase + (uint32_t)((s & 1) * STAGE_BYTES + lane * 8);
+    if (active) {
+      for (int m = m0; m < mLast; ++m) {
+        bcast_idx(sidx, vidx);
+        if (m + 1 < mEnd) vload_idx(vidx, rowsC + (size_t)(m + 1) * p.Ct, vzero);
+        gather_apply<CPW>(acc, sidx, stage, 1);
+      }
     }
-
-    if (more) {
-      char* nstage = lds + ((s + 1) & 1) * STAGE_BYTES;
-      if (KT > 0) mfma_store<KTT>(ops, nstage, ksteps, Cs, p.D, m0 + G, mEnd, wave, lane);
-      else build_stage_exact(nstage, xbase, 0u, p.ctrd, K, Cs, p.D, G, m0 + G, mEnd, wave, lane);
-    }
-    __syncthreads();
+    barrier_plain();
   }
 
-  if (ccnt > 0) {
+  if (active) {
     float* base = (p.msplit > 1) ? p.partial + (size_t)split * p.panels * p.Ct * PANEL : p.dst;
     float* o = base + ((size_t)panel * p.Ct + cw0) * PANEL + 2 * lane;
 #pragma unroll
@@ -596,19 +786,20 @@ __global__ __launch_bounds__(256) void k_unpack(const float* __restrict__ src, f
 
 inline int panels_of(int n) { return (n + PANEL - 1) / PANEL; }
 
-template <int TH, int TW, int CPW>
+template <int TH, int TW, int SW, int CPW>
 hipError_t launch_conv(const ConvParams& p, int lutMode, hipStream_t st) {
+  constexpr int NC = NGW / (TH * (TW / SW));
   const int Ctg = p.Ct / p.grp;
   const int tilesX = (p.Wo + TW - 1) / TW, tilesY = (p.Ho + TH - 1) / TH;
-  const int chunksPerGrp = (Ctg + NW * CPW - 1) / (NW * CPW);
+  const int chunksPerGrp = (Ctg + NC * CPW - 1) / (NC * CPW);
   const dim3 grid(tilesX * tilesY, chunksPerGrp * p.grp, p.panels);
   const size_t shm = (size_t)2 * STAGE_BYTES;
   const int G = qcnn_stage_group(p.K);
-  auto kern = k_conv_aprx<TH, TW, CPW, 0>;
-  if (lutMode == 1 && p.K == 128) kern = k_conv_aprx<TH, TW, CPW, 8>;
-  if (lutMode == 1 && p.K == 64) kern = k_conv_aprx<TH, TW, CPW, 4>;
-  if (lutMode == 1 && p.K == 32) kern = k_conv_aprx<TH, TW, CPW, 2>;
-  if (lutMode == 1 && p.K == 16) kern = k_conv_aprx<TH, TW, CPW, 1>;
+  auto kern = k_conv_aprx<TH, TW, SW, CPW, 0>;
+  if (lutMode == 1 && p.K == 128) kern = k_conv_aprx<TH, TW, SW, CPW, 8>;
+  if (lutMode == 1 && p.K == 64) kern = k_conv_aprx<TH, TW, SW, CPW, 4>;
+  if (lutMode == 1 && p.K == 32) kern = k_conv_aprx<TH, TW, SW, CPW, 2>;
+  if (lutMode == 1 && p.K == 16) kern = k_conv_aprx<TH, TW, SW, CPW, 1>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)shm);
   if (e != hipSuccess) return e;
@@ -621,7 +812,7 @@ hipError_t launch_fc(const FcParams& p, int lutMode, hipStream_t st) {
   const int G = qcnn_stage_group(p.K);
   const int stages = (p.M + G - 1) / G;
   const int stagesPerSplit = (stages + p.msplit - 1) / p.msplit;
-  const dim3 grid((p.Ct + NW * CPW - 1) / (NW * CPW), p.panels, p.msplit);
+  const dim3 grid((p.Ct + NGW * CPW - 1) / (NGW * CPW), p.panels, p.msplit);
   const size_t shm = (size_t)2 * STAGE_BYTES;
   auto kern = k_fc_aprx<CPW, 0>;
   if (lutMode == 1 && p.K == 128) kern = k_fc_aprx<CPW, 8>;
@@ -637,29 +828,34 @@ hipError_t launch_fc(const FcParams& p, int lutMode, hipStream_t st) {
 
 }  // namespace
 
-// Tile selection: 8 waves; channels-per-wave from the group's channel count; the position tile is as
-// large as ~72 float2 accumulators per lane allow (more starve the LDS-read pipeline of registers).
-// The MFMA builder is instantiated for K in {16, 32, 64, 128}; any other K <= 128 runs the exact builder.
+// Tile selection (12 gather waves): the workgroup covers all channels of a group whenever <= 32 float2
+// accumulators per wave allow it (every further channel chunk would rebuild the same LUT stages), and
+// as many positions as the accumulators then leave room for.  The MFMA builder is instantiated for K in
+// {16, 32, 64, 128}; any other K <= 128 runs the exact builder.
 hipError_t qk_conv_aprx(const ConvParams& p, int lutMode, hipStream_t st) {
   const int Ctg = p.Ct / p.grp;
   if (Ctg % 4 || p.Cs > QCNN_MAX_CS || p.K > QCNN_MAX_K) return hipErrorInvalidValue;
-  if (Ctg % 384 == 0) return launch_conv<1, 1, 48>(p, lutMode, st);
-  if (Ctg % 256 == 0) return launch_conv<1, 2, 32>(p, lutMode, st);
-  if (Ctg % 192 == 0) return launch_conv<1, 3, 24>(p, lutMode, st);
-  if (Ctg % 128 == 0) return launch_conv<2, 2, 16>(p, lutMode, st);
-  if (Ctg % 96 == 0) return launch_conv<2, 3, 12>(p, lutMode, st);
-  if (Ctg % 64 == 0) return launch_conv<2, 4, 8>(p, lutMode, st);
-  if (Ctg > 64) return launch_conv<2, 2, 16>(p, lutMode, st);
-  return launch_conv<3, 4, 4>(p, lutMode, st);
+  if (Ctg % 384 == 0) return launch_conv<1, 1, 1, 32>(p, lutMode, st);    // 12 x 32
+  if (Ctg > 192 && Ctg <= 288) return launch_conv<1, 1, 1, 24>(p, lutMode, st);   // 12 x 24
+  if (Ctg % 192 == 0) return launch_conv<1, 2, 1, 32>(p, lutMode, st);    // 2 positions x 6 x 32
+  if (Ctg % 128 == 0) return launch_conv<1, 3, 1, 32>(p, lutMode, st);    // 3 positions x 4 x 32
+  if (Ctg % 96 == 0) return launch_conv<2, 2, 2, 16>(p, lutMode, st);     // 2 strips of 2 x 6 x 16
+  if (Ctg % 64 == 0) return launch_conv<1, 6, 2, 16>(p, lutMode, st);     // 3 strips of 2 x 4 x 16
+  if (Ctg <= 48) return launch_conv<1, 4, 4, 4>(p, lutMode, st);          // 1 strip of 4 x 12 x 4
+  return launch_conv<1, 3, 1, 32>(p, lutMode, st);
 }
+
+static int fc_channels_per_wave(int Ct) { return Ct >= 384 ? 32 : (Ct >= 96 ? 8 : 4); }
+int qk_fc_channels_per_block(int Ct) { return NGW * fc_channels_per_wave(Ct); }
 
 // p.msplit is chosen by the caller (engine): 1 keeps the reference's summation order.
 hipError_t qk_fc_aprx(const FcParams& p, int lutMode, hipStream_t st) {
   if (p.Ct % 4 || p.Cs > QCNN_MAX_CS || p.K > QCNN_MAX_K || p.msplit < 1) return hipErrorInvalidValue;
-  if (p.Ct >= 2048) return launch_fc<64>(p, lutMode, st);
-  if (p.Ct >= 512) return launch_fc<32>(p, lutMode, st);
-  if (p.Ct >= 64) return launch_fc<8>(p, lutMode, st);
-  return launch_fc<4>(p, lutMode, st);
+  switch (fc_channels_per_wave(p.Ct)) {
+    case 32: return launch_fc<32>(p, lutMode, st);
+    case 8: return launch_fc<8>(p, lutMode, st);
+    default: return launch_fc<4>(p, lutMode, st);
+  }
 }
 
 hipError_t qk_sum_partials(const float* partial, float* dst, int msplit, size_t n, int relu, hipStream_t st) {
