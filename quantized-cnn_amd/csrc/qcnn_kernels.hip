@@ -46,6 +46,34 @@ __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlan
 __device__ __forceinline__ void barrier_after_lds_writes() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ void barrier_plain() { asm volatile("s_barrier" ::: "memory"); }
 
+// Role assignment.  The matrix pipe is per SIMD, so the four builder waves must sit on four DIFFERENT
+// SIMDs; which SIMD a wave lands on is the dispatcher's choice (not a function of the wave index that
+// software may rely on), so every wave publishes its SIMD id (HW_REG_HW_ID[5:4]) through LDS and the
+// first wave of each SIMD becomes that SIMD's builder (bw = SIMD id); the other twelve waves get dense
+// gather indices.  128 VGPRs per wave force exactly four waves per SIMD for a 16-wave workgroup.
+struct WaveRole {
+  bool builder;
+  int idx;      // builder: 0..3 (SIMD id); gather wave: 0..11
+};
+__device__ __forceinline__ WaveRole assign_roles(char* lds, int wave, int lane) {
+  int* tab = reinterpret_cast<int*>(lds);
+  const int simd = (int)(__builtin_amdgcn_s_getreg(4 | (4 << 6) | (1 << 11)) & 3u);   // hwreg(HW_REG_HW_ID, 4, 2)
+  if (lane == 0) tab[wave] = simd;
+  __syncthreads();
+  WaveRole r = {false, 0};
+  int seen = 0, gathers = 0;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) {
+    const int sw = uni(tab[w]);
+    const bool b = !((seen >> sw) & 1);
+    seen |= 1 << sw;
+    if (w == wave) { r.builder = b; r.idx = b ? sw : gathers; }
+    if (!b) ++gathers;
+  }
+  __syncthreads();   // the table is dead: the first LUT stage may overwrite it
+  return r;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Gather (gather waves).  The code-word ROW INDICES (uint8, 0..127: (m mod G)*K + assignment) of
 // CPW consecutive output channels are wave-uniform.  They are prefetched one group ahead as packed
@@ -79,57 +107,57 @@ __device__ __forceinline__ void sload_idx(Idx<N4>& o, const uint8_t* __restrict_
   for (int j = 0; j < N4; ++j) o.w[j] = (uint32_t)__builtin_amdgcn_readfirstlane((int)ap4[j]);
 }
 
-// One hand-scheduled block of 4 (gather4) or 8 (gather8) look-ups: row byte offsets on the scalar unit
-// (s_and/s_bfe/s_lshr + s_mulk 528), v_add_u32 with the lane's stage address, all ds_read_b64 issued
-// back to back, then counted s_waitcnt + v_pk_add_f32 IN PLACE (tied operands: an accumulator never
-// changes register).  The counted waits stay correct with other lgkm operations outstanding at entry:
-// LDS returns in order, so "at most N outstanding" implies the first 8-N reads of the block are back.
-// `valid` (wave-uniform) = 0 skips the block with a branch INSIDE the asm text, so that the compiler
-// sees straight-line code and keeps every accumulator in one register for the whole kernel.
-#define QCNN_LK(ext, w, a, v)                                                                      \
-  ext " %[t], %[" w "]\n\ts_mulk_i32 %[t], 0x210\n\tv_add_u32 %[" a "], %[t], %[b]\n\tds_read_b64 %[" v "], %[" a "]\n\t"
-#define QCNN_LK4(w, v0, v1, v2, v3)                                                               \
-  "s_and_b32 %[t], %[" w "], 0xff\n\ts_mulk_i32 %[t], 0x210\n\tv_add_u32 %[a0], %[t], %[b]\n\tds_read_b64 %[" v0 "], %[a0]\n\t" \
-  "s_bfe_u32 %[t], %[" w "], 0x80008\n\ts_mulk_i32 %[t], 0x210\n\tv_add_u32 %[a1], %[t], %[b]\n\tds_read_b64 %[" v1 "], %[a1]\n\t" \
-  "s_bfe_u32 %[t], %[" w "], 0x80010\n\ts_mulk_i32 %[t], 0x210\n\tv_add_u32 %[a0], %[t], %[b]\n\tds_read_b64 %[" v2 "], %[a0]\n\t" \
-  "s_lshr_b32 %[t], %[" w "], 24\n\ts_mulk_i32 %[t], 0x210\n\tv_add_u32 %[a1], %[t], %[b]\n\tds_read_b64 %[" v3 "], %[a1]\n\t"
-static_assert(QCNN_ROW_BYTES == 0x210, "the look-up blocks multiply by the literal row stride");
+// One hand-scheduled block of 4 (gather4) or 8 (gather8) look-ups, software-pipelined so that no
+// instruction depends on its predecessor: all row indices are extracted on the scalar unit
+// (s_and/s_bfe/s_lshr), then all addresses are formed (v_mad_u32_u24: row * 528 + the lane's stage
+// address), then all ds_read_b64 are issued back to back, then counted s_waitcnt + v_pk_add_f32 IN PLACE
+// (tied operands: an accumulator never changes register).  The counted waits stay correct with other
+// lgkm operations outstanding at entry: LDS returns in order, so "at most N outstanding" implies the
+// first 8-N reads of the block are back.  `valid` (wave-uniform) = 0 skips the block with a branch
+// INSIDE the asm text, so that the compiler sees straight-line code and keeps every accumulator in one
+// register for the whole kernel.
+#define QCNN_X4(w, t0, t1, t2, t3)                                                                         \
+  "s_and_b32 %[" t0 "], %[" w "], 0xff\n\ts_bfe_u32 %[" t1 "], %[" w "], 0x80008\n\t"                    \
+  "s_bfe_u32 %[" t2 "], %[" w "], 0x80010\n\ts_lshr_b32 %[" t3 "], %[" w "], 24\n\t"
+#define QCNN_MAD(a, t) "v_mad_u32_u24 %[" a "], %[" t "], %[rb], %[b]\n\t"
+#define QCNN_RD(v, a) "ds_read_b64 %[" v "], %[" a "]\n\t"
+#define QCNN_ACC(n, c, v) "s_waitcnt lgkmcnt(" n ")\n\tv_pk_add_f32 %[" c "], %[" v "], %[" c "]\n\t"
 
-__device__ __forceinline__ void gather8(f32x2* acc, uint32_t w0, uint32_t w1, uint32_t base, int valid) {
+__device__ __forceinline__ void gather8(f32x2* acc, uint32_t w0, uint32_t w1, uint32_t base, uint32_t rowb, int valid) {
   f32x2 v0, v1, v2, v3, v4, v5, v6, v7;
-  uint32_t a0, a1, t;
+  uint32_t a0, a1, a2, a3, a4, a5, a6, a7, t0, t1, t2, t3, t4, t5, t6, t7;
   asm volatile("s_cmp_eq_u32 %[ok], 0\n\ts_cbranch_scc1 .Lqskip%=\n\t"
-               QCNN_LK4("w0", "v0", "v1", "v2", "v3") QCNN_LK4("w1", "v4", "v5", "v6", "v7")
-               "s_waitcnt lgkmcnt(7)\n\tv_pk_add_f32 %[c0], %[v0], %[c0]\n\t"
-               "s_waitcnt lgkmcnt(6)\n\tv_pk_add_f32 %[c1], %[v1], %[c1]\n\t"
-               "s_waitcnt lgkmcnt(5)\n\tv_pk_add_f32 %[c2], %[v2], %[c2]\n\t"
-               "s_waitcnt lgkmcnt(4)\n\tv_pk_add_f32 %[c3], %[v3], %[c3]\n\t"
-               "s_waitcnt lgkmcnt(3)\n\tv_pk_add_f32 %[c4], %[v4], %[c4]\n\t"
-               "s_waitcnt lgkmcnt(2)\n\tv_pk_add_f32 %[c5], %[v5], %[c5]\n\t"
-               "s_waitcnt lgkmcnt(1)\n\tv_pk_add_f32 %[c6], %[v6], %[c6]\n\t"
-               "s_waitcnt lgkmcnt(0)\n\tv_pk_add_f32 %[c7], %[v7], %[c7]\n"
-               ".Lqskip%=:"
+               QCNN_X4("w0", "t0", "t1", "t2", "t3") QCNN_X4("w1", "t4", "t5", "t6", "t7")
+               QCNN_MAD("a0", "t0") QCNN_MAD("a1", "t1") QCNN_MAD("a2", "t2") QCNN_MAD("a3", "t3")
+               QCNN_MAD("a4", "t4") QCNN_MAD("a5", "t5") QCNN_MAD("a6", "t6") QCNN_MAD("a7", "t7")
+               QCNN_RD("v0", "a0") QCNN_RD("v1", "a1") QCNN_RD("v2", "a2") QCNN_RD("v3", "a3")
+               QCNN_RD("v4", "a4") QCNN_RD("v5", "a5") QCNN_RD("v6", "a6") QCNN_RD("v7", "a7")
+               QCNN_ACC("7", "c0", "v0") QCNN_ACC("6", "c1", "v1") QCNN_ACC("5", "c2", "v2") QCNN_ACC("4", "c3", "v3")
+               QCNN_ACC("3", "c4", "v4") QCNN_ACC("2", "c5", "v5") QCNN_ACC("1", "c6", "v6") QCNN_ACC("0", "c7", "v7")
+               "\n.Lqskip%=:"
                : [c0] "+v"(acc[0]), [c1] "+v"(acc[1]), [c2] "+v"(acc[2]), [c3] "+v"(acc[3]), [c4] "+v"(acc[4]),
                  [c5] "+v"(acc[5]), [c6] "+v"(acc[6]), [c7] "+v"(acc[7]), [v0] "=&v"(v0), [v1] "=&v"(v1),
                  [v2] "=&v"(v2), [v3] "=&v"(v3), [v4] "=&v"(v4), [v5] "=&v"(v5), [v6] "=&v"(v6), [v7] "=&v"(v7),
-                 [a0] "=&v"(a0), [a1] "=&v"(a1), [t] "=&s"(t)
-               : [w0] "s"(w0), [w1] "s"(w1), [b] "v"(base), [ok] "s"(valid)
+                 [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3), [a4] "=&v"(a4), [a5] "=&v"(a5),
+                 [a6] "=&v"(a6), [a7] "=&v"(a7), [t0] "=&s"(t0), [t1] "=&s"(t1), [t2] "=&s"(t2), [t3] "=&s"(t3),
+                 [t4] "=&s"(t4), [t5] "=&s"(t5), [t6] "=&s"(t6), [t7] "=&s"(t7)
+               : [w0] "s"(w0), [w1] "s"(w1), [b] "v"(base), [rb] "v"(rowb), [ok] "s"(valid)
                : "scc");
 }
 
-__device__ __forceinline__ void gather4(f32x2* acc, uint32_t w0, uint32_t base, int valid) {
+__device__ __forceinline__ void gather4(f32x2* acc, uint32_t w0, uint32_t base, uint32_t rowb, int valid) {
   f32x2 v0, v1, v2, v3;
-  uint32_t a0, a1, t;
+  uint32_t a0, a1, a2, a3, t0, t1, t2, t3;
   asm volatile("s_cmp_eq_u32 %[ok], 0\n\ts_cbranch_scc1 .Lqskip%=\n\t"
-               QCNN_LK4("w0", "v0", "v1", "v2", "v3")
-               "s_waitcnt lgkmcnt(3)\n\tv_pk_add_f32 %[c0], %[v0], %[c0]\n\t"
-               "s_waitcnt lgkmcnt(2)\n\tv_pk_add_f32 %[c1], %[v1], %[c1]\n\t"
-               "s_waitcnt lgkmcnt(1)\n\tv_pk_add_f32 %[c2], %[v2], %[c2]\n\t"
-               "s_waitcnt lgkmcnt(0)\n\tv_pk_add_f32 %[c3], %[v3], %[c3]\n"
-               ".Lqskip%=:"
+               QCNN_X4("w0", "t0", "t1", "t2", "t3")
+               QCNN_MAD("a0", "t0") QCNN_MAD("a1", "t1") QCNN_MAD("a2", "t2") QCNN_MAD("a3", "t3")
+               QCNN_RD("v0", "a0") QCNN_RD("v1", "a1") QCNN_RD("v2", "a2") QCNN_RD("v3", "a3")
+               QCNN_ACC("3", "c0", "v0") QCNN_ACC("2", "c1", "v1") QCNN_ACC("1", "c2", "v2") QCNN_ACC("0", "c3", "v3")
+               "\n.Lqskip%=:"
                : [c0] "+v"(acc[0]), [c1] "+v"(acc[1]), [c2] "+v"(acc[2]), [c3] "+v"(acc[3]), [v0] "=&v"(v0),
-                 [v1] "=&v"(v1), [v2] "=&v"(v2), [v3] "=&v"(v3), [a0] "=&v"(a0), [a1] "=&v"(a1), [t] "=&s"(t)
-               : [w0] "s"(w0), [b] "v"(base), [ok] "s"(valid)
+                 [v1] "=&v"(v1), [v2] "=&v"(v2), [v3] "=&v"(v3), [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2),
+                 [a3] "=&v"(a3), [t0] "=&s"(t0), [t1] "=&s"(t1), [t2] "=&s"(t2), [t3] "=&s"(t3)
+               : [w0] "s"(w0), [b] "v"(base), [rb] "v"(rowb), [ok] "s"(valid)
                : "scc");
 }
 
@@ -137,9 +165,11 @@ __device__ __forceinline__ void gather4(f32x2* acc, uint32_t w0, uint32_t base, 
 template <int CPW>
 __device__ __forceinline__ void gather_apply(f32x2 (&acc)[CPW], const Idx<CPW / 4>& o, uint32_t stage, int valid) {
   static_assert(CPW % 4 == 0, "indices are fetched as packed dwords");
+  uint32_t rowb;
+  asm volatile("v_mov_b32 %0, 0x210" : "=v"(rowb));   // QCNN_ROW_BYTES, kept in a VGPR for v_mad_u32_u24
 #pragma unroll
-  for (int j = 0; j + 1 < CPW / 4; j += 2) gather8(&acc[4 * j], o.w[j], o.w[j + 1], stage, valid);
-  if ((CPW / 4) % 2) gather4(&acc[CPW - 4], o.w[CPW / 4 - 1], stage, valid);
+  for (int j = 0; j + 1 < CPW / 4; j += 2) gather8(&acc[4 * j], o.w[j], o.w[j + 1], stage, rowb, valid);
+  if ((CPW / 4) % 2) gather4(&acc[CPW - 4], o.w[CPW / 4 - 1], stage, rowb, valid);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -192,54 +222,57 @@ __device__ __forceinline__ void build_stage_exact(char* stage, const char* __res
 // loads are UNCONDITIONAL, at wave-uniform base + per-lane constant + immediate (device buffers carry
 // slack for the over-read of dims / sub-spaces that do not exist); what must not contribute is zeroed
 // by a select at use.
-template <int KT>
+template <int KT, int KS>
 struct MfmaOps {
   static constexpr int SUBS = 8 / KT;   // sub-spaces per stage
-  float a[8][2];          // code-book operand per row tile and k-step
-  float b[2][SUBS][2];    // activation operand per image tile, sub-space and k-step
+  float a[8][KS];          // code-book operand per row tile and k-step (KS = 1: Cs <= 4 dims, 2: Cs <= 8)
+  float b[2][SUBS][KS];    // activation operand per image tile, sub-space and k-step
 };
 
-template <int KT>
-__device__ __forceinline__ void mfma_load(MfmaOps<KT>& o, const char* __restrict__ xbase, uint32_t xoff0,
-                                          const float* __restrict__ ctrd, int Cs, int ksteps, int m0, int bw,
-                                          int lane) {
+// Addresses are (wave-uniform pointer) + (32-bit lane offset) so that the loads take the
+// "SGPR base + VGPR offset" form and need no per-load 64-bit vector arithmetic.
+template <int KT, int KS>
+__device__ __forceinline__ void mfma_load(MfmaOps<KT, KS>& o, const char* __restrict__ xbase, uint32_t xoff0,
+                                          const float* __restrict__ ctrd, int Cs, int m0, int bw, int lane) {
   constexpr int K = KT * 16;
-  constexpr int SUBS = MfmaOps<KT>::SUBS;
-  const int li = lane & 15, lk = lane >> 4;
-  const float* __restrict__ cb = ctrd + (size_t)m0 * Cs * K + (lk * K + li);
-  const char* __restrict__ xb =
-      xbase + xoff0 + (uint32_t)(m0 * Cs) * (uint32_t)XROWB + (lk * XROWB + (bw * 32 + li) * 4);
+  constexpr int SUBS = MfmaOps<KT, KS>::SUBS;
+  const uint32_t li = lane & 15, lk = lane >> 4;
+  const uint32_t laneA = lk * K + li;                                   // floats
+  const uint32_t laneB = lk * XROWB + li * 4;                            // bytes
+  const float* __restrict__ cbU = ctrd + (size_t)m0 * Cs * K;            // uniform
+  const char* __restrict__ xbU = xbase + xoff0 + (uint32_t)(m0 * Cs) * (uint32_t)XROWB + bw * 128;   // uniform
 #pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
-    if (ks < ksteps) {
+  for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int mi = i / KT, kk = (i % KT) * 16;             // compile-time
-        o.a[i][ks] = cb[(mi * Cs + ks * 4) * K + kk];
-      }
-#pragma unroll
-      for (int it = 0; it < 2; ++it)
-#pragma unroll
-        for (int sub = 0; sub < SUBS; ++sub)
-          o.b[it][sub][ks] = *reinterpret_cast<const float*>(xb + (sub * Cs + ks * 4) * XROWB + it * 64);
+    for (int i = 0; i < 8; ++i) {
+      const int mi = i / KT, kk = (i % KT) * 16;             // compile-time
+      o.a[i][ks] = (cbU + ((mi * Cs + ks * 4) * K + kk))[laneA];
     }
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+      for (int sub = 0; sub < SUBS; ++sub)
+        o.b[it][sub][ks] = *reinterpret_cast<const float*>(xbU + ((sub * Cs + ks * 4) * XROWB + it * 64) + laneB);
   }
 }
 
-// The stage described by (m0, mEnd, D, Cs) is the one `o` was loaded for.
-template <int KT>
-__device__ __forceinline__ void mfma_store(MfmaOps<KT>& o, char* stage, int ksteps, int Cs, int D, int m0, int mEnd,
-                                           int bw, int lane) {
-  constexpr int SUBS = MfmaOps<KT>::SUBS;
+// Multiply the stage `o` was loaded for (m0, mEnd, D, Cs) out into LDS.  The 16 tiles of the wave are
+// walked in pairs with a hand-made software pipeline: MFMA(pair n) is interleaved instruction by
+// instruction with the LDS writes of pair n-1, so that a write (which a single wave issues every ~15
+// cycles) always sits in the 32-cycle shadow of a matrix instruction and never waits for its own result.
+template <int KT, int KS>
+__device__ __forceinline__ void mfma_store(MfmaOps<KT, KS>& o, char* stage, int Cs, int D, int m0, int mEnd, int bw,
+                                           int lane) {
+  constexpr int SUBS = MfmaOps<KT, KS>::SUBS;
   const int li = lane & 15, lk = lane >> 4;
-  // plain: every sub-space of the stage exists and has all Cs (4 or 8) dims -> nothing to zero
-  const bool plain = (m0 + SUBS <= mEnd) && (D - (m0 + SUBS - 1) * Cs >= Cs) && (Cs == 4 || Cs == 8);
+  // plain: every sub-space of the stage exists and has all 4*KS dims -> nothing to zero
+  const bool plain = (m0 + SUBS <= mEnd) && (D - (m0 + SUBS - 1) * Cs >= 4 * KS) && (Cs == 4 * KS);
   if (!plain) {
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
       for (int sub = 0; sub < SUBS; ++sub) {
-        const bool ok = (ks < ksteps) && (m0 + sub < mEnd) && (ks * 4 + lk < min(D - (m0 + sub) * Cs, Cs));
+        const bool ok = (m0 + sub < mEnd) && (ks * 4 + lk < min(D - (m0 + sub) * Cs, Cs));
 #pragma unroll
         for (int it = 0; it < 2; ++it) o.b[it][sub][ks] = ok ? o.b[it][sub][ks] : 0.0f;
 #pragma unroll
@@ -248,33 +281,34 @@ __device__ __forceinline__ void mfma_store(MfmaOps<KT>& o, char* stage, int kste
     }
   }
   const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+  char* wl = stage + (lk * 4) * ROWB + (bw * 32 + li) * 4;
+  f32x4 pa = zero, pb = zero;           // results of the previous pair, still to be written
+  char *wa = wl, *wb = wl;
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int it = 0; it < 2; ++it) {
-    char* w0 = stage + (lk * 4) * ROWB + (bw * 32 + it * 16 + li) * 4;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {            // batches of four independent tiles
-      f32x4 acc[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int i = 4 * h + j;
-        acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a[i][0], o.b[it][i / KT][0], zero, 0, 0, 0);
-      }
-      if (ksteps > 1) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int i = 4 * h + j;
-          acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a[i][1], o.b[it][i / KT][1], acc[j], 0, 0, 0);
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        char* w = w0 + (4 * h + j) * 16 * ROWB;
-        *reinterpret_cast<float*>(w) = acc[j][0];
-        *reinterpret_cast<float*>(w + ROWB) = acc[j][1];
-        *reinterpret_cast<float*>(w + 2 * ROWB) = acc[j][2];
-        *reinterpret_cast<float*>(w + 3 * ROWB) = acc[j][3];
-      }
-    }
+  for (int n = 0; n <= 8; ++n) {        // pair n = tiles (it, i), (it, i+1) with it = n / 4, i = 2 * (n % 4)
+    const int it = (n < 8 ? n : 0) / 4, i = 2 * ((n < 8 ? n : 0) % 4);
+    f32x4 ca = zero, cb = zero;
+    if (n < 8) ca = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a[i][0], o.b[it][i / KT][0], zero, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (n > 0) { *reinterpret_cast<float*>(wa) = pa[0]; *reinterpret_cast<float*>(wa + ROWB) = pa[1]; }
+    __builtin_amdgcn_sched_barrier(0);
+    if (n < 8) cb = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a[i + 1][0], o.b[it][(i + 1) / KT][0], zero, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (n > 0) { *reinterpret_cast<float*>(wa + 2 * ROWB) = pa[2]; *reinterpret_cast<float*>(wa + 3 * ROWB) = pa[3]; }
+    __builtin_amdgcn_sched_barrier(0);
+    if (KS > 1 && n < 8) ca = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a[i][KS - 1], o.b[it][i / KT][KS - 1], ca, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (n > 0) { *reinterpret_cast<float*>(wb) = pb[0]; *reinterpret_cast<float*>(wb + ROWB) = pb[1]; }
+    __builtin_amdgcn_sched_barrier(0);
+    if (KS > 1 && n < 8)
+      cb = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a[i + 1][KS - 1], o.b[it][(i + 1) / KT][KS - 1], cb, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (n > 0) { *reinterpret_cast<float*>(wb + 2 * ROWB) = pb[2]; *reinterpret_cast<float*>(wb + 3 * ROWB) = pb[3]; }
+    __builtin_amdgcn_sched_barrier(0);
+    pa = ca; pb = cb;
+    wa = wl + it * 64 + i * 16 * ROWB;
+    wb = wa + 16 * ROWB;
   }
 }
 
@@ -345,7 +379,7 @@ __device__ __forceinline__ void conv_gather(f32x2 (&acc)[SW][CPW], const Idx<CPW
   }
 }
 
-template <int TH, int TW, int SW, int CPW, int KT>
+template <int TH, int TW, int SW, int CPW, int KT, int KS>
 __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX, int chunksPerGrp, int G) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   static_assert(TW % SW == 0, "strips tile the row");
@@ -371,41 +405,71 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
   g.wiL = max(0, wo0 * p.stride - p.pad);
   g.wiU = min(p.W - 1, woL * p.stride - p.pad + p.knl - 1);
   const int S = (hiU - hiL + 1) * (g.wiU - g.wiL + 1) * g.MG;
+  const int Sp = (S + 1) & ~1;                      // every wave runs Sp stage periods (barriers)
   const StagePos first = {hiL, g.wiL, 0};
 
-  if (wave < NBW) {
+  const WaveRole role = assign_roles(lds, wave, lane);
+  if (role.builder) {
     // ---------------------------------------------------------------- builder wave ----
-    const int bw = wave;
+    const int bw = role.idx;
     const int K = p.K, Cs = p.Cs;
-    const int ksteps = (min(Cg, Cs) > 4) ? 2 : 1;      // MFMA k-steps (4 dims each) that carry data
     const char* __restrict__ xbase =
         reinterpret_cast<const char*>(p.src + ((size_t)panel * p.H * p.W * p.Cin + (size_t)grp * Cg) * PANEL);
-    MfmaOps<KTT> ops;
-    StagePos c1 = next_pos(first, g);
-    StagePos c2 = next_pos(c1, g);
+    // Two operand sets: while stage s+1 is multiplied out of one, the other one already holds (or is
+    // receiving) stage s+2, and the loads of stage s+3 are issued as soon as the first is consumed, so
+    // an operand fetch has a whole stage period to land.
+    MfmaOps<KTT, KS> opsA, opsB;
+    StagePos q1 = next_pos(first, g);
+    StagePos q2 = next_pos(q1, g);
+    StagePos q3 = next_pos(q2, g);
     if (KT > 0) {
-      mfma_load<KTT>(ops, xbase, pixel_off(first, g), p.ctrd, Cs, ksteps, 0, bw, lane);
-      mfma_store<KTT>(ops, lds, ksteps, Cs, Cg, 0, M, bw, lane);
-      if (S > 1) mfma_load<KTT>(ops, xbase, pixel_off(c1, g), p.ctrd, Cs, ksteps, c1.mg * G, bw, lane);
+      mfma_load<KTT, KS>(opsA, xbase, pixel_off(first, g), p.ctrd, Cs, 0, bw, lane);
+      mfma_store<KTT, KS>(opsA, lds, Cs, Cg, 0, M, bw, lane);
+      {
+        const StagePos qa = (q1.hi > hiU) ? first : q1, qb = (q2.hi > hiU) ? first : q2;
+        mfma_load<KTT, KS>(opsA, xbase, pixel_off(qa, g), p.ctrd, Cs, qa.mg * G, bw, lane);
+        __builtin_amdgcn_sched_barrier(0);             // keep set A's loads older than set B's (vmcnt accounting)
+        mfma_load<KTT, KS>(opsB, xbase, pixel_off(qb, g), p.ctrd, Cs, qb.mg * G, bw, lane);
+      }
     } else {
       build_stage_exact(lds, xbase, pixel_off(first, g), p.ctrd, K, Cs, Cg, G, 0, M, bw, lane);
     }
     barrier_after_lds_writes();
-    for (int s = 0; s < S; ++s) {
-      if (s + 1 < S) {
-        char* nstage = lds + ((s + 1) & 1) * STAGE_BYTES;
-        if (KT > 0) mfma_store<KTT>(ops, nstage, ksteps, Cs, Cg, c1.mg * G, M, bw, lane);
-        else build_stage_exact(nstage, xbase, pixel_off(c1, g), p.ctrd, K, Cs, Cg, G, c1.mg * G, M, bw, lane);
+    // Straight-line body (no VMEM operation under a condition), so that the compiler's vmcnt waits are
+    // exact: "all but the 2*(8+2*SUBS) loads of the other set".  Sp rounds S up to even; the surplus
+    // stage is built from re-fetched operands into a buffer nobody reads.
+    const bool tr = p.trace && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && bw == 0 && lane == 0;
+    for (int s = 0; s < Sp; s += 2) {
+      if (tr) p.trace[s * 4 + 0] = __builtin_readcyclecounter();
+      if (KT > 0) {                                    // stage s+1 -> buffer 1, from set A
+        mfma_store<KTT, KS>(opsA, lds + STAGE_BYTES, Cs, Cg, q1.mg * G, M, bw, lane);
+        if (tr) p.trace[s * 4 + 1] = __builtin_readcyclecounter();
+        const StagePos qf = (q3.hi > hiU) ? first : q3;
+        mfma_load<KTT, KS>(opsA, xbase, pixel_off(qf, g), p.ctrd, Cs, qf.mg * G, bw, lane);
+        if (tr) p.trace[s * 4 + 2] = __builtin_readcyclecounter();
+      } else if (s + 1 < S) {
+        build_stage_exact(lds + STAGE_BYTES, xbase, pixel_off(q1, g), p.ctrd, K, Cs, Cg, G, q1.mg * G, M, bw, lane);
       }
-      if (KT > 0 && s + 2 < S) mfma_load<KTT>(ops, xbase, pixel_off(c2, g), p.ctrd, Cs, ksteps, c2.mg * G, bw, lane);
       barrier_after_lds_writes();
-      c1 = c2; c2 = next_pos(c2, g);
+      if (tr) p.trace[s * 4 + 3] = __builtin_readcyclecounter();
+      q1 = q2; q2 = q3; q3 = next_pos(q3, g);
+      if (KT > 0) {                                    // stage s+2 -> buffer 0, from set B
+        mfma_store<KTT, KS>(opsB, lds, Cs, Cg, q1.mg * G, M, bw, lane);
+        if (tr) p.trace[s * 4 + 4] = __builtin_readcyclecounter();
+        const StagePos qf = (q3.hi > hiU) ? first : q3;
+        mfma_load<KTT, KS>(opsB, xbase, pixel_off(qf, g), p.ctrd, Cs, qf.mg * G, bw, lane);
+        if (tr) p.trace[s * 4 + 5] = __builtin_readcyclecounter();
+      } else if (s + 2 < S) {
+        build_stage_exact(lds, xbase, pixel_off(q1, g), p.ctrd, K, Cs, Cg, G, q1.mg * G, M, bw, lane);
+      }
+      barrier_after_lds_writes();
+      q1 = q2; q2 = q3; q3 = next_pos(q3, g);
     }
     return;
   }
 
   // ------------------------------------------------------------------ gather wave ----
-  const int gw = wave - NBW;
+  const int gw = role.idx;
   const int strip = gw / NC, cc = gw % NC;
   const int sdy = strip / SPR, sdx0 = (strip % SPR) * SW;
   const int cw0 = chunk * (NC * CPW) + cc * CPW;     // first channel of this wave inside the group
@@ -435,7 +499,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
   }
   // first source row / column of the strip's positions; positions outside the map get a start that can
   // never match a tap
-  const int rowStart = active ? ho * p.stride - p.pad : -(1 << 28);
+  const int rowStart = (active && !(p.dbg & 1)) ? ho * p.stride - p.pad : -(1 << 28);
   int colStart[SW];
 #pragma unroll
   for (int dx = 0; dx < SW; ++dx) {
@@ -448,13 +512,18 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
   StagePos c1p = next_pos(c0p, g);
   conv_prefetch_idx<SW, CPW>(vidx, c0p, g, rowsC, rowStart, colStart, vzero);
   barrier_plain();
-  for (int s = 0; s < S; ++s) {
+  const bool trg = p.trace && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && gw == 0 && lane == 0;
+  for (int s = 0; s < Sp; ++s) {
+    if (trg) p.trace[32768 + s * 4 + 0] = __builtin_readcyclecounter();
 #pragma unroll
     for (int dx = 0; dx < SW; ++dx) bcast_idx(sidx[dx], vidx[dx]);
     conv_prefetch_idx<SW, CPW>(vidx, c1p, g, rowsC, rowStart, colStart, vzero);   // past the last stage: clamped, unused
-    conv_gather<SW, CPW, KT == 8>(acc, sidx, c0p, g, rowsC, rowStart, colStart,
+    if (trg) p.trace[32768 + s * 4 + 1] = __builtin_readcyclecounter();
+    conv_gather<SW, CPW, KT == 8>(acc, sidx, c0p, g, rowsC, (s < S) ? rowStart : -(1 << 28), colStart,
                                   ldsBase + (uint32_t)((s & 1) * STAGE_BYTES + lane * 8));
+    if (trg) p.trace[32768 + s * 4 + 2] = __builtin_readcyclecounter();
     barrier_plain();
+    if (trg) p.trace[32768 + s * 4 + 3] = __builtin_readcyclecounter();
     c0p = c1p; c1p = next_pos(c1p, g);
   }
 
@@ -487,7 +556,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
 // next group always in flight.  Optional split over the sub-space axis (blockIdx.z): partial sums go
 // to p.partial and are reduced by k_sum_partials.
 // ------------------------------------------------------------------------------------------------
-template <int CPW, int KT>
+template <int CPW, int KT, int KS>
 __global__ __launch_bounds__(NW * 64) void k_fc_aprx(FcParams p, int G, int stagesPerSplit) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   constexpr int KTT = KT > 0 ? KT : 1;
@@ -499,37 +568,48 @@ __global__ __launch_bounds__(NW * 64) void k_fc_aprx(FcParams p, int G, int stag
   const int mBeg = split * stagesPerSplit * G;
   const int mEnd = min(M, mBeg + stagesPerSplit * G);
   const int S = (mEnd - mBeg + G - 1) / G;
+  const int Sp = (S + 1) & ~1;                      // every wave runs Sp stage periods (barriers)
 
-  if (wave < NBW) {
-    const int bw = wave;
+  const WaveRole role = assign_roles(lds, wave, lane);
+  if (role.builder) {
+    const int bw = role.idx;
     const int K = p.K, Cs = p.Cs;
     const char* __restrict__ xbase = reinterpret_cast<const char*>(p.src + (size_t)panel * p.D * PANEL);
-    const int ksteps = (min(p.D, Cs) > 4) ? 2 : 1;
-    MfmaOps<KTT> ops;
+    MfmaOps<KTT, KS> opsA, opsB;                          // two operand sets, see k_conv_aprx
+    const int mLastStage = mBeg + max(S - 1, 0) * G;  // operand prefetches past the end re-fetch the last stage
     if (S > 0) {
       if (KT > 0) {
-        mfma_load<KTT>(ops, xbase, 0u, p.ctrd, Cs, ksteps, mBeg, bw, lane);
-        mfma_store<KTT>(ops, lds, ksteps, Cs, p.D, mBeg, mEnd, bw, lane);
-        if (S > 1) mfma_load<KTT>(ops, xbase, 0u, p.ctrd, Cs, ksteps, mBeg + G, bw, lane);
+        mfma_load<KTT, KS>(opsA, xbase, 0u, p.ctrd, Cs, mBeg, bw, lane);
+        mfma_store<KTT, KS>(opsA, lds, Cs, p.D, mBeg, mEnd, bw, lane);
+        mfma_load<KTT, KS>(opsA, xbase, 0u, p.ctrd, Cs, min(mBeg + G, mLastStage), bw, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_load<KTT, KS>(opsB, xbase, 0u, p.ctrd, Cs, min(mBeg + 2 * G, mLastStage), bw, lane);
       } else {
         build_stage_exact(lds, xbase, 0u, p.ctrd, K, Cs, p.D, G, mBeg, mEnd, bw, lane);
       }
     }
     barrier_after_lds_writes();
-    for (int s = 0; s < S; ++s) {
+    for (int s = 0; s < Sp; s += 2) {                  // straight-line body, see k_conv_aprx
       const int m0 = mBeg + s * G;
-      if (s + 1 < S) {
-        char* nstage = lds + ((s + 1) & 1) * STAGE_BYTES;
-        if (KT > 0) mfma_store<KTT>(ops, nstage, ksteps, Cs, p.D, m0 + G, mEnd, bw, lane);
-        else build_stage_exact(nstage, xbase, 0u, p.ctrd, K, Cs, p.D, G, m0 + G, mEnd, bw, lane);
+      if (KT > 0) {
+        mfma_store<KTT, KS>(opsA, lds + STAGE_BYTES, Cs, p.D, min(m0 + G, mLastStage), mEnd, bw, lane);
+        mfma_load<KTT, KS>(opsA, xbase, 0u, p.ctrd, Cs, min(m0 + 3 * G, mLastStage), bw, lane);
+      } else if (s + 1 < S) {
+        build_stage_exact(lds + STAGE_BYTES, xbase, 0u, p.ctrd, K, Cs, p.D, G, m0 + G, mEnd, bw, lane);
       }
-      if (KT > 0 && s + 2 < S) mfma_load<KTT>(ops, xbase, 0u, p.ctrd, Cs, ksteps, m0 + 2 * G, bw, lane);
+      barrier_after_lds_writes();
+      if (KT > 0) {
+        mfma_store<KTT, KS>(opsB, lds, Cs, p.D, min(m0 + 2 * G, mLastStage), mEnd, bw, lane);
+        mfma_load<KTT, KS>(opsB, xbase, 0u, p.ctrd, Cs, min(m0 + 4 * G, mLastStage), bw, lane);
+      } else if (s + 2 < S) {
+        build_stage_exact(lds, xbase, 0u, p.ctrd, K, Cs, p.D, G, m0 + 2 * G, mEnd, bw, lane);
+      }
       barrier_after_lds_writes();
     }
     return;
   }
 
-  const int gw = wave - NBW;
+  const int gw = role.idx;
   const int cw0r = blockIdx.x * (NGW * CPW) + gw * CPW;
   const int ccnt = min(CPW, p.Ct - cw0r);
   const bool active = ccnt > 0;
@@ -558,7 +638,7 @@ __global__ __launch_bounds__(NW * 64) void k_fc_aprx(FcParams p, int G, int stag
   Idx<CPW / 4> vidx, sidx;
   if (S > 0) vload_idx(vidx, rowsC + (size_t)mBeg * p.Ct, vzero);
   barrier_plain();
-  for (int s = 0; s < S; ++s) {
+  for (int s = 0; s < Sp; ++s) {
     const int m0 = mBeg + s * G;
     const int mLast = min(mEnd, m0 + G);
     const uint32_t stage = ldsBase + (uint32_t)((s & 1) * STAGE_BYTES + lane * 8);
@@ -795,11 +875,12 @@ hipError_t launch_conv(const ConvParams& p, int lutMode, hipStream_t st) {
   const dim3 grid(tilesX * tilesY, chunksPerGrp * p.grp, p.panels);
   const size_t shm = (size_t)2 * STAGE_BYTES;
   const int G = qcnn_stage_group(p.K);
-  auto kern = k_conv_aprx<TH, TW, SW, CPW, 0>;
-  if (lutMode == 1 && p.K == 128) kern = k_conv_aprx<TH, TW, SW, CPW, 8>;
-  if (lutMode == 1 && p.K == 64) kern = k_conv_aprx<TH, TW, SW, CPW, 4>;
-  if (lutMode == 1 && p.K == 32) kern = k_conv_aprx<TH, TW, SW, CPW, 2>;
-  if (lutMode == 1 && p.K == 16) kern = k_conv_aprx<TH, TW, SW, CPW, 1>;
+  const bool two = min(p.Cin / p.grp, p.Cs) > 4;      // MFMA k-steps (4 dims each) that carry data
+  auto kern = k_conv_aprx<TH, TW, SW, CPW, 0, 1>;
+  if (lutMode == 1 && p.K == 128) kern = two ? k_conv_aprx<TH, TW, SW, CPW, 8, 2> : k_conv_aprx<TH, TW, SW, CPW, 8, 1>;
+  if (lutMode == 1 && p.K == 64) kern = two ? k_conv_aprx<TH, TW, SW, CPW, 4, 2> : k_conv_aprx<TH, TW, SW, CPW, 4, 1>;
+  if (lutMode == 1 && p.K == 32) kern = two ? k_conv_aprx<TH, TW, SW, CPW, 2, 2> : k_conv_aprx<TH, TW, SW, CPW, 2, 1>;
+  if (lutMode == 1 && p.K == 16) kern = two ? k_conv_aprx<TH, TW, SW, CPW, 1, 2> : k_conv_aprx<TH, TW, SW, CPW, 1, 1>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)shm);
   if (e != hipSuccess) return e;
@@ -814,11 +895,12 @@ hipError_t launch_fc(const FcParams& p, int lutMode, hipStream_t st) {
   const int stagesPerSplit = (stages + p.msplit - 1) / p.msplit;
   const dim3 grid((p.Ct + NGW * CPW - 1) / (NGW * CPW), p.panels, p.msplit);
   const size_t shm = (size_t)2 * STAGE_BYTES;
-  auto kern = k_fc_aprx<CPW, 0>;
-  if (lutMode == 1 && p.K == 128) kern = k_fc_aprx<CPW, 8>;
-  if (lutMode == 1 && p.K == 64) kern = k_fc_aprx<CPW, 4>;
-  if (lutMode == 1 && p.K == 32) kern = k_fc_aprx<CPW, 2>;
-  if (lutMode == 1 && p.K == 16) kern = k_fc_aprx<CPW, 1>;
+  const bool two = min(p.D, p.Cs) > 4;
+  auto kern = k_fc_aprx<CPW, 0, 1>;
+  if (lutMode == 1 && p.K == 128) kern = two ? k_fc_aprx<CPW, 8, 2> : k_fc_aprx<CPW, 8, 1>;
+  if (lutMode == 1 && p.K == 64) kern = two ? k_fc_aprx<CPW, 4, 2> : k_fc_aprx<CPW, 4, 1>;
+  if (lutMode == 1 && p.K == 32) kern = two ? k_fc_aprx<CPW, 2, 2> : k_fc_aprx<CPW, 2, 1>;
+  if (lutMode == 1 && p.K == 16) kern = two ? k_fc_aprx<CPW, 1, 2> : k_fc_aprx<CPW, 1, 1>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)shm);
   if (e != hipSuccess) return e;

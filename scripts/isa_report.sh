@@ -7,7 +7,7 @@ mkdir -p /tmp/isa && cd /tmp/isa && rm -f *.s log.txt
 /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=off -save-temps \
   -Rpass-analysis=kernel-resource-usage -c /root/repo/quantized-cnn_amd/csrc/qcnn_kernels.hip -o /tmp/isa/k.o > log.txt 2>&1 || { grep error log.txt | head; exit 1; }
 S=qcnn_kernels-hip-amdgcn-amd-amdhsa-gfx950.s
-for k in $(grep -o "^_ZN12_GLOBAL__N_1[0-9]*k_[a-z]*_aprxI[A-Za-z0-9]*EEv[0-9A-Za-z]*" $S | sort -u | grep -v "${SKIP:-Li0EEEv}"); do
+for k in $(grep -o "^_ZN12_GLOBAL__N_1[0-9]*k_[a-z]*_aprxI[A-Za-z0-9]*EEv[0-9A-Za-z]*" $S | sort -u | grep -v "${SKIP:-Li0ELi1EEEv}"); do
   awk "/^${k}:/,/s_endpgm/" $S > x.s
   v=$(grep -A3 "Function Name: ${k}" log.txt | grep " VGPRs:" | head -1 | sed 's/.*VGPRs: \([0-9]*\).*/\1/')
   sg=$(grep -A3 "Function Name: ${k}" log.txt | grep " SGPRs:" | head -1 | sed 's/.*SGPRs: \([0-9]*\).*/\1/')
