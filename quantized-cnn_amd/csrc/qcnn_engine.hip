@@ -169,28 +169,6 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
       p.knl = d.knlSiz; p.stride = d.stride; p.pad = d.padSiz; p.grp = d.grpCnt;
       p.M = s.M; p.Cs = s.Cs; p.K = s.K; p.relu = fuseRelu ? 1 : 0; p.panels = panels;
       { const char* d_ = getenv("QCNN_DBG"); p.dbg = d_ ? atoi(d_) : 0; }
-      p.trace = nullptr;
-      {   // QCNN_TRACE=<layer>: dump s_memtime stamps of workgroup 0 to gpurun_out/trace_<layer>.txt (experiments only)
-        const char* t_ = getenv("QCNN_TRACE");
-        if (t_ && atoi(t_) == l) {
-          static unsigned long long* tbuf = nullptr;
-          const size_t n = 1 << 16;
-          if (!tbuf) (void)hipMalloc(&tbuf, n * 8);
-          (void)hipMemsetAsync(tbuf, 0, n * 8, c->stream);
-          p.trace = tbuf;
-          e = qk_conv_aprx(p, c->lutMode, c->stream);
-          (void)hipStreamSynchronize(c->stream);
-          std::vector<unsigned long long> h(n);
-          (void)hipMemcpy(h.data(), tbuf, n * 8, hipMemcpyDeviceToHost);
-          char fn[64]; snprintf(fn, sizeof(fn), "gpurun_out/trace_%d.txt", l);
-          if (FILE* f = fopen(fn, "w")) {
-            for (size_t i = 0; i + 7 < n; i += 8)
-              if (h[i] || h[i + 4]) fprintf(f, "%zu %llu %llu %llu %llu %llu %llu %llu %llu\n", i, h[i], h[i+1], h[i+2], h[i+3], h[i+4], h[i+5], h[i+6], h[i+7]);
-            fclose(f);
-          }
-          break;
-        }
-      }
       e = qk_conv_aprx(p, c->lutMode, c->stream);
       break;
     }

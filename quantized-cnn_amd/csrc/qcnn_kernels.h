@@ -36,7 +36,6 @@ struct ConvParams {
   int relu;              // fuse max(0, x) into the store
   int panels;
   int dbg;               // timing experiments only (QCNN_DBG): 1 no gather
-  unsigned long long* trace;   // timing experiments only (QCNN_TRACE): s_memtime stamps of workgroup 0, or NULL
 };
 
 struct FcParams {

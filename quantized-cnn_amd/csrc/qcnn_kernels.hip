@@ -438,27 +438,20 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
     // Straight-line body (no VMEM operation under a condition), so that the compiler's vmcnt waits are
     // exact: "all but the 2*(8+2*SUBS) loads of the other set".  Sp rounds S up to even; the surplus
     // stage is built from re-fetched operands into a buffer nobody reads.
-    const bool tr = p.trace && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && bw == 0 && lane == 0;
     for (int s = 0; s < Sp; s += 2) {
-      if (tr) p.trace[s * 4 + 0] = __builtin_readcyclecounter();
       if (KT > 0) {                                    // stage s+1 -> buffer 1, from set A
         mfma_store<KTT, KS>(opsA, lds + STAGE_BYTES, Cs, Cg, q1.mg * G, M, bw, lane);
-        if (tr) p.trace[s * 4 + 1] = __builtin_readcyclecounter();
         const StagePos qf = (q3.hi > hiU) ? first : q3;
         mfma_load<KTT, KS>(opsA, xbase, pixel_off(qf, g), p.ctrd, Cs, qf.mg * G, bw, lane);
-        if (tr) p.trace[s * 4 + 2] = __builtin_readcyclecounter();
       } else if (s + 1 < S) {
         build_stage_exact(lds + STAGE_BYTES, xbase, pixel_off(q1, g), p.ctrd, K, Cs, Cg, G, q1.mg * G, M, bw, lane);
       }
       barrier_after_lds_writes();
-      if (tr) p.trace[s * 4 + 3] = __builtin_readcyclecounter();
       q1 = q2; q2 = q3; q3 = next_pos(q3, g);
       if (KT > 0) {                                    // stage s+2 -> buffer 0, from set B
         mfma_store<KTT, KS>(opsB, lds, Cs, Cg, q1.mg * G, M, bw, lane);
-        if (tr) p.trace[s * 4 + 4] = __builtin_readcyclecounter();
         const StagePos qf = (q3.hi > hiU) ? first : q3;
         mfma_load<KTT, KS>(opsB, xbase, pixel_off(qf, g), p.ctrd, Cs, qf.mg * G, bw, lane);
-        if (tr) p.trace[s * 4 + 5] = __builtin_readcyclecounter();
       } else if (s + 2 < S) {
         build_stage_exact(lds, xbase, pixel_off(q1, g), p.ctrd, K, Cs, Cg, G, q1.mg * G, M, bw, lane);
       }
@@ -507,24 +500,25 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
     colStart[dx] = (wo < p.Wo) ? wo * p.stride - p.pad : -(1 << 28);
   }
 
+  // Per stage: [gather stage s][broadcast the indices of stage s+1][prefetch those of stage s+2][barrier].
+  // The index hand-over sits BEFORE the barrier, i.e. in the time an early wave would spend waiting for
+  // the slowest one anyway; right after the barrier every gather wave starts reading LDS.
   Idx<CPW / 4> vidx[SW], sidx[SW];
   StagePos c0p = first;
   StagePos c1p = next_pos(c0p, g);
   conv_prefetch_idx<SW, CPW>(vidx, c0p, g, rowsC, rowStart, colStart, vzero);
-  barrier_plain();
-  const bool trg = p.trace && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && gw == 0 && lane == 0;
-  for (int s = 0; s < Sp; ++s) {
-    if (trg) p.trace[32768 + s * 4 + 0] = __builtin_readcyclecounter();
 #pragma unroll
-    for (int dx = 0; dx < SW; ++dx) bcast_idx(sidx[dx], vidx[dx]);
-    conv_prefetch_idx<SW, CPW>(vidx, c1p, g, rowsC, rowStart, colStart, vzero);   // past the last stage: clamped, unused
-    if (trg) p.trace[32768 + s * 4 + 1] = __builtin_readcyclecounter();
+  for (int dx = 0; dx < SW; ++dx) bcast_idx(sidx[dx], vidx[dx]);
+  conv_prefetch_idx<SW, CPW>(vidx, c1p, g, rowsC, rowStart, colStart, vzero);
+  barrier_plain();
+  for (int s = 0; s < Sp; ++s) {
     conv_gather<SW, CPW, KT == 8>(acc, sidx, c0p, g, rowsC, (s < S) ? rowStart : -(1 << 28), colStart,
                                   ldsBase + (uint32_t)((s & 1) * STAGE_BYTES + lane * 8));
-    if (trg) p.trace[32768 + s * 4 + 2] = __builtin_readcyclecounter();
-    barrier_plain();
-    if (trg) p.trace[32768 + s * 4 + 3] = __builtin_readcyclecounter();
     c0p = c1p; c1p = next_pos(c1p, g);
+#pragma unroll
+    for (int dx = 0; dx < SW; ++dx) bcast_idx(sidx[dx], vidx[dx]);                   // indices of stage s+1
+    conv_prefetch_idx<SW, CPW>(vidx, c1p, g, rowsC, rowStart, colStart, vzero);    // of stage s+2 (past the end: clamped, unused)
+    barrier_plain();
   }
 
   if (active) {
@@ -635,8 +629,13 @@ __global__ __launch_bounds__(NW * 64) void k_fc_aprx(FcParams p, int G, int stag
     }
   }
 
+  // group stream: sidx always holds the (already broadcast) indices of the next group to gather, vidx
+  // the prefetch of the one after it, so that the hand-over never sits right behind a barrier
   Idx<CPW / 4> vidx, sidx;
-  if (S > 0) vload_idx(vidx, rowsC + (size_t)mBeg * p.Ct, vzero);
+  const int mClamp = max(mEnd - 1, mBeg);
+  vload_idx(vidx, rowsC + (size_t)mBeg * p.Ct, vzero);
+  bcast_idx(sidx, vidx);
+  vload_idx(vidx, rowsC + (size_t)min(mBeg + 1, mClamp) * p.Ct, vzero);
   barrier_plain();
   for (int s = 0; s < Sp; ++s) {
     const int m0 = mBeg + s * G;
@@ -644,9 +643,9 @@ __global__ __launch_bounds__(NW * 64) void k_fc_aprx(FcParams p, int G, int stag
     const uint32_t stage = ldsBase + (uint32_t)((s & 1) * STAGE_BYTES + lane * 8);
     if (active) {
       for (int m = m0; m < mLast; ++m) {
-        bcast_idx(sidx, vidx);
-        if (m + 1 < mEnd) vload_idx(vidx, rowsC + (size_t)(m + 1) * p.Ct, vzero);
         gather_apply<CPW>(acc, sidx, stage, 1);
+        bcast_idx(sidx, vidx);
+        vload_idx(vidx, rowsC + (size_t)min(m + 2, mClamp) * p.Ct, vzero);
       }
     }
     barrier_plain();
