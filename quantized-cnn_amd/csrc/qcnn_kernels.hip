@@ -715,6 +715,61 @@ __global__ void k_relu(const float4* __restrict__ src, float4* __restrict__ dst,
   }
 }
 
+// LRN, streaming form.  A thread owns one pixel and four images (float4: 32 lanes = one 512-byte row, a
+// wave = two pixels) and walks the channels once, keeping the window of N scaled squares and raw values
+// in registers: every element is read exactly once.  Same arithmetic and the same summation order as
+// k_lrn below (window j ascending; channels outside [0, C) contribute an exact +0.0f instead of being
+// skipped, which leaves s > 0 bit-identical).
+template <int N>
+__global__ __launch_bounds__(256) void k_lrn_stream(const float4* __restrict__ src, float4* __restrict__ dst,
+                                                    size_t pixels, int C, float coeff, float nbet, float ini) {
+  constexpr int RAD = (N - 1) / 2;
+  const size_t px = blockIdx.x * (size_t)(blockDim.x >> 5) + (threadIdx.x >> 5);
+  if (px >= pixels) return;
+  const int q = threadIdx.x & 31;
+  const float4* __restrict__ x = src + px * (size_t)C * 32 + q;
+  float4* __restrict__ y = dst + px * (size_t)C * 32 + q;
+  const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  float4 raw[N], sq[N];          // ring: slot (t % N) holds channel t
+#pragma unroll
+  for (int j = 0; j < N; ++j) { raw[j] = zero; sq[j] = zero; }
+  // channels 0 .. RAD-1 enter the window before the first output
+#pragma unroll
+  for (int t = 0; t < RAD; ++t) {
+    const float4 v = (t < C) ? x[(size_t)t * 32] : zero;
+    raw[t % N] = v;
+    sq[t % N] = make_float4(__fmul_rn(__fmul_rn(v.x, v.x), coeff), __fmul_rn(__fmul_rn(v.y, v.y), coeff),
+                            __fmul_rn(__fmul_rn(v.z, v.z), coeff), __fmul_rn(__fmul_rn(v.w, v.w), coeff));
+  }
+  for (int c0 = 0; c0 < C; c0 += N) {
+#pragma unroll
+    for (int u = 0; u < N; ++u) {
+      const int c = c0 + u;                 // output channel; slot of channel k is (k + N*8) % N = (u + k - c) % N
+      const int tin = c + RAD;              // channel entering the window
+      const float4 v = (tin < C) ? x[(size_t)tin * 32] : zero;
+      raw[(u + RAD) % N] = v;
+      sq[(u + RAD) % N] = make_float4(__fmul_rn(__fmul_rn(v.x, v.x), coeff), __fmul_rn(__fmul_rn(v.y, v.y), coeff),
+                                      __fmul_rn(__fmul_rn(v.z, v.z), coeff), __fmul_rn(__fmul_rn(v.w, v.w), coeff));
+      if (c < C) {
+        float4 sacc = make_float4(ini, ini, ini, ini);
+#pragma unroll
+        for (int j = 0; j < N; ++j) {       // window channel c - RAD + j lives in slot (u - RAD + j) mod N
+          const float4 w = sq[(u - RAD + j + N) % N];
+          sacc.x = __fadd_rn(sacc.x, w.x); sacc.y = __fadd_rn(sacc.y, w.y);
+          sacc.z = __fadd_rn(sacc.z, w.z); sacc.w = __fadd_rn(sacc.w, w.w);
+        }
+        const float4 xc = raw[u % N];
+        float4 o;
+        o.x = __fmul_rn(xc.x, expf(__fmul_rn(nbet, logf(sacc.x))));
+        o.y = __fmul_rn(xc.y, expf(__fmul_rn(nbet, logf(sacc.y))));
+        o.z = __fmul_rn(xc.z, expf(__fmul_rn(nbet, logf(sacc.z))));
+        o.w = __fmul_rn(xc.w, expf(__fmul_rn(nbet, logf(sacc.w))));
+        y[(size_t)c * 32] = o;
+      }
+    }
+  }
+}
+
 // src/CaffeEva.cc:1038-1089: s = k; s += (x*x)*(alpha/n) over the channel window, j ascending (zero pad);
 // y = x * expf(-beta * logf(s)).
 __global__ void k_lrn(const float* __restrict__ src, float* __restrict__ dst, size_t rows, int C, int lrnSiz,
@@ -772,6 +827,102 @@ __global__ void k_pool(const float* __restrict__ src, float* __restrict__ dst, i
         first = false;
       }
     *reinterpret_cast<f32x2*>(dst + r * PANEL + 2 * lane) = v;
+  }
+}
+
+// max-pool, four images per thread (32 lanes = one row, a wave = two adjacent channels): same window rule
+__global__ __launch_bounds__(256) void k_pool4(const float4* __restrict__ src, float4* __restrict__ dst, int panels,
+                                               int H, int W, int C, int Ho, int Wo, int knl, int stride, int pad) {
+  const size_t rows = (size_t)panels * Ho * Wo * C;
+  const size_t r = blockIdx.x * (size_t)(blockDim.x >> 5) + (threadIdx.x >> 5);
+  if (r >= rows) return;
+  const int q = threadIdx.x & 31;
+  const int c = (int)(r % C);
+  size_t t = r / C;
+  const int wo = (int)(t % Wo);
+  t /= Wo;
+  const int ho = (int)(t % Ho);
+  const int panel = (int)(t / Ho);
+  const int hL = max(0, ho * stride - pad), hU = min(H, ho * stride + knl - pad) - 1;
+  const int wL = max(0, wo * stride - pad), wU = min(W, wo * stride + knl - pad) - 1;
+  const float4* base = src + (size_t)panel * H * W * C * 32 + q;
+  float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  bool first = true;
+  for (int h = hL; h <= hU; ++h)
+    for (int w = wL; w <= wU; ++w) {
+      const float4 sv = base[((size_t)(h * W + w) * C + c) * 32];
+      if (first) {
+        v = sv;
+      } else {
+        v.x = (sv.x < v.x) ? v.x : sv.x;
+        v.y = (sv.y < v.y) ? v.y : sv.y;
+        v.z = (sv.z < v.z) ? v.z : sv.z;
+        v.w = (sv.w < v.w) ? v.w : sv.w;
+      }
+      first = false;
+    }
+  dst[r * 32 + q] = v;
+}
+
+// Softmax through LDS: a block = 32 images x 8 class lanes.  expf of every logit in parallel into an
+// LDS tile [C][32], the reference's SEQUENTIAL float sum over the classes (src/CaffeEva.cc:1107-1114) by
+// one thread per image out of LDS, then the division in parallel.  Same values as k_softmax.
+__global__ __launch_bounds__(256) void k_softmax_lds(const float* __restrict__ src, float* __restrict__ dst, int C) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  float* tile = reinterpret_cast<float*>(lds);            // [C][32]
+  float* sums = tile + (size_t)C * 32;                    // [32]
+  const int img = threadIdx.x & 31, cl = threadIdx.x >> 5;
+  const size_t off = (size_t)blockIdx.y * C * PANEL + blockIdx.x * 32 + img;
+  const float* x = src + off;
+  float* y = dst + off;
+  for (int c = cl; c < C; c += 8) tile[c * 32 + img] = expf(x[(size_t)c * PANEL]);
+  __syncthreads();
+  if (cl == 0) {
+    float sum = 0.0f;
+    for (int c = 0; c < C; ++c) sum = __fadd_rn(sum, tile[c * 32 + img]);
+    sums[img] = sum;
+  }
+  __syncthreads();
+  const float sum = sums[img];
+  for (int c = cl; c < C; c += 8) y[(size_t)c * PANEL] = __fdiv_rn(tile[c * 32 + img], sum);
+}
+
+// Top-5 through LDS: a block = 32 images x 8 class lanes; per sweep every class lane finds the first
+// maximum (strict '<' from FLT_MIN) of its classes, the eight candidates are merged (larger value, then
+// lower index = the sequential sweep's first occurrence), the winner is zeroed (src/CaffeEva.cc:1173-1188).
+__global__ __launch_bounds__(256) void k_top5_lds(const float* __restrict__ prob, uint16_t* __restrict__ out, int n,
+                                                  int C) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  float* tile = reinterpret_cast<float*>(lds);            // [C][32]
+  float* candV = tile + (size_t)C * 32;                   // [8][32]
+  int* candI = reinterpret_cast<int*>(candV + 8 * 32);    // [8][32]
+  const int img = threadIdx.x & 31, cl = threadIdx.x >> 5;
+  const int gi = blockIdx.y * PANEL + blockIdx.x * 32 + img;
+  const float* x = prob + (size_t)blockIdx.y * C * PANEL + blockIdx.x * 32 + img;
+  for (int c = cl; c < C; c += 8) tile[c * 32 + img] = x[(size_t)c * PANEL];
+  __syncthreads();
+  for (int r = 0; r < 5; ++r) {
+    float best = FLT_MIN;
+    int bi = 0;
+    for (int c = cl; c < C; c += 8) {
+      const float v = tile[c * 32 + img];
+      if (best < v) { best = v; bi = c; }
+    }
+    candV[cl * 32 + img] = best;
+    candI[cl * 32 + img] = bi;
+    __syncthreads();
+    if (cl == 0) {
+      float b = candV[img];
+      int i = candI[img];
+      for (int k = 1; k < 8; ++k) {
+        const float v = candV[k * 32 + img];
+        const int vi = candI[k * 32 + img];
+        if (b < v || (b == v && vi < i)) { b = v; i = vi; }
+      }
+      if (gi < n) out[(size_t)gi * 5 + r] = (uint16_t)i;
+      tile[i * 32 + img] = 0.0f;
+    }
+    __syncthreads();
   }
 }
 
@@ -966,6 +1117,17 @@ hipError_t qk_lrn(const float* src, float* dst, int panels, int HW, int C, int l
                   hipStream_t st) {
   const size_t rows = (size_t)panels * HW * C;
   const float coeff = alp / lrnSiz;   // float / int, as src/CaffeEva.cc:1055
+  if (lrnSiz == 5 || lrnSiz == 3) {   // streaming kernel: 8 pixels per block
+    const size_t pixels = (size_t)panels * HW;
+    const dim3 grid((unsigned)((pixels + 7) / 8));
+    if (lrnSiz == 5)
+      hipLaunchKernelGGL(k_lrn_stream<5>, grid, dim3(256), 0, st, reinterpret_cast<const float4*>(src),
+                         reinterpret_cast<float4*>(dst), pixels, C, coeff, -bet, ini);
+    else
+      hipLaunchKernelGGL(k_lrn_stream<3>, grid, dim3(256), 0, st, reinterpret_cast<const float4*>(src),
+                         reinterpret_cast<float4*>(dst), pixels, C, coeff, -bet, ini);
+    return hipGetLastError();
+  }
   const int blocks = (int)((rows + 3) / 4 < 8192 ? (rows + 3) / 4 : 8192);
   hipLaunchKernelGGL(k_lrn, dim3(blocks ? blocks : 1), dim3(256), 0, st, src, dst, rows, C, lrnSiz, coeff, -bet, ini);
   return hipGetLastError();
@@ -974,6 +1136,11 @@ hipError_t qk_lrn(const float* src, float* dst, int panels, int HW, int C, int l
 hipError_t qk_pool(const float* src, float* dst, int panels, int H, int W, int C, int Ho, int Wo, int knl, int stride,
                    int pad, hipStream_t st) {
   const size_t rows = (size_t)panels * Ho * Wo * C;
+  if ((rows + 7) / 8 < (size_t)1 << 31) {
+    hipLaunchKernelGGL(k_pool4, dim3((unsigned)((rows + 7) / 8)), dim3(256), 0, st, reinterpret_cast<const float4*>(src),
+                       reinterpret_cast<float4*>(dst), panels, H, W, C, Ho, Wo, knl, stride, pad);
+    return hipGetLastError();
+  }
   const int blocks = (int)((rows + 3) / 4 < 8192 ? (rows + 3) / 4 : 8192);
   hipLaunchKernelGGL(k_pool, dim3(blocks ? blocks : 1), dim3(256), 0, st, src, dst, panels, H, W, C, Ho, Wo, knl,
                      stride, pad);
@@ -981,11 +1148,27 @@ hipError_t qk_pool(const float* src, float* dst, int panels, int H, int W, int C
 }
 
 hipError_t qk_softmax(const float* src, float* dst, int panels, int C, hipStream_t st) {
+  const size_t shm = ((size_t)C * 32 + 32) * sizeof(float);
+  if (shm <= 160 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_softmax_lds),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_softmax_lds, dim3(PANEL / 32, panels), dim3(256), shm, st, src, dst, C);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(k_softmax, dim3((panels * PANEL + 63) / 64), dim3(64), 0, st, src, dst, panels, C);
   return hipGetLastError();
 }
 
 hipError_t qk_top5(const float* prob, uint16_t* out, int n, int C, hipStream_t st) {
+  const size_t shm = ((size_t)C * 32 + 2 * 8 * 32) * sizeof(float);
+  if (shm <= 160 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_top5_lds),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_top5_lds, dim3(PANEL / 32, panels_of(n)), dim3(256), shm, st, prob, out, n, C);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(k_top5, dim3((n + 63) / 64), dim3(64), 0, st, prob, out, n, C);
   return hipGetLastError();
 }

@@ -50,12 +50,19 @@ __global__ __launch_bounds__(1024) void kg(float* out, uint64_t* cyc, int iters,
     for (int it = 0; it < iters; ++it) {
       // one stage = 16 tiles x 4 dwords per lane for this wave (64 KB / 4 waves)
       for (int tl = 0; tl < 16; tl += 4) {
-        if (MF) {
+        if (MF == 1) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ma, mb, acc[j], 0, 0, 0);
             acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(mb, ma, acc[j], 0, 0, 0);
           }
+        }
+        if (MF == 2) {   // one bf16 16x16x32 per tile (hi/lo split operands) instead of two f32 16x16x4
+          typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+          bf16x8 va, vb;
+          for (int q = 0; q < 8; ++q) { va[q] = (__bf16)(ma + q); vb[q] = (__bf16)(mb - q); }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, vb, acc[j], 0, 0, 0);
         }
         if (WRITERS == 1) {
           char* w0 = lds + 67584 * (it & 1) + ((lane >> 4) * 4) * 528 + (wave * 32 + (lane & 15)) * 4 + tl * 16 * 528 / 2;
@@ -119,7 +126,7 @@ int main() {
   auto report = [&](const char* name, int readers) {
     hipDeviceSynchronize(); hipMemset(cyc, 0, sizeof(h)); };
   (void)report;
-  for (int mode = 0; mode < 7; ++mode)
+  for (int mode = 0; mode < 9; ++mode)
     for (int readers : {0, 4, 8, 12}) {
       if (mode == 0 && readers == 0) continue;
       if (mode >= 3 && readers != 12) continue;
@@ -131,12 +138,14 @@ int main() {
       if (mode == 4) hipLaunchKernelGGL((kg<1, 0, 1>), dim3(256), dim3(1024), 163840, 0, out, cyc, iters, readers, idx);
       if (mode == 5) hipLaunchKernelGGL((kg<1, 1, 1>), dim3(256), dim3(1024), 163840, 0, out, cyc, iters, readers, idx);
       if (mode == 6) hipLaunchKernelGGL((kg<2, 1, 1>), dim3(256), dim3(1024), 163840, 0, out, cyc, iters, readers, idx);
+      if (mode == 7) hipLaunchKernelGGL((kg<1, 1, 2>), dim3(256), dim3(1024), 163840, 0, out, cyc, iters, readers, idx);
+      if (mode == 8) hipLaunchKernelGGL((kg<2, 1, 2>), dim3(256), dim3(1024), 163840, 0, out, cyc, iters, readers, idx);
       hipError_t e = hipDeviceSynchronize();
       hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost);
       double mr = 0, mw = 0;
       for (int b = 0; b < 256; ++b) for (int w = 0; w < 16; ++w) { double v = (double)h[b * 16 + w]; if (w < 4) mw = v > mw ? v : mw; else mr = v > mr ? v : mr; }
       printf("writers=%s readers=%2d : reader cycles per 32 look-ups (slowest wave) %7.1f   writer cycles per 64KB stage %7.1f  (%s)\n",
-             mode == 0 ? "none  " : (mode == 1 ? "write2" : (mode == 2 ? "addtid" : (mode == 3 ? "write2+barrier" : (mode == 4 ? "write2+mfma" : (mode == 5 ? "write2+mfma+barrier" : "addtid+mfma+barrier"))))), readers, mr / iters, mw / iters, hipGetErrorString(e));
+             mode == 0 ? "none  " : (mode == 1 ? "write2" : (mode == 2 ? "addtid" : (mode == 3 ? "write2+barrier" : (mode == 4 ? "write2+mfma" : (mode == 5 ? "write2+mfma+barrier" : (mode == 6 ? "addtid+mfma+barrier" : (mode == 7 ? "write2+bf16mfma+barrier" : "addtid+bf16mfma+barrier"))))))), readers, mr / iters, mw / iters, hipGetErrorString(e));
     }
   return 0;
 }
