@@ -232,3 +232,51 @@ def test_alexnet_full_batch_properties():
         e_inf, e_l2 = rel_err(prob[i], ref[j])
         assert e_inf <= TOL and e_l2 <= TOL, "image %d: %g %g" % (i, e_inf, e_l2)
         assert np.array_equal(top5[i], orc.top5(ref[j]))
+
+
+# ---------------------------------------------------------------- dispatch coverage ----
+def _run_vs_oracle(in_chw, layers, spec_kw, n_img, seed):
+    spec = synth.quant_spec(in_chw, layers, **spec_kw)
+    params = synth.make_params(in_chw, layers, seed=seed, spec=spec)
+    imgs = synth.make_images(n_img, in_chw, seed=seed + 1)
+    orc = po.COracle(in_chw, layers)
+    orc.set_params(params)
+    orc.forward(imgs)
+    L = len(layers)
+    for lut in (capi.LUT_EXACT, capi.LUT_MFMA):
+        eng = make_engine(in_chw, layers, params, n_img, lut=lut)
+        prob, top5 = eng.forward_host(imgs)
+        for l, ly in enumerate(layers):
+            fm = eng.layer_output(l + 1, n_img)
+            if lut == capi.LUT_EXACT and ly["type"] in (topo.CONV, topo.FCNT):
+                # layer in isolation on the oracle's own input: bit-identical
+                y = eng.run_layer(l, consumption_order(layers, l, orc.fm(l)), n_img)
+                assert np.array_equal(y, orc.fm(l + 1)), "layer %d (%s) %r" % (l, topo.TYPE_NAMES[ly["type"]], spec_kw)
+            e_inf, e_l2 = rel_err(fm, orc.fm(l + 1))
+            assert e_inf <= TOL and e_l2 <= TOL, "lut %d fm[%d] %r: %g %g" % (lut, l + 1, spec_kw, e_inf, e_l2)
+        tops = np.stack([orc.top5(orc.fm(L)[i]) for i in range(n_img)])
+        assert np.array_equal(top5, tops)
+        eng.close()
+
+
+@pytest.mark.parametrize("spec_kw", [
+    dict(conv_k=32, conv_cs=4, fc_k=128, fc_cs=8, last_k=16, last_cs=2),   # conv stages of 4 sub-spaces; FC K=128, 2 k-steps
+    dict(conv_k=64, conv_cs=8, fc_k=16, fc_cs=4, last_k=32, last_cs=1),    # conv stages of 2 sub-spaces, 2 k-steps
+    dict(conv_k=16, conv_cs=2, fc_k=64, fc_cs=2, last_k=128, last_cs=4),   # 8 sub-spaces per stage, Cs < 4
+    dict(conv_k=48, conv_cs=8, fc_k=24, fc_cs=4, last_k=10, last_cs=1),    # K without an MFMA builder -> exact builder
+])
+def test_tiny_other_quantisation_shapes(spec_kw):
+    """Quantisation shapes the shipped models do not use (K < 128 conv, K = 128 FC, Cs in {1, 2, 4, 8},
+    K that is not a multiple of 16): every template branch of the two hot kernels against the oracle."""
+    in_chw, layers = topo.tiny_model()
+    _run_vs_oracle(in_chw, layers, spec_kw, 5, seed=41)
+
+
+def test_vgg_style_channel_counts():
+    """3x3/1/1 convolutions with 64/128/256/512/48 output channels (the VGG-16 layer widths, BASELINE.json
+    configs[3], on a small map): every conv tile configuration of qk_conv_aprx against the oracle."""
+    layers = [topo.conv(1, 3, 64, 1, 1), topo.relu(), topo.conv(1, 3, 128, 1, 1), topo.relu(), topo.pool(0, 2, 2),
+              topo.conv(1, 3, 256, 1, 1), topo.relu(), topo.conv(1, 3, 512, 1, 1), topo.relu(), topo.pool(0, 2, 2),
+              topo.conv(1, 3, 48, 1, 1), topo.relu(), topo.conv(0, 1, 384, 2, 1), topo.relu(),
+              topo.fcnt(400), topo.relu(), topo.drpt(0.5), topo.fcnt(40), topo.smax()]
+    _run_vs_oracle((3, 12, 12), layers, {}, 3, seed=43)
