@@ -9,7 +9,6 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
-#include <stdlib.h>
 
 #include <algorithm>
 #include <string>
@@ -168,7 +167,6 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
       p.H = a.h; p.W = a.w; p.Cin = a.c; p.Ho = b.h; p.Wo = b.w; p.Ct = b.c;
       p.knl = d.knlSiz; p.stride = d.stride; p.pad = d.padSiz; p.grp = d.grpCnt;
       p.M = s.M; p.Cs = s.Cs; p.K = s.K; p.relu = fuseRelu ? 1 : 0; p.panels = panels;
-      { const char* d_ = getenv("QCNN_DBG"); p.dbg = d_ ? atoi(d_) : 0; }
       e = qk_conv_aprx(p, c->lutMode, c->stream);
       break;
     }
@@ -193,13 +191,20 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
       if (c->lutMode == 1) {
         const int G = qcnn_stage_group(s.K);
         const int stages = (s.M + G - 1) / G;
-        // batch-independent choice (a given image must produce the same bits in any batch):
-        // aim at >= 64 workgroups per panel, keep >= 16 stages per workgroup, at most 16 splits
+        // batch-independent choice (a given image must produce the same bits in any batch): the split count
+        // that fills 256 CUs best at the design point of 8 panels (1000 images) while every workgroup keeps
+        // >= 24 stages; ties go to fewer splits.  (A grid of chunks x splits x panels workgroups runs in
+        // ceil(grid / 256) rounds: 528 workgroups cost as much as 768.)
         const int cpb = qk_fc_channels_per_block(p.Ct);
         const int chunks = (p.Ct + cpb - 1) / cpb;
-        int ms = (64 + chunks - 1) / chunks;
-        if (ms > 16) ms = 16;
-        while (ms > 1 && stages / ms < 16) --ms;
+        int ms = 1;
+        double bestFill = 0.0;
+        for (int cand = 1; cand <= 16; ++cand) {
+          if (cand > 1 && stages / cand < 24) break;
+          const int grid = chunks * cand * 8;
+          const double fill = (double)grid / (256.0 * ((grid + 255) / 256));
+          if (fill > bestFill + 1e-9) { bestFill = fill; ms = cand; }
+        }
         const size_t need = (size_t)ms * panels * p.Ct * QCNN_PANEL;
         if (ms > 1 && need <= c->fcPartialElems) { p.msplit = ms; p.partial = c->fcPartial; }
       }

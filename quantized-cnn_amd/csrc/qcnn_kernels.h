@@ -35,7 +35,6 @@ struct ConvParams {
   int M, Cs, K;
   int relu;              // fuse max(0, x) into the store
   int panels;
-  int dbg;               // timing experiments only (QCNN_DBG): 1 no gather
 };
 
 struct FcParams {

@@ -492,7 +492,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
   }
   // first source row / column of the strip's positions; positions outside the map get a start that can
   // never match a tap
-  const int rowStart = (active && !(p.dbg & 1)) ? ho * p.stride - p.pad : -(1 << 28);
+  const int rowStart = active ? ho * p.stride - p.pad : -(1 << 28);
   int colStart[SW];
 #pragma unroll
   for (int dx = 0; dx < SW; ++dx) {
