@@ -12,8 +12,9 @@ outside the timed region.  Scaling is therefore "weak" (per-GPU work fixed).
 
 Extra objects on the JSON line:
   roofline      dominant kernel (largest mean HIP-event time over the timed steps), algorithmic HBM
-                bytes per launch / its duration against 8 TB/s, plus the LDS look-up rate that actually
-                bounds it.
+                bytes per launch / its duration against 8 TB/s; `traffic` = that kernel's HBM bytes from
+                the committed rocprofv3 --pmc passes (profiles/); plus the LDS look-up rate against the
+                ds_read_b64 peak, the resource that actually bounds the kernel.
   cpu_baseline  the reference itself (oracle/_ref/libqcnn_ref.so, kind "reference") — or the C port
                 when that was never built — timed single-threaded on this host on a bounded sample.
 """
@@ -36,7 +37,19 @@ def pkg(name=""):
 
 
 HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-LDS_B32_LOOKUPS_PER_S = 256 * 32 * 2.4e9    # 256 CU x 128 B/clk (ds_read_b32) / 4 B x 2.4 GHz
+LDS_B64_LOOKUPS_PER_S = 256 * 64 * 2.4e9    # 256 CU x 256 B/clk (ds_read_b64, an image pair per lane) / 4 B x 2.4 GHz
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r1_v6", "traffic.json")   # PMC HBM bytes of the dominant kernel
+
+
+def pmc_traffic(layer):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
+    (FETCH_SIZE + WRITE_SIZE, separate passes, mean per dispatch), or None when no profile covers it."""
+    try:
+        with open(TRAFFIC_JSON) as f:
+            t = json.load(f)
+        return int(t["bytes"]) if int(t["layer"]) == int(layer) else None
+    except (OSError, ValueError, KeyError):
+        return None
 
 
 def algorithmic_bytes(sizes, layers, params, l, batch, fused):
@@ -210,12 +223,13 @@ def main():
         name = "%s%d" % (topo.TYPE_NAMES[layers[dom]["type"]], (conv_idx.index(dom) + 1) if dom in conv_idx else dom)
         roof = dict(bound="hbm", kernel="k_%s_aprx (layer %d, %s)" % ("conv" if dom in conv_idx else "fc", dom, name),
                     achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(achieved / HBM_PEAK_GBS, 5), traffic=None,
+                    frac=round(achieved / HBM_PEAK_GBS, 5),
+                    traffic=(pmc_traffic(dom) if (B == 1000 and args.model == "AlexNet") else None),
                     ms_per_launch=round(dom_ms, 4), launches_timed=recorded,
                     algorithmic_bytes_per_launch=int(abytes),
                     lds_lookups_per_s=round(lk / (dom_ms * 1e-3), 0) if dom_ms > 0 else 0,
-                    lds_lookup_peak_b32=LDS_B32_LOOKUPS_PER_S,
-                    lds_frac=round(lk / (dom_ms * 1e-3) / LDS_B32_LOOKUPS_PER_S, 4) if dom_ms > 0 else 0,
+                    lds_lookup_peak_b64=LDS_B64_LOOKUPS_PER_S,
+                    lds_frac=round(lk / (dom_ms * 1e-3) / LDS_B64_LOOKUPS_PER_S, 4) if dom_ms > 0 else 0,
                     layer_ms={"%02d_%s" % (i, topo.TYPE_NAMES[layers[i]["type"]]): round(float(m), 4)
                               for i, m in enumerate(layer_ms) if m > 0})
         out = {
