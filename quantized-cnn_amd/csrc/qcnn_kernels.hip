@@ -6,25 +6,25 @@
 // Glue kernels (row a9): ReLU :1027, LRN :1038, max-pool :870, softmax :1098, top-5 :1162,
 // NCHW<->panel conversions (:1146-1160, :187-189).
 //
-// Mapping (see qcnn_kernels.h for the HBM layout): a lane carries an image pair.  A workgroup (8 waves)
-// owns one 128-image panel, one tile of output positions and one slice of output channels; every wave
-// keeps (positions x channels-per-wave) float2 accumulators in VGPRs.  The look-up table is never
-// materialised in HBM: it is produced one STAGE at a time in LDS — a stage = 128 code-word rows =
-// G = 128/K consecutive sub-spaces of one source pixel (conv) or of the input vector (FC) for the 128
-// images; a row is 512 contiguous bytes (+16 B pad) = one conflict-free ds_read_b64 per wave.  Stages
-// are double buffered: while the waves gather from stage s, the MFMA operands of stage s+1 are already
-// in flight and its tiles (v_mfma_f32_16x16x4_f32, or ordered VALU mul+add in "exact" mode) are written
-// to the other buffer; one s_barrier per stage.  Stages are visited in (pixel row-major, sub-space
-// ascending) order, which for any one output is exactly the reference's (kh, kw, m) summation order
-// (:840-863), so with the exact builder conv/FC outputs are bit-identical to the reference.  Code-word
-// offsets are wave-uniform and arrive through scalar loads.
+// Mapping (see qcnn_kernels.h for the HBM layout, DESIGN.md §3 for the measurements behind it): a lane
+// carries an image pair.  A workgroup (16 waves, one per CU) owns one 128-image panel, one tile of output
+// positions and one slice of output channels.  The look-up table is never materialised in HBM: it is
+// produced one STAGE at a time in LDS — a stage = 128 code-word rows = G = 128/K consecutive sub-spaces of
+// one source pixel (conv) or of the input vector (FC) for the 128 images; a row is 512 contiguous bytes
+// (+16 B pad) = one conflict-free ds_read_b64 per wave.  Stages are double buffered, one s_barrier per
+// stage.  The waves are specialised: four BUILDER waves (one per SIMD) multiply stage s+1 out
+// (v_mfma_f32_16x16x4_f32, or ordered VALU mul+add in "exact" mode) and store it, twelve GATHER waves
+// keep (positions x channels-per-wave) float2 accumulators in VGPRs and consume stage s.  Stages are
+// visited in (pixel row-major, sub-space ascending) order, which for any one output is exactly the
+// reference's (kh, kw, m) summation order (:840-863), so with the exact builder conv/FC outputs are
+// bit-identical to the reference.  Code-word row indices (uint8) are wave-uniform; they are prefetched
+// through the vector memory path and broadcast into SGPRs.
 #include "qcnn_kernels.h"
 
 #include <float.h>
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
