@@ -57,6 +57,18 @@ __global__ __launch_bounds__(1024) void kg(float* out, uint64_t* cyc, int iters,
             acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(mb, ma, acc[j], 0, 0, 0);
           }
         }
+        if (MF == 3) {   // three bf16 16x16x32 per tile (exact 3-way split of both operands) + ~6 VALU per tile of operand prep
+          typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+          bf16x8 va, vb, vc;
+          for (int q = 0; q < 8; ++q) { va[q] = (__bf16)(ma + q); vb[q] = (__bf16)(mb - q); vc[q] = (__bf16)(ma * 0.5f + q); }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, vb, acc[j], 0, 0, 0);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, vc, acc[j], 0, 0, 0);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vc, vb, acc[j], 0, 0, 0);
+          ma = ma * 1.0001f + 0.5f; mb = mb * 0.9999f + 0.25f;
+        }
         if (MF == 2) {   // one bf16 16x16x32 per tile (hi/lo split operands) instead of two f32 16x16x4
           typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
           bf16x8 va, vb;
@@ -126,7 +138,7 @@ int main() {
   auto report = [&](const char* name, int readers) {
     hipDeviceSynchronize(); hipMemset(cyc, 0, sizeof(h)); };
   (void)report;
-  for (int mode = 0; mode < 9; ++mode)
+  for (int mode = 0; mode < 11; ++mode)
     for (int readers : {0, 4, 8, 12}) {
       if (mode == 0 && readers == 0) continue;
       if (mode >= 3 && readers != 12) continue;
@@ -140,12 +152,14 @@ int main() {
       if (mode == 6) hipLaunchKernelGGL((kg<2, 1, 1>), dim3(256), dim3(1024), 163840, 0, out, cyc, iters, readers, idx);
       if (mode == 7) hipLaunchKernelGGL((kg<1, 1, 2>), dim3(256), dim3(1024), 163840, 0, out, cyc, iters, readers, idx);
       if (mode == 8) hipLaunchKernelGGL((kg<2, 1, 2>), dim3(256), dim3(1024), 163840, 0, out, cyc, iters, readers, idx);
+      if (mode == 9) hipLaunchKernelGGL((kg<1, 1, 3>), dim3(256), dim3(1024), 163840, 0, out, cyc, iters, readers, idx);
+      if (mode == 10) hipLaunchKernelGGL((kg<2, 1, 3>), dim3(256), dim3(1024), 163840, 0, out, cyc, iters, readers, idx);
       hipError_t e = hipDeviceSynchronize();
       hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost);
       double mr = 0, mw = 0;
       for (int b = 0; b < 256; ++b) for (int w = 0; w < 16; ++w) { double v = (double)h[b * 16 + w]; if (w < 4) mw = v > mw ? v : mw; else mr = v > mr ? v : mr; }
       printf("writers=%s readers=%2d : reader cycles per 32 look-ups (slowest wave) %7.1f   writer cycles per 64KB stage %7.1f  (%s)\n",
-             mode == 0 ? "none  " : (mode == 1 ? "write2" : (mode == 2 ? "addtid" : (mode == 3 ? "write2+barrier" : (mode == 4 ? "write2+mfma" : (mode == 5 ? "write2+mfma+barrier" : (mode == 6 ? "addtid+mfma+barrier" : (mode == 7 ? "write2+bf16mfma+barrier" : "addtid+bf16mfma+barrier"))))))), readers, mr / iters, mw / iters, hipGetErrorString(e));
+             mode == 0 ? "none  " : (mode == 1 ? "write2" : (mode == 2 ? "addtid" : (mode == 3 ? "write2+barrier" : (mode == 4 ? "write2+mfma" : (mode == 5 ? "write2+mfma+barrier" : (mode == 6 ? "addtid+mfma+barrier" : (mode == 7 ? "write2+bf16mfma+barrier" : (mode == 8 ? "addtid+bf16mfma+barrier" : (mode == 9 ? "write2+3xbf16mfma+barrier" : "addtid+3xbf16mfma+barrier"))))))))), readers, mr / iters, mw / iters, hipGetErrorString(e));
     }
   return 0;
 }
