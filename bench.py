@@ -197,7 +197,7 @@ def main():
     layer_ms, recorded = eng.layer_ms()
     ok = bool(torch.isfinite(prob).all().item())
 
-    h2d = None
+    h2d = h2d_u8 = None
     if args.h2d_steps > 0 and rank == 0:
         pinned = torch.empty(imgs.shape, dtype=torch.float32, pin_memory=True)
         pinned.copy_(imgs)
@@ -209,6 +209,20 @@ def main():
             eng.forward_dev(staging.data_ptr(), B, prob.data_ptr(), top5.data_ptr())
         torch.cuda.synchronize(dev)
         h2d = B * args.h2d_steps / (time.perf_counter() - t1)
+        # same with the device-side input pipeline: 8-bit 256x256 source images + mean image, crop on the device
+        hs, ws = max(in_chw[1], 256), max(in_chw[2], 256)
+        px = torch.randint(0, 256, (B, in_chw[0], hs, ws), dtype=torch.uint8)
+        pinned_u8 = torch.empty(px.shape, dtype=torch.uint8, pin_memory=True)
+        pinned_u8.copy_(px)
+        staging_u8 = torch.empty(px.shape, dtype=torch.uint8, device=dev)
+        mean_img = torch.full((in_chw[0], hs, ws), 110.0, dtype=torch.float32, device=dev)
+        torch.cuda.synchronize(dev)
+        t2 = time.perf_counter()
+        for _ in range(args.h2d_steps):
+            staging_u8.copy_(pinned_u8, non_blocking=True)
+            eng.forward_u8_dev(staging_u8.data_ptr(), hs, ws, mean_img.data_ptr(), B, prob.data_ptr(), top5.data_ptr())
+        torch.cuda.synchronize(dev)
+        h2d_u8 = B * args.h2d_steps / (time.perf_counter() - t2)
 
     if rank == 0:
         ms_step = 1000.0 * dt / args.steps
@@ -249,6 +263,7 @@ def main():
         }
         if h2d is not None:
             out["value_incl_pinned_h2d"] = round(h2d, 2)
+            out["value_incl_pinned_h2d_u8"] = round(h2d_u8, 2)
         if args.cpu_sample > 0 and world == 1:
             imgs_host = imgs[: args.cpu_sample].cpu().numpy()
             out["cpu_baseline"] = cpu_baseline(in_chw, layers, params, imgs_host, args.cpu_sample)

@@ -21,6 +21,7 @@
  *                               -> GetInPdMat (look-up-table build)        src/CaffeEva.cc:1261-1296
  *                               -> _ReLu/_LoRN/_Pool/_Drpt/_SMax           src/CaffeEva.cc:870-921,1027-1116
  *                               + CvtFeatMapToLablVec (top-5)              src/CaffeEva.cc:1162-1190
+ *   qcnn_forward_u8             BmpImgIO::RmMeanImg + CropImg in front     src/BmpImgIO.cc:180-224
  *   qcnn_run_layer              CaffeEva::CalcFeatMap on one layer         src/CaffeEva.cc:625-670
  *   qcnn_get_layer_output       featMapLst[l] read-back (parity dumps)     include/CaffeEva.h:109
  *   qcnn_get_layer_ms           swIndvLayerLst / DispElpsTime              src/CaffeEva.cc:297-326
@@ -97,6 +98,13 @@ int qcnn_fm_dims(QcnnCtx* ctx, int l, int* hwc3);
 /* Device-resident forward of n <= max_batch images, asynchronous on the context's stream.
  * in_nchw_dev [n][C][H][W] fp32; prob_dev [n][classes] fp32 or NULL; top5_dev [n][5] uint16 or NULL. */
 int qcnn_forward(QcnnCtx* ctx, const float* in_nchw_dev, int n, float* prob_dev, uint16_t* top5_dev);
+/* Same with the reference's image pre-processing done on the device (BmpImgIO::RmMeanImg + CropImg,
+ * src/BmpImgIO.cc:180-224): in_u8_dev [n][C][src_h][src_w] planar 8-bit (B, G, R planes, as
+ * BmpImgIO::LoadBmpImg :84-96 stores them), mean_dev [C][src_h][src_w] fp32 or NULL; the network input is
+ * the centre crop of float(pixel) - mean.  Bit-identical to qcnn_forward on the host-preprocessed image;
+ * a quarter of the host-to-device bytes. */
+int qcnn_forward_u8(QcnnCtx* ctx, const uint8_t* in_u8_dev, int src_h, int src_w, const float* mean_dev, int n,
+                    float* prob_dev, uint16_t* top5_dev);
 /* Blocking convenience: host in, host out (H2D + forward + D2H + sync). */
 int qcnn_forward_host(QcnnCtx* ctx, const float* in_nchw_host, int n, float* prob_host, uint16_t* top5_host);
 /* Feature map l of the last forward, images [0, n), NHWC per image, to host (blocking).

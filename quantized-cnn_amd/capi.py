@@ -65,6 +65,7 @@ def load():
     lib.qcnn_model_mark_loaded.argtypes = [vp]
     lib.qcnn_fm_dims.argtypes = [vp, i, C.POINTER(i)]
     lib.qcnn_forward.argtypes = [vp, f32p, i, f32p, u16p]
+    lib.qcnn_forward_u8.argtypes = [vp, u8p, i, i, f32p, i, f32p, u16p]
     lib.qcnn_forward_host.argtypes = [vp, f32p, i, f32p, u16p]
     lib.qcnn_get_layer_output.argtypes = [vp, i, i, f32p]
     lib.qcnn_run_layer.argtypes = [vp, i, f32p, i, f32p]

@@ -507,14 +507,12 @@ int qcnn_fm_dims(QcnnCtx* c, int l, int* hwc3) {
   return 0;
 }
 
-int qcnn_forward(QcnnCtx* c, const float* in_nchw_dev, int n, float* prob_dev, uint16_t* top5_dev) {
-  HIP_TRY(c, hipSetDevice(c->device));
-  if (!c->committed) return fail(c, "model not committed");
-  if (n <= 0 || n > c->maxBatch) return fail(c, "batch %d outside (0, %d]", n, c->maxBatch);
-  hipError_t e = qk_pack_nchw(in_nchw_dev, c->fmBuf[0], n, c->inC, c->inH, c->inW, c->stream);
-  if (e != hipSuccess) return fail(c, "input pack launch failed: %s", hipGetErrorString(e));
+namespace {
+// layers + output conversion of a forward whose input panel (fmBuf[0]) has just been enqueued
+int forward_tail(QcnnCtx* c, int n, float* prob_dev, uint16_t* top5_dev) {
   if (run_layers(c, n)) return 1;
   const int classes = (int)fm_elems(c, c->L);
+  hipError_t e;
   if (prob_dev) {
     e = qk_unpack_rows(c->lastFm[c->L], prob_dev, n, classes, c->stream);
     if (e != hipSuccess) return fail(c, "output unpack launch failed: %s", hipGetErrorString(e));
@@ -524,6 +522,28 @@ int qcnn_forward(QcnnCtx* c, const float* in_nchw_dev, int n, float* prob_dev, u
     if (e != hipSuccess) return fail(c, "top-5 launch failed: %s", hipGetErrorString(e));
   }
   return 0;
+}
+}  // namespace
+
+int qcnn_forward(QcnnCtx* c, const float* in_nchw_dev, int n, float* prob_dev, uint16_t* top5_dev) {
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (!c->committed) return fail(c, "model not committed");
+  if (n <= 0 || n > c->maxBatch) return fail(c, "batch %d outside (0, %d]", n, c->maxBatch);
+  hipError_t e = qk_pack_nchw(in_nchw_dev, c->fmBuf[0], n, c->inC, c->inH, c->inW, c->stream);
+  if (e != hipSuccess) return fail(c, "input pack launch failed: %s", hipGetErrorString(e));
+  return forward_tail(c, n, prob_dev, top5_dev);
+}
+
+int qcnn_forward_u8(QcnnCtx* c, const uint8_t* in_u8_dev, int src_h, int src_w, const float* mean_dev, int n,
+                    float* prob_dev, uint16_t* top5_dev) {
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (!c->committed) return fail(c, "model not committed");
+  if (n <= 0 || n > c->maxBatch) return fail(c, "batch %d outside (0, %d]", n, c->maxBatch);
+  if (src_h < c->inH || src_w < c->inW)
+    return fail(c, "source images %dx%d are smaller than the network input %dx%d", src_h, src_w, c->inH, c->inW);
+  hipError_t e = qk_pack_u8(in_u8_dev, mean_dev, c->fmBuf[0], n, c->inC, c->inH, c->inW, src_h, src_w, c->stream);
+  if (e != hipSuccess) return fail(c, "input pack launch failed: %s", hipGetErrorString(e));
+  return forward_tail(c, n, prob_dev, top5_dev);
 }
 
 int qcnn_forward_host(QcnnCtx* c, const float* in_nchw_host, int n, float* prob_host, uint16_t* top5_host) {

@@ -71,6 +71,9 @@ hipError_t qk_top5(const float* prob, uint16_t* out, int n, int C, hipStream_t s
 
 // [n][C][H][W] -> panels [H*W*C][128] (lanes >= n zero-filled)
 hipError_t qk_pack_nchw(const float* in, float* dst, int n, int C, int H, int W, hipStream_t st);
+// 8-bit planar [n][C][Hs][Ws] minus mean [C][Hs][Ws] (or NULL), centre crop H x W -> panels [H*W*C][128]
+hipError_t qk_pack_u8(const uint8_t* in, const float* mean, float* dst, int n, int C, int H, int W, int Hs, int Ws,
+                      hipStream_t st);
 // [n][E] (already in NHWC / flat order) -> panels [E][128]
 hipError_t qk_pack_rows(const float* in, float* dst, int n, int E, hipStream_t st);
 // panels [E][128] -> [n][E]

@@ -993,6 +993,43 @@ __global__ __launch_bounds__(256) void k_pack(const float* __restrict__ in, floa
   }
 }
 
+// Device-side input pipeline: 8-bit planar images [n][C][Hs][Ws] (the B, G, R planes as
+// BmpImgIO::LoadBmpImg stores them, src/BmpImgIO.cc:84-96) minus the mean image [C][Hs][Ws]
+// (RmMeanImg, :203-224), centre crop to H x W (CropImg, :180-201), straight into the panel layout.  Same
+// arithmetic as the host path — float(pixel) - mean — so the result is bit-identical to packing the
+// host-preprocessed fp32 image, at a quarter of the PCIe bytes.
+__global__ __launch_bounds__(256) void k_pack_u8(const uint8_t* __restrict__ in, const float* __restrict__ mean,
+                                                 float* __restrict__ dst, int n, int C, int H, int W, int Hs, int Ws) {
+  __shared__ float tile[PANEL][65];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int HW = H * W, E = C * HW;
+  const int oy = (Hs - H) / 2, ox = (Ws - W) / 2;
+  const int e0 = blockIdx.x * 64;
+  const int panel = blockIdx.y;
+  const int e = e0 + lane;
+  size_t soff = 0;
+  float m = 0.0f;
+  if (e < E) {
+    const int c = e / HW, y = (e % HW) / W, x = e % W;
+    soff = ((size_t)c * Hs + (y + oy)) * Ws + (x + ox);
+    if (mean) m = mean[soff];
+  }
+  const size_t srcImg = (size_t)C * Hs * Ws;
+  for (int i = wave; i < PANEL; i += 4) {
+    const int img = panel * PANEL + i;
+    tile[i][lane] = (img < n && e < E) ? ((float)in[(size_t)img * srcImg + soff] - m) : 0.0f;
+  }
+  __syncthreads();
+  for (int j = wave; j < 64; j += 4) {
+    const int ee = e0 + j;
+    if (ee < E) {
+      const int c = ee / HW, hw = ee % HW;
+      *reinterpret_cast<f32x2*>(dst + ((size_t)panel * E + (size_t)hw * C + c) * PANEL + 2 * lane) =
+          f32x2{tile[2 * lane][j], tile[2 * lane + 1][j]};
+    }
+  }
+}
+
 // panels [E][128] -> [n][E]
 __global__ __launch_bounds__(256) void k_unpack(const float* __restrict__ src, float* __restrict__ out, int n, int E) {
   __shared__ float tile[64][PANEL + 1];
@@ -1176,6 +1213,13 @@ hipError_t qk_top5(const float* prob, uint16_t* out, int n, int C, hipStream_t s
 hipError_t qk_pack_nchw(const float* in, float* dst, int n, int C, int H, int W, hipStream_t st) {
   const int E = C * H * W;
   hipLaunchKernelGGL(k_pack, dim3((E + 63) / 64, panels_of(n)), dim3(256), 0, st, in, dst, n, E, C, H * W, 1);
+  return hipGetLastError();
+}
+
+hipError_t qk_pack_u8(const uint8_t* in, const float* mean, float* dst, int n, int C, int H, int W, int Hs, int Ws,
+                      hipStream_t st) {
+  const int E = C * H * W;
+  hipLaunchKernelGGL(k_pack_u8, dim3((E + 63) / 64, panels_of(n)), dim3(256), 0, st, in, mean, dst, n, C, H, W, Hs, Ws);
   return hipGetLastError();
 }
 

@@ -104,6 +104,15 @@ class QcnnEngine:
                                         C.c_void_p(prob_ptr) if prob_ptr else None,
                                         C.c_void_p(top5_ptr) if top5_ptr else None))
 
+    def forward_u8_dev(self, in_ptr: int, src_h: int, src_w: int, mean_ptr: int | None, n: int,
+                       prob_ptr: int | None = None, top5_ptr: int | None = None):
+        """Asynchronous, device pointers: 8-bit planar images [n][C][src_h][src_w], mean [C][src_h][src_w] or None;
+        mean subtraction + centre crop happen on the device (BmpImgIO::RmMeanImg/CropImg)."""
+        self._chk(self.lib.qcnn_forward_u8(self.h, C.c_void_p(in_ptr), src_h, src_w,
+                                           C.c_void_p(mean_ptr) if mean_ptr else None, n,
+                                           C.c_void_p(prob_ptr) if prob_ptr else None,
+                                           C.c_void_p(top5_ptr) if top5_ptr else None))
+
     def forward_host(self, imgs_nchw, want_prob=True, want_top5=True):
         imgs = np.ascontiguousarray(imgs_nchw, np.float32)
         n = imgs.shape[0]

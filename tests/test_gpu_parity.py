@@ -280,3 +280,74 @@ def test_vgg_style_channel_counts():
               topo.conv(1, 3, 48, 1, 1), topo.relu(), topo.conv(0, 1, 384, 2, 1), topo.relu(),
               topo.fcnt(400), topo.relu(), topo.drpt(0.5), topo.fcnt(40), topo.smax()]
     _run_vs_oracle((3, 12, 12), layers, {}, 3, seed=43)
+
+
+# ---------------------------------------------------------------- the other topologies of src/CaffePara.cc ----
+@pytest.mark.parametrize("model,n_img", [("CaffeNet", 2), ("VggCnnS", 2), ("CaffeNetFGD", 2), ("VGG16", 1)])
+def test_other_reference_topologies(model, n_img):
+    """Every layer table the reference knows besides AlexNet (src/CaffePara.cc:54-237; BASELINE.json configs[3] =
+    VGG-16), full size, synthetic parameters in the shipped quantisation layout: all feature maps against the
+    oracle (MFMA builder, <= 1e-4) and every conv/FC layer in isolation with the exact builder (bit-identical).
+    CaffeNetFGB (518 classes, not a multiple of 4; the reference itself overruns there) is rejected by design."""
+    in_chw, layers, _, _ = topo.MODELS[model]
+    params = synth.make_params(in_chw, layers, seed=51)
+    imgs = synth.make_images(n_img, in_chw, seed=52)
+    orc = po.COracle(in_chw, layers)
+    orc.set_params(params)
+    orc.forward(imgs)
+    L = len(layers)
+    eng = make_engine(in_chw, layers, params, n_img, lut=capi.LUT_MFMA)
+    prob, top5 = eng.forward_host(imgs)
+    for l in range(L + 1):
+        e_inf, e_l2 = rel_err(eng.layer_output(l, n_img), orc.fm(l))
+        assert e_inf <= TOL and e_l2 <= TOL, "%s fm[%d]: %g %g" % (model, l, e_inf, e_l2)
+    assert np.array_equal(top5, np.stack([orc.top5(orc.fm(L)[i]) for i in range(n_img)]))
+    eng.set_option(capi.OPT_LUT_MODE, capi.LUT_EXACT)
+    for l, ly in enumerate(layers):
+        if ly["type"] in (topo.CONV, topo.FCNT):
+            y = eng.run_layer(l, consumption_order(layers, l, orc.fm(l)), n_img)
+            assert np.array_equal(y, orc.fm(l + 1)), "%s layer %d (%s)" % (model, l, topo.TYPE_NAMES[ly["type"]])
+    eng.close()
+
+
+def test_caffenet_fgb_is_rejected():
+    in_chw, layers, _, _ = topo.MODELS["CaffeNetFGB"]
+    params = synth.make_params(in_chw, layers, seed=53)
+    eng = pkg("engine").QcnnEngine(0)
+    with pytest.raises(pkg("engine").QcnnError):
+        eng.load_model(in_chw, layers, params, 1)
+
+
+# ---------------------------------------------------------------- device-side input pipeline ----
+@pytest.mark.parametrize("with_mean", [True, False])
+def test_u8_input_pipeline_is_bit_identical_to_host_preprocessing(golden_tiny, with_mean):
+    """qcnn_forward_u8 (mean subtraction + centre crop on the device, BmpImgIO::RmMeanImg / CropImg
+    src/BmpImgIO.cc:180-224) against the same pre-processing done on the host in fp32."""
+    import torch
+    z = golden_tiny
+    in_chw, layers = topo.tiny_model()
+    c, h, w = in_chw
+    hs, ws, n = h + 9, w + 14, 131                                        # ragged batch, odd crop offsets
+    rng = np.random.default_rng(61)
+    px = rng.integers(0, 256, size=(n, c, hs, ws), dtype=np.uint8)
+    mean = (rng.standard_normal((c, hs, ws)) * 20 + 110).astype(np.float32) if with_mean else None
+    oy, ox = (hs - h) // 2, (ws - w) // 2
+    full = px.astype(np.float32) - (mean[None] if with_mean else np.float32(0))
+    host = np.ascontiguousarray(full[:, :, oy:oy + h, ox:ox + w])
+    eng = make_engine(in_chw, layers, tiny_params_from_golden(z, layers), n, lut=capi.LUT_MFMA)
+    p_ref, t_ref = eng.forward_host(host)
+    fm0_ref = eng.layer_output(0, n)
+    dev = torch.device("cuda", 0)
+    d_px = torch.from_numpy(px).to(dev)
+    d_mean = torch.from_numpy(mean).to(dev) if with_mean else None
+    d_prob = torch.empty((n, p_ref.shape[1]), dtype=torch.float32, device=dev)
+    d_top5 = torch.empty((n, 5), dtype=torch.int16, device=dev)
+    torch.cuda.synchronize()
+    eng.forward_u8_dev(d_px.data_ptr(), hs, ws, d_mean.data_ptr() if with_mean else None, n,
+                       d_prob.data_ptr(), d_top5.data_ptr())
+    pkg("capi").load().qcnn_sync(eng.h)
+    assert np.array_equal(eng.layer_output(0, n), fm0_ref)
+    assert np.array_equal(d_prob.cpu().numpy(), p_ref)
+    assert np.array_equal(d_top5.cpu().numpy().view(np.uint16), t_ref)
+    with pytest.raises(pkg("engine").QcnnError):
+        eng.forward_u8_dev(d_px.data_ptr(), h - 1, ws, None, n)            # source smaller than the network input
