@@ -145,7 +145,11 @@ def main():
     params = synth.make_params(in_chw, layers, seed=0)      # every rank knows the SHAPES; rank 0 owns the VALUES
     B = args.batch
 
-    stream = torch.cuda.current_stream(dev)
+    # one explicit stream for everything (torch ops, H2D copies and the engine's kernels): the default stream's
+    # handle is NULL, which the C-ABI reads as "create your own stream" — the copies would then not be ordered
+    # with the forward passes
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
     eng = pkg("engine").QcnnEngine(local, stream.cuda_stream)
     eng.set_option(capi.OPT_LUT_MODE, capi.LUT_MFMA if args.lut == "mfma" else capi.LUT_EXACT)
     eng.set_option(capi.OPT_KEEP_ALL, 0)
