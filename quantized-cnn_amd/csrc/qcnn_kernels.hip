@@ -327,6 +327,26 @@ __device__ __forceinline__ void mfma_store(MfmaOps<KT, KS>& o, char* stage, int 
 struct ConvGeom {
   int W, Cin, knl, M, Ct, MG, G, wiL, wiU;
 };
+// Workgroups are dispatched in linear order, so the tiles are numbered heaviest first: interior tiles
+// (full receptive field = most stages), then the four edges, then the corners.  With ~5 workgroups per
+// CU in the 13x13 layers the last dispatch round is then made of the short border tiles instead of
+// whatever row-major order leaves over (longest-processing-time-first).
+__device__ __forceinline__ void tile_of_rank(int r, int tilesY, int tilesX, int& ty, int& tx) {
+  if (tilesY < 3 || tilesX < 3) { ty = r / tilesX; tx = r % tilesX; return; }
+  const int iy = tilesY - 2, ix = tilesX - 2;
+  if (r < iy * ix) { ty = 1 + r / ix; tx = 1 + r % ix; return; }
+  r -= iy * ix;
+  if (r < ix) { ty = 0; tx = 1 + r; return; }
+  r -= ix;
+  if (r < ix) { ty = tilesY - 1; tx = 1 + r; return; }
+  r -= ix;
+  if (r < iy) { ty = 1 + r; tx = 0; return; }
+  r -= iy;
+  if (r < iy) { ty = 1 + r; tx = tilesX - 1; return; }
+  r -= iy;
+  ty = (r >> 1) ? tilesY - 1 : 0;
+  tx = (r & 1) ? tilesX - 1 : 0;
+}
 struct StagePos {
   int hi, wi, mg;
 };
@@ -380,7 +400,7 @@ __device__ __forceinline__ void conv_gather(f32x2 (&acc)[SW][CPW], const Idx<CPW
 }
 
 template <int TH, int TW, int SW, int CPW, int KT, int KS>
-__global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX, int chunksPerGrp, int G) {
+__global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX, int tilesY, int chunksPerGrp, int G) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   static_assert(TW % SW == 0, "strips tile the row");
   constexpr int SPR = TW / SW;            // strips per tile row
@@ -390,9 +410,10 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
   constexpr int KTT = KT > 0 ? KT : 1;
   const int lane = threadIdx.x & 63;
   const int wave = uni(threadIdx.x >> 6);
-  const int ty = blockIdx.x / tilesX, tx = blockIdx.x % tilesX;
+  int ty, tx;                                       // blockIdx.x = tile rank (heaviest first) * panels + panel
+  tile_of_rank((int)(blockIdx.x / (unsigned)p.panels), tilesY, tilesX, ty, tx);
+  const int panel = (int)(blockIdx.x % (unsigned)p.panels);
   const int grp = blockIdx.y / chunksPerGrp, chunk = blockIdx.y % chunksPerGrp;
-  const int panel = blockIdx.z;
   const int Cg = p.Cin / p.grp, Ctg = p.Ct / p.grp;
   const int M = p.M;
 
@@ -1059,7 +1080,7 @@ hipError_t launch_conv(const ConvParams& p, int lutMode, hipStream_t st) {
   const int Ctg = p.Ct / p.grp;
   const int tilesX = (p.Wo + TW - 1) / TW, tilesY = (p.Ho + TH - 1) / TH;
   const int chunksPerGrp = (Ctg + NC * CPW - 1) / (NC * CPW);
-  const dim3 grid(tilesX * tilesY, chunksPerGrp * p.grp, p.panels);
+  const dim3 grid(tilesX * tilesY * p.panels, chunksPerGrp * p.grp, 1);
   const size_t shm = (size_t)2 * STAGE_BYTES;
   const int G = qcnn_stage_group(p.K);
   const bool two = min(p.Cin / p.grp, p.Cs) > 4;      // MFMA k-steps (4 dims each) that carry data
@@ -1071,7 +1092,7 @@ hipError_t launch_conv(const ConvParams& p, int lutMode, hipStream_t st) {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)shm);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, grid, dim3(NW * 64), shm, st, p, tilesX, chunksPerGrp, G);
+  hipLaunchKernelGGL(kern, grid, dim3(NW * 64), shm, st, p, tilesX, tilesY, chunksPerGrp, G);
   return hipGetLastError();
 }
 
