@@ -49,27 +49,34 @@ __device__ __forceinline__ void barrier_plain() { asm volatile("s_barrier" ::: "
 // Role assignment.  The matrix pipe is per SIMD, so the four builder waves must sit on four DIFFERENT
 // SIMDs; which SIMD a wave lands on is the dispatcher's choice (not a function of the wave index that
 // software may rely on), so every wave publishes its SIMD id (HW_REG_HW_ID[5:4]) through LDS and the
-// first wave of each SIMD becomes that SIMD's builder (bw = SIMD id); the other twelve waves get dense
-// gather indices.  128 VGPRs per wave force exactly four waves per SIMD for a 16-wave workgroup.
+// first wave of each SIMD becomes a builder; the other twelve waves get dense gather indices.  (128 VGPRs
+// per wave force exactly four waves per SIMD for a 16-wave workgroup; the smaller instantiations fall back
+// to "lowest remaining waves" if a SIMD should have none.)
 struct WaveRole {
   bool builder;
-  int idx;      // builder: 0..3 (SIMD id); gather wave: 0..11
+  int idx;      // builder: 0..3; gather wave: 0..11
 };
 __device__ __forceinline__ WaveRole assign_roles(char* lds, int wave, int lane) {
   int* tab = reinterpret_cast<int*>(lds);
   const int simd = (int)(__builtin_amdgcn_s_getreg(4 | (4 << 6) | (1 << 11)) & 3u);   // hwreg(HW_REG_HW_ID, 4, 2)
   if (lane == 0) tab[wave] = simd;
   __syncthreads();
-  WaveRole r = {false, 0};
-  int seen = 0, gathers = 0;
+  // every wave derives the same assignment from the table: first wave of each SIMD, and — should the
+  // dispatcher ever have left a SIMD without a wave of this workgroup — the lowest remaining waves
+  int seen = 0, builders = 0, bmask = 0;
 #pragma unroll
   for (int w = 0; w < NW; ++w) {
     const int sw = uni(tab[w]);
-    const bool b = !((seen >> sw) & 1);
+    if (!((seen >> sw) & 1) && builders < NBW) { bmask |= 1 << w; ++builders; }
     seen |= 1 << sw;
-    if (w == wave) { r.builder = b; r.idx = b ? sw : gathers; }
-    if (!b) ++gathers;
   }
+#pragma unroll
+  for (int w = 0; w < NW; ++w)
+    if (builders < NBW && !((bmask >> w) & 1)) { bmask |= 1 << w; ++builders; }
+  WaveRole r;
+  r.builder = (bmask >> wave) & 1;
+  const int below = bmask & ((1 << wave) - 1);
+  r.idx = r.builder ? __builtin_popcount(below) : wave - __builtin_popcount(below);
   __syncthreads();   // the table is dead: the first LUT stage may overwrite it
   return r;
 }
