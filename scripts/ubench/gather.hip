@@ -36,7 +36,7 @@ __device__ __forceinline__ void gather8(f32x2* acc, uint32_t w0, uint32_t w1, ui
 // variant: 16 reads in flight (two index words pairs), waits only twice
 // WRITERS: 0 none, 1 four waves ds_write2_b32 (64 KB per iteration in total), 2 four waves ds_write_addtid_b32
 template <int WRITERS, int BAR, int MF>
-__global__ __launch_bounds__(1024) void kg(float* out, uint64_t* cyc, int iters, int readers, const uint32_t* idx) {
+__global__ __launch_bounds__(1024) void kg(float* out, uint64_t* cyc, int iters, int readers, const uint32_t* idx, int rblocks = 4, int mfhalf = 0) {
   extern __shared__ char lds[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   for (int i = threadIdx.x; i < 160 * 1024 / 4; i += blockDim.x) reinterpret_cast<float*>(lds)[i] = 1.0f;
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(1024) void kg(float* out, uint64_t* cyc, int iters,
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ma, mb, acc[j], 0, 0, 0);
-            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(mb, ma, acc[j], 0, 0, 0);
+            if (!mfhalf) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(mb, ma, acc[j], 0, 0, 0);
           }
         }
         if (MF == 3) {   // three bf16 16x16x32 per tile (exact 3-way split of both operands) + ~6 VALU per tile of operand prep
@@ -117,9 +117,9 @@ __global__ __launch_bounds__(1024) void kg(float* out, uint64_t* cyc, int iters,
     const uint32_t st = base + 67584u * (it & 1);
     const int nblk = __builtin_amdgcn_readfirstlane((wave - 4 >= readers) ? 0 : 1);
     gather8(&acc[0], w[0], w[1], st, rowb, nblk);
-    gather8(&acc[8], w[2], w[3], st, rowb, nblk);
-    gather8(&acc[16], w[4], w[5], st, rowb, nblk);
-    gather8(&acc[24], w[6], w[7], st, rowb, nblk);
+    gather8(&acc[8], w[2], w[3], st, rowb, __builtin_amdgcn_readfirstlane(nblk && rblocks > 1));
+    gather8(&acc[16], w[4], w[5], st, rowb, __builtin_amdgcn_readfirstlane(nblk && rblocks > 2));
+    gather8(&acc[24], w[6], w[7], st, rowb, __builtin_amdgcn_readfirstlane(nblk && rblocks > 3));
     if (BAR) asm volatile("s_barrier" ::: "memory");
   }
   uint64_t t1 = __builtin_readcyclecounter();
@@ -160,6 +160,17 @@ int main() {
       for (int b = 0; b < 256; ++b) for (int w = 0; w < 16; ++w) { double v = (double)h[b * 16 + w]; if (w < 4) mw = v > mw ? v : mw; else mr = v > mr ? v : mr; }
       printf("writers=%s readers=%2d : reader cycles per 32 look-ups (slowest wave) %7.1f   writer cycles per 64KB stage %7.1f  (%s)\n",
              mode == 0 ? "none  " : (mode == 1 ? "write2" : (mode == 2 ? "addtid" : (mode == 3 ? "write2+barrier" : (mode == 4 ? "write2+mfma" : (mode == 5 ? "write2+mfma+barrier" : (mode == 6 ? "addtid+mfma+barrier" : (mode == 7 ? "write2+bf16mfma+barrier" : (mode == 8 ? "addtid+bf16mfma+barrier" : (mode == 9 ? "write2+3xbf16mfma+barrier" : "addtid+3xbf16mfma+barrier"))))))))), readers, mr / iters, mw / iters, hipGetErrorString(e));
+    }
+  // conv1-like stage: 12 readers x 2 blocks (16 look-ups), writers 16 f32 MFMA + 64 KB, barrier
+  for (int rb : {1, 2, 3, 4})
+    for (int half : {1, 0}) {
+      hipMemset(cyc, 0, sizeof(h));
+      hipLaunchKernelGGL((kg<1, 1, 1>), dim3(256), dim3(1024), 163840, 0, out, cyc, iters, 12, idx, rb, half);
+      hipDeviceSynchronize();
+      hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost);
+      double mr = 0;
+      for (int b = 0; b < 256; ++b) for (int w = 4; w < 16; ++w) { double v = (double)h[b * 16 + w]; mr = v > mr ? v : mr; }
+      printf("write2+mfma+barrier, 12 readers x %d blocks of 8 look-ups, %d f32 MFMA per writer: %7.1f cycles per stage\n", rb, half ? 16 : 32, mr / iters);
     }
   return 0;
 }
