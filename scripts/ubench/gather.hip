@@ -33,9 +33,46 @@ __device__ __forceinline__ void gather8(f32x2* acc, uint32_t w0, uint32_t w1, ui
                : [w0] "s"(w0), [w1] "s"(w1), [b] "v"(base), [rb] "v"(rowb), [ok] "s"(valid)
                : "scc");
 }
+// 16 look-ups in flight: temporaries are FIXED physical registers named in the clobber list (an asm statement
+// may have at most 30 operands): values v[96:127], addresses v[88:95] (reused for the second half as soon as the
+// first eight reads are issued), scalars s[84:91]
+#define G16_X4(w, t0, t1, t2, t3)                                                                 \
+  "s_and_b32 " t0 ", %[" w "], 0xff\n\ts_bfe_u32 " t1 ", %[" w "], 0x80008\n\t"                 \
+  "s_bfe_u32 " t2 ", %[" w "], 0x80010\n\ts_lshr_b32 " t3 ", %[" w "], 24\n\t"
+#define G16_MAD(a, t) "v_mad_u32_u24 " a ", " t ", %[rb], %[b]\n\t"
+#define G16_RD(v, a) "ds_read_b64 " v ", " a "\n\t"
+#define G16_ACC(n, c, v) "s_waitcnt lgkmcnt(" n ")\n\tv_pk_add_f32 %[" c "], " v ", %[" c "]\n\t"
+__device__ __forceinline__ void gather16(f32x2* acc, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t base,
+                                         uint32_t rowb, int valid) {
+  asm volatile("s_cmp_eq_u32 %[ok], 0\n\ts_cbranch_scc1 .Lqskip%=\n\t"
+               G16_X4("w0", "s84", "s85", "s86", "s87") G16_X4("w1", "s88", "s89", "s90", "s91")
+               G16_MAD("v88", "s84") G16_MAD("v89", "s85") G16_MAD("v90", "s86") G16_MAD("v91", "s87")
+               G16_MAD("v92", "s88") G16_MAD("v93", "s89") G16_MAD("v94", "s90") G16_MAD("v95", "s91")
+               G16_RD("v[96:97]", "v88") G16_RD("v[98:99]", "v89") G16_RD("v[100:101]", "v90") G16_RD("v[102:103]", "v91")
+               G16_RD("v[104:105]", "v92") G16_RD("v[106:107]", "v93") G16_RD("v[108:109]", "v94") G16_RD("v[110:111]", "v95")
+               G16_X4("w2", "s84", "s85", "s86", "s87") G16_X4("w3", "s88", "s89", "s90", "s91")
+               G16_MAD("v88", "s84") G16_MAD("v89", "s85") G16_MAD("v90", "s86") G16_MAD("v91", "s87")
+               G16_MAD("v92", "s88") G16_MAD("v93", "s89") G16_MAD("v94", "s90") G16_MAD("v95", "s91")
+               G16_RD("v[112:113]", "v88") G16_RD("v[114:115]", "v89") G16_RD("v[116:117]", "v90") G16_RD("v[118:119]", "v91")
+               G16_RD("v[120:121]", "v92") G16_RD("v[122:123]", "v93") G16_RD("v[124:125]", "v94") G16_RD("v[126:127]", "v95")
+               G16_ACC("15", "c0", "v[96:97]") G16_ACC("14", "c1", "v[98:99]") G16_ACC("13", "c2", "v[100:101]") G16_ACC("12", "c3", "v[102:103]")
+               G16_ACC("11", "c4", "v[104:105]") G16_ACC("10", "c5", "v[106:107]") G16_ACC("9", "c6", "v[108:109]") G16_ACC("8", "c7", "v[110:111]")
+               G16_ACC("7", "c8", "v[112:113]") G16_ACC("6", "c9", "v[114:115]") G16_ACC("5", "c10", "v[116:117]") G16_ACC("4", "c11", "v[118:119]")
+               G16_ACC("3", "c12", "v[120:121]") G16_ACC("2", "c13", "v[122:123]") G16_ACC("1", "c14", "v[124:125]") G16_ACC("0", "c15", "v[126:127]")
+               "\n.Lqskip%=:"
+               : [c0] "+v"(acc[0]), [c1] "+v"(acc[1]), [c2] "+v"(acc[2]), [c3] "+v"(acc[3]), [c4] "+v"(acc[4]),
+                 [c5] "+v"(acc[5]), [c6] "+v"(acc[6]), [c7] "+v"(acc[7]), [c8] "+v"(acc[8]), [c9] "+v"(acc[9]),
+                 [c10] "+v"(acc[10]), [c11] "+v"(acc[11]), [c12] "+v"(acc[12]), [c13] "+v"(acc[13]), [c14] "+v"(acc[14]),
+                 [c15] "+v"(acc[15])
+               : [w0] "s"(w0), [w1] "s"(w1), [w2] "s"(w2), [w3] "s"(w3), [b] "v"(base), [rb] "v"(rowb), [ok] "s"(valid)
+               : "scc", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "v88", "v89", "v90", "v91", "v92", "v93", "v94",
+                 "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108",
+                 "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121",
+                 "v122", "v123", "v124", "v125", "v126", "v127");
+}
 // variant: 16 reads in flight (two index words pairs), waits only twice
 // WRITERS: 0 none, 1 four waves ds_write2_b32 (64 KB per iteration in total), 2 four waves ds_write_addtid_b32
-template <int WRITERS, int BAR, int MF>
+template <int WRITERS, int BAR, int MF, int G16 = 0>
 __global__ __launch_bounds__(1024) void kg(float* out, uint64_t* cyc, int iters, int readers, const uint32_t* idx, int rblocks = 4, int mfhalf = 0) {
   extern __shared__ char lds[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -116,6 +153,12 @@ __global__ __launch_bounds__(1024) void kg(float* out, uint64_t* cyc, int iters,
   for (int it = 0; it < iters; ++it) {
     const uint32_t st = base + 67584u * (it & 1);
     const int nblk = __builtin_amdgcn_readfirstlane((wave - 4 >= readers) ? 0 : 1);
+    if (G16) {
+      gather16(&acc[0], w[0], w[1], w[2], w[3], st, rowb, nblk);
+      gather16(&acc[16], w[4], w[5], w[6], w[7], st, rowb, __builtin_amdgcn_readfirstlane(nblk && rblocks > 2));
+      if (BAR) asm volatile("s_barrier" ::: "memory");
+      continue;
+    }
     gather8(&acc[0], w[0], w[1], st, rowb, nblk);
     gather8(&acc[8], w[2], w[3], st, rowb, __builtin_amdgcn_readfirstlane(nblk && rblocks > 1));
     gather8(&acc[16], w[4], w[5], st, rowb, __builtin_amdgcn_readfirstlane(nblk && rblocks > 2));
@@ -160,6 +203,22 @@ int main() {
       for (int b = 0; b < 256; ++b) for (int w = 0; w < 16; ++w) { double v = (double)h[b * 16 + w]; if (w < 4) mw = v > mw ? v : mw; else mr = v > mr ? v : mr; }
       printf("writers=%s readers=%2d : reader cycles per 32 look-ups (slowest wave) %7.1f   writer cycles per 64KB stage %7.1f  (%s)\n",
              mode == 0 ? "none  " : (mode == 1 ? "write2" : (mode == 2 ? "addtid" : (mode == 3 ? "write2+barrier" : (mode == 4 ? "write2+mfma" : (mode == 5 ? "write2+mfma+barrier" : (mode == 6 ? "addtid+mfma+barrier" : (mode == 7 ? "write2+bf16mfma+barrier" : (mode == 8 ? "addtid+bf16mfma+barrier" : (mode == 9 ? "write2+3xbf16mfma+barrier" : "addtid+3xbf16mfma+barrier"))))))))), readers, mr / iters, mw / iters, hipGetErrorString(e));
+    }
+  for (int g16 = 0; g16 < 2; ++g16)
+    for (int cfg = 0; cfg < 3; ++cfg) {
+      hipMemset(cyc, 0, sizeof(h));
+      const int rb = cfg == 2 ? 2 : 4, half = cfg == 2 ? 1 : 0;
+      if (cfg == 0) { if (g16) hipLaunchKernelGGL((kg<0, 0, 0, 1>), dim3(256), dim3(1024), 163840, 0, out, cyc, iters, 12, idx, 4, 0);
+                      else hipLaunchKernelGGL((kg<0, 0, 0, 0>), dim3(256), dim3(1024), 163840, 0, out, cyc, iters, 12, idx, 4, 0); }
+      else { if (g16) hipLaunchKernelGGL((kg<1, 1, 1, 1>), dim3(256), dim3(1024), 163840, 0, out, cyc, iters, 12, idx, rb, half);
+             else hipLaunchKernelGGL((kg<1, 1, 1, 0>), dim3(256), dim3(1024), 163840, 0, out, cyc, iters, 12, idx, rb, half); }
+      hipError_t e = hipDeviceSynchronize();
+      hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost);
+      double mr = 0;
+      for (int b = 0; b < 256; ++b) for (int w = 4; w < 16; ++w) { double v = (double)h[b * 16 + w]; mr = v > mr ? v : mr; }
+      printf("%s look-up blocks, %s: %7.1f cycles per stage (%s)\n", g16 ? "16-deep" : " 8-deep",
+             cfg == 0 ? "12 readers alone, 32 look-ups" : (cfg == 1 ? "32 look-ups + write2 + 32 MFMA + barrier" : "16 look-ups + write2 + 16 MFMA + barrier"),
+             mr / iters, hipGetErrorString(e));
     }
   // conv1-like stage: 12 readers x 2 blocks (16 look-ups), writers 16 f32 MFMA + 64 KB, barrier
   for (int rb : {1, 2, 3, 4})
