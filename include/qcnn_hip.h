@@ -54,7 +54,9 @@ typedef struct {
 enum {
   QCNN_OPT_LUT_MODE = 0,   /* 0 = exact (VALU mul+add in the reference's order: conv/FC outputs are
                               bit-identical to the reference's -O2 native build); 1 = MFMA
-                              (v_mfma_f32_16x16x4_f32, fused multiply-add chain; default) */
+                              (v_mfma_f32_16x16x4_f32, fused multiply-add chain; default); 2 = as 1 with every
+                              table entry rounded to fp16 before it is stored (accumulation stays fp32): the
+                              tolerance study of BASELINE.json configs[4], not a faster path */
   QCNN_OPT_KEEP_ALL = 1,   /* 1 = every layer writes its own feature map (layer-for-layer dumps, default);
                               0 = fast path: ReLU fused into the producing conv/FC epilogue */
   QCNN_OPT_PROFILE = 2     /* 1 = bracket every layer with HIP events (qcnn_get_layer_ms) */

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(PKG, "libqcnn_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(PKG), "include", "qcnn_hip.h")
 
 OPT_LUT_MODE, OPT_KEEP_ALL, OPT_PROFILE = 0, 1, 2
-LUT_EXACT, LUT_MFMA = 0, 1
+LUT_EXACT, LUT_MFMA, LUT_MFMA_F16 = 0, 1, 2
 
 
 class QcnnLayerDesc(C.Structure):

@@ -188,7 +188,7 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
       // Split the sub-space axis over workgroups when the (channel chunk x panel) grid cannot fill the
       // chip; the exact builder keeps one pass so that the summation order stays the reference's.
       p.msplit = 1; p.partial = nullptr;
-      if (c->lutMode == 1) {
+      if (c->lutMode >= 1) {
         const int G = qcnn_stage_group(s.K);
         const int stages = (s.M + G - 1) / G;
         // batch-independent choice (a given image must produce the same bits in any batch): the split count
@@ -337,7 +337,7 @@ int qcnn_ctx_destroy(QcnnCtx* c) {
 
 int qcnn_set_option(QcnnCtx* c, int option, int value) {
   switch (option) {
-    case QCNN_OPT_LUT_MODE: if (value != 0 && value != 1) return fail(c, "LUT mode must be 0 or 1"); c->lutMode = value; return 0;
+    case QCNN_OPT_LUT_MODE: if (value < 0 || value > 2) return fail(c, "LUT mode must be 0, 1 or 2"); c->lutMode = value; return 0;
     case QCNN_OPT_KEEP_ALL: c->keepAll = value ? 1 : 0; return 0;
     case QCNN_OPT_PROFILE: c->profile = value ? 1 : 0; return 0;
     default: return fail(c, "unknown option %d", option);

@@ -35,6 +35,7 @@ struct ConvParams {
   int M, Cs, K;
   int relu;              // fuse max(0, x) into the store
   int panels;
+  int lutF16;            // tolerance study (BASELINE configs[4]): table entries rounded to fp16 before they are stored
 };
 
 struct FcParams {
@@ -48,9 +49,10 @@ struct FcParams {
   int D, Ct, M, Cs, K;
   int relu;
   int panels;
+  int lutF16;            // as ConvParams::lutF16
 };
 
-// lutMode: 0 exact VALU, 1 MFMA.  Return hipError_t of the launch.
+// lutMode: 0 exact VALU, 1 MFMA (2 = MFMA with fp16-rounded table entries, see lutF16).  Return hipError_t of the launch.
 hipError_t qk_conv_aprx(const ConvParams& p, int lutMode, hipStream_t st);
 hipError_t qk_fc_aprx(const FcParams& p, int lutMode, hipStream_t st);
 int qk_fc_channels_per_block(int Ct);   // output channels one k_fc_aprx workgroup covers

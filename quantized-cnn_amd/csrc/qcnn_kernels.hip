@@ -267,9 +267,13 @@ __device__ __forceinline__ void mfma_load(MfmaOps<KT, KS>& o, const char* __rest
 // walked in pairs with a hand-made software pipeline: MFMA(pair n) is interleaved instruction by
 // instruction with the LDS writes of pair n-1, so that a write (which a single wave issues every ~15
 // cycles) always sits in the 32-cycle shadow of a matrix instruction and never waits for its own result.
+__device__ __forceinline__ f32x4 round_f16(f32x4 v) {
+  return f32x4{(float)(_Float16)v[0], (float)(_Float16)v[1], (float)(_Float16)v[2], (float)(_Float16)v[3]};
+}
+
 template <int KT, int KS>
 __device__ __forceinline__ void mfma_store(MfmaOps<KT, KS>& o, char* stage, int Cs, int D, int m0, int mEnd, int bw,
-                                           int lane) {
+                                           int lane, int f16) {
   constexpr int SUBS = MfmaOps<KT, KS>::SUBS;
   const int li = lane & 15, lk = lane >> 4;
   // plain: every sub-space of the stage exists and has all 4*KS dims -> nothing to zero
@@ -314,6 +318,7 @@ __device__ __forceinline__ void mfma_store(MfmaOps<KT, KS>& o, char* stage, int 
     if (n > 0) { *reinterpret_cast<float*>(wb + 2 * ROWB) = pb[2]; *reinterpret_cast<float*>(wb + 3 * ROWB) = pb[3]; }
     __builtin_amdgcn_sched_barrier(0);
     pa = ca; pb = cb;
+    if (f16) { pa = round_f16(pa); pb = round_f16(pb); }   // tolerance study only (uniform branch)
     wa = wl + it * 64 + i * 16 * ROWB;
     wb = wa + 16 * ROWB;
   }
@@ -452,7 +457,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
     StagePos q3 = next_pos(q2, g);
     if (KT > 0) {
       mfma_load<KTT, KS>(opsA, xbase, pixel_off(first, g), p.ctrd, Cs, 0, bw, lane);
-      mfma_store<KTT, KS>(opsA, lds, Cs, Cg, 0, M, bw, lane);
+      mfma_store<KTT, KS>(opsA, lds, Cs, Cg, 0, M, bw, lane, p.lutF16);
       {
         const StagePos qa = (q1.hi > hiU) ? first : q1, qb = (q2.hi > hiU) ? first : q2;
         mfma_load<KTT, KS>(opsA, xbase, pixel_off(qa, g), p.ctrd, Cs, qa.mg * G, bw, lane);
@@ -468,7 +473,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
     // stage is built from re-fetched operands into a buffer nobody reads.
     for (int s = 0; s < Sp; s += 2) {
       if (KT > 0) {                                    // stage s+1 -> buffer 1, from set A
-        mfma_store<KTT, KS>(opsA, lds + STAGE_BYTES, Cs, Cg, q1.mg * G, M, bw, lane);
+        mfma_store<KTT, KS>(opsA, lds + STAGE_BYTES, Cs, Cg, q1.mg * G, M, bw, lane, p.lutF16);
         const StagePos qf = (q3.hi > hiU) ? first : q3;
         mfma_load<KTT, KS>(opsA, xbase, pixel_off(qf, g), p.ctrd, Cs, qf.mg * G, bw, lane);
       } else if (s + 1 < S) {
@@ -477,7 +482,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
       barrier_after_lds_writes();
       q1 = q2; q2 = q3; q3 = next_pos(q3, g);
       if (KT > 0) {                                    // stage s+2 -> buffer 0, from set B
-        mfma_store<KTT, KS>(opsB, lds, Cs, Cg, q1.mg * G, M, bw, lane);
+        mfma_store<KTT, KS>(opsB, lds, Cs, Cg, q1.mg * G, M, bw, lane, p.lutF16);
         const StagePos qf = (q3.hi > hiU) ? first : q3;
         mfma_load<KTT, KS>(opsB, xbase, pixel_off(qf, g), p.ctrd, Cs, qf.mg * G, bw, lane);
       } else if (s + 2 < S) {
@@ -602,7 +607,7 @@ __global__ __launch_bounds__(NW * 64) void k_fc_aprx(FcParams p, int G, int stag
     if (S > 0) {
       if (KT > 0) {
         mfma_load<KTT, KS>(opsA, xbase, 0u, p.ctrd, Cs, mBeg, bw, lane);
-        mfma_store<KTT, KS>(opsA, lds, Cs, p.D, mBeg, mEnd, bw, lane);
+        mfma_store<KTT, KS>(opsA, lds, Cs, p.D, mBeg, mEnd, bw, lane, p.lutF16);
         mfma_load<KTT, KS>(opsA, xbase, 0u, p.ctrd, Cs, min(mBeg + G, mLastStage), bw, lane);
         __builtin_amdgcn_sched_barrier(0);
         mfma_load<KTT, KS>(opsB, xbase, 0u, p.ctrd, Cs, min(mBeg + 2 * G, mLastStage), bw, lane);
@@ -614,14 +619,14 @@ __global__ __launch_bounds__(NW * 64) void k_fc_aprx(FcParams p, int G, int stag
     for (int s = 0; s < Sp; s += 2) {                  // straight-line body, see k_conv_aprx
       const int m0 = mBeg + s * G;
       if (KT > 0) {
-        mfma_store<KTT, KS>(opsA, lds + STAGE_BYTES, Cs, p.D, min(m0 + G, mLastStage), mEnd, bw, lane);
+        mfma_store<KTT, KS>(opsA, lds + STAGE_BYTES, Cs, p.D, min(m0 + G, mLastStage), mEnd, bw, lane, p.lutF16);
         mfma_load<KTT, KS>(opsA, xbase, 0u, p.ctrd, Cs, min(m0 + 3 * G, mLastStage), bw, lane);
       } else if (s + 1 < S) {
         build_stage_exact(lds + STAGE_BYTES, xbase, 0u, p.ctrd, K, Cs, p.D, G, m0 + G, mEnd, bw, lane);
       }
       barrier_after_lds_writes();
       if (KT > 0) {
-        mfma_store<KTT, KS>(opsB, lds, Cs, p.D, min(m0 + 2 * G, mLastStage), mEnd, bw, lane);
+        mfma_store<KTT, KS>(opsB, lds, Cs, p.D, min(m0 + 2 * G, mLastStage), mEnd, bw, lane, p.lutF16);
         mfma_load<KTT, KS>(opsB, xbase, 0u, p.ctrd, Cs, min(m0 + 4 * G, mLastStage), bw, lane);
       } else if (s + 2 < S) {
         build_stage_exact(lds, xbase, 0u, p.ctrd, K, Cs, p.D, G, m0 + 2 * G, mEnd, bw, lane);
@@ -1129,7 +1134,10 @@ hipError_t launch_fc(const FcParams& p, int lutMode, hipStream_t st) {
 // accumulators per wave allow it (every further channel chunk would rebuild the same LUT stages), and
 // as many positions as the accumulators then leave room for.  The MFMA builder is instantiated for K in
 // {16, 32, 64, 128}; any other K <= 128 runs the exact builder.
-hipError_t qk_conv_aprx(const ConvParams& p, int lutMode, hipStream_t st) {
+hipError_t qk_conv_aprx(const ConvParams& pIn, int lutMode, hipStream_t st) {
+  ConvParams p = pIn;
+  p.lutF16 = (lutMode == 2) ? 1 : 0;
+  if (lutMode == 2) lutMode = 1;
   const int Ctg = p.Ct / p.grp;
   if (Ctg % 4 || p.Cs > QCNN_MAX_CS || p.K > QCNN_MAX_K) return hipErrorInvalidValue;
   if (Ctg % 384 == 0) return launch_conv<1, 1, 1, 32>(p, lutMode, st);    // 12 x 32
@@ -1146,7 +1154,10 @@ static int fc_channels_per_wave(int Ct) { return Ct >= 384 ? 32 : (Ct >= 96 ? 8 
 int qk_fc_channels_per_block(int Ct) { return NGW * fc_channels_per_wave(Ct); }
 
 // p.msplit is chosen by the caller (engine): 1 keeps the reference's summation order.
-hipError_t qk_fc_aprx(const FcParams& p, int lutMode, hipStream_t st) {
+hipError_t qk_fc_aprx(const FcParams& pIn, int lutMode, hipStream_t st) {
+  FcParams p = pIn;
+  p.lutF16 = (lutMode == 2) ? 1 : 0;
+  if (lutMode == 2) lutMode = 1;
   if (p.Ct % 4 || p.Cs > QCNN_MAX_CS || p.K > QCNN_MAX_K || p.msplit < 1) return hipErrorInvalidValue;
   switch (fc_channels_per_wave(p.Ct)) {
     case 32: return launch_fc<32>(p, lutMode, st);

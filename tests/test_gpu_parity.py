@@ -351,3 +351,29 @@ def test_u8_input_pipeline_is_bit_identical_to_host_preprocessing(golden_tiny, w
     assert np.array_equal(d_top5.cpu().numpy().view(np.uint16), t_ref)
     with pytest.raises(pkg("engine").QcnnError):
         eng.forward_u8_dev(d_px.data_ptr(), h - 1, ws, None, n)            # source smaller than the network input
+
+
+# ---------------------------------------------------------------- fp16 table entries: tolerance study ----
+def test_fp16_lut_tolerance_study(golden_alex_syn):
+    """BASELINE.json configs[4]: AlexNet with the look-up-table entries rounded to fp16 (accumulation fp32),
+    against the reference's fp32 feature maps.  This is a study, not a parity claim: the bar is the fp16
+    rounding itself (2^-11 per entry), the measured per-layer errors are printed."""
+    z = golden_alex_syn
+    in_chw, layers, _, _ = topo.MODELS["AlexNet"]
+    params = synth.make_params(in_chw, layers, seed=7)
+    imgs = synth.make_images(2, in_chw, seed=8)
+    eng = make_engine(in_chw, layers, params, 2, lut=capi.LUT_MFMA_F16)
+    prob, top5 = eng.forward_host(imgs)
+    rows = []
+    for l in range(len(layers) + 1):
+        fm = eng.layer_output(l, 2)
+        smp = fm.reshape(2, -1)[:, ::SAMPLE_STRIDE]
+        scale = max(abs(z["fp_%02d" % l][:, 3]).max(), abs(z["fp_%02d" % l][:, 4]).max())
+        err = np.abs(smp.astype(np.float64) - z["smp_%02d" % l]).max() / scale
+        rows.append((l, err))
+        assert err <= 2e-3, "fm[%d]: %g" % (l, err)
+    agree = float(np.mean(top5 == z["top5"]))
+    print("fp16-rounded LUT, max-norm relative error per feature map: " +
+          " ".join("fm%d=%.1e" % r for r in rows if r[1] > 0) + "; top-5 agreement %.2f" % agree)
+    assert max(e for _, e in rows) > 1e-6          # the mode really rounds
+    assert agree >= 0.8
