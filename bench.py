@@ -41,13 +41,15 @@ LDS_B64_LOOKUPS_PER_S = 256 * 64 * 2.4e9    # 256 CU x 256 B/clk (ds_read_b64, a
 TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r1_v6", "traffic.json")   # PMC HBM bytes of the dominant kernel
 
 
-def pmc_traffic(layer):
+def pmc_traffic(layer, launches_per_forward):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
     (FETCH_SIZE + WRITE_SIZE, separate passes, mean per dispatch), or None when no profile covers it."""
     try:
         with open(TRAFFIC_JSON) as f:
             t = json.load(f)
-        return int(t["bytes"]) if int(t["layer"]) == int(layer) else None
+        if int(t["layer"]) != int(layer) or int(t.get("launches_per_forward", 1)) != int(launches_per_forward):
+            return None
+        return int(t["bytes"])
     except (OSError, ValueError, KeyError):
         return None
 
@@ -121,6 +123,10 @@ def main():
     ap.add_argument("--lut", default="mfma", choices=["mfma", "exact"])
     ap.add_argument("--cpu-sample", type=int, default=100, help="images for the CPU baseline (0 = skip)")
     ap.add_argument("--h2d-steps", type=int, default=2, help="extra steps timed including pinned-host H2D (0 = skip)")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="sub-batches of whole panels run concurrently on separate HIP streams (QCNN_OPT_STREAMS; the "
+                         "library default is 2).  1 keeps one launch per layer, so that the per-kernel HIP-event "
+                         "durations behind `roofline` are those of kernels that own the whole GPU")
     args = ap.parse_args()
 
     import torch
@@ -154,6 +160,7 @@ def main():
     eng.set_option(capi.OPT_LUT_MODE, capi.LUT_MFMA if args.lut == "mfma" else capi.LUT_EXACT)
     eng.set_option(capi.OPT_KEEP_ALL, 0)
     eng.set_option(capi.OPT_PROFILE, 1)
+    eng.set_option(capi.OPT_STREAMS, args.streams)
     shapes = {i: tuple(int(x) for x in p["ctrd"].shape) for i, p in params.items()}
     eng.configure(in_chw, layers, shapes)
     arena = torch.zeros(eng.arena_bytes(), dtype=torch.uint8, device=dev)
@@ -201,7 +208,20 @@ def main():
     layer_ms, recorded = eng.layer_ms()
     ok = bool(torch.isfinite(prob).all().item())
 
-    h2d = h2d_u8 = None
+    h2d = h2d_u8 = two_streams = None
+    if args.h2d_steps > 0 and rank == 0 and args.streams == 1:
+        # the library's default execution mode: two sub-batches on two streams (glue kernels of one overlap the
+        # conv tails of the other); reported next to `value`, which stays the one-launch-per-layer measurement
+        eng.set_option(capi.OPT_STREAMS, 2)
+        eng.set_option(capi.OPT_PROFILE, 0)
+        step()
+        torch.cuda.synchronize(dev)
+        t3 = time.perf_counter()
+        for _ in range(max(args.h2d_steps, 3)):
+            step()
+        torch.cuda.synchronize(dev)
+        two_streams = B * max(args.h2d_steps, 3) / (time.perf_counter() - t3)
+        eng.set_option(capi.OPT_STREAMS, 1)
     if args.h2d_steps > 0 and rank == 0:
         pinned = torch.empty(imgs.shape, dtype=torch.float32, pin_memory=True)
         pinned.copy_(imgs)
@@ -233,17 +253,23 @@ def main():
         value = world * B * args.steps / dt
         dom = int(np.argmax(layer_ms))
         dom_ms = float(layer_ms[dom])
-        abytes = algorithmic_bytes(sizes, layers, params, dom, B, True)
+        # a layer is launched once per sub-batch (QCNN_OPT_STREAMS): layer_ms is the mean duration of ONE launch,
+        # so the algorithmic bytes / look-ups are those of one launch (its share of the panels)
+        panels = (B + 127) // 128
+        ns = max(1, min(args.streams, panels))
+        launch_images = B / ns
+        abytes = algorithmic_bytes(sizes, layers, params, dom, launch_images, True)
         achieved = abytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        lk = lookups_per_image(sizes, layers, params, dom) * B
+        lk = lookups_per_image(sizes, layers, params, dom) * launch_images
         total_lk = sum(lookups_per_image(sizes, layers, params, l) for l in range(len(layers)))
         conv_idx = [i for i, l in enumerate(layers) if l["type"] == topo.CONV]
         name = "%s%d" % (topo.TYPE_NAMES[layers[dom]["type"]], (conv_idx.index(dom) + 1) if dom in conv_idx else dom)
         roof = dict(bound="hbm", kernel="k_%s_aprx (layer %d, %s)" % ("conv" if dom in conv_idx else "fc", dom, name),
                     achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(achieved / HBM_PEAK_GBS, 5),
-                    traffic=(pmc_traffic(dom) if (B == 1000 and args.model == "AlexNet") else None),
-                    ms_per_launch=round(dom_ms, 4), launches_timed=recorded,
+                    traffic=(pmc_traffic(dom, ns) if (B == 1000 and args.model == "AlexNet") else None),
+                    ms_per_launch=round(dom_ms, 4), launches_timed=recorded * ns, launches_per_step=ns,
+                    images_per_launch=launch_images,
                     algorithmic_bytes_per_launch=int(abytes),
                     lds_lookups_per_s=round(lk / (dom_ms * 1e-3), 0) if dom_ms > 0 else 0,
                     lds_lookup_peak_b64=LDS_B64_LOOKUPS_PER_S,
@@ -259,6 +285,7 @@ def main():
                                    "device-resident" % (args.model, B, in_chw[1], in_chw[2]),
                        "images_per_gpu": B, "global_batch": B * world, "lut_builder": args.lut,
                        "parameters": "seeded synthetic, shipped AlexNet quantisation shapes",
+                       "streams_per_gpu": ns,
                        "parallelism": "images sharded over %d GPU(s), parameters replicated by one RCCL broadcast" % world},
             "outputs_finite": ok,
             "lookups_per_image": int(total_lk),
@@ -268,6 +295,8 @@ def main():
         if h2d is not None:
             out["value_incl_pinned_h2d"] = round(h2d, 2)
             out["value_incl_pinned_h2d_u8"] = round(h2d_u8, 2)
+        if two_streams is not None:
+            out["value_two_streams"] = round(two_streams, 2)
         if args.cpu_sample > 0 and world == 1:
             imgs_host = imgs[: args.cpu_sample].cpu().numpy()
             out["cpu_baseline"] = cpu_baseline(in_chw, layers, params, imgs_host, args.cpu_sample)

@@ -59,7 +59,10 @@ enum {
                               tolerance study of BASELINE.json configs[4], not a faster path */
   QCNN_OPT_KEEP_ALL = 1,   /* 1 = every layer writes its own feature map (layer-for-layer dumps, default);
                               0 = fast path: ReLU fused into the producing conv/FC epilogue */
-  QCNN_OPT_PROFILE = 2     /* 1 = bracket every layer with HIP events (qcnn_get_layer_ms) */
+  QCNN_OPT_PROFILE = 2,    /* 1 = bracket every layer launch with HIP events (qcnn_get_layer_ms) */
+  QCNN_OPT_STREAMS = 3     /* 1..4 (default 2): a forward is cut into that many sub-batches of whole 128-image
+                              panels which run concurrently on separate HIP streams (LDS-bound conv/FC kernels
+                              of one overlap HBM-bound glue kernels of another); results do not depend on it */
 };
 
 /* ---- context ---- */
@@ -117,7 +120,8 @@ int qcnn_get_layer_output(QcnnCtx* ctx, int l, int n, float* host_out);
 int qcnn_run_layer(QcnnCtx* ctx, int layer, const float* in_host, int n, float* out_host);
 
 /* ---- timing (QCNN_OPT_PROFILE = 1) ---- */
-/* Mean milliseconds per layer over the forwards recorded since the last reset; ms[layer_cnt]. */
+/* Mean milliseconds of one LAUNCH per layer (a forward issues QCNN_OPT_STREAMS launches per layer, each over
+ * its share of the panels) over the forwards recorded since the last reset; ms[layer_cnt]. */
 int qcnn_get_layer_ms(QcnnCtx* ctx, float* ms, int* forwards_recorded);
 int qcnn_reset_layer_ms(QcnnCtx* ctx);
 

@@ -13,7 +13,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG, "libqcnn_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(PKG), "include", "qcnn_hip.h")
 
-OPT_LUT_MODE, OPT_KEEP_ALL, OPT_PROFILE = 0, 1, 2
+OPT_LUT_MODE, OPT_KEEP_ALL, OPT_PROFILE, OPT_STREAMS = 0, 1, 2, 3
 LUT_EXACT, LUT_MFMA, LUT_MFMA_F16 = 0, 1, 2
 
 

@@ -31,7 +31,8 @@ struct LayerShape {
 
 struct FmDims { int h, w, c; };
 
-constexpr int kProfRing = 128;   // forwards whose per-layer events are kept
+constexpr int kProfRing = 64;    // forwards whose per-layer events are kept
+constexpr int kMaxStreams = 4;   // sub-batches (streams) of one forward
 constexpr size_t kSlack = 64 * 1024;   // bytes of slack behind every device buffer: the MFMA operand loads are
                                         // unconditional and may read a few rows past the last dim / sub-space
 
@@ -43,6 +44,9 @@ struct QcnnCtx {
   bool ownStream = false;
   std::string err;
   int lutMode = 1, keepAll = 1, profile = 0;
+  int nStreams = 2;                  // QCNN_OPT_STREAMS: sub-batches of whole panels run concurrently
+  hipStream_t aux[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t evFork = nullptr, evJoin[3] = {nullptr, nullptr, nullptr};
 
   int L = 0, inC = 0, inH = 0, inW = 0;
   std::vector<QcnnLayerDesc> layers;
@@ -63,12 +67,15 @@ struct QcnnCtx {
   float* fcFlat = nullptr;           // first FC layer's input in consumption order
   float* fcPartial = nullptr;        // split-M partial sums of the FC layers
   size_t fcPartialElems = 0;
+  size_t fcMaxCt = 0;
   int lastN = 0;
   std::vector<float*> lastFm;        // pointer table of the last forward
 
-  std::vector<hipEvent_t> ev;        // kProfRing * L * 2
+  std::vector<hipEvent_t> ev;        // kProfRing * kMaxStreams * L * 2
   int profCount = 0;
+  std::vector<int> profStreams;      // sub-batches of each recorded forward
   std::vector<double> profSum;
+  std::vector<long long> profLaunches;
   int profForwards = 0;
 };
 
@@ -150,7 +157,9 @@ int ensure_stage(QcnnCtx* c) {
 
 // One layer on `panels` panels: src/dst in panel layout.  flatFcInput: the FC input rows are already
 // in consumption order (qcnn_run_layer), so the NCHW-flatten map is not applied.
-int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bool fuseRelu, bool flatFcInput) {
+// p0: first panel of the sub-batch (offsets into the scratch buffers), st: the stream it runs on
+int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bool fuseRelu, bool flatFcInput,
+                 int p0, hipStream_t st) {
   const QcnnLayerDesc& d = c->layers[l];
   const FmDims& a = c->dims[l];
   const FmDims& b = c->dims[l + 1];
@@ -167,7 +176,7 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
       p.H = a.h; p.W = a.w; p.Cin = a.c; p.Ho = b.h; p.Wo = b.w; p.Ct = b.c;
       p.knl = d.knlSiz; p.stride = d.stride; p.pad = d.padSiz; p.grp = d.grpCnt;
       p.M = s.M; p.Cs = s.Cs; p.K = s.K; p.relu = fuseRelu ? 1 : 0; p.panels = panels;
-      e = qk_conv_aprx(p, c->lutMode, c->stream);
+      e = qk_conv_aprx(p, c->lutMode, st);
       break;
     }
     case QCNN_FCNT: {
@@ -178,10 +187,11 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
       p.ctrd = reinterpret_cast<const float*>(c->arena + s.offCtrd);
       p.rows = reinterpret_cast<const uint8_t*>(c->arena + s.offAsmt);
       if (s.hasDmap && !flatFcInput) {   // NHWC -> consumption order (NCHW flatten) into the scratch map
-        e = qk_permute_rows(src, c->fcFlat, reinterpret_cast<const int*>(c->arena + s.offDmap), a.h * a.w * a.c,
-                            panels, c->stream);
+        float* flat = c->fcFlat + (size_t)p0 * fm_elems(c, l) * QCNN_PANEL;
+        e = qk_permute_rows(src, flat, reinterpret_cast<const int*>(c->arena + s.offDmap), a.h * a.w * a.c,
+                            panels, st);
         if (e != hipSuccess) break;
-        p.src = c->fcFlat;
+        p.src = flat;
       }
       p.D = a.h * a.w * a.c; p.Ct = b.c; p.M = s.M; p.Cs = s.Cs; p.K = s.K;
       p.relu = fuseRelu ? 1 : 0; p.panels = panels;
@@ -206,28 +216,29 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
           if (fill > bestFill + 1e-9) { bestFill = fill; ms = cand; }
         }
         const size_t need = (size_t)ms * panels * p.Ct * QCNN_PANEL;
-        if (ms > 1 && need <= c->fcPartialElems) { p.msplit = ms; p.partial = c->fcPartial; }
+        const size_t poff = (size_t)16 * p0 * c->fcMaxCt * QCNN_PANEL;    // every sub-batch has its own slab
+        if (ms > 1 && poff + need <= c->fcPartialElems) { p.msplit = ms; p.partial = c->fcPartial + poff; }
       }
-      e = qk_fc_aprx(p, c->lutMode, c->stream);
+      e = qk_fc_aprx(p, c->lutMode, st);
       if (e == hipSuccess && p.msplit > 1)
-        e = qk_sum_partials(p.partial, dst, p.msplit, (size_t)panels * p.Ct * QCNN_PANEL, p.relu, c->stream);
+        e = qk_sum_partials(p.partial, dst, p.msplit, (size_t)panels * p.Ct * QCNN_PANEL, p.relu, st);
       break;
     }
     case QCNN_POOL:
-      e = qk_pool(src, dst, panels, a.h, a.w, a.c, b.h, b.w, d.knlSiz, d.stride, d.padSiz, c->stream);
+      e = qk_pool(src, dst, panels, a.h, a.w, a.c, b.h, b.w, d.knlSiz, d.stride, d.padSiz, st);
       break;
     case QCNN_RELU:
-      e = qk_relu(src, dst, (size_t)panels * fm_elems(c, l) * QCNN_PANEL, c->stream);
+      e = qk_relu(src, dst, (size_t)panels * fm_elems(c, l) * QCNN_PANEL, st);
       break;
     case QCNN_LORN:
-      e = qk_lrn(src, dst, panels, a.h * a.w, a.c, d.lrnSiz, d.lrnAlp, d.lrnBet, d.lrnIni, c->stream);
+      e = qk_lrn(src, dst, panels, a.h * a.w, a.c, d.lrnSiz, d.lrnAlp, d.lrnBet, d.lrnIni, st);
       break;
     case QCNN_DRPT:   // test-time dropout is a copy (src/CaffeEva.cc:1091-1096); only reached by qcnn_run_layer
       e = hipMemcpyAsync(dst, src, (size_t)panels * fm_elems(c, l) * QCNN_PANEL * sizeof(float),
-                         hipMemcpyDeviceToDevice, c->stream);
+                         hipMemcpyDeviceToDevice, st);
       break;
     case QCNN_SMAX:
-      e = qk_softmax(src, dst, panels, a.h * a.w * a.c, c->stream);
+      e = qk_softmax(src, dst, panels, a.h * a.w * a.c, st);
       break;
     default:
       return fail(c, "layer %d: invalid layer type %d", l, d.type);
@@ -236,49 +247,74 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
   return 0;
 }
 
+// The layers of one forward.  The batch is cut into up to nStreams sub-batches of whole panels; sub-batch 0
+// runs on the context's stream, the others on auxiliary streams forked from / joined to it with events, so
+// that the LDS-bound conv/FC kernels of one sub-batch overlap the HBM-bound glue kernels of another and the
+// last dispatch round of one kernel is filled by the next.  Every image still sees exactly the same
+// arithmetic (panels are independent), so results do not depend on the number of streams.
 int run_layers(QcnnCtx* c, int n) {
   const int panels = (n + QCNN_PANEL - 1) / QCNN_PANEL;
+  const int ns = std::max(1, std::min(std::min(c->nStreams, kMaxStreams), panels));
   const bool prof = c->profile && c->profCount < kProfRing;
   c->lastFm.assign(c->L + 1, nullptr);
   c->lastFm[0] = c->fmBuf[0];
-  for (int l = 0; l < c->L; ++l) {
+  for (int l = 0; l < c->L; ++l) {              // pointer table (aliases) — identical for every sub-batch
     const int type = c->layers[l].type;
-    const float* src = c->lastFm[l];
-    float* dst = c->fmBuf[l + 1];
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (prof) {
-      e0 = c->ev[((size_t)c->profCount * c->L + l) * 2];
-      e1 = c->ev[((size_t)c->profCount * c->L + l) * 2 + 1];
-      HIP_TRY(c, hipEventRecord(e0, c->stream));
-    }
     const bool prevFused = l > 0 && !c->keepAll && type == QCNN_RELU &&
                            (c->layers[l - 1].type == QCNN_CONV || c->layers[l - 1].type == QCNN_FCNT);
-    if (type == QCNN_DRPT || prevFused) {
-      c->lastFm[l + 1] = const_cast<float*>(src);          // alias: copy semantics, no traffic
-    } else {
-      const bool fuse = !c->keepAll && (type == QCNN_CONV || type == QCNN_FCNT) && l + 1 < c->L &&
-                        c->layers[l + 1].type == QCNN_RELU;
-      if (launch_layer(c, l, src, dst, panels, fuse, false)) return 1;
-      c->lastFm[l + 1] = dst;
-    }
-    if (prof) HIP_TRY(c, hipEventRecord(e1, c->stream));
+    c->lastFm[l + 1] = (type == QCNN_DRPT || prevFused) ? c->lastFm[l] : c->fmBuf[l + 1];
   }
-  if (prof) c->profCount++;
+  if (ns > 1) {
+    HIP_TRY(c, hipEventRecord(c->evFork, c->stream));
+    for (int k = 1; k < ns; ++k) HIP_TRY(c, hipStreamWaitEvent(c->aux[k - 1], c->evFork, 0));
+  }
+  for (int l = 0; l < c->L; ++l) {              // layer-major issue order: the streams advance together
+    const int type = c->layers[l].type;
+    if (c->lastFm[l + 1] == c->lastFm[l]) continue;          // alias: copy semantics, no traffic
+    const bool fuse = !c->keepAll && (type == QCNN_CONV || type == QCNN_FCNT) && l + 1 < c->L &&
+                      c->layers[l + 1].type == QCNN_RELU;
+    for (int k = 0; k < ns; ++k) {
+      const int p0 = (int)((long long)panels * k / ns), p1 = (int)((long long)panels * (k + 1) / ns);
+      if (p1 <= p0) continue;
+      hipStream_t st = k == 0 ? c->stream : c->aux[k - 1];
+      const float* src = c->lastFm[l] + (size_t)p0 * fm_elems(c, l) * QCNN_PANEL;
+      float* dst = c->lastFm[l + 1] + (size_t)p0 * fm_elems(c, l + 1) * QCNN_PANEL;
+      hipEvent_t e0 = nullptr, e1 = nullptr;
+      if (prof) {
+        const size_t slot = (((size_t)c->profCount * kMaxStreams + k) * c->L + l) * 2;
+        e0 = c->ev[slot]; e1 = c->ev[slot + 1];
+        HIP_TRY(c, hipEventRecord(e0, st));
+      }
+      if (launch_layer(c, l, src, dst, p1 - p0, fuse, false, p0, st)) return 1;
+      if (prof) HIP_TRY(c, hipEventRecord(e1, st));
+    }
+  }
+  for (int k = 1; k < ns; ++k) {
+    HIP_TRY(c, hipEventRecord(c->evJoin[k - 1], c->aux[k - 1]));
+    HIP_TRY(c, hipStreamWaitEvent(c->stream, c->evJoin[k - 1], 0));
+  }
+  if (prof) { c->profStreams.push_back(ns); c->profCount++; }
   c->lastN = n;
   return 0;
 }
 
+// per layer: mean duration of one LAUNCH (a forward with k sub-batches has k launches per layer)
 int drain_profile(QcnnCtx* c) {
   if (!c->profCount) return 0;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   for (int f = 0; f < c->profCount; ++f)
-    for (int l = 0; l < c->L; ++l) {
-      float ms = 0.0f;
-      HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[((size_t)f * c->L + l) * 2], c->ev[((size_t)f * c->L + l) * 2 + 1]));
-      c->profSum[l] += ms;
-    }
+    for (int k = 0; k < c->profStreams[f]; ++k)
+      for (int l = 0; l < c->L; ++l) {
+        if ((int)c->lastFm.size() == c->L + 1 && c->lastFm[l + 1] == c->lastFm[l]) continue;
+        const size_t slot = (((size_t)f * kMaxStreams + k) * c->L + l) * 2;
+        float ms = 0.0f;
+        HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[slot], c->ev[slot + 1]));
+        c->profSum[l] += ms;
+        c->profLaunches[l] += 1;
+      }
   c->profForwards += c->profCount;
   c->profCount = 0;
+  c->profStreams.clear();
   return 0;
 }
 
@@ -330,6 +366,11 @@ int qcnn_ctx_destroy(QcnnCtx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   free_model(c);
+  for (int k = 0; k < kMaxStreams - 1; ++k) {
+    if (c->aux[k]) (void)hipStreamDestroy(c->aux[k]);
+    if (c->evJoin[k]) (void)hipEventDestroy(c->evJoin[k]);
+  }
+  if (c->evFork) (void)hipEventDestroy(c->evFork);
   if (c->ownStream) (void)hipStreamDestroy(c->stream);
   delete c;
   return 0;
@@ -340,6 +381,9 @@ int qcnn_set_option(QcnnCtx* c, int option, int value) {
     case QCNN_OPT_LUT_MODE: if (value < 0 || value > 2) return fail(c, "LUT mode must be 0, 1 or 2"); c->lutMode = value; return 0;
     case QCNN_OPT_KEEP_ALL: c->keepAll = value ? 1 : 0; return 0;
     case QCNN_OPT_PROFILE: c->profile = value ? 1 : 0; return 0;
+    case QCNN_OPT_STREAMS:
+      if (value < 1 || value > kMaxStreams) return fail(c, "streams must be in [1, %d]", kMaxStreams);
+      c->nStreams = value; return 0;
     default: return fail(c, "unknown option %d", option);
   }
 }
@@ -433,15 +477,22 @@ int qcnn_model_commit(QcnnCtx* c, int max_batch, void* dev_arena) {
     size_t maxCt = 0;
     for (int l = 0; l < c->L; ++l)
       if (c->layers[l].type == QCNN_FCNT) maxCt = std::max<size_t>(maxCt, c->dims[l + 1].c);
+    c->fcMaxCt = maxCt;
     c->fcPartialElems = (size_t)16 * c->maxPanels * maxCt * QCNN_PANEL;
     if (c->fcPartialElems) HIP_TRY(c, hipMalloc(&c->fcPartial, c->fcPartialElems * sizeof(float)));
     if (c->firstFc >= 0 && c->shapes[c->firstFc].hasDmap)
       HIP_TRY(c, hipMalloc(&c->fcFlat, (size_t)c->maxPanels * fm_elems(c, c->firstFc) * QCNN_PANEL * sizeof(float) + kSlack));
   }
-  c->ev.resize((size_t)kProfRing * c->L * 2);
+  c->ev.resize((size_t)kProfRing * kMaxStreams * c->L * 2);
   for (hipEvent_t& e : c->ev) HIP_TRY(c, hipEventCreate(&e));
   c->profSum.assign(c->L, 0.0);
-  c->profCount = 0; c->profForwards = 0;
+  c->profLaunches.assign(c->L, 0);
+  c->profCount = 0; c->profForwards = 0; c->profStreams.clear();
+  for (int k = 0; k < kMaxStreams - 1; ++k) {
+    if (!c->aux[k]) HIP_TRY(c, hipStreamCreateWithFlags(&c->aux[k], hipStreamNonBlocking));
+    if (!c->evJoin[k]) HIP_TRY(c, hipEventCreateWithFlags(&c->evJoin[k], hipEventDisableTiming));
+  }
+  if (!c->evFork) HIP_TRY(c, hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming));
   // first-FC flatten map: consumption index d = (ch*H + y)*W + x  ->  NHWC row (y*W + x)*C + ch  (src/CaffeEva.cc:187-189)
   for (int l = 0; l < c->L; ++l) {
     const LayerShape& s = c->shapes[l];
@@ -599,7 +650,7 @@ int qcnn_run_layer(QcnnCtx* c, int layer, const float* in_host, int n, float* ou
   HIP_TRY(c, hipMemcpyAsync(c->stageIn, in_host, (size_t)n * Ein * sizeof(float), hipMemcpyHostToDevice, c->stream));
   hipError_t e = qk_pack_rows(c->stageIn, src, n, Ein, c->stream);
   if (e != hipSuccess) return fail(c, "pack launch failed: %s", hipGetErrorString(e));
-  if (launch_layer(c, layer, src, dst, panels, false, true)) return 1;
+  if (launch_layer(c, layer, src, dst, panels, false, true, 0, c->stream)) return 1;
   e = qk_unpack_rows(dst, c->stageOut, n, Eout, c->stream);
   if (e != hipSuccess) return fail(c, "unpack launch failed: %s", hipGetErrorString(e));
   HIP_TRY(c, hipMemcpyAsync(out_host, c->stageOut, (size_t)n * Eout * sizeof(float), hipMemcpyDeviceToHost, c->stream));
@@ -610,7 +661,7 @@ int qcnn_run_layer(QcnnCtx* c, int layer, const float* in_host, int n, float* ou
 int qcnn_get_layer_ms(QcnnCtx* c, float* ms, int* forwards_recorded) {
   HIP_TRY(c, hipSetDevice(c->device));
   if (drain_profile(c)) return 1;
-  for (int l = 0; l < c->L; ++l) ms[l] = c->profForwards ? (float)(c->profSum[l] / c->profForwards) : 0.0f;
+  for (int l = 0; l < c->L; ++l) ms[l] = c->profLaunches[l] ? (float)(c->profSum[l] / c->profLaunches[l]) : 0.0f;
   if (forwards_recorded) *forwards_recorded = c->profForwards;
   return 0;
 }
@@ -619,6 +670,7 @@ int qcnn_reset_layer_ms(QcnnCtx* c) {
   HIP_TRY(c, hipSetDevice(c->device));
   if (drain_profile(c)) return 1;
   c->profSum.assign(c->L, 0.0);
+  c->profLaunches.assign(c->L, 0);
   c->profForwards = 0;
   return 0;
 }

@@ -377,3 +377,25 @@ def test_fp16_lut_tolerance_study(golden_alex_syn):
           " ".join("fm%d=%.1e" % r for r in rows if r[1] > 0) + "; top-5 agreement %.2f" % agree)
     assert max(e for _, e in rows) > 1e-6          # the mode really rounds
     assert agree >= 0.8
+
+
+def test_result_does_not_depend_on_the_number_of_streams(golden_tiny):
+    """QCNN_OPT_STREAMS cuts a forward into sub-batches of whole panels on concurrent HIP streams: same bits."""
+    z = golden_tiny
+    in_chw, layers = topo.tiny_model()
+    params = tiny_params_from_golden(z, layers)
+    imgs = synth.make_images(5 * 128 + 7, in_chw, seed=71)               # 6 panels, the last one ragged
+    ref = None
+    for ns in (1, 2, 3, 4):
+        eng = make_engine(in_chw, layers, params, imgs.shape[0], lut=capi.LUT_MFMA, keep_all=0)
+        eng.set_option(capi.OPT_STREAMS, ns)
+        for _ in range(2):                                                # back-to-back forwards reuse the buffers
+            prob, top5 = eng.forward_host(imgs)
+        fm = eng.layer_output(4, imgs.shape[0])
+        if ref is None:
+            ref = (prob, top5, fm)
+        assert np.array_equal(prob, ref[0]) and np.array_equal(top5, ref[1]) and np.array_equal(fm, ref[2]), ns
+        eng.close()
+    with pytest.raises(pkg("engine").QcnnError):
+        eng2 = pkg("engine").QcnnEngine(0)
+        eng2.set_option(capi.OPT_STREAMS, 9)
