@@ -31,7 +31,7 @@ struct LayerShape {
 
 struct FmDims { int h, w, c; };
 
-constexpr int kProfRing = 64;    // forwards whose per-layer events are kept
+constexpr int kProfRing = 32;    // forwards whose per-layer events are kept
 constexpr int kMaxStreams = 4;   // sub-batches (streams) of one forward
 constexpr size_t kSlack = 64 * 1024;   // bytes of slack behind every device buffer: the MFMA operand loads are
                                         // unconditional and may read a few rows past the last dim / sub-space
