@@ -117,7 +117,10 @@ int plan_arena(QcnnCtx* c) {
     const int Ct = c->dims[l + 1].c;
     s.offBias = off; off = align_up(off + sizeof(float) * Ct, 256);
     s.offCtrd = off; off = align_up(off + sizeof(float) * (size_t)s.M * s.Cs * s.K, 256);
-    s.asmtBytes = (d.type == QCNN_CONV) ? (size_t)d.knlSiz * d.knlSiz * s.M * Ct : (size_t)s.M * Ct;   // entries
+    // row-offset table: uint16 entries in the order the gather waves consume them (QkSlots, qcnn_kernels.h)
+    const QkSlots sl = (d.type == QCNN_CONV) ? qk_conv_slots(Ct / d.grpCnt, d.grpCnt) : qk_fc_slots(Ct);
+    const size_t taps = (d.type == QCNN_CONV) ? (size_t)d.knlSiz * d.knlSiz : 1;
+    s.asmtBytes = taps * s.M * sl.rowStride * sizeof(uint16_t);
     s.offAsmt = off; off = align_up(off + s.asmtBytes + QCNN_ROWS_PAD, 256);
     s.hasDmap = (d.type == QCNN_FCNT && l == c->firstFc && c->dims[l].h * c->dims[l].w > 1);
     if (s.hasDmap) { s.offDmap = off; off = align_up(off + sizeof(int) * fm_elems(c, l), 256); }
@@ -172,7 +175,7 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
       p.src = src; p.dst = dst;
       p.bias = reinterpret_cast<const float*>(c->arena + s.offBias);
       p.ctrd = reinterpret_cast<const float*>(c->arena + s.offCtrd);
-      p.rows = reinterpret_cast<const uint8_t*>(c->arena + s.offAsmt);
+      p.rows = reinterpret_cast<const uint16_t*>(c->arena + s.offAsmt);
       p.H = a.h; p.W = a.w; p.Cin = a.c; p.Ho = b.h; p.Wo = b.w; p.Ct = b.c;
       p.knl = d.knlSiz; p.stride = d.stride; p.pad = d.padSiz; p.grp = d.grpCnt;
       p.M = s.M; p.Cs = s.Cs; p.K = s.K; p.relu = fuseRelu ? 1 : 0; p.panels = panels;
@@ -185,7 +188,7 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
       p.src = src; p.dst = dst;
       p.bias = reinterpret_cast<const float*>(c->arena + s.offBias);
       p.ctrd = reinterpret_cast<const float*>(c->arena + s.offCtrd);
-      p.rows = reinterpret_cast<const uint8_t*>(c->arena + s.offAsmt);
+      p.rows = reinterpret_cast<const uint16_t*>(c->arena + s.offAsmt);
       if (s.hasDmap && !flatFcInput) {   // NHWC -> consumption order (NCHW flatten) into the scratch map
         float* flat = c->fcFlat + (size_t)p0 * fm_elems(c, l) * QCNN_PANEL;
         e = qk_permute_rows(src, flat, reinterpret_cast<const int*>(c->arena + s.offDmap), a.h * a.w * a.c,
@@ -441,7 +444,7 @@ int qcnn_model_set_layer_shape(QcnnCtx* c, int layer, int M, int K, int Cs) {
   if ((M - 1) * Cs >= D) return fail(c, "layer %d: sub-space %d starts beyond the %d input dims", layer, M - 1, D);
   const int Ct = c->dims[layer + 1].c;
   const int Ctg = (d.type == QCNN_CONV) ? Ct / d.grpCnt : Ct;
-  if (Ctg % 4) return fail(c, "layer %d: %d output channels per group is not a multiple of 4", layer, Ctg);
+  if (Ctg % 2) return fail(c, "layer %d: %d output channels per group is not even", layer, Ctg);
   c->shapes[layer].M = M; c->shapes[layer].K = K; c->shapes[layer].Cs = Cs;
   return 0;
 }
@@ -524,21 +527,26 @@ int qcnn_model_set_layer_params(QcnnCtx* c, int layer, const float* bias, const 
   for (int m = 0; m < M; ++m)
     for (int k = 0; k < K; ++k)
       for (int dd = 0; dd < Cs; ++dd) ctrd[((size_t)m * Cs + dd) * K + k] = ctrd_file[((size_t)m * K + k) * Cs + dd];
-  // PrepAsmtBuf: conv [Ct][kh][kw][M] -> [kh][kw][M][Ct] (:585-586); FC [Ct][M] -> [M][Ct] (:610-611);
-  // stored as the row index of the code word inside a LUT stage: (m % G) * K + index  (< 128)
-  std::vector<uint8_t> asmt(s.asmtBytes + QCNN_ROWS_PAD, 0);
+  // PrepAsmtBuf: conv [Ct][kh][kw][M] -> [kh][kw][M][Ct] (:585-586); FC [Ct][M] -> [M][Ct] (:610-611).  Stored as
+  // the pre-scaled LDS offset of the code word's row inside a LUT stage (row = (m % G) * K + index < 128), with the
+  // channel axis in the order the gather waves consume it (QkSlots); padding entries point at row 0.
   const int G = qcnn_stage_group(K);
   const size_t taps = (d.type == QCNN_CONV) ? (size_t)d.knlSiz * d.knlSiz : 1;
-  for (int ch = 0; ch < Ct; ++ch)
+  const int groups = (d.type == QCNN_CONV) ? d.grpCnt : 1;
+  const QkSlots sl = (d.type == QCNN_CONV) ? qk_conv_slots(Ct / groups, groups) : qk_fc_slots(Ct);
+  std::vector<uint16_t> asmt(s.asmtBytes / sizeof(uint16_t) + QCNN_ROWS_PAD / sizeof(uint16_t), 0);
+  for (int ch = 0; ch < Ct; ++ch) {
+    const int entry = qk_slot_entry(sl, ch / sl.C, ch % sl.C);
     for (size_t t = 0; t < taps; ++t)
       for (int m = 0; m < M; ++m) {
         const uint8_t v = asmt_file[((size_t)ch * taps + t) * M + m];
         if (v >= K) return fail(c, "layer %d: assignment %u >= K = %d", layer, (unsigned)v, K);
-        asmt[(t * M + m) * Ct + ch] = (uint8_t)((m % G) * K + v);
+        asmt[(t * M + m) * sl.rowStride + entry] = qcnn_row_offset((m % G) * K + v);
       }
+  }
   HIP_TRY(c, hipMemcpyAsync(c->arena + s.offBias, bias, sizeof(float) * Ct, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipMemcpyAsync(c->arena + s.offCtrd, ctrd.data(), sizeof(float) * ctrd.size(), hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(c->arena + s.offAsmt, asmt.data(), asmt.size(), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->arena + s.offAsmt, asmt.data(), asmt.size() * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   s.loaded = true;
   return 0;

@@ -2,11 +2,17 @@
 //
 // Activation layout in HBM ("image-minor panels"): a batch is cut into panels of QCNN_PANEL = 128
 // images; feature map l of one panel is a row-major matrix [E_l][128] with E_l = H*W*C elements in the
-// reference's NHWC order and the 128 images of the panel innermost.  One wavefront lane carries an
-// image PAIR (images 2*lane, 2*lane+1 of the panel): every load/store of a wave is a full 512-byte row,
-// a table look-up is one conflict-free ds_read_b64 and the accumulation one v_pk_add_f32.  The
-// code-word index of the approximate layers is wave-uniform (it depends on the layer's assignment table
-// only): it is fetched as packed uint8 and broadcast into SGPRs.
+// reference's NHWC order and the 128 images of the panel innermost: every load/store of a wave is made of
+// full 512-byte rows.  The code-word index of a look-up depends on the layer's assignment table only, so
+// it is the same for all images: a "gather" is a contiguous LDS row read, not 128 random ones.
+//
+// LUT stage in LDS: [8 image tiles][128 row slots][16 images] fp32 = 64 KB; inside tile t the position of a
+// slot within its aligned group of four is XOR-ed with t >> 1, which puts the four tiles a 16-lane read group
+// of ds_read_b128 touches on distinct banks.  A gather lane carries FOUR images and one
+// ds_read_b128 serves TWO look-ups: lanes 0-31 read the row of one output channel, lanes 32-63 the row of
+// another.  Inside a tile the 16 rows of an MFMA result tile are stored in the order ds_write_addtid_b32
+// produces them (qcnn_row_slot).  Assignment tables live on the device as pre-scaled uint16 LDS offsets
+// (slot * 64 B) in the order the gather waves consume them (QkSlots).
 #ifndef QCNN_KERNELS_H_
 #define QCNN_KERNELS_H_
 
@@ -16,20 +22,64 @@
 #define QCNN_PANEL 128
 #define QCNN_MAX_CS 8          // dims per sub-space supported by the LUT builders
 #define QCNN_MAX_K 128         // code words per sub-space supported (a LUT stage holds 128 rows)
-#define QCNN_ROWS_PAD 256      // bytes of slack after every row-index table (over-read of the last groups)
+#define QCNN_ROWS_PAD 256      // bytes of slack after every row-offset table (over-read of the last groups)
 #define QCNN_STAGE_ROWS 128    // code-word rows of one LUT stage in LDS
-#define QCNN_ROW_BYTES 528     // LDS row stride: 128 images * 4 B + 16 B pad (conflict-free MFMA tile writes)
+#define QCNN_TILE_BYTES 8192   // one image tile of a stage: 128 rows x 16 images x 4 B
+#define QCNN_STAGE_BYTES (8 * QCNN_TILE_BYTES)
+#define QCNN_GATHER_WAVES 12   // gather waves of a conv/FC workgroup (of 16; the other four build the stages)
 
 // A LUT stage holds G = qcnn_stage_group(K) consecutive sub-spaces of one source pixel (conv) / of the
-// input vector (FC): G * K <= 128 rows.  Assignment tables are stored on the device as uint8 ROW INDICES
-// of the code word inside a stage:  row = (m % G) * K + assignment  (< 128).
+// input vector (FC): G * K <= 128 rows;  stage row of a code word = (m % G) * K + assignment  (< 128).
 static inline int qcnn_stage_group(int K) { return K <= 64 ? QCNN_STAGE_ROWS / K : 1; }
+// Slot of stage row r inside an image tile: v_mfma_f32_16x16x4_f32 leaves row 16i + 4q + e of a result tile in
+// element e of lane group q, and ds_write_addtid_b32 of element e stores the four lane groups back to back,
+// so the row lands in slot 16i + 4e + q (the two 2-bit fields swapped).
+static inline int qcnn_row_slot(int r) { return (r & 0x70) | ((r & 3) << 2) | ((r >> 2) & 3); }
+// pre-scaled LDS byte offset of a stage row inside an image tile (what the assignment tables hold)
+static inline uint16_t qcnn_row_offset(int r) { return (uint16_t)(qcnn_row_slot(r) * 64); }
+
+// How the 12 gather waves of a workgroup split `C` output channels (conv: the channels of one group; FC: all
+// of them), and the device layout of the row-offset table that follows from it.  A wave owns `cpw`
+// consecutive channels: lanes 0-31 the first cpw/2, lanes 32-63 the second cpw/2.  Per (tap, sub-space) the
+// table holds, for every wave slot (group-major, then chunk, then wave) and each half, `hp` uint16 offsets
+// (cpw/2 used, padded to a whole number of dwords).
+struct QkSlots {
+  int cpw;        // channels per gather wave
+  int hp;         // uint16 entries per half-wave and (tap, sub-space)
+  int chunks;     // workgroups along the channel axis (per group)
+  int groups;
+  int C;          // channels per group
+  int rowStride;  // uint16 entries per (tap, sub-space) = groups * chunks * 12 * 2 * hp
+};
+static inline QkSlots qk_make_slots(int C, int groups, int cpw) {
+  QkSlots s;
+  s.cpw = cpw; s.C = C; s.groups = groups;
+  s.hp = ((cpw / 2 + 1) / 2) * 2;
+  s.chunks = (C + QCNN_GATHER_WAVES * cpw - 1) / (QCNN_GATHER_WAVES * cpw);
+  s.rowStride = groups * s.chunks * QCNN_GATHER_WAVES * 2 * s.hp;
+  return s;
+}
+// conv: channels per wave by the channel count of one group (then as many positions per wave as 64-72
+// accumulator registers allow: qk_conv_positions)
+static inline QkSlots qk_conv_slots(int Ctg, int groups) {
+  const int chunks = (Ctg + 383) / 384;
+  const int per = (Ctg + chunks - 1) / chunks;       // channels one workgroup has to cover
+  const int cpw = per <= 48 ? 4 : per <= 72 ? 6 : per <= 96 ? 8 : per <= 144 ? 12 : per <= 192 ? 16 : per <= 288 ? 24 : 32;
+  return qk_make_slots(Ctg, groups, cpw);
+}
+static inline QkSlots qk_fc_slots(int Ct) { return qk_make_slots(Ct, 1, Ct >= 384 ? 32 : (Ct >= 96 ? 8 : 4)); }
+// table position (in uint16 entries, inside one (tap, sub-space) row) of channel c of group g, or -1
+static inline int qk_slot_entry(const QkSlots& s, int g, int c) {
+  if (c < 0 || c >= s.C) return -1;
+  const int wave = c / s.cpw, k = c % s.cpw, hc = s.cpw / 2;
+  return ((g * s.chunks * QCNN_GATHER_WAVES + wave) * 2 + k / hc) * s.hp + k % hc;
+}
 struct ConvParams {
   const float* src;      // [panels][H*W*Cin][128]
   float* dst;            // [panels][Ho*Wo*Ct][128]
   const float* bias;     // [Ct]
   const float* ctrd;     // [M][Cs][K]      (PrepCtrdBuf layout, src/CaffeEva.cc:556-557)
-  const uint8_t* rows;   // [kh][kw][M][Ct] (PrepAsmtBuf layout, src/CaffeEva.cc:585-586), stage row indices
+  const uint16_t* rows;  // [kh][kw][M][rowStride] (PrepAsmtBuf order, src/CaffeEva.cc:585-586): row offsets, QkSlots order
   int H, W, Cin, Ho, Wo, Ct;
   int knl, stride, pad, grp;
   int M, Cs, K;
@@ -45,7 +95,7 @@ struct FcParams {
   float* dst;            // [panels][Ct][128]
   const float* bias;
   const float* ctrd;     // [M][Cs][K]
-  const uint8_t* rows;   // [M][Ct]         (src/CaffeEva.cc:610-611), stage row indices
+  const uint16_t* rows;  // [M][rowStride]  (src/CaffeEva.cc:610-611): row offsets, QkSlots order
   int D, Ct, M, Cs, K;
   int relu;
   int panels;

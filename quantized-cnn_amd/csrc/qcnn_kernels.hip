@@ -6,19 +6,21 @@
 // Glue kernels (row a9): ReLU :1027, LRN :1038, max-pool :870, softmax :1098, top-5 :1162,
 // NCHW<->panel conversions (:1146-1160, :187-189).
 //
-// Mapping (see qcnn_kernels.h for the HBM layout, DESIGN.md §3 for the measurements behind it): a lane
-// carries an image pair.  A workgroup (16 waves, one per CU) owns one 128-image panel, one tile of output
-// positions and one slice of output channels.  The look-up table is never materialised in HBM: it is
-// produced one STAGE at a time in LDS — a stage = 128 code-word rows = G = 128/K consecutive sub-spaces of
-// one source pixel (conv) or of the input vector (FC) for the 128 images; a row is 512 contiguous bytes
-// (+16 B pad) = one conflict-free ds_read_b64 per wave.  Stages are double buffered, one s_barrier per
-// stage.  The waves are specialised: four BUILDER waves (one per SIMD) multiply stage s+1 out
-// (v_mfma_f32_16x16x4_f32, or ordered VALU mul+add in "exact" mode) and store it, twelve GATHER waves
-// keep (positions x channels-per-wave) float2 accumulators in VGPRs and consume stage s.  Stages are
-// visited in (pixel row-major, sub-space ascending) order, which for any one output is exactly the
-// reference's (kh, kw, m) summation order (:840-863), so with the exact builder conv/FC outputs are
-// bit-identical to the reference.  Code-word row indices (uint8) are wave-uniform; they are prefetched
-// through the vector memory path and broadcast into SGPRs.
+// Mapping (see qcnn_kernels.h for the HBM and LDS layouts, DESIGN.md §3 for the measurements behind it): a
+// workgroup (16 waves, one per CU) owns one 128-image panel, one tile of output positions and one slice of
+// output channels.  The look-up table is never materialised in HBM: it is produced one STAGE at a time in
+// LDS — a stage = 128 code-word rows = G = 128/K consecutive sub-spaces of one source pixel (conv) or of the
+// input vector (FC) for the 128 images, laid out [8 image tiles][128 rows][16 images].  Stages are double
+// buffered, one s_barrier per stage.  The waves are specialised: four BUILDER waves (one per SIMD) multiply
+// stage s+1 out (v_mfma_f32_16x16x4_f32, or ordered VALU mul+add in "exact" mode) and store it with
+// ds_write_addtid_b32; twelve GATHER waves consume stage s.  A gather lane carries FOUR images; lanes 0-31 of a
+// wave work on one half of the wave's output channels and lanes 32-63 on the other half, so that one
+// ds_read_b128 performs two look-ups (two rows x 128 images) and two v_pk_add_f32 accumulate them.  Every
+// gather wave owns ALL positions of the workgroup's tile and a slice of the channels: in every stage all
+// twelve waves have the same number of look-ups.  Stages are visited in (pixel row-major, sub-space
+// ascending) order, which for any one output is exactly the reference's (kh, kw, m) summation order
+// (:840-863), so with the exact builder conv/FC outputs are bit-identical to the reference.  The row offsets
+// of the look-ups (uint16, pre-scaled) are prefetched one stage ahead through the vector memory path.
 #include "qcnn_kernels.h"
 
 #include <float.h>
@@ -30,12 +32,13 @@ namespace {
 
 constexpr int PANEL = QCNN_PANEL;              // images per panel
 constexpr int NW = 16;                         // waves per workgroup of the two hot kernels (4 per SIMD)
-constexpr int NBW = 4;                         // builder waves (waves 0..3: one per SIMD) — MFMA + LDS writes
-constexpr int NGW = NW - NBW;                  // gather waves (waves 4..15) — LDS reads + packed adds
-constexpr int ROWB = QCNN_ROW_BYTES;           // LDS bytes per code-word row
+constexpr int NBW = 4;                         // builder waves (one per SIMD) — MFMA + LDS writes
+constexpr int NGW = QCNN_GATHER_WAVES;         // gather waves — LDS reads + packed adds
+constexpr int TILEB = QCNN_TILE_BYTES;         // LDS bytes of one image tile of a stage
 constexpr int STAGE_ROWS = QCNN_STAGE_ROWS;
-constexpr int STAGE_BYTES = STAGE_ROWS * ROWB;  // 67 584 B; two stages = 132 KB of the 160 KB LDS
+constexpr int STAGE_BYTES = QCNN_STAGE_BYTES;  // 64 KB; two stages = 128 KB of the 160 KB LDS
 constexpr int XROWB = PANEL * 4;               // bytes of one activation row in HBM
+static_assert(NW == NBW + NGW, "wave roles");
 
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
@@ -50,8 +53,8 @@ __device__ __forceinline__ void barrier_plain() { asm volatile("s_barrier" ::: "
 // SIMDs; which SIMD a wave lands on is the dispatcher's choice (not a function of the wave index that
 // software may rely on), so every wave publishes its SIMD id (HW_REG_HW_ID[5:4]) through LDS and the
 // first wave of each SIMD becomes a builder; the other twelve waves get dense gather indices.  (128 VGPRs
-// per wave force exactly four waves per SIMD for a 16-wave workgroup; the smaller instantiations fall back
-// to "lowest remaining waves" if a SIMD should have none.)
+// per wave force exactly four waves per SIMD for a 16-wave workgroup; the fallback "lowest remaining
+// waves" covers a SIMD that should have none.)
 struct WaveRole {
   bool builder;
   int idx;      // builder: 0..3; gather wave: 0..11
@@ -61,8 +64,6 @@ __device__ __forceinline__ WaveRole assign_roles(char* lds, int wave, int lane) 
   const int simd = (int)(__builtin_amdgcn_s_getreg(4 | (4 << 6) | (1 << 11)) & 3u);   // hwreg(HW_REG_HW_ID, 4, 2)
   if (lane == 0) tab[wave] = simd;
   __syncthreads();
-  // every wave derives the same assignment from the table: first wave of each SIMD, and — should the
-  // dispatcher ever have left a SIMD without a wave of this workgroup — the lowest remaining waves
   int seen = 0, builders = 0, bmask = 0;
 #pragma unroll
   for (int w = 0; w < NW; ++w) {
@@ -82,101 +83,141 @@ __device__ __forceinline__ WaveRole assign_roles(char* lds, int wave, int lane) 
 }
 
 // ------------------------------------------------------------------------------------------------
-// Gather (gather waves).  The code-word ROW INDICES (uint8, 0..127: (m mod G)*K + assignment) of
-// CPW consecutive output channels are wave-uniform.  They are prefetched one group ahead as packed
-// dwords through the VECTOR memory path (every lane loads the same address; tracked by vmcnt, so the
-// prefetch never blocks an lgkmcnt wait of the LDS look-ups) and broadcast into SGPRs with
-// v_readfirstlane when the group starts.  Every look-up is then s_bfe_u32 + s_mul (row byte offset),
-// v_add_u32 (+ lane*8), ds_read_b64 (image pair), v_pk_add_f32.
+// Gather (gather waves).  The wave owns CPW = 2*HC consecutive output channels; lane half h = lane >> 5
+// works on channels h*HC .. h*HC+HC-1 and carries images 4*(lane & 31) .. +3 of the panel.  The row
+// offsets (uint16, slot * 64 B) of the HC channels of a half are fetched as packed dwords (per-lane
+// address: the two halves read different table entries) a stage ahead.  A look-up pair is then
+//   v_add_u32_sdwa (lane address + WORD_k of the packed offsets), ds_read_b128, 2 x v_pk_add_f32.
+// Blocks of up to eight reads are hand-scheduled: all addresses, all reads back to back, then counted
+// s_waitcnt + adds IN PLACE (tied operands: an accumulator never changes register).  The counted waits stay
+// correct with other lgkm operations outstanding at entry: LDS returns in order.  `valid` (wave-uniform)
+// = 0 skips the block with a branch INSIDE the asm text, so that the compiler sees straight-line code and
+// keeps every accumulator in one register for the whole kernel.  The read temporaries are FIXED physical
+// registers named in the clobber lists (an asm operand cannot be sliced into the halves the adds need):
+// blocks of eight use v[96:127], smaller blocks v[112:127].
 // ------------------------------------------------------------------------------------------------
-template <int N4>
+template <int DW>
 struct Idx {
-  uint32_t w[N4];
+  uint32_t w[DW];
 };
 
-// per-lane (vector) load of N4 dwords at base + vzero (vzero: a VGPR holding 0 the compiler cannot see through)
-template <int N4>
-__device__ __forceinline__ void vload_idx(Idx<N4>& o, const uint8_t* __restrict__ ap, uint32_t vzero) {
-  const uint32_t* __restrict__ ap4 = reinterpret_cast<const uint32_t*>(__builtin_assume_aligned(ap + vzero, 4));
+template <int DW>
+__device__ __forceinline__ void vload_idx(Idx<DW>& o, const uint16_t* __restrict__ ap, uint32_t laneOff) {
+  const uint32_t* __restrict__ ap4 =
+      reinterpret_cast<const uint32_t*>(__builtin_assume_aligned(reinterpret_cast<const char*>(ap) + laneOff, 4));
 #pragma unroll
-  for (int j = 0; j < N4; ++j) o.w[j] = ap4[j];
-}
-template <int N4>
-__device__ __forceinline__ void bcast_idx(Idx<N4>& s, const Idx<N4>& v) {
-#pragma unroll
-  for (int j = 0; j < N4; ++j) s.w[j] = (uint32_t)__builtin_amdgcn_readfirstlane((int)v.w[j]);
-}
-// immediate load (fallback for groups that were not prefetched); the result is forced into SGPRs
-template <int N4>
-__device__ __forceinline__ void sload_idx(Idx<N4>& o, const uint8_t* __restrict__ ap) {
-  const uint32_t* __restrict__ ap4 = reinterpret_cast<const uint32_t*>(__builtin_assume_aligned(ap, 4));
-#pragma unroll
-  for (int j = 0; j < N4; ++j) o.w[j] = (uint32_t)__builtin_amdgcn_readfirstlane((int)ap4[j]);
+  for (int j = 0; j < DW; ++j) o.w[j] = ap4[j];
 }
 
-// One hand-scheduled block of 4 (gather4) or 8 (gather8) look-ups, software-pipelined so that no
-// instruction depends on its predecessor: all row indices are extracted on the scalar unit
-// (s_and/s_bfe/s_lshr), then all addresses are formed (v_mad_u32_u24: row * 528 + the lane's stage
-// address), then all ds_read_b64 are issued back to back, then counted s_waitcnt + v_pk_add_f32 IN PLACE
-// (tied operands: an accumulator never changes register).  The counted waits stay correct with other
-// lgkm operations outstanding at entry: LDS returns in order, so "at most N outstanding" implies the
-// first 8-N reads of the block are back.  `valid` (wave-uniform) = 0 skips the block with a branch
-// INSIDE the asm text, so that the compiler sees straight-line code and keeps every accumulator in one
-// register for the whole kernel.
-#define QCNN_X4(w, t0, t1, t2, t3)                                                                         \
-  "s_and_b32 %[" t0 "], %[" w "], 0xff\n\ts_bfe_u32 %[" t1 "], %[" w "], 0x80008\n\t"                    \
-  "s_bfe_u32 %[" t2 "], %[" w "], 0x80010\n\ts_lshr_b32 %[" t3 "], %[" w "], 24\n\t"
-#define QCNN_MAD(a, t) "v_mad_u32_u24 %[" a "], %[" t "], %[rb], %[b]\n\t"
-#define QCNN_RD(v, a) "ds_read_b64 %[" v "], %[" a "]\n\t"
-#define QCNN_ACC(n, c, v) "s_waitcnt lgkmcnt(" n ")\n\tv_pk_add_f32 %[" c "], %[" v "], %[" c "]\n\t"
+#define Q_AD(a, w, sel) "v_xor_b32_sdwa " a ", %[" w "], %[b] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" sel " src1_sel:DWORD\n\t"
+#define Q_RD(v, a) "ds_read_b128 " v ", " a "\n\t"
+#define Q_ACC(n, c0, c1, lo, hi) \
+  "s_waitcnt lgkmcnt(" n ")\n\tv_pk_add_f32 %[" c0 "], " lo ", %[" c0 "]\n\tv_pk_add_f32 %[" c1 "], " hi ", %[" c1 "]\n\t"
+#define Q_SKIP "s_cmp_eq_u32 %[ok], 0\n\ts_cbranch_scc1 .Lqskip%=\n\t"
+#define Q_CLOB8 "scc", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107",     \
+                "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120",    \
+                "v121", "v122", "v123", "v124", "v125", "v126", "v127"
+#define Q_CLOB4 "scc", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123",   \
+                "v124", "v125", "v126", "v127"
 
-__device__ __forceinline__ void gather8(f32x2* acc, uint32_t w0, uint32_t w1, uint32_t base, uint32_t rowb, int valid) {
-  f32x2 v0, v1, v2, v3, v4, v5, v6, v7;
-  uint32_t a0, a1, a2, a3, a4, a5, a6, a7, t0, t1, t2, t3, t4, t5, t6, t7;
-  asm volatile("s_cmp_eq_u32 %[ok], 0\n\ts_cbranch_scc1 .Lqskip%=\n\t"
-               QCNN_X4("w0", "t0", "t1", "t2", "t3") QCNN_X4("w1", "t4", "t5", "t6", "t7")
-               QCNN_MAD("a0", "t0") QCNN_MAD("a1", "t1") QCNN_MAD("a2", "t2") QCNN_MAD("a3", "t3")
-               QCNN_MAD("a4", "t4") QCNN_MAD("a5", "t5") QCNN_MAD("a6", "t6") QCNN_MAD("a7", "t7")
-               QCNN_RD("v0", "a0") QCNN_RD("v1", "a1") QCNN_RD("v2", "a2") QCNN_RD("v3", "a3")
-               QCNN_RD("v4", "a4") QCNN_RD("v5", "a5") QCNN_RD("v6", "a6") QCNN_RD("v7", "a7")
-               QCNN_ACC("7", "c0", "v0") QCNN_ACC("6", "c1", "v1") QCNN_ACC("5", "c2", "v2") QCNN_ACC("4", "c3", "v3")
-               QCNN_ACC("3", "c4", "v4") QCNN_ACC("2", "c5", "v5") QCNN_ACC("1", "c6", "v6") QCNN_ACC("0", "c7", "v7")
+// eight reads = 16 look-ups; acc[2j], acc[2j+1] = the four images of channel j.  The address of a read lives in the
+// first register of its own destination quad (the address is consumed at issue).
+__device__ __forceinline__ void gq8(f32x2* acc, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t base, int valid) {
+  asm volatile(Q_SKIP
+               Q_AD("v96", "w0", "WORD_0") Q_AD("v100", "w0", "WORD_1") Q_AD("v104", "w1", "WORD_0") Q_AD("v108", "w1", "WORD_1")
+               Q_AD("v112", "w2", "WORD_0") Q_AD("v116", "w2", "WORD_1") Q_AD("v120", "w3", "WORD_0") Q_AD("v124", "w3", "WORD_1")
+               Q_RD("v[96:99]", "v96") Q_RD("v[100:103]", "v100") Q_RD("v[104:107]", "v104") Q_RD("v[108:111]", "v108")
+               Q_RD("v[112:115]", "v112") Q_RD("v[116:119]", "v116") Q_RD("v[120:123]", "v120") Q_RD("v[124:127]", "v124")
+               Q_ACC("7", "c0", "c1", "v[96:97]", "v[98:99]") Q_ACC("6", "c2", "c3", "v[100:101]", "v[102:103]")
+               Q_ACC("5", "c4", "c5", "v[104:105]", "v[106:107]") Q_ACC("4", "c6", "c7", "v[108:109]", "v[110:111]")
+               Q_ACC("3", "c8", "c9", "v[112:113]", "v[114:115]") Q_ACC("2", "c10", "c11", "v[116:117]", "v[118:119]")
+               Q_ACC("1", "c12", "c13", "v[120:121]", "v[122:123]") Q_ACC("0", "c14", "c15", "v[124:125]", "v[126:127]")
                "\n.Lqskip%=:"
                : [c0] "+v"(acc[0]), [c1] "+v"(acc[1]), [c2] "+v"(acc[2]), [c3] "+v"(acc[3]), [c4] "+v"(acc[4]),
-                 [c5] "+v"(acc[5]), [c6] "+v"(acc[6]), [c7] "+v"(acc[7]), [v0] "=&v"(v0), [v1] "=&v"(v1),
-                 [v2] "=&v"(v2), [v3] "=&v"(v3), [v4] "=&v"(v4), [v5] "=&v"(v5), [v6] "=&v"(v6), [v7] "=&v"(v7),
-                 [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3), [a4] "=&v"(a4), [a5] "=&v"(a5),
-                 [a6] "=&v"(a6), [a7] "=&v"(a7), [t0] "=&s"(t0), [t1] "=&s"(t1), [t2] "=&s"(t2), [t3] "=&s"(t3),
-                 [t4] "=&s"(t4), [t5] "=&s"(t5), [t6] "=&s"(t6), [t7] "=&s"(t7)
-               : [w0] "s"(w0), [w1] "s"(w1), [b] "v"(base), [rb] "v"(rowb), [ok] "s"(valid)
-               : "scc");
+                 [c5] "+v"(acc[5]), [c6] "+v"(acc[6]), [c7] "+v"(acc[7]), [c8] "+v"(acc[8]), [c9] "+v"(acc[9]),
+                 [c10] "+v"(acc[10]), [c11] "+v"(acc[11]), [c12] "+v"(acc[12]), [c13] "+v"(acc[13]), [c14] "+v"(acc[14]),
+                 [c15] "+v"(acc[15])
+               : [w0] "v"(w0), [w1] "v"(w1), [w2] "v"(w2), [w3] "v"(w3), [b] "v"(base), [ok] "s"(valid)
+               : Q_CLOB8);
 }
-
-__device__ __forceinline__ void gather4(f32x2* acc, uint32_t w0, uint32_t base, uint32_t rowb, int valid) {
-  f32x2 v0, v1, v2, v3;
-  uint32_t a0, a1, a2, a3, t0, t1, t2, t3;
-  asm volatile("s_cmp_eq_u32 %[ok], 0\n\ts_cbranch_scc1 .Lqskip%=\n\t"
-               QCNN_X4("w0", "t0", "t1", "t2", "t3")
-               QCNN_MAD("a0", "t0") QCNN_MAD("a1", "t1") QCNN_MAD("a2", "t2") QCNN_MAD("a3", "t3")
-               QCNN_RD("v0", "a0") QCNN_RD("v1", "a1") QCNN_RD("v2", "a2") QCNN_RD("v3", "a3")
-               QCNN_ACC("3", "c0", "v0") QCNN_ACC("2", "c1", "v1") QCNN_ACC("1", "c2", "v2") QCNN_ACC("0", "c3", "v3")
+// four reads = 8 look-ups
+__device__ __forceinline__ void gq4(f32x2* acc, uint32_t w0, uint32_t w1, uint32_t base, int valid) {
+  asm volatile(Q_SKIP
+               Q_AD("v112", "w0", "WORD_0") Q_AD("v116", "w0", "WORD_1") Q_AD("v120", "w1", "WORD_0") Q_AD("v124", "w1", "WORD_1")
+               Q_RD("v[112:115]", "v112") Q_RD("v[116:119]", "v116") Q_RD("v[120:123]", "v120") Q_RD("v[124:127]", "v124")
+               Q_ACC("3", "c0", "c1", "v[112:113]", "v[114:115]") Q_ACC("2", "c2", "c3", "v[116:117]", "v[118:119]")
+               Q_ACC("1", "c4", "c5", "v[120:121]", "v[122:123]") Q_ACC("0", "c6", "c7", "v[124:125]", "v[126:127]")
                "\n.Lqskip%=:"
-               : [c0] "+v"(acc[0]), [c1] "+v"(acc[1]), [c2] "+v"(acc[2]), [c3] "+v"(acc[3]), [v0] "=&v"(v0),
-                 [v1] "=&v"(v1), [v2] "=&v"(v2), [v3] "=&v"(v3), [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2),
-                 [a3] "=&v"(a3), [t0] "=&s"(t0), [t1] "=&s"(t1), [t2] "=&s"(t2), [t3] "=&s"(t3)
-               : [w0] "s"(w0), [b] "v"(base), [rb] "v"(rowb), [ok] "s"(valid)
-               : "scc");
+               : [c0] "+v"(acc[0]), [c1] "+v"(acc[1]), [c2] "+v"(acc[2]), [c3] "+v"(acc[3]), [c4] "+v"(acc[4]),
+                 [c5] "+v"(acc[5]), [c6] "+v"(acc[6]), [c7] "+v"(acc[7])
+               : [w0] "v"(w0), [w1] "v"(w1), [b] "v"(base), [ok] "s"(valid)
+               : Q_CLOB4);
+}
+// three reads = 6 look-ups; FIRST = 1: entries (w0.lo, w0.hi, w1.lo), FIRST = 0: (w0.hi, w1.lo, w1.hi)
+template <int FIRST>
+__device__ __forceinline__ void gq3(f32x2* acc, uint32_t w0, uint32_t w1, uint32_t base, int valid) {
+  if (FIRST) {
+    asm volatile(Q_SKIP
+                 Q_AD("v112", "w0", "WORD_0") Q_AD("v116", "w0", "WORD_1") Q_AD("v120", "w1", "WORD_0")
+                 Q_RD("v[112:115]", "v112") Q_RD("v[116:119]", "v116") Q_RD("v[120:123]", "v120")
+                 Q_ACC("2", "c0", "c1", "v[112:113]", "v[114:115]") Q_ACC("1", "c2", "c3", "v[116:117]", "v[118:119]")
+                 Q_ACC("0", "c4", "c5", "v[120:121]", "v[122:123]")
+                 "\n.Lqskip%=:"
+                 : [c0] "+v"(acc[0]), [c1] "+v"(acc[1]), [c2] "+v"(acc[2]), [c3] "+v"(acc[3]), [c4] "+v"(acc[4]),
+                   [c5] "+v"(acc[5])
+                 : [w0] "v"(w0), [w1] "v"(w1), [b] "v"(base), [ok] "s"(valid)
+                 : Q_CLOB4);
+  } else {
+    asm volatile(Q_SKIP
+                 Q_AD("v112", "w0", "WORD_1") Q_AD("v116", "w1", "WORD_0") Q_AD("v120", "w1", "WORD_1")
+                 Q_RD("v[112:115]", "v112") Q_RD("v[116:119]", "v116") Q_RD("v[120:123]", "v120")
+                 Q_ACC("2", "c0", "c1", "v[112:113]", "v[114:115]") Q_ACC("1", "c2", "c3", "v[116:117]", "v[118:119]")
+                 Q_ACC("0", "c4", "c5", "v[120:121]", "v[122:123]")
+                 "\n.Lqskip%=:"
+                 : [c0] "+v"(acc[0]), [c1] "+v"(acc[1]), [c2] "+v"(acc[2]), [c3] "+v"(acc[3]), [c4] "+v"(acc[4]),
+                   [c5] "+v"(acc[5])
+                 : [w0] "v"(w0), [w1] "v"(w1), [b] "v"(base), [ok] "s"(valid)
+                 : Q_CLOB4);
+  }
+}
+// two reads = 4 look-ups
+__device__ __forceinline__ void gq2(f32x2* acc, uint32_t w0, uint32_t base, int valid) {
+  asm volatile(Q_SKIP
+               Q_AD("v112", "w0", "WORD_0") Q_AD("v116", "w0", "WORD_1")
+               Q_RD("v[112:115]", "v112") Q_RD("v[116:119]", "v116")
+               Q_ACC("1", "c0", "c1", "v[112:113]", "v[114:115]") Q_ACC("0", "c2", "c3", "v[116:117]", "v[118:119]")
+               "\n.Lqskip%=:"
+               : [c0] "+v"(acc[0]), [c1] "+v"(acc[1]), [c2] "+v"(acc[2]), [c3] "+v"(acc[3])
+               : [w0] "v"(w0), [b] "v"(base), [ok] "s"(valid)
+               : Q_CLOB4);
 }
 
-// CPW look-ups of one group; `stage` = LDS byte address of the lane's image pair in row 0 of the stage
+// dwords of packed offsets per half-wave for CPW channels per wave
+__host__ __device__ constexpr int idx_dwords(int CPW) { return (CPW / 2 + 1) / 2; }
+
+// the CPW look-ups (CPW/2 reads) of one position / sub-space; `stage` = LDS byte address of the lane's four
+// images in slot 0 of the stage
 template <int CPW>
-__device__ __forceinline__ void gather_apply(f32x2 (&acc)[CPW], const Idx<CPW / 4>& o, uint32_t stage, int valid) {
-  static_assert(CPW % 4 == 0, "indices are fetched as packed dwords");
-  uint32_t rowb;
-  asm volatile("v_mov_b32 %0, 0x210" : "=v"(rowb));   // QCNN_ROW_BYTES, kept in a VGPR for v_mad_u32_u24
-#pragma unroll
-  for (int j = 0; j + 1 < CPW / 4; j += 2) gather8(&acc[4 * j], o.w[j], o.w[j + 1], stage, rowb, valid);
-  if ((CPW / 4) % 2) gather4(&acc[CPW - 4], o.w[CPW / 4 - 1], stage, rowb, valid);
+__device__ __forceinline__ void gather_apply(f32x2 (&acc)[CPW], const Idx<idx_dwords(CPW)>& o, uint32_t stage, int valid) {
+  static_assert(CPW == 4 || CPW == 6 || CPW == 8 || CPW == 12 || CPW == 16 || CPW == 24 || CPW == 32, "channel slices");
+  if constexpr (CPW == 32) {
+    gq8(&acc[0], o.w[0], o.w[1], o.w[2], o.w[3], stage, valid);
+    gq8(&acc[16], o.w[4], o.w[5], o.w[6], o.w[7], stage, valid);
+  } else if constexpr (CPW == 24) {
+    gq8(&acc[0], o.w[0], o.w[1], o.w[2], o.w[3], stage, valid);
+    gq4(&acc[16], o.w[4], o.w[5], stage, valid);
+  } else if constexpr (CPW == 16) {
+    gq8(&acc[0], o.w[0], o.w[1], o.w[2], o.w[3], stage, valid);
+  } else if constexpr (CPW == 12) {
+    gq3<1>(&acc[0], o.w[0], o.w[1], stage, valid);
+    gq3<0>(&acc[6], o.w[1], o.w[2], stage, valid);
+  } else if constexpr (CPW == 8) {
+    gq4(&acc[0], o.w[0], o.w[1], stage, valid);
+  } else if constexpr (CPW == 6) {
+    gq3<1>(&acc[0], o.w[0], o.w[1], stage, valid);
+  } else {
+    gq2(&acc[0], o.w[0], stage, valid);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -184,6 +225,9 @@ __device__ __forceinline__ void gather_apply(f32x2 (&acc)[CPW], const Idx<CPW / 
 // each.  The 128-image activation row of dim d of sub-space m starts at
 // xbase + xoff0 + (m*Cs + d) * 512 bytes.
 // ------------------------------------------------------------------------------------------------
+
+// LDS slot of a stage row (device copy of qcnn_row_slot)
+__device__ __forceinline__ int row_slot(int r) { return (r & 0x70) | ((r & 3) << 2) | ((r >> 2) & 3); }
 
 // exact: y = ((0 + x0*c0) + x1*c1) + ...  with separately rounded product and sum, the order of the
 // reference's saxpy chain (src/CaffeEva.cc:1284-1289, include/BlasWrapper.h:164-184).  Any K <= 128.
@@ -194,6 +238,8 @@ __device__ __forceinline__ void build_stage_exact(char* stage, const char* __res
   const int kpw = (K + NBW - 1) / NBW;
   const int k0 = bw * kpw;
   const int k1 = min(K, k0 + kpw);
+  char* wl = stage + (lane >> 3) * TILEB + (lane & 7) * 8;     // images 2*lane, 2*lane+1: tile lane/8, 8 B in
+  const int swz = lane >> 4;                                   // slot swizzle of that tile (tile >> 1)
   for (int g = 0; g < G; ++g) {
     const int m = m0 + g;
     if (m >= mEnd) break;
@@ -216,7 +262,7 @@ __device__ __forceinline__ void build_stage_exact(char* stage, const char* __res
           v1 = __fadd_rn(v1, __fmul_rn(xv[d].y, c));
         }
       }
-      *reinterpret_cast<f32x2*>(stage + (g * K + k) * ROWB + lane * 8) = f32x2{v0, v1};
+      *reinterpret_cast<f32x2*>(wl + (row_slot(g * K + k) ^ swz) * 64) = f32x2{v0, v1};
     }
   }
 }
@@ -236,15 +282,13 @@ struct MfmaOps {
   float b[2][SUBS][KS];    // activation operand per image tile, sub-space and k-step
 };
 
-// Addresses are (wave-uniform pointer) + (32-bit lane offset) so that the loads take the
-// "SGPR base + VGPR offset" form and need no per-load 64-bit vector arithmetic.
 template <int KT, int KS>
 __device__ __forceinline__ void mfma_load(MfmaOps<KT, KS>& o, const char* __restrict__ xbase, uint32_t xoff0,
                                           const float* __restrict__ ctrd, int Cs, int m0, int bw, int lane) {
   constexpr int K = KT * 16;
   constexpr int SUBS = MfmaOps<KT, KS>::SUBS;
   const uint32_t li = lane & 15, lk = lane >> 4;
-  const uint32_t laneA = lk * K + li;                                   // floats
+  const uint32_t laneA = lk * K + (li ^ ((uint32_t)bw << 2));           // floats; rows pre-swizzled for the wave's tiles (mfma_pair)
   const uint32_t laneB = lk * XROWB + li * 4;                            // bytes
   const float* __restrict__ cbU = ctrd + (size_t)m0 * Cs * K;            // uniform
   const char* __restrict__ xbU = xbase + xoff0 + (uint32_t)(m0 * Cs) * (uint32_t)XROWB + bw * 128;   // uniform
@@ -263,19 +307,67 @@ __device__ __forceinline__ void mfma_load(MfmaOps<KT, KS>& o, const char* __rest
   }
 }
 
-// Multiply the stage `o` was loaded for (m0, mEnd, D, Cs) out into LDS.  The 16 tiles of the wave are
-// walked in pairs with a hand-made software pipeline: MFMA(pair n) is interleaved instruction by
-// instruction with the LDS writes of pair n-1, so that a write (which a single wave issues every ~15
-// cycles) always sits in the 32-cycle shadow of a matrix instruction and never waits for its own result.
 __device__ __forceinline__ f32x4 round_f16(f32x4 v) {
   return f32x4{(float)(_Float16)v[0], (float)(_Float16)v[1], (float)(_Float16)v[2], (float)(_Float16)v[3]};
 }
 
-template <int KT, int KS>
-__device__ __forceinline__ void mfma_store(MfmaOps<KT, KS>& o, char* stage, int Cs, int D, int m0, int mEnd, int bw,
-                                           int lane, int f16) {
+// Result tile (image tile `it` of this wave, row tile I) -> LDS: element e of the four result registers goes
+// to slots 16I + 4e .. 4e+3 of the tile, 256 contiguous bytes, by ONE ds_write_addtid_b32 (address = M0[15:0] +
+// 16-bit offset + 4 * lane: no address register, half the LDS-path cycles of ds_write_b32).  The position of a
+// slot inside its aligned group of four is XOR-ed with (tile >> 1) (bank spreading for the readers, see
+// qcnn_kernels.h); both tiles of builder wave bw have tile >> 1 == bw, and the wave fetched its code-book rows
+// pre-swizzled (mfma_load), so lane group q already holds the rows that belong at position q.  M0 holds the
+// full byte address of the tile (measured on gfx950: all of M0 is added, not 16 bits of it); an SALU write of
+// M0 needs one wait state before an add-TID LDS instruction reads it (without the s_nop the store uses the
+// previous M0: scripts/ubench/addtid_probe.hip).
+#define QCNN_WR2(ea, eb, oa, ob)                                                                                   \
+  asm volatile("s_mov_b32 m0, %[m]\n\ts_nop 0\n\tds_write_addtid_b32 %[" ea "] offset:%[" oa "]\n\t"              \
+               "ds_write_addtid_b32 %[" eb "] offset:%[" ob "]"                                                      \
+               :: [m] "s"(m0v), [e0] "v"(v[0]), [e1] "v"(v[1]), [e2] "v"(v[2]), [e3] "v"(v[3]),                      \
+                  [o0] "n"(I * 1024), [o1] "n"(I * 1024 + 256), [o2] "n"(I * 1024 + 512), [o3] "n"(I * 1024 + 768)   \
+               : "m0", "memory")
+template <int I>
+__device__ __forceinline__ void store_tile_lo(const f32x4& v, uint32_t m0v) { QCNN_WR2("e0", "e1", "o0", "o1"); }
+template <int I>
+__device__ __forceinline__ void store_tile_hi(const f32x4& v, uint32_t m0v) { QCNN_WR2("e2", "e3", "o2", "o3"); }
+
+// Multiply the stage `o` was loaded for (m0, mEnd, D, Cs) out into stage buffer BUF.  The 16 tiles of the wave
+// are walked in pairs with a hand-made software pipeline: MFMA(pair n) is interleaved instruction by
+// instruction with the LDS writes of pair n-1, so that a write (which a single wave can only issue every ~15
+// cycles) sits in the shadow of a matrix instruction and never waits for its own result.
+template <int KT, int KS, int BUF, int N>
+__device__ __forceinline__ void mfma_pair(MfmaOps<KT, KS>& o, f32x4& pa, f32x4& pb, int bw, int f16) {
+  constexpr int it = (N < 8 ? N : 0) / 4, i = 2 * ((N < 8 ? N : 0) % 4);          // this pair: tiles (it, i), (it, i+1)
+  constexpr int pit = (N > 0 ? N - 1 : 0) / 4, pi = 2 * ((N > 0 ? N - 1 : 0) % 4);  // previous pair (results in pa, pb)
+  const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+  const uint32_t m0v = (uint32_t)BUF * STAGE_BYTES + (uint32_t)(2 * bw + pit) * TILEB;
+  f32x4 ca = zero, cb = zero;
+  __builtin_amdgcn_sched_barrier(0);
+  if (N < 8) ca = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a[i][0], o.b[it][i / KT][0], zero, 0, 0, 0);
+  __builtin_amdgcn_sched_barrier(0);
+  if (N > 0) store_tile_lo<pi>(pa, m0v);
+  __builtin_amdgcn_sched_barrier(0);
+  if (N < 8) cb = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a[i + 1][0], o.b[it][(i + 1) / KT][0], zero, 0, 0, 0);
+  __builtin_amdgcn_sched_barrier(0);
+  if (N > 0) store_tile_hi<pi>(pa, m0v);
+  __builtin_amdgcn_sched_barrier(0);
+  if (KS > 1 && N < 8) ca = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a[i][KS - 1], o.b[it][i / KT][KS - 1], ca, 0, 0, 0);
+  __builtin_amdgcn_sched_barrier(0);
+  if (N > 0) store_tile_lo<pi + 1>(pb, m0v);
+  __builtin_amdgcn_sched_barrier(0);
+  if (KS > 1 && N < 8)
+    cb = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a[i + 1][KS - 1], o.b[it][(i + 1) / KT][KS - 1], cb, 0, 0, 0);
+  __builtin_amdgcn_sched_barrier(0);
+  if (N > 0) store_tile_hi<pi + 1>(pb, m0v);
+  __builtin_amdgcn_sched_barrier(0);
+  pa = ca; pb = cb;
+  if (f16) { pa = round_f16(pa); pb = round_f16(pb); }   // tolerance study only (uniform branch)
+}
+
+template <int KT, int KS, int BUF>
+__device__ __forceinline__ void mfma_store(MfmaOps<KT, KS>& o, int Cs, int D, int m0, int mEnd, int bw, int lane, int f16) {
   constexpr int SUBS = MfmaOps<KT, KS>::SUBS;
-  const int li = lane & 15, lk = lane >> 4;
+  const int lk = lane >> 4;
   // plain: every sub-space of the stage exists and has all 4*KS dims -> nothing to zero
   const bool plain = (m0 + SUBS <= mEnd) && (D - (m0 + SUBS - 1) * Cs >= 4 * KS) && (Cs == 4 * KS);
   if (!plain) {
@@ -291,58 +383,37 @@ __device__ __forceinline__ void mfma_store(MfmaOps<KT, KS>& o, char* stage, int 
       }
     }
   }
-  const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
-  char* wl = stage + (lk * 4) * ROWB + (bw * 32 + li) * 4;
-  f32x4 pa = zero, pb = zero;           // results of the previous pair, still to be written
-  char *wa = wl, *wb = wl;
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int n = 0; n <= 8; ++n) {        // pair n = tiles (it, i), (it, i+1) with it = n / 4, i = 2 * (n % 4)
-    const int it = (n < 8 ? n : 0) / 4, i = 2 * ((n < 8 ? n : 0) % 4);
-    f32x4 ca = zero, cb = zero;
-    if (n < 8) ca = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a[i][0], o.b[it][i / KT][0], zero, 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    if (n > 0) { *reinterpret_cast<float*>(wa) = pa[0]; *reinterpret_cast<float*>(wa + ROWB) = pa[1]; }
-    __builtin_amdgcn_sched_barrier(0);
-    if (n < 8) cb = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a[i + 1][0], o.b[it][(i + 1) / KT][0], zero, 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    if (n > 0) { *reinterpret_cast<float*>(wa + 2 * ROWB) = pa[2]; *reinterpret_cast<float*>(wa + 3 * ROWB) = pa[3]; }
-    __builtin_amdgcn_sched_barrier(0);
-    if (KS > 1 && n < 8) ca = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a[i][KS - 1], o.b[it][i / KT][KS - 1], ca, 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    if (n > 0) { *reinterpret_cast<float*>(wb) = pb[0]; *reinterpret_cast<float*>(wb + ROWB) = pb[1]; }
-    __builtin_amdgcn_sched_barrier(0);
-    if (KS > 1 && n < 8)
-      cb = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a[i + 1][KS - 1], o.b[it][(i + 1) / KT][KS - 1], cb, 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    if (n > 0) { *reinterpret_cast<float*>(wb + 2 * ROWB) = pb[2]; *reinterpret_cast<float*>(wb + 3 * ROWB) = pb[3]; }
-    __builtin_amdgcn_sched_barrier(0);
-    pa = ca; pb = cb;
-    if (f16) { pa = round_f16(pa); pb = round_f16(pb); }   // tolerance study only (uniform branch)
-    wa = wl + it * 64 + i * 16 * ROWB;
-    wb = wa + 16 * ROWB;
-  }
+  f32x4 pa = {0.0f, 0.0f, 0.0f, 0.0f}, pb = pa;   // results of the previous pair, still to be written
+  mfma_pair<KT, KS, BUF, 0>(o, pa, pb, bw, f16);
+  mfma_pair<KT, KS, BUF, 1>(o, pa, pb, bw, f16);
+  mfma_pair<KT, KS, BUF, 2>(o, pa, pb, bw, f16);
+  mfma_pair<KT, KS, BUF, 3>(o, pa, pb, bw, f16);
+  mfma_pair<KT, KS, BUF, 4>(o, pa, pb, bw, f16);
+  mfma_pair<KT, KS, BUF, 5>(o, pa, pb, bw, f16);
+  mfma_pair<KT, KS, BUF, 6>(o, pa, pb, bw, f16);
+  mfma_pair<KT, KS, BUF, 7>(o, pa, pb, bw, f16);
+  mfma_pair<KT, KS, BUF, 8>(o, pa, pb, bw, f16);
 }
 
 // ------------------------------------------------------------------------------------------------
-// conv.  Workgroup = 16 waves = one 128-image panel x a TH x TW tile of output positions x NC*CPW
-// output channels of one group.  Stages (source pixel row-major, sub-space group ascending) are double
-// buffered in LDS, one s_barrier per stage.  The waves are SPECIALISED, so that the chain "MFMA -> LDS
-// write" of stage s+1 and the chain "LDS read -> add" of stage s run concurrently instead of one after
-// the other in every wave:
-//   builder waves 0..3 (one per SIMD):  [build stage s+1 from operands in registers] [fetch operands s+2]
-//   gather waves 4..15:                 [broadcast indices of stage s] [prefetch indices s+1] [gather stage s]
-// The tile is cut into 1 x SW strips; gather wave gw owns strip gw / NC and channels (gw % NC)*CPW ..
-// +CPW-1 and keeps SW x CPW float2 accumulators.  KT = K/16 selects the MFMA builder, KT = 0 the exact
-// builder (any K <= 128).
+// conv.  Workgroup = 16 waves = one 128-image panel x a TH x TW tile of output positions x 12*CPW output
+// channels of one group.  Stages (source pixel row-major, sub-space group ascending) are double buffered in
+// LDS, one s_barrier per stage.  The waves are SPECIALISED, so that the chain "MFMA -> LDS write" of stage
+// s+1 and the chain "LDS read -> add" of stage s run concurrently instead of one after the other in every
+// wave:
+//   builder waves (one per SIMD):  [build stage s+1 from operands in registers] [fetch operands s+2]
+//   gather waves:                  [prefetch offsets of stage s+1] [gather stage s]
+// Gather wave gw owns channels gw*CPW .. +CPW-1 of the workgroup's slice for ALL TH*TW positions and keeps
+// TH*TW x CPW float2 accumulators.  KT = K/16 selects the MFMA builder, KT = 0 the exact builder (any
+// K <= 128).
 // ------------------------------------------------------------------------------------------------
 struct ConvGeom {
-  int W, Cin, knl, M, Ct, MG, G, wiL, wiU;
+  int W, Cin, knl, M, MG, G, wiL, wiU;
+  uint32_t rowStride;   // uint16 entries of one (tap, sub-space) row of the offset table
 };
 // Workgroups are dispatched in linear order, so the tiles are numbered heaviest first: interior tiles
-// (full receptive field = most stages), then the four edges, then the corners.  With ~5 workgroups per
-// CU in the 13x13 layers the last dispatch round is then made of the short border tiles instead of
-// whatever row-major order leaves over (longest-processing-time-first).
+// (full receptive field = most stages), then the four edges, then the corners.  With a few workgroups per
+// CU the last dispatch round is then made of the short border tiles (longest-processing-time-first).
 __device__ __forceinline__ void tile_of_rank(int r, int tilesY, int tilesX, int& ty, int& tx) {
   if (tilesY < 3 || tilesX < 3) { ty = r / tilesX; tx = r % tilesX; return; }
   const int iy = tilesY - 2, ix = tilesX - 2;
@@ -374,51 +445,57 @@ __device__ __forceinline__ uint32_t pixel_off(const StagePos& c, const ConvGeom&
   return (uint32_t)(c.hi * g.W + c.wi) * (uint32_t)g.Cin * (uint32_t)XROWB;
 }
 
-// indices of the first sub-space of stage c for every position of the wave's strip (taps that do not
-// exist are clamped to an existing one: the load is harmless, the gather skips them)
-template <int SW, int CPW>
-__device__ __forceinline__ void conv_prefetch_idx(Idx<CPW / 4> (&v)[SW], const StagePos& c, const ConvGeom& g,
-                                                  const uint8_t* __restrict__ rowsC, int rowStart,
-                                                  const int (&colStart)[SW], uint32_t vzero) {
-  const int kh = min(max(c.hi - rowStart, 0), g.knl - 1);
+// offsets of the first sub-space of stage c for every position of the tile (taps that do not exist are
+// clamped to an existing one: the load is harmless, the gather skips them)
+template <int TH, int TW, int CPW>
+__device__ __forceinline__ void conv_prefetch_idx(Idx<idx_dwords(CPW)> (&v)[TH * TW], const StagePos& c, const ConvGeom& g,
+                                                  const uint16_t* __restrict__ rowsW, const int (&rowStart)[TH],
+                                                  const int (&colStart)[TW], uint32_t laneOff) {
 #pragma unroll
-  for (int dx = 0; dx < SW; ++dx) {
-    const int kw = min(max(c.wi - colStart[dx], 0), g.knl - 1);
-    vload_idx(v[dx], rowsC + (size_t)((kh * g.knl + kw) * g.M + c.mg * g.G) * g.Ct, vzero);
+  for (int dy = 0; dy < TH; ++dy) {
+    const int kh = min(max(c.hi - rowStart[dy], 0), g.knl - 1);
+#pragma unroll
+    for (int dx = 0; dx < TW; ++dx) {
+      const int kw = min(max(c.wi - colStart[dx], 0), g.knl - 1);
+      vload_idx(v[dy * TW + dx], rowsW + (size_t)((kh * g.knl + kw) * g.M + c.mg * g.G) * g.rowStride, laneOff);
+    }
   }
 }
 
-template <int SW, int CPW, bool ONE>
-__device__ __forceinline__ void conv_gather(f32x2 (&acc)[SW][CPW], const Idx<CPW / 4> (&first)[SW], const StagePos& c,
-                                            const ConvGeom& g, const uint8_t* __restrict__ rowsC, int rowStart,
-                                            const int (&colStart)[SW], uint32_t stage) {
-  const int kh = c.hi - rowStart;
-  const bool rowOk = (unsigned)kh < (unsigned)g.knl;
+template <int TH, int TW, int CPW, bool ONE>
+__device__ __forceinline__ void conv_gather(f32x2 (&acc)[TH * TW][CPW], const Idx<idx_dwords(CPW)> (&first)[TH * TW],
+                                            const StagePos& c, const ConvGeom& g, const uint16_t* __restrict__ rowsW,
+                                            const int (&rowStart)[TH], const int (&colStart)[TW], uint32_t stage,
+                                            uint32_t laneOff, bool live) {
 #pragma unroll
-  for (int dx = 0; dx < SW; ++dx) {
-    const int kw = c.wi - colStart[dx];
-    const int valid = uni((rowOk && (unsigned)kw < (unsigned)g.knl) ? 1 : 0);
-    gather_apply<CPW>(acc[dx], first[dx], stage, valid);
-    if (!ONE) {                              // further sub-spaces of the stage (K <= 64 only)
-      const int m0 = c.mg * g.G;
-      const int n = valid ? min(g.M, m0 + g.G) - m0 : 0;
-      for (int i = 1; i < n; ++i) {
-        Idx<CPW / 4> more;
-        sload_idx(more, rowsC + (size_t)((kh * g.knl + kw) * g.M + m0 + i) * g.Ct);
-        gather_apply<CPW>(acc[dx], more, stage, 1);
+  for (int dy = 0; dy < TH; ++dy) {
+    const int kh = c.hi - rowStart[dy];
+    const bool rowOk = live && (unsigned)kh < (unsigned)g.knl;
+#pragma unroll
+    for (int dx = 0; dx < TW; ++dx) {
+      const int kw = c.wi - colStart[dx];
+      const int valid = uni((rowOk && (unsigned)kw < (unsigned)g.knl) ? 1 : 0);
+      gather_apply<CPW>(acc[dy * TW + dx], first[dy * TW + dx], stage, valid);
+      if (!ONE) {                              // further sub-spaces of the stage (K <= 64 only)
+        const int m0 = c.mg * g.G;
+        const int n = valid ? min(g.M, m0 + g.G) - m0 : 0;
+        for (int i = 1; i < n; ++i) {
+          Idx<idx_dwords(CPW)> more;
+          vload_idx(more, rowsW + (size_t)((kh * g.knl + kw) * g.M + m0 + i) * g.rowStride, laneOff);
+          gather_apply<CPW>(acc[dy * TW + dx], more, stage, 1);
+        }
       }
     }
   }
 }
 
-template <int TH, int TW, int SW, int CPW, int KT, int KS>
-__global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX, int tilesY, int chunksPerGrp, int G) {
+template <int TH, int TW, int CPW, int KT, int KS>
+__global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX, int tilesY, int chunksPerGrp, int G,
+                                                        int rowStride) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  static_assert(TW % SW == 0, "strips tile the row");
-  constexpr int SPR = TW / SW;            // strips per tile row
-  constexpr int NSTRIP = TH * SPR;
-  static_assert(NGW % NSTRIP == 0, "gather waves split evenly over strips");
-  constexpr int NC = NGW / NSTRIP;        // channel chunks (of CPW) inside the workgroup
+  constexpr int NP = TH * TW;
+  constexpr int HC = CPW / 2;
+  constexpr int DW = idx_dwords(CPW);
   constexpr int KTT = KT > 0 ? KT : 1;
   const int lane = threadIdx.x & 63;
   const int wave = uni(threadIdx.x >> 6);
@@ -433,13 +510,14 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
   const int hoL = min(ho0 + TH, p.Ho) - 1, woL = min(wo0 + TW, p.Wo) - 1;   // last real position of the tile
   const int hiL = max(0, ho0 * p.stride - p.pad), hiU = min(p.H - 1, hoL * p.stride - p.pad + p.knl - 1);
   ConvGeom g;
-  g.W = p.W; g.Cin = p.Cin; g.knl = p.knl; g.M = M; g.Ct = p.Ct; g.G = G;
+  g.W = p.W; g.Cin = p.Cin; g.knl = p.knl; g.M = M; g.G = G; g.rowStride = (uint32_t)rowStride;
   g.MG = (M + G - 1) / G;                           // stages per source pixel
   g.wiL = max(0, wo0 * p.stride - p.pad);
   g.wiU = min(p.W - 1, woL * p.stride - p.pad + p.knl - 1);
   const int S = (hiU - hiL + 1) * (g.wiU - g.wiL + 1) * g.MG;
   const int Sp = (S + 1) & ~1;                      // every wave runs Sp stage periods (barriers)
   const StagePos first = {hiL, g.wiL, 0};
+  if ((uint32_t)(uintptr_t)lds != 0u) __builtin_trap();   // the stage addressing assumes the dynamic segment starts at LDS byte 0
 
   const WaveRole role = assign_roles(lds, wave, lane);
   if (role.builder) {
@@ -457,7 +535,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
     StagePos q3 = next_pos(q2, g);
     if (KT > 0) {
       mfma_load<KTT, KS>(opsA, xbase, pixel_off(first, g), p.ctrd, Cs, 0, bw, lane);
-      mfma_store<KTT, KS>(opsA, lds, Cs, Cg, 0, M, bw, lane, p.lutF16);
+      mfma_store<KTT, KS, 0>(opsA, Cs, Cg, 0, M, bw, lane, p.lutF16);
       {
         const StagePos qa = (q1.hi > hiU) ? first : q1, qb = (q2.hi > hiU) ? first : q2;
         mfma_load<KTT, KS>(opsA, xbase, pixel_off(qa, g), p.ctrd, Cs, qa.mg * G, bw, lane);
@@ -469,11 +547,11 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
     }
     barrier_after_lds_writes();
     // Straight-line body (no VMEM operation under a condition), so that the compiler's vmcnt waits are
-    // exact: "all but the 2*(8+2*SUBS) loads of the other set".  Sp rounds S up to even; the surplus
-    // stage is built from re-fetched operands into a buffer nobody reads.
+    // exact: "all but the loads of the other set".  Sp rounds S up to even; the surplus stage is built
+    // from re-fetched operands into a buffer nobody reads.
     for (int s = 0; s < Sp; s += 2) {
       if (KT > 0) {                                    // stage s+1 -> buffer 1, from set A
-        mfma_store<KTT, KS>(opsA, lds + STAGE_BYTES, Cs, Cg, q1.mg * G, M, bw, lane, p.lutF16);
+        mfma_store<KTT, KS, 1>(opsA, Cs, Cg, q1.mg * G, M, bw, lane, p.lutF16);
         const StagePos qf = (q3.hi > hiU) ? first : q3;
         mfma_load<KTT, KS>(opsA, xbase, pixel_off(qf, g), p.ctrd, Cs, qf.mg * G, bw, lane);
       } else if (s + 1 < S) {
@@ -482,7 +560,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
       barrier_after_lds_writes();
       q1 = q2; q2 = q3; q3 = next_pos(q3, g);
       if (KT > 0) {                                    // stage s+2 -> buffer 0, from set B
-        mfma_store<KTT, KS>(opsB, lds, Cs, Cg, q1.mg * G, M, bw, lane, p.lutF16);
+        mfma_store<KTT, KS, 0>(opsB, Cs, Cg, q1.mg * G, M, bw, lane, p.lutF16);
         const StagePos qf = (q3.hi > hiU) ? first : q3;
         mfma_load<KTT, KS>(opsB, xbase, pixel_off(qf, g), p.ctrd, Cs, qf.mg * G, bw, lane);
       } else if (s + 2 < S) {
@@ -496,83 +574,69 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
 
   // ------------------------------------------------------------------ gather wave ----
   const int gw = role.idx;
-  const int strip = gw / NC, cc = gw % NC;
-  const int sdy = strip / SPR, sdx0 = (strip % SPR) * SW;
-  const int cw0 = chunk * (NC * CPW) + cc * CPW;     // first channel of this wave inside the group
-  const int ccnt = min(CPW, Ctg - cw0);
-  const int ho = ho0 + sdy;
-  const bool active = ccnt > 0 && ho < p.Ho;         // waves without channels / outside the map only keep the barriers
-  const int c0 = grp * Ctg + (active ? cw0 : 0);
-  const uint8_t* __restrict__ rowsC = p.rows + c0;
-  uint32_t vzero;
-  asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
-  const uint32_t ldsBase = (uint32_t)(uintptr_t)lds;   // LDS byte address of the dynamic segment
+  const int half = lane >> 5, quad = lane & 31;
+  const int cw0 = (chunk * NGW + gw) * CPW;          // first channel of this wave inside the group
+  const bool active = cw0 < Ctg;                     // waves without channels only keep the barriers
+  const int cl0 = cw0 + half * HC;                   // first channel of this lane's half inside the group
+  // this wave's entries inside one (tap, sub-space) row of the offset table; the two halves read different ones
+  const uint16_t* __restrict__ rowsW = p.rows + (size_t)((grp * chunksPerGrp + chunk) * NGW + gw) * 2 * (2 * DW);
+  const uint32_t laneOff = (uint32_t)half * (2 * DW) * 2;   // bytes
+  // XOR-ed with a pre-scaled row offset it gives the lane's read address: tile, slot swizzle (tile >> 1), 16-byte quarter
+  const uint32_t laneLds = (uint32_t)(quad >> 2) * TILEB | (uint32_t)(quad >> 3) * 64 | (uint32_t)(quad & 3) * 16;
 
-  f32x2 acc[SW][CPW];
+  f32x2 acc[NP][CPW];
   {
-    const float* __restrict__ bp = p.bias + c0;   // reads past the last channel stay inside the arena
+    const float* __restrict__ bp = p.bias + grp * Ctg + (active ? cl0 : 0);   // reads past the last channel stay inside the arena
 #pragma unroll
-    for (int cb = 0; cb < CPW; cb += 4) {         // four at a time: few bias temporaries alive
-      float b[4];
+    for (int j = 0; j < HC; ++j) {
+      const float b = bp[j];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) b[j] = bp[cb + j];
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int dx = 0; dx < SW; ++dx) acc[dx][cb + j] = f32x2{b[j], b[j]};
-      __builtin_amdgcn_sched_barrier(0);
+      for (int q = 0; q < NP; ++q) { acc[q][2 * j] = f32x2{b, b}; acc[q][2 * j + 1] = f32x2{b, b}; }
     }
   }
-  // first source row / column of the strip's positions; positions outside the map get a start that can
-  // never match a tap
-  const int rowStart = active ? ho * p.stride - p.pad : -(1 << 28);
-  int colStart[SW];
+  // first source row / column of every position; positions outside the map get a start that can never match a tap
+  int rowStart[TH], colStart[TW];
 #pragma unroll
-  for (int dx = 0; dx < SW; ++dx) {
-    const int wo = wo0 + sdx0 + dx;
-    colStart[dx] = (wo < p.Wo) ? wo * p.stride - p.pad : -(1 << 28);
-  }
+  for (int dy = 0; dy < TH; ++dy) rowStart[dy] = (ho0 + dy < p.Ho) ? (ho0 + dy) * p.stride - p.pad : -(1 << 28);
+#pragma unroll
+  for (int dx = 0; dx < TW; ++dx) colStart[dx] = (wo0 + dx < p.Wo) ? (wo0 + dx) * p.stride - p.pad : -(1 << 28);
 
-  // Per stage: [gather stage s][broadcast the indices of stage s+1][prefetch those of stage s+2][barrier].
-  // The index hand-over sits BEFORE the barrier, i.e. in the time an early wave would spend waiting for
-  // the slowest one anyway; right after the barrier every gather wave starts reading LDS.
-  Idx<CPW / 4> vidx[SW], sidx[SW];
+  // Per stage: [prefetch the offsets of stage s+1][gather stage s][barrier]; two offset sets alternate.
+  Idx<DW> ia[NP], ib[NP];
   StagePos c0p = first;
   StagePos c1p = next_pos(c0p, g);
-  conv_prefetch_idx<SW, CPW>(vidx, c0p, g, rowsC, rowStart, colStart, vzero);
-#pragma unroll
-  for (int dx = 0; dx < SW; ++dx) bcast_idx(sidx[dx], vidx[dx]);
-  conv_prefetch_idx<SW, CPW>(vidx, c1p, g, rowsC, rowStart, colStart, vzero);
+  conv_prefetch_idx<TH, TW, CPW>(ia, c0p, g, rowsW, rowStart, colStart, laneOff);
   __builtin_amdgcn_s_setprio(2);   // the gather waves are the critical path of a stage: they win issue arbitration
-                                   // against the builder of their SIMD (+1.6 %; a priority rising with the wave age
-                                   // to equalise arrival at the barrier measured the same)
+                                   // against the builder of their SIMD
   barrier_plain();
-  for (int s = 0; s < Sp; ++s) {
-    conv_gather<SW, CPW, KT == 8>(acc, sidx, c0p, g, rowsC, (s < S) ? rowStart : -(1 << 28), colStart,
-                                  ldsBase + (uint32_t)((s & 1) * STAGE_BYTES + lane * 8));
+  for (int s = 0; s < Sp; s += 2) {
+    conv_prefetch_idx<TH, TW, CPW>(ib, c1p, g, rowsW, rowStart, colStart, laneOff);    // stage s+1 (past the end: clamped, unused)
+    conv_gather<TH, TW, CPW, KT == 8>(acc, ia, c0p, g, rowsW, rowStart, colStart, laneLds, laneOff, active);
     c0p = c1p; c1p = next_pos(c1p, g);
-#pragma unroll
-    for (int dx = 0; dx < SW; ++dx) bcast_idx(sidx[dx], vidx[dx]);                   // indices of stage s+1
-    conv_prefetch_idx<SW, CPW>(vidx, c1p, g, rowsC, rowStart, colStart, vzero);    // of stage s+2 (past the end: clamped, unused)
+    barrier_plain();
+    conv_prefetch_idx<TH, TW, CPW>(ia, c1p, g, rowsW, rowStart, colStart, laneOff);    // stage s+2
+    conv_gather<TH, TW, CPW, KT == 8>(acc, ib, c0p, g, rowsW, rowStart, colStart, laneLds | STAGE_BYTES, laneOff,
+                                      active && s + 1 < S);
+    c0p = c1p; c1p = next_pos(c1p, g);
     barrier_plain();
   }
 
   if (active) {
     float* __restrict__ dst = p.dst + (size_t)panel * p.Ho * p.Wo * p.Ct * PANEL;
 #pragma unroll
-    for (int dx = 0; dx < SW; ++dx) {
-      const int wo = wo0 + sdx0 + dx;
-      if (wo < p.Wo) {
-        float* o = dst + ((size_t)(ho * p.Wo + wo) * p.Ct + c0) * PANEL + 2 * lane;
+    for (int q = 0; q < NP; ++q) {
+      const int ho = ho0 + q / TW, wo = wo0 + q % TW;
+      if (ho < p.Ho && wo < p.Wo) {
+        float* o = dst + ((size_t)(ho * p.Wo + wo) * p.Ct + grp * Ctg + cl0) * PANEL + 4 * quad;
 #pragma unroll
-        for (int c = 0; c < CPW; ++c) {
-          if (c < ccnt) {
-            f32x2 v = acc[dx][c];
+        for (int j = 0; j < HC; ++j) {
+          if (cl0 + j < Ctg) {
+            f32x4 v = {acc[q][2 * j].x, acc[q][2 * j].y, acc[q][2 * j + 1].x, acc[q][2 * j + 1].y};
             if (p.relu) {
-              v.x = (0.0f < v.x) ? v.x : 0.0f;
-              v.y = (0.0f < v.y) ? v.y : 0.0f;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = (0.0f < v[e]) ? v[e] : 0.0f;
             }
-            *reinterpret_cast<f32x2*>(o + c * PANEL) = v;
+            *reinterpret_cast<f32x4*>(o + j * PANEL) = v;
           }
         }
       }
@@ -582,14 +646,16 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
 
 // ------------------------------------------------------------------------------------------------
 // fully connected: stages of G sub-spaces; 4 builder waves + 12 gather waves x CPW channels, as in the
-// conv kernel; the gather waves walk a stream of groups (one sub-space each) with the indices of the
-// next group always in flight.  Optional split over the sub-space axis (blockIdx.z): partial sums go
-// to p.partial and are reduced by k_sum_partials.
+// conv kernel; the gather waves walk the sub-spaces with the offsets of the next two always in flight.
+// Optional split over the sub-space axis (blockIdx.z): partial sums go to p.partial and are reduced by
+// k_sum_partials.
 // ------------------------------------------------------------------------------------------------
 template <int CPW, int KT, int KS>
-__global__ __launch_bounds__(NW * 64) void k_fc_aprx(FcParams p, int G, int stagesPerSplit) {
+__global__ __launch_bounds__(NW * 64) void k_fc_aprx(FcParams p, int G, int stagesPerSplit, int rowStride) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   constexpr int KTT = KT > 0 ? KT : 1;
+  constexpr int HC = CPW / 2;
+  constexpr int DW = idx_dwords(CPW);
   const int lane = threadIdx.x & 63;
   const int wave = uni(threadIdx.x >> 6);
   const int panel = blockIdx.y;
@@ -599,6 +665,7 @@ __global__ __launch_bounds__(NW * 64) void k_fc_aprx(FcParams p, int G, int stag
   const int mEnd = min(M, mBeg + stagesPerSplit * G);
   const int S = (mEnd - mBeg + G - 1) / G;
   const int Sp = (S + 1) & ~1;                      // every wave runs Sp stage periods (barriers)
+  if ((uint32_t)(uintptr_t)lds != 0u) __builtin_trap();   // see k_conv_aprx
 
   const WaveRole role = assign_roles(lds, wave, lane);
   if (role.builder) {
@@ -610,7 +677,7 @@ __global__ __launch_bounds__(NW * 64) void k_fc_aprx(FcParams p, int G, int stag
     if (S > 0) {
       if (KT > 0) {
         mfma_load<KTT, KS>(opsA, xbase, 0u, p.ctrd, Cs, mBeg, bw, lane);
-        mfma_store<KTT, KS>(opsA, lds, Cs, p.D, mBeg, mEnd, bw, lane, p.lutF16);
+        mfma_store<KTT, KS, 0>(opsA, Cs, p.D, mBeg, mEnd, bw, lane, p.lutF16);
         mfma_load<KTT, KS>(opsA, xbase, 0u, p.ctrd, Cs, min(mBeg + G, mLastStage), bw, lane);
         __builtin_amdgcn_sched_barrier(0);
         mfma_load<KTT, KS>(opsB, xbase, 0u, p.ctrd, Cs, min(mBeg + 2 * G, mLastStage), bw, lane);
@@ -622,14 +689,14 @@ __global__ __launch_bounds__(NW * 64) void k_fc_aprx(FcParams p, int G, int stag
     for (int s = 0; s < Sp; s += 2) {                  // straight-line body, see k_conv_aprx
       const int m0 = mBeg + s * G;
       if (KT > 0) {
-        mfma_store<KTT, KS>(opsA, lds + STAGE_BYTES, Cs, p.D, min(m0 + G, mLastStage), mEnd, bw, lane, p.lutF16);
+        mfma_store<KTT, KS, 1>(opsA, Cs, p.D, min(m0 + G, mLastStage), mEnd, bw, lane, p.lutF16);
         mfma_load<KTT, KS>(opsA, xbase, 0u, p.ctrd, Cs, min(m0 + 3 * G, mLastStage), bw, lane);
       } else if (s + 1 < S) {
         build_stage_exact(lds + STAGE_BYTES, xbase, 0u, p.ctrd, K, Cs, p.D, G, m0 + G, mEnd, bw, lane);
       }
       barrier_after_lds_writes();
       if (KT > 0) {
-        mfma_store<KTT, KS>(opsB, lds, Cs, p.D, min(m0 + 2 * G, mLastStage), mEnd, bw, lane, p.lutF16);
+        mfma_store<KTT, KS, 0>(opsB, Cs, p.D, min(m0 + 2 * G, mLastStage), mEnd, bw, lane, p.lutF16);
         mfma_load<KTT, KS>(opsB, xbase, 0u, p.ctrd, Cs, min(m0 + 4 * G, mLastStage), bw, lane);
       } else if (s + 2 < S) {
         build_stage_exact(lds, xbase, 0u, p.ctrd, K, Cs, p.D, G, m0 + 2 * G, mEnd, bw, lane);
@@ -640,66 +707,64 @@ __global__ __launch_bounds__(NW * 64) void k_fc_aprx(FcParams p, int G, int stag
   }
 
   const int gw = role.idx;
-  const int cw0r = blockIdx.x * (NGW * CPW) + gw * CPW;
-  const int ccnt = min(CPW, p.Ct - cw0r);
-  const bool active = ccnt > 0;
-  const int cw0 = active ? cw0r : 0;
-  const uint8_t* __restrict__ rowsC = p.rows + cw0;
-  uint32_t vzero;
-  asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
-  const uint32_t ldsBase = (uint32_t)(uintptr_t)lds;   // LDS byte address of the dynamic segment
+  const int half = lane >> 5, quad = lane & 31;
+  const int cw0 = (blockIdx.x * NGW + gw) * CPW;
+  const bool active = cw0 < p.Ct;
+  const int cl0 = cw0 + half * HC;
+  const uint16_t* __restrict__ rowsW = p.rows + (size_t)(blockIdx.x * NGW + gw) * 2 * (2 * DW);
+  const uint32_t laneOff = (uint32_t)half * (2 * DW) * 2;
+  // XOR-ed with a pre-scaled row offset it gives the lane's read address: tile, slot swizzle (tile >> 1), 16-byte quarter
+  const uint32_t laneLds = (uint32_t)(quad >> 2) * TILEB | (uint32_t)(quad >> 3) * 64 | (uint32_t)(quad & 3) * 16;
 
   f32x2 acc[CPW];
 #pragma unroll
   for (int c = 0; c < CPW; ++c) acc[c] = f32x2{0.0f, 0.0f};
   if (split == 0) {
-    const float* __restrict__ bp = p.bias + cw0;   // over-read stays inside the arena
+    const float* __restrict__ bp = p.bias + (active ? cl0 : 0);   // over-read stays inside the arena
 #pragma unroll
-    for (int cb = 0; cb < CPW; cb += 4) {
-      float b[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) b[j] = bp[cb + j];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[cb + j] = f32x2{b[j], b[j]};
-      __builtin_amdgcn_sched_barrier(0);
+    for (int j = 0; j < HC; ++j) {
+      const float b = bp[j];
+      acc[2 * j] = f32x2{b, b}; acc[2 * j + 1] = f32x2{b, b};
     }
   }
 
-  // group stream: sidx always holds the (already broadcast) indices of the next group to gather, vidx
-  // the prefetch of the one after it, so that the hand-over never sits right behind a barrier
-  Idx<CPW / 4> vidx, sidx;
+  // sub-space stream: two offset sets alternate, each refilled (two sub-spaces ahead) right after its use; a
+  // barrier closes a stage every G sub-spaces (a pair may straddle it).  Sub-spaces past mEnd (ragged last
+  // stage) are skipped inside the look-up blocks; the stream is padded to Sp stages so that every wave meets
+  // the same barriers.
+  Idx<DW> ia, ib;
   const int mClamp = max(mEnd - 1, mBeg);
-  vload_idx(vidx, rowsC + (size_t)mBeg * p.Ct, vzero);
-  bcast_idx(sidx, vidx);
-  vload_idx(vidx, rowsC + (size_t)min(mBeg + 1, mClamp) * p.Ct, vzero);
+  vload_idx(ia, rowsW + (size_t)mBeg * rowStride, laneOff);
+  vload_idx(ib, rowsW + (size_t)min(mBeg + 1, mClamp) * rowStride, laneOff);
   __builtin_amdgcn_s_setprio(2);   // see k_conv_aprx
   barrier_plain();
-  for (int s = 0; s < Sp; ++s) {
-    const int m0 = mBeg + s * G;
-    const int mLast = min(mEnd, m0 + G);
-    const uint32_t stage = ldsBase + (uint32_t)((s & 1) * STAGE_BYTES + lane * 8);
-    if (active) {
-      for (int m = m0; m < mLast; ++m) {
-        gather_apply<CPW>(acc, sidx, stage, 1);
-        bcast_idx(sidx, vidx);
-        vload_idx(vidx, rowsC + (size_t)min(m + 2, mClamp) * p.Ct, vzero);
-      }
+  {
+    int r = 0;                      // sub-spaces of the current stage already consumed
+    uint32_t stage = laneLds;
+    const int T = Sp * G;           // sub-space slots incl. padding (even)
+    for (int k = 0; k < T; k += 2) {
+      const int m = mBeg + k;
+      gather_apply<CPW>(acc, ia, stage, uni(active && m < mEnd));
+      vload_idx(ia, rowsW + (size_t)min(m + 2, mClamp) * rowStride, laneOff);
+      if (++r == G) { r = 0; stage ^= STAGE_BYTES; barrier_plain(); }
+      gather_apply<CPW>(acc, ib, stage, uni(active && m + 1 < mEnd));
+      vload_idx(ib, rowsW + (size_t)min(m + 3, mClamp) * rowStride, laneOff);
+      if (++r == G) { r = 0; stage ^= STAGE_BYTES; barrier_plain(); }
     }
-    barrier_plain();
   }
 
   if (active) {
     float* base = (p.msplit > 1) ? p.partial + (size_t)split * p.panels * p.Ct * PANEL : p.dst;
-    float* o = base + ((size_t)panel * p.Ct + cw0) * PANEL + 2 * lane;
+    float* o = base + ((size_t)panel * p.Ct + cl0) * PANEL + 4 * quad;
 #pragma unroll
-    for (int c = 0; c < CPW; ++c) {
-      if (c < ccnt) {
-        f32x2 v = acc[c];
+    for (int j = 0; j < HC; ++j) {
+      if (cl0 + j < p.Ct) {
+        f32x4 v = {acc[2 * j].x, acc[2 * j].y, acc[2 * j + 1].x, acc[2 * j + 1].y};
         if (p.relu && p.msplit == 1) {
-          v.x = (0.0f < v.x) ? v.x : 0.0f;
-          v.y = (0.0f < v.y) ? v.y : 0.0f;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (0.0f < v[e]) ? v[e] : 0.0f;
         }
-        *reinterpret_cast<f32x2*>(o + c * PANEL) = v;
+        *reinterpret_cast<f32x4*>(o + j * PANEL) = v;
       }
     }
   }
@@ -1090,34 +1155,31 @@ __global__ __launch_bounds__(256) void k_unpack(const float* __restrict__ src, f
 
 inline int panels_of(int n) { return (n + PANEL - 1) / PANEL; }
 
-template <int TH, int TW, int SW, int CPW>
-hipError_t launch_conv(const ConvParams& p, int lutMode, hipStream_t st) {
-  constexpr int NC = NGW / (TH * (TW / SW));
-  const int Ctg = p.Ct / p.grp;
+template <int TH, int TW, int CPW>
+hipError_t launch_conv(const ConvParams& p, const QkSlots& sl, int lutMode, hipStream_t st) {
   const int tilesX = (p.Wo + TW - 1) / TW, tilesY = (p.Ho + TH - 1) / TH;
-  const int chunksPerGrp = (Ctg + NC * CPW - 1) / (NC * CPW);
-  const dim3 grid(tilesX * tilesY * p.panels, chunksPerGrp * p.grp, 1);
+  const dim3 grid(tilesX * tilesY * p.panels, sl.chunks * p.grp, 1);
   const size_t shm = (size_t)2 * STAGE_BYTES;
   const int G = qcnn_stage_group(p.K);
   const bool two = min(p.Cin / p.grp, p.Cs) > 4;      // MFMA k-steps (4 dims each) that carry data
-  auto kern = k_conv_aprx<TH, TW, SW, CPW, 0, 1>;
-  if (lutMode == 1 && p.K == 128) kern = two ? k_conv_aprx<TH, TW, SW, CPW, 8, 2> : k_conv_aprx<TH, TW, SW, CPW, 8, 1>;
-  if (lutMode == 1 && p.K == 64) kern = two ? k_conv_aprx<TH, TW, SW, CPW, 4, 2> : k_conv_aprx<TH, TW, SW, CPW, 4, 1>;
-  if (lutMode == 1 && p.K == 32) kern = two ? k_conv_aprx<TH, TW, SW, CPW, 2, 2> : k_conv_aprx<TH, TW, SW, CPW, 2, 1>;
-  if (lutMode == 1 && p.K == 16) kern = two ? k_conv_aprx<TH, TW, SW, CPW, 1, 2> : k_conv_aprx<TH, TW, SW, CPW, 1, 1>;
+  auto kern = k_conv_aprx<TH, TW, CPW, 0, 1>;
+  if (lutMode == 1 && p.K == 128) kern = two ? k_conv_aprx<TH, TW, CPW, 8, 2> : k_conv_aprx<TH, TW, CPW, 8, 1>;
+  if (lutMode == 1 && p.K == 64) kern = two ? k_conv_aprx<TH, TW, CPW, 4, 2> : k_conv_aprx<TH, TW, CPW, 4, 1>;
+  if (lutMode == 1 && p.K == 32) kern = two ? k_conv_aprx<TH, TW, CPW, 2, 2> : k_conv_aprx<TH, TW, CPW, 2, 1>;
+  if (lutMode == 1 && p.K == 16) kern = two ? k_conv_aprx<TH, TW, CPW, 1, 2> : k_conv_aprx<TH, TW, CPW, 1, 1>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)shm);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, grid, dim3(NW * 64), shm, st, p, tilesX, tilesY, chunksPerGrp, G);
+  hipLaunchKernelGGL(kern, grid, dim3(NW * 64), shm, st, p, tilesX, tilesY, sl.chunks, G, sl.rowStride);
   return hipGetLastError();
 }
 
 template <int CPW>
-hipError_t launch_fc(const FcParams& p, int lutMode, hipStream_t st) {
+hipError_t launch_fc(const FcParams& p, const QkSlots& sl, int lutMode, hipStream_t st) {
   const int G = qcnn_stage_group(p.K);
   const int stages = (p.M + G - 1) / G;
   const int stagesPerSplit = (stages + p.msplit - 1) / p.msplit;
-  const dim3 grid((p.Ct + NGW * CPW - 1) / (NGW * CPW), p.panels, p.msplit);
+  const dim3 grid(sl.chunks, p.panels, p.msplit);
   const size_t shm = (size_t)2 * STAGE_BYTES;
   const bool two = min(p.D, p.Cs) > 4;
   auto kern = k_fc_aprx<CPW, 0, 1>;
@@ -1128,45 +1190,47 @@ hipError_t launch_fc(const FcParams& p, int lutMode, hipStream_t st) {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)shm);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, grid, dim3(NW * 64), shm, st, p, G, stagesPerSplit);
+  hipLaunchKernelGGL(kern, grid, dim3(NW * 64), shm, st, p, G, stagesPerSplit, sl.rowStride);
   return hipGetLastError();
 }
 
 }  // namespace
 
-// Tile selection (12 gather waves): the workgroup covers all channels of a group whenever <= 32 float2
-// accumulators per wave allow it (every further channel chunk would rebuild the same LUT stages), and
-// as many positions as the accumulators then leave room for.  The MFMA builder is instantiated for K in
-// {16, 32, 64, 128}; any other K <= 128 runs the exact builder.
+// Tile selection: the 12 gather waves split the channels of one group (qk_conv_slots: the workgroup covers
+// all of them whenever 12 x 32 allow it — every further channel chunk would rebuild the same LUT stages); each
+// wave then owns as many positions as 64-72 accumulator registers leave room for.  The MFMA builder is
+// instantiated for K in {16, 32, 64, 128}; any other K <= 128 runs the exact builder.
 hipError_t qk_conv_aprx(const ConvParams& pIn, int lutMode, hipStream_t st) {
   ConvParams p = pIn;
   p.lutF16 = (lutMode == 2) ? 1 : 0;
   if (lutMode == 2) lutMode = 1;
   const int Ctg = p.Ct / p.grp;
-  if (Ctg % 4 || p.Cs > QCNN_MAX_CS || p.K > QCNN_MAX_K) return hipErrorInvalidValue;
-  if (Ctg % 384 == 0) return launch_conv<1, 1, 1, 32>(p, lutMode, st);    // 12 x 32
-  if (Ctg > 192 && Ctg <= 288) return launch_conv<1, 1, 1, 24>(p, lutMode, st);   // 12 x 24
-  if (Ctg % 192 == 0) return launch_conv<1, 2, 1, 32>(p, lutMode, st);    // 2 positions x 6 x 32
-  if (Ctg % 128 == 0) return launch_conv<1, 3, 1, 32>(p, lutMode, st);    // 3 positions x 4 x 32
-  if (Ctg % 96 == 0) return launch_conv<2, 2, 2, 16>(p, lutMode, st);     // 2 strips of 2 x 6 x 16
-  if (Ctg % 64 == 0) return launch_conv<1, 6, 2, 16>(p, lutMode, st);     // 3 strips of 2 x 4 x 16
-  if (Ctg <= 48) return launch_conv<1, 4, 4, 4>(p, lutMode, st);          // 1 strip of 4 x 12 x 4
-  return launch_conv<1, 3, 1, 32>(p, lutMode, st);
+  if (Ctg % 2 || p.Cs > QCNN_MAX_CS || p.K > QCNN_MAX_K) return hipErrorInvalidValue;
+  const QkSlots sl = qk_conv_slots(Ctg, p.grp);
+  switch (sl.cpw) {
+    case 32: return launch_conv<1, 1, 32>(p, sl, lutMode, st);   // 1 position  x 12 x 32 channels
+    case 24: return launch_conv<1, 1, 24>(p, sl, lutMode, st);   // 1 position  x 12 x 24
+    case 16: return launch_conv<1, 2, 16>(p, sl, lutMode, st);   // 2 positions x 12 x 16
+    case 12: return launch_conv<1, 3, 12>(p, sl, lutMode, st);   // 3 positions x 12 x 12
+    case 8: return launch_conv<2, 2, 8>(p, sl, lutMode, st);     // 4 positions x 12 x 8
+    case 6: return launch_conv<2, 3, 6>(p, sl, lutMode, st);     // 6 positions x 12 x 6
+    default: return launch_conv<2, 4, 4>(p, sl, lutMode, st);    // 8 positions x 12 x 4
+  }
 }
 
-static int fc_channels_per_wave(int Ct) { return Ct >= 384 ? 32 : (Ct >= 96 ? 8 : 4); }
-int qk_fc_channels_per_block(int Ct) { return NGW * fc_channels_per_wave(Ct); }
+int qk_fc_channels_per_block(int Ct) { return NGW * qk_fc_slots(Ct).cpw; }
 
 // p.msplit is chosen by the caller (engine): 1 keeps the reference's summation order.
 hipError_t qk_fc_aprx(const FcParams& pIn, int lutMode, hipStream_t st) {
   FcParams p = pIn;
   p.lutF16 = (lutMode == 2) ? 1 : 0;
   if (lutMode == 2) lutMode = 1;
-  if (p.Ct % 4 || p.Cs > QCNN_MAX_CS || p.K > QCNN_MAX_K || p.msplit < 1) return hipErrorInvalidValue;
-  switch (fc_channels_per_wave(p.Ct)) {
-    case 32: return launch_fc<32>(p, lutMode, st);
-    case 8: return launch_fc<8>(p, lutMode, st);
-    default: return launch_fc<4>(p, lutMode, st);
+  if (p.Ct % 2 || p.Cs > QCNN_MAX_CS || p.K > QCNN_MAX_K || p.msplit < 1) return hipErrorInvalidValue;
+  const QkSlots sl = qk_fc_slots(p.Ct);
+  switch (sl.cpw) {
+    case 32: return launch_fc<32>(p, sl, lutMode, st);
+    case 8: return launch_fc<8>(p, sl, lutMode, st);
+    default: return launch_fc<4>(p, sl, lutMode, st);
   }
 }
 
