@@ -2,8 +2,8 @@
 // re-implemented for MI355X: the ten public methods keep their names, arguments and return
 // conventions (bool success / printf("[ERROR] ...")), so src/Main.cc + src/UnitTest.cc of the reference
 // drive it unchanged.  Everything private is different: there are no host feature maps or buffers —
-// the object owns one device context (include/qcnn_hip.h) and all arithmetic of the approximate
-// forward pass runs there.
+// the object owns one device group (include/qcnn_hip.h: a context per GPU) and all arithmetic of the
+// approximate forward pass runs there.
 //
 // Behavioural notes
 //  * Only the approximate path exists (Init(true)).  Init(false) makes LoadCaffePara() fail with an
@@ -13,7 +13,11 @@
 //    the DEFAULTS of two environment variables read at LoadCaffePara():
 //        QCNN_BATCH    images per forward pass       (default 1)
 //        QCNN_BATCHES  forward passes to run         (default 100)
-//        QCNN_DEVICE   HIP device ordinal            (default 0)
+//        QCNN_DEVICES  "all" (default) | "0,1,.."    GPUs the batch is sharded over (RCCL parameter broadcast)
+//        QCNN_DEVICE   one HIP device ordinal        (shorthand for a one-GPU group)
+//        QCNN_MAX_INFLIGHT  images per device batch  (default 1024): ExecForwardPass(void) hands the
+//                      QCNN_BATCHES x QCNN_BATCH images to the GPUs in chunks of that size — the same images,
+//                      prints and results as one batch at a time (QCNN_COALESCE=0 restores that)
 //        QCNN_LUT      "mfma" (default) | "exact"    look-up-table builder (exact = bit-identical conv/FC)
 //  * DispElpsTime() prints the reference's stop-watch names; the values are HIP-event times of the
 //    layers (LUT build and look-up are one fused kernel, so swCompLkupTbl* report 0 and swEstiInPdVal*
@@ -30,7 +34,8 @@
 #include "../include/Matrix.h"
 #include "../include/StopWatch.h"
 
-struct QcnnCtx;   // include/qcnn_hip.h
+struct QcnnCtx;     // include/qcnn_hip.h
+struct QcnnGroup;
 
 class CaffeEva {
  public:
@@ -67,10 +72,12 @@ class CaffeEva {
   Matrix<uint16_t> lablVecGrth;     // ground truth, 0-based
   Matrix<uint16_t> lablVecPred;     // [N, 5]
 
-  QcnnCtx* ctx_;                    // device context; owns every activation / parameter buffer
+  QcnnGroup* grp_;                  // device group (one context per GPU + RCCL communicator); owns every device buffer
+  QcnnCtx* ctx_;                    // rank 0 of the group: single-image passes, feature-map dumps, timers
   bool modelReady_;
   int batchSize_;                   // QCNN_BATCH
   int batchCnt_;                    // QCNN_BATCHES
+  int inflight_;                    // images handed to the device group at once
   int imagesDone_;                  // images classified by the last ExecForwardPass(void)
   std::string lastError_;
   StopWatch swWall_;                // wall clock around the forward passes (host view)

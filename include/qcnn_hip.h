@@ -25,6 +25,8 @@
  *   qcnn_run_layer              CaffeEva::CalcFeatMap on one layer         src/CaffeEva.cc:625-670
  *   qcnn_get_layer_output       featMapLst[l] read-back (parity dumps)     include/CaffeEva.h:109
  *   qcnn_get_layer_ms           swIndvLayerLst / DispElpsTime              src/CaffeEva.cc:297-326
+ *   qcnn_group_*                the image loop of ExecForwardPass(void)    src/CaffeEva.cc:151-211
+ *                               spread over the GPUs of one node (the reference has one loop on one core)
  */
 #ifndef QCNN_HIP_H_
 #define QCNN_HIP_H_
@@ -36,7 +38,7 @@
 extern "C" {
 #endif
 
-#define QCNN_ABI_VERSION 1
+#define QCNN_ABI_VERSION 2
 
 typedef struct QcnnCtx QcnnCtx;
 
@@ -76,6 +78,8 @@ int qcnn_abi_version(void);
 int qcnn_device_count(int* count);
 int qcnn_set_option(QcnnCtx* ctx, int option, int value);
 int qcnn_sync(QcnnCtx* ctx);
+int qcnn_ctx_device(const QcnnCtx* ctx);          /* HIP device ordinal of the context */
+void* qcnn_ctx_stream(const QcnnCtx* ctx);        /* the hipStream_t the context enqueues on */
 
 /* ---- model ---- */
 int qcnn_model_begin(QcnnCtx* ctx, int layer_cnt, const QcnnLayerDesc* layers, int in_c, int in_h, int in_w);
@@ -88,6 +92,8 @@ int qcnn_model_arena_bytes(QcnnCtx* ctx, size_t* bytes);
  * qcnn_model_arena_bytes() bytes (so that a communicator can broadcast it), or NULL to let the
  * library allocate it. */
 int qcnn_model_commit(QcnnCtx* ctx, int max_batch, void* dev_arena);
+/* Device address and size of the packed parameter arena (after commit): what a communicator broadcasts. */
+int qcnn_model_arena_ptr(QcnnCtx* ctx, void** dev_ptr, size_t* bytes);
 /* Upload one conv/FC layer's parameters from host memory in the reference's FILE layout:
  * bias [Ct]; ctrd [M][K][Cs]; asmt 0-based uint8, [Ct][kh][kw][M] (conv) or [Ct][M] (FC).
  * Performs the PrepCtrdBuf / PrepAsmtBuf permutations into the arena.  After commit. */
@@ -123,7 +129,35 @@ int qcnn_run_layer(QcnnCtx* ctx, int layer, const float* in_host, int n, float* 
 /* Mean milliseconds of one LAUNCH per layer (a forward issues QCNN_OPT_STREAMS launches per layer, each over
  * its share of the panels) over the forwards recorded since the last reset; ms[layer_cnt]. */
 int qcnn_get_layer_ms(QcnnCtx* ctx, float* ms, int* forwards_recorded);
+/* Per layer: milliseconds SUMMED over every launch recorded since the last reset, and the number of launches
+ * (either output may be NULL); nothing is dropped however many forwards were run. */
+int qcnn_get_layer_total_ms(QcnnCtx* ctx, double* total_ms, long long* launches, int* forwards_recorded);
 int qcnn_reset_layer_ms(QcnnCtx* ctx);
+
+/* ---- device group: one batch sharded over the GPUs of a node ----
+ * One context per device + one RCCL communicator over them (single process).  Images are independent: image i of
+ * a batch of n goes to rank i * G / n (contiguous blocks); the only collective is the one-time ncclBroadcast of
+ * rank 0's parameter arena over xGMI.  Model calls mirror the per-context ones and apply to every rank. */
+typedef struct QcnnGroup QcnnGroup;
+/* device_ids == NULL or n_dev <= 0: every visible device */
+int qcnn_group_create(const int* device_ids, int n_dev, QcnnGroup** out);
+int qcnn_group_destroy(QcnnGroup* grp);
+const char* qcnn_group_last_error(const QcnnGroup* grp);   /* grp == NULL: error of qcnn_group_create */
+int qcnn_group_size(const QcnnGroup* grp);
+QcnnCtx* qcnn_group_ctx(QcnnGroup* grp, int rank);         /* per-rank context: options, dumps, timing */
+int qcnn_group_shard_bounds(const QcnnGroup* grp, int n, int rank, int* first, int* count);
+int qcnn_group_set_option(QcnnGroup* grp, int option, int value);
+int qcnn_group_model_begin(QcnnGroup* grp, int layer_cnt, const QcnnLayerDesc* layers, int in_c, int in_h, int in_w);
+int qcnn_group_model_set_layer_shape(QcnnGroup* grp, int layer, int M, int K, int Cs);
+/* max_batch: images of one GLOBAL batch; every rank plans the largest block it can be handed */
+int qcnn_group_model_commit(QcnnGroup* grp, int max_batch);
+/* uploads to rank 0 only; qcnn_group_model_broadcast then ships the packed arena to the other ranks */
+int qcnn_group_model_set_layer_params(QcnnGroup* grp, int layer, const float* bias, const float* ctrd_file,
+                                      const uint8_t* asmt_file);
+int qcnn_group_model_broadcast(QcnnGroup* grp, float* elapsed_ms);
+/* Blocking: host in, host out; one host thread per GPU runs its block on its own context and stream. */
+int qcnn_group_forward_host(QcnnGroup* grp, const float* in_nchw_host, int n, float* prob_host, uint16_t* top5_host);
+int qcnn_group_sync(QcnnGroup* grp);
 
 #ifdef __cplusplus
 }

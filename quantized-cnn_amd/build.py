@@ -25,7 +25,7 @@ BIN_DIR = os.path.join(ROOT, "build", "bin")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
-HIP_SOURCES = ["qcnn_kernels.hip", "qcnn_engine.hip"]
+HIP_SOURCES = ["qcnn_kernels.hip", "qcnn_engine.hip", "qcnn_group.hip"]
 HIP_FLAGS = ["-O3", "-std=c++17", "--offload-arch=" + ARCH, "-fPIC", "-ffp-contract=off", "-Wall",
              "-Wno-unused-function"]
 
@@ -53,7 +53,8 @@ def build_hip(force: bool = False, extra_flags=()) -> str:
             if force or _newer(o, deps):
                 _run([HIPCC] + HIP_FLAGS + list(extra_flags) + ["-c", s, "-o", o])
             objs.append(o)
-        _run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", HIP_SO] + objs)
+        _run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", HIP_SO] + objs +
+             ["-L/opt/rocm/lib", "-lrccl", "-lpthread"])     # RCCL: the device group's parameter broadcast
     return HIP_SO
 
 

@@ -10,7 +10,7 @@ import os
 import re
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG, "libqcnn_hip.so")
+LIB_PATH = os.environ.get("QCNN_HIP_LIB") or os.path.join(PKG, "libqcnn_hip.so")   # QCNN_HIP_LIB: an experimental build of the same library
 HEADER_PATH = os.path.join(os.path.dirname(PKG), "include", "qcnn_hip.h")
 
 OPT_LUT_MODE, OPT_KEEP_ALL, OPT_PROFILE, OPT_STREAMS = 0, 1, 2, 3
@@ -71,5 +71,27 @@ def load():
     lib.qcnn_run_layer.argtypes = [vp, i, f32p, i, f32p]
     lib.qcnn_get_layer_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(i)]
     lib.qcnn_reset_layer_ms.argtypes = [vp]
+    lib.qcnn_get_layer_total_ms.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(i)]
+    lib.qcnn_ctx_device.argtypes = [vp]
+    lib.qcnn_ctx_stream.argtypes = [vp]
+    lib.qcnn_ctx_stream.restype = vp
+    lib.qcnn_model_arena_ptr.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    # device group
+    lib.qcnn_group_create.argtypes = [C.POINTER(i), i, C.POINTER(vp)]
+    lib.qcnn_group_destroy.argtypes = [vp]
+    lib.qcnn_group_last_error.restype = C.c_char_p
+    lib.qcnn_group_last_error.argtypes = [vp]
+    lib.qcnn_group_size.argtypes = [vp]
+    lib.qcnn_group_ctx.argtypes = [vp, i]
+    lib.qcnn_group_ctx.restype = vp
+    lib.qcnn_group_shard_bounds.argtypes = [vp, i, i, C.POINTER(i), C.POINTER(i)]
+    lib.qcnn_group_set_option.argtypes = [vp, i, i]
+    lib.qcnn_group_model_begin.argtypes = [vp, i, C.POINTER(QcnnLayerDesc), i, i, i]
+    lib.qcnn_group_model_set_layer_shape.argtypes = [vp, i, i, i, i]
+    lib.qcnn_group_model_commit.argtypes = [vp, i]
+    lib.qcnn_group_model_set_layer_params.argtypes = [vp, i, f32p, f32p, u8p]
+    lib.qcnn_group_model_broadcast.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.qcnn_group_forward_host.argtypes = [vp, f32p, i, f32p, u16p]
+    lib.qcnn_group_sync.argtypes = [vp]
     _lib = lib
     return lib

@@ -72,9 +72,10 @@ struct QcnnCtx {
   std::vector<float*> lastFm;        // pointer table of the last forward
 
   std::vector<hipEvent_t> ev;        // kProfRing * kMaxStreams * L * 2
-  int profCount = 0;
-  std::vector<int> profStreams;      // sub-batches of each recorded forward
-  std::vector<double> profSum;
+  int profCount = 0;                 // forwards in the ring, not yet drained
+  struct ProfRec { size_t slot; int layer; };
+  std::vector<ProfRec> profPending;  // event pairs recorded since the last drain (only layers that were launched)
+  std::vector<double> profSum;       // per layer: ms summed over every recorded launch
   std::vector<long long> profLaunches;
   int profForwards = 0;
 };
@@ -144,6 +145,8 @@ void free_model(QcnnCtx* c) {
   c->fcPartial = nullptr; c->fcPartialElems = 0;
   for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
   c->ev.clear();
+  c->profCount = 0; c->profPending.clear(); c->profForwards = 0;
+  c->lastFm.clear(); c->lastN = 0;       // nothing of the old model can be read back any more
   c->committed = false;
 }
 
@@ -250,6 +253,22 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
   return 0;
 }
 
+// accumulate the recorded event pairs into the per-layer sums (blocks until the recorded work is done)
+int drain_profile(QcnnCtx* c) {
+  if (c->profPending.empty()) { c->profForwards += c->profCount; c->profCount = 0; return 0; }
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  for (const QcnnCtx::ProfRec& r : c->profPending) {
+    float ms = 0.0f;
+    HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[r.slot], c->ev[r.slot + 1]));
+    c->profSum[r.layer] += ms;
+    c->profLaunches[r.layer] += 1;
+  }
+  c->profForwards += c->profCount;
+  c->profCount = 0;
+  c->profPending.clear();
+  return 0;
+}
+
 // The layers of one forward.  The batch is cut into up to nStreams sub-batches of whole panels; sub-batch 0
 // runs on the context's stream, the others on auxiliary streams forked from / joined to it with events, so
 // that the LDS-bound conv/FC kernels of one sub-batch overlap the HBM-bound glue kernels of another and the
@@ -258,7 +277,8 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
 int run_layers(QcnnCtx* c, int n) {
   const int panels = (n + QCNN_PANEL - 1) / QCNN_PANEL;
   const int ns = std::max(1, std::min(std::min(c->nStreams, kMaxStreams), panels));
-  const bool prof = c->profile && c->profCount < kProfRing;
+  if (c->profile && c->profCount == kProfRing && drain_profile(c)) return 1;   // ring full: fold it into the sums
+  const bool prof = c->profile != 0;
   c->lastFm.assign(c->L + 1, nullptr);
   c->lastFm[0] = c->fmBuf[0];
   for (int l = 0; l < c->L; ++l) {              // pointer table (aliases) — identical for every sub-batch
@@ -289,35 +309,18 @@ int run_layers(QcnnCtx* c, int n) {
         HIP_TRY(c, hipEventRecord(e0, st));
       }
       if (launch_layer(c, l, src, dst, p1 - p0, fuse, false, p0, st)) return 1;
-      if (prof) HIP_TRY(c, hipEventRecord(e1, st));
+      if (prof) {
+        HIP_TRY(c, hipEventRecord(e1, st));
+        c->profPending.push_back(QcnnCtx::ProfRec{(((size_t)c->profCount * kMaxStreams + k) * c->L + l) * 2, l});
+      }
     }
   }
   for (int k = 1; k < ns; ++k) {
     HIP_TRY(c, hipEventRecord(c->evJoin[k - 1], c->aux[k - 1]));
     HIP_TRY(c, hipStreamWaitEvent(c->stream, c->evJoin[k - 1], 0));
   }
-  if (prof) { c->profStreams.push_back(ns); c->profCount++; }
+  if (prof) c->profCount++;
   c->lastN = n;
-  return 0;
-}
-
-// per layer: mean duration of one LAUNCH (a forward with k sub-batches has k launches per layer)
-int drain_profile(QcnnCtx* c) {
-  if (!c->profCount) return 0;
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  for (int f = 0; f < c->profCount; ++f)
-    for (int k = 0; k < c->profStreams[f]; ++k)
-      for (int l = 0; l < c->L; ++l) {
-        if ((int)c->lastFm.size() == c->L + 1 && c->lastFm[l + 1] == c->lastFm[l]) continue;
-        const size_t slot = (((size_t)f * kMaxStreams + k) * c->L + l) * 2;
-        float ms = 0.0f;
-        HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[slot], c->ev[slot + 1]));
-        c->profSum[l] += ms;
-        c->profLaunches[l] += 1;
-      }
-  c->profForwards += c->profCount;
-  c->profCount = 0;
-  c->profStreams.clear();
   return 0;
 }
 
@@ -391,6 +394,9 @@ int qcnn_set_option(QcnnCtx* c, int option, int value) {
   }
 }
 
+int qcnn_ctx_device(const QcnnCtx* c) { return c->device; }
+void* qcnn_ctx_stream(const QcnnCtx* c) { return c->stream; }
+
 int qcnn_sync(QcnnCtx* c) {
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return 0;
@@ -455,6 +461,13 @@ int qcnn_model_arena_bytes(QcnnCtx* c, size_t* bytes) {
   return 0;
 }
 
+int qcnn_model_arena_ptr(QcnnCtx* c, void** dev_ptr, size_t* bytes) {
+  if (!c->committed) return fail(c, "model not committed");
+  if (dev_ptr) *dev_ptr = c->arena;
+  if (bytes) *bytes = c->arenaBytes;
+  return 0;
+}
+
 int qcnn_model_commit(QcnnCtx* c, int max_batch, void* dev_arena) {
   HIP_TRY(c, hipSetDevice(c->device));
   if (c->committed) return fail(c, "model already committed");
@@ -490,7 +503,7 @@ int qcnn_model_commit(QcnnCtx* c, int max_batch, void* dev_arena) {
   for (hipEvent_t& e : c->ev) HIP_TRY(c, hipEventCreate(&e));
   c->profSum.assign(c->L, 0.0);
   c->profLaunches.assign(c->L, 0);
-  c->profCount = 0; c->profForwards = 0; c->profStreams.clear();
+  c->profCount = 0; c->profForwards = 0; c->profPending.clear();
   for (int k = 0; k < kMaxStreams - 1; ++k) {
     if (!c->aux[k]) HIP_TRY(c, hipStreamCreateWithFlags(&c->aux[k], hipStreamNonBlocking));
     if (!c->evJoin[k]) HIP_TRY(c, hipEventCreateWithFlags(&c->evJoin[k], hipEventDisableTiming));
@@ -670,6 +683,17 @@ int qcnn_get_layer_ms(QcnnCtx* c, float* ms, int* forwards_recorded) {
   HIP_TRY(c, hipSetDevice(c->device));
   if (drain_profile(c)) return 1;
   for (int l = 0; l < c->L; ++l) ms[l] = c->profLaunches[l] ? (float)(c->profSum[l] / c->profLaunches[l]) : 0.0f;
+  if (forwards_recorded) *forwards_recorded = c->profForwards;
+  return 0;
+}
+
+int qcnn_get_layer_total_ms(QcnnCtx* c, double* total_ms, long long* launches, int* forwards_recorded) {
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (drain_profile(c)) return 1;
+  for (int l = 0; l < c->L; ++l) {
+    total_ms[l] = c->profSum[l];
+    if (launches) launches[l] = c->profLaunches[l];
+  }
   if (forwards_recorded) *forwards_recorded = c->profForwards;
   return 0;
 }

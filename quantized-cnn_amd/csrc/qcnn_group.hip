@@ -1,0 +1,228 @@
+// qcnn_group.hip — several MI355X behind the C-ABI (include/qcnn_hip.h, "device group" section).
+//
+// The reference classifies its images one after the other in a single loop (src/CaffeEva.cc:151-211); images
+// are independent, so a batch shards over the GPUs of a node without any exchange during the forward pass
+// (SURVEY.md §8e).  A QcnnGroup owns one QcnnCtx per device and one RCCL communicator over them (single
+// process, ncclCommInitAll).  The only collective is the one-time ncclBroadcast of rank 0's packed parameter
+// arena (biases, permuted codebooks, row-offset tables) over xGMI at load time; a forward pass is one host
+// thread per GPU, each running its contiguous block of the batch on its own context and stream.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <chrono>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/qcnn_hip.h"
+
+struct QcnnGroup {
+  std::vector<int> devs;
+  std::vector<QcnnCtx*> ctx;
+  std::vector<ncclComm_t> comm;
+  std::string err;
+  int classes = 0;
+  size_t inElems = 0;
+  float bcastMs = 0.0f;
+  bool broadcastDone = false;
+};
+
+namespace {
+
+std::string g_groupCreateError;
+
+int gfail(QcnnGroup* g, const char* fmt, ...) {
+  char buf[768];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (g) g->err = buf; else g_groupCreateError = buf;
+  return 1;
+}
+
+// contiguous block of rank r: image i goes to rank i * G / n (the same rule as dist.shard_bounds)
+void shard(int n, int r, int G, int* first, int* count) {
+  const long long lo = (long long)n * r / G, hi = (long long)n * (r + 1) / G;
+  *first = (int)lo;
+  *count = (int)(hi - lo);
+}
+
+#define FOR_ALL(g, call)                                                                                \
+  do {                                                                                                  \
+    for (size_t r_ = 0; r_ < (g)->ctx.size(); ++r_) {                                                   \
+      QcnnCtx* c = (g)->ctx[r_];                                                                        \
+      if (call) return gfail((g), "rank %zu (device %d): %s", r_, (g)->devs[r_], qcnn_last_error(c));   \
+    }                                                                                                   \
+  } while (0)
+
+}  // namespace
+
+extern "C" {
+
+const char* qcnn_group_last_error(const QcnnGroup* g) { return g ? g->err.c_str() : g_groupCreateError.c_str(); }
+
+int qcnn_group_create(const int* device_ids, int n_dev, QcnnGroup** out) {
+  if (!out) return gfail(nullptr, "qcnn_group_create: out == NULL");
+  *out = nullptr;
+  int visible = 0;
+  if (qcnn_device_count(&visible) || visible <= 0)
+    return gfail(nullptr, "no HIP device available (%s); this library has no CPU path", qcnn_last_error(nullptr));
+  QcnnGroup* g = new QcnnGroup;
+  if (!device_ids || n_dev <= 0) {
+    for (int d = 0; d < visible; ++d) g->devs.push_back(d);
+  } else {
+    for (int i = 0; i < n_dev; ++i) {
+      for (int j = 0; j < i; ++j)
+        if (device_ids[j] == device_ids[i]) { delete g; return gfail(nullptr, "device %d listed twice", device_ids[i]); }
+      g->devs.push_back(device_ids[i]);
+    }
+  }
+  for (int d : g->devs) {
+    QcnnCtx* c = nullptr;
+    if (qcnn_ctx_create(d, nullptr, &c)) {
+      gfail(nullptr, "device %d: %s", d, qcnn_last_error(nullptr));
+      for (QcnnCtx* k : g->ctx) qcnn_ctx_destroy(k);
+      delete g;
+      return 1;
+    }
+    g->ctx.push_back(c);
+  }
+  g->comm.assign(g->devs.size(), nullptr);
+  const ncclResult_t nr = ncclCommInitAll(g->comm.data(), (int)g->devs.size(), g->devs.data());
+  if (nr != ncclSuccess) {
+    gfail(nullptr, "ncclCommInitAll over %zu device(s) -> %s", g->devs.size(), ncclGetErrorString(nr));
+    for (QcnnCtx* k : g->ctx) qcnn_ctx_destroy(k);
+    delete g;
+    return 1;
+  }
+  *out = g;
+  return 0;
+}
+
+int qcnn_group_destroy(QcnnGroup* g) {
+  if (!g) return 0;
+  for (size_t r = 0; r < g->comm.size(); ++r)
+    if (g->comm[r]) { (void)hipSetDevice(g->devs[r]); (void)ncclCommDestroy(g->comm[r]); }
+  for (QcnnCtx* c : g->ctx) qcnn_ctx_destroy(c);
+  delete g;
+  return 0;
+}
+
+int qcnn_group_size(const QcnnGroup* g) { return (int)g->ctx.size(); }
+
+QcnnCtx* qcnn_group_ctx(QcnnGroup* g, int rank) {
+  return (rank >= 0 && rank < (int)g->ctx.size()) ? g->ctx[rank] : nullptr;
+}
+
+int qcnn_group_shard_bounds(const QcnnGroup* g, int n, int rank, int* first, int* count) {
+  if (rank < 0 || rank >= (int)g->ctx.size() || n < 0) return 1;
+  shard(n, rank, (int)g->ctx.size(), first, count);
+  return 0;
+}
+
+int qcnn_group_set_option(QcnnGroup* g, int option, int value) {
+  FOR_ALL(g, qcnn_set_option(c, option, value));
+  return 0;
+}
+
+int qcnn_group_model_begin(QcnnGroup* g, int layer_cnt, const QcnnLayerDesc* layers, int in_c, int in_h, int in_w) {
+  g->broadcastDone = false;
+  FOR_ALL(g, qcnn_model_begin(c, layer_cnt, layers, in_c, in_h, in_w));
+  int hwc[3];
+  if (qcnn_fm_dims(g->ctx[0], layer_cnt, hwc)) return gfail(g, "%s", qcnn_last_error(g->ctx[0]));
+  g->classes = hwc[0] * hwc[1] * hwc[2];
+  g->inElems = (size_t)in_c * in_h * in_w;
+  return 0;
+}
+
+int qcnn_group_model_set_layer_shape(QcnnGroup* g, int layer, int M, int K, int Cs) {
+  FOR_ALL(g, qcnn_model_set_layer_shape(c, layer, M, K, Cs));
+  return 0;
+}
+
+int qcnn_group_model_commit(QcnnGroup* g, int max_batch) {
+  if (max_batch <= 0) return gfail(g, "max_batch must be positive");
+  const int G = (int)g->ctx.size();
+  const int share = (max_batch + G - 1) / G;          // the largest block shard_bounds can hand to a rank
+  FOR_ALL(g, qcnn_model_commit(c, share, nullptr));
+  return 0;
+}
+
+int qcnn_group_model_set_layer_params(QcnnGroup* g, int layer, const float* bias, const float* ctrd_file,
+                                      const uint8_t* asmt_file) {
+  if (qcnn_model_set_layer_params(g->ctx[0], layer, bias, ctrd_file, asmt_file))
+    return gfail(g, "rank 0 (device %d): %s", g->devs[0], qcnn_last_error(g->ctx[0]));
+  g->broadcastDone = false;
+  return 0;
+}
+
+int qcnn_group_model_broadcast(QcnnGroup* g, float* elapsed_ms) {
+  const int G = (int)g->ctx.size();
+  std::vector<void*> arena(G, nullptr);
+  size_t bytes = 0;
+  for (int r = 0; r < G; ++r) {
+    size_t b = 0;
+    if (qcnn_model_arena_ptr(g->ctx[r], &arena[r], &b)) return gfail(g, "rank %d: %s", r, qcnn_last_error(g->ctx[r]));
+    if (r && b != bytes) return gfail(g, "rank %d plans a %zu-byte arena, rank 0 %zu", r, b, bytes);
+    bytes = b;
+  }
+  for (int r = 0; r < G; ++r)
+    if (qcnn_sync(g->ctx[r])) return gfail(g, "rank %d: %s", r, qcnn_last_error(g->ctx[r]));
+  const auto t0 = std::chrono::steady_clock::now();
+  ncclResult_t nr = ncclGroupStart();
+  for (int r = 0; r < G && nr == ncclSuccess; ++r) {
+    (void)hipSetDevice(g->devs[r]);
+    nr = ncclBroadcast(arena[r], arena[r], bytes, ncclUint8, 0, g->comm[r],
+                       static_cast<hipStream_t>(qcnn_ctx_stream(g->ctx[r])));
+  }
+  const ncclResult_t ne = ncclGroupEnd();
+  if (nr != ncclSuccess || ne != ncclSuccess)
+    return gfail(g, "ncclBroadcast of the %zu-byte parameter arena -> %s", bytes,
+                 ncclGetErrorString(nr != ncclSuccess ? nr : ne));
+  for (int r = 0; r < G; ++r)
+    if (qcnn_sync(g->ctx[r])) return gfail(g, "rank %d: %s", r, qcnn_last_error(g->ctx[r]));
+  g->bcastMs = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  for (int r = 1; r < G; ++r)
+    if (qcnn_model_mark_loaded(g->ctx[r])) return gfail(g, "rank %d: %s", r, qcnn_last_error(g->ctx[r]));
+  g->broadcastDone = true;
+  if (elapsed_ms) *elapsed_ms = g->bcastMs;
+  return 0;
+}
+
+int qcnn_group_forward_host(QcnnGroup* g, const float* in_nchw_host, int n, float* prob_host, uint16_t* top5_host) {
+  const int G = (int)g->ctx.size();
+  if (n <= 0) return gfail(g, "batch %d must be positive", n);
+  if (G > 1 && !g->broadcastDone) return gfail(g, "qcnn_group_model_broadcast must follow the parameter upload");
+  std::vector<int> rc(G, 0);
+  auto work = [&](int r) {
+    int first = 0, count = 0;
+    shard(n, r, G, &first, &count);
+    if (count == 0) return;
+    rc[r] = qcnn_forward_host(g->ctx[r], in_nchw_host + (size_t)first * g->inElems, count,
+                              prob_host ? prob_host + (size_t)first * g->classes : nullptr,
+                              top5_host ? top5_host + (size_t)first * 5 : nullptr);
+  };
+  if (G == 1) {
+    work(0);
+  } else {
+    std::vector<std::thread> th;
+    for (int r = 1; r < G; ++r) th.emplace_back(work, r);
+    work(0);
+    for (std::thread& t : th) t.join();
+  }
+  for (int r = 0; r < G; ++r)
+    if (rc[r]) return gfail(g, "rank %d (device %d): %s", r, g->devs[r], qcnn_last_error(g->ctx[r]));
+  return 0;
+}
+
+int qcnn_group_sync(QcnnGroup* g) {
+  FOR_ALL(g, qcnn_sync(c));
+  return 0;
+}
+
+}  // extern "C"

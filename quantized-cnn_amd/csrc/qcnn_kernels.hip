@@ -38,6 +38,15 @@ constexpr int TILEB = QCNN_TILE_BYTES;         // LDS bytes of one image tile of
 constexpr int STAGE_ROWS = QCNN_STAGE_ROWS;
 constexpr int STAGE_BYTES = QCNN_STAGE_BYTES;  // 64 KB; two stages = 128 KB of the 160 KB LDS
 constexpr int XROWB = PANEL * 4;               // bytes of one activation row in HBM
+// s_setprio of the two wave roles.  Measured (profiles/r2_*/variants.log): any setting with the gather waves
+// ABOVE the builders costs 6 % (the builder's store stream is the pole of most stages); equal priorities and
+// builder-above-gather measure the same.
+#ifndef QCNN_PRIO_BUILDER
+#define QCNN_PRIO_BUILDER 0
+#endif
+#ifndef QCNN_PRIO_GATHER
+#define QCNN_PRIO_GATHER 0
+#endif
 static_assert(NW == NBW + NGW, "wave roles");
 
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -48,6 +57,23 @@ __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlan
 // in flight).  The "memory" clobber keeps the compiler from moving LDS accesses across it.
 __device__ __forceinline__ void barrier_after_lds_writes() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ void barrier_plain() { asm volatile("s_barrier" ::: "memory"); }
+
+#ifdef QCNN_TRACE
+// Debug build only (scripts/trace_stage.py): workgroup `qcnn_trace_block` records, for every wave and the first
+// 64 stage periods, the cycle at which it arrives at the stage barrier and the cycle at which it leaves it.
+__device__ unsigned long long qcnn_trace_buf[16 * 64 * 2 + 16];
+__device__ int qcnn_trace_block = 0;
+#define TR_ARRIVE(s) do { if ((int)blockIdx.x == qcnn_trace_block && blockIdx.y == 0 && blockIdx.z == 0 && (s) < 64 && (threadIdx.x & 63) == 0) \
+    qcnn_trace_buf[((threadIdx.x >> 6) * 64 + (s)) * 2] = __builtin_readcyclecounter(); } while (0)
+#define TR_LEAVE(s) do { if ((int)blockIdx.x == qcnn_trace_block && blockIdx.y == 0 && blockIdx.z == 0 && (s) < 64 && (threadIdx.x & 63) == 0) \
+    qcnn_trace_buf[((threadIdx.x >> 6) * 64 + (s)) * 2 + 1] = __builtin_readcyclecounter(); } while (0)
+#define TR_ROLE(r) do { if ((int)blockIdx.x == qcnn_trace_block && blockIdx.y == 0 && blockIdx.z == 0 && (threadIdx.x & 63) == 0) \
+    qcnn_trace_buf[16 * 64 * 2 + (threadIdx.x >> 6)] = (r).builder ? 100 + (r).idx : (r).idx; } while (0)
+#else
+#define TR_ARRIVE(s) do {} while (0)
+#define TR_LEAVE(s) do {} while (0)
+#define TR_ROLE(r) do {} while (0)
+#endif
 
 // Role assignment.  The matrix pipe is per SIMD, so the four builder waves must sit on four DIFFERENT
 // SIMDs; which SIMD a wave lands on is the dispatcher's choice (not a function of the wave index that
@@ -520,10 +546,12 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
   if ((uint32_t)(uintptr_t)lds != 0u) __builtin_trap();   // the stage addressing assumes the dynamic segment starts at LDS byte 0
 
   const WaveRole role = assign_roles(lds, wave, lane);
+  TR_ROLE(role);
   if (role.builder) {
     // ---------------------------------------------------------------- builder wave ----
     const int bw = role.idx;
     const int K = p.K, Cs = p.Cs;
+    __builtin_amdgcn_s_setprio(QCNN_PRIO_BUILDER);
     const char* __restrict__ xbase =
         reinterpret_cast<const char*>(p.src + ((size_t)panel * p.H * p.W * p.Cin + (size_t)grp * Cg) * PANEL);
     // Two operand sets: while stage s+1 is multiplied out of one, the other one already holds (or is
@@ -557,7 +585,9 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
       } else if (s + 1 < S) {
         build_stage_exact(lds + STAGE_BYTES, xbase, pixel_off(q1, g), p.ctrd, K, Cs, Cg, G, q1.mg * G, M, bw, lane);
       }
+      TR_ARRIVE(s);
       barrier_after_lds_writes();
+      TR_LEAVE(s);
       q1 = q2; q2 = q3; q3 = next_pos(q3, g);
       if (KT > 0) {                                    // stage s+2 -> buffer 0, from set B
         mfma_store<KTT, KS, 0>(opsB, Cs, Cg, q1.mg * G, M, bw, lane, p.lutF16);
@@ -566,7 +596,9 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
       } else if (s + 2 < S) {
         build_stage_exact(lds, xbase, pixel_off(q1, g), p.ctrd, K, Cs, Cg, G, q1.mg * G, M, bw, lane);
       }
+      TR_ARRIVE(s + 1);
       barrier_after_lds_writes();
+      TR_LEAVE(s + 1);
       q1 = q2; q2 = q3; q3 = next_pos(q3, g);
     }
     return;
@@ -606,19 +638,22 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
   StagePos c0p = first;
   StagePos c1p = next_pos(c0p, g);
   conv_prefetch_idx<TH, TW, CPW>(ia, c0p, g, rowsW, rowStart, colStart, laneOff);
-  __builtin_amdgcn_s_setprio(2);   // the gather waves are the critical path of a stage: they win issue arbitration
-                                   // against the builder of their SIMD
+  __builtin_amdgcn_s_setprio(QCNN_PRIO_GATHER);
   barrier_plain();
   for (int s = 0; s < Sp; s += 2) {
     conv_prefetch_idx<TH, TW, CPW>(ib, c1p, g, rowsW, rowStart, colStart, laneOff);    // stage s+1 (past the end: clamped, unused)
     conv_gather<TH, TW, CPW, KT == 8>(acc, ia, c0p, g, rowsW, rowStart, colStart, laneLds, laneOff, active);
     c0p = c1p; c1p = next_pos(c1p, g);
+    TR_ARRIVE(s);
     barrier_plain();
+    TR_LEAVE(s);
     conv_prefetch_idx<TH, TW, CPW>(ia, c1p, g, rowsW, rowStart, colStart, laneOff);    // stage s+2
     conv_gather<TH, TW, CPW, KT == 8>(acc, ib, c0p, g, rowsW, rowStart, colStart, laneLds | STAGE_BYTES, laneOff,
                                       active && s + 1 < S);
     c0p = c1p; c1p = next_pos(c1p, g);
+    TR_ARRIVE(s + 1);
     barrier_plain();
+    TR_LEAVE(s + 1);
   }
 
   if (active) {
@@ -671,6 +706,7 @@ __global__ __launch_bounds__(NW * 64) void k_fc_aprx(FcParams p, int G, int stag
   if (role.builder) {
     const int bw = role.idx;
     const int K = p.K, Cs = p.Cs;
+    __builtin_amdgcn_s_setprio(QCNN_PRIO_BUILDER);
     const char* __restrict__ xbase = reinterpret_cast<const char*>(p.src + (size_t)panel * p.D * PANEL);
     MfmaOps<KTT, KS> opsA, opsB;                          // two operand sets, see k_conv_aprx
     const int mLastStage = mBeg + max(S - 1, 0) * G;  // operand prefetches past the end re-fetch the last stage
@@ -736,7 +772,7 @@ __global__ __launch_bounds__(NW * 64) void k_fc_aprx(FcParams p, int G, int stag
   const int mClamp = max(mEnd - 1, mBeg);
   vload_idx(ia, rowsW + (size_t)mBeg * rowStride, laneOff);
   vload_idx(ib, rowsW + (size_t)min(mBeg + 1, mClamp) * rowStride, laneOff);
-  __builtin_amdgcn_s_setprio(2);   // see k_conv_aprx
+  __builtin_amdgcn_s_setprio(QCNN_PRIO_GATHER);
   barrier_plain();
   {
     int r = 0;                      // sub-spaces of the current stage already consumed
@@ -1152,6 +1188,17 @@ __global__ __launch_bounds__(256) void k_unpack(const float* __restrict__ src, f
     if (img < n && e < E) out[(size_t)img * E + e] = tile[lane][i];
   }
 }
+
+#ifdef QCNN_TRACE
+}  // namespace
+extern "C" int qcnn_debug_trace_read(unsigned long long* host, int block) {
+  hipError_t e = hipMemcpyFromSymbol(host, HIP_SYMBOL(qcnn_trace_buf), sizeof(unsigned long long) * (16 * 64 * 2 + 16));
+  if (e != hipSuccess) return 1;
+  e = hipMemcpyToSymbol(HIP_SYMBOL(qcnn_trace_block), &block, sizeof(int));
+  return e == hipSuccess ? 0 : 1;
+}
+namespace {
+#endif
 
 inline int panels_of(int n) { return (n + PANEL - 1) / PANEL; }
 

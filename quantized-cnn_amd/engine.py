@@ -144,5 +144,86 @@ class QcnnEngine:
         self._chk(self.lib.qcnn_get_layer_ms(self.h, ms, C.byref(cnt)))
         return np.array(ms[:], np.float64), cnt.value
 
+    def layer_total_ms(self):
+        """(ms summed over every recorded launch, launches) per layer, forwards recorded."""
+        tot = (C.c_double * self.L)()
+        cnt = (C.c_longlong * self.L)()
+        fw = C.c_int(0)
+        self._chk(self.lib.qcnn_get_layer_total_ms(self.h, tot, cnt, C.byref(fw)))
+        return np.array(tot[:], np.float64), np.array(cnt[:], np.int64), fw.value
+
     def reset_layer_ms(self):
         self._chk(self.lib.qcnn_reset_layer_ms(self.h))
+
+
+class QcnnDeviceGroup:
+    """One batch sharded over several GPUs of this process (qcnn_group_* of include/qcnn_hip.h): contiguous image
+    blocks, parameters uploaded to rank 0 and broadcast to the others with RCCL, one host thread per GPU."""
+
+    def __init__(self, devices=None):
+        self.lib = capi.load()
+        h = C.c_void_p()
+        if devices:
+            arr = (C.c_int * len(devices))(*devices)
+            rc = self.lib.qcnn_group_create(arr, len(devices), C.byref(h))
+        else:
+            rc = self.lib.qcnn_group_create(None, 0, C.byref(h))
+        if rc:
+            raise QcnnError(self.lib.qcnn_group_last_error(None).decode())
+        self.h = h
+        self.size = self.lib.qcnn_group_size(h)
+        self.L = 0
+        self.classes = 0
+        self.broadcast_ms = None
+
+    def _chk(self, rc):
+        if rc:
+            raise QcnnError(self.lib.qcnn_group_last_error(self.h).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.qcnn_group_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_option(self, opt, value):
+        self._chk(self.lib.qcnn_group_set_option(self.h, opt, value))
+
+    def shard_bounds(self, n, rank):
+        a, b = C.c_int(0), C.c_int(0)
+        self._chk(self.lib.qcnn_group_shard_bounds(self.h, n, rank, C.byref(a), C.byref(b)))
+        return a.value, a.value + b.value
+
+    def load_model(self, in_chw, layers, params, max_batch):
+        shapes = {i: tuple(int(x) for x in p["ctrd"].shape) for i, p in params.items()}
+        arr = (capi.QcnnLayerDesc * len(layers))(*[capi.layer_desc(l) for l in layers])
+        self._chk(self.lib.qcnn_group_model_begin(self.h, len(layers), arr, in_chw[0], in_chw[1], in_chw[2]))
+        for i, (m, k, cs) in shapes.items():
+            self._chk(self.lib.qcnn_group_model_set_layer_shape(self.h, i, m, k, cs))
+        self._chk(self.lib.qcnn_group_model_commit(self.h, max_batch))
+        for i, p in params.items():
+            bias = np.ascontiguousarray(p["bias"], np.float32)
+            ctrd = np.ascontiguousarray(p["ctrd"], np.float32)
+            asmt = np.ascontiguousarray(p["asmt"], np.uint8)
+            self._chk(self.lib.qcnn_group_model_set_layer_params(self.h, i, bias.ctypes.data, ctrd.ctypes.data,
+                                                                 asmt.ctypes.data))
+        ms = C.c_float(0.0)
+        self._chk(self.lib.qcnn_group_model_broadcast(self.h, C.byref(ms)))
+        self.broadcast_ms = ms.value
+        self.L = len(layers)
+        d = (C.c_int * 3)()
+        self.lib.qcnn_fm_dims(self.lib.qcnn_group_ctx(self.h, 0), self.L, d)
+        self.classes = int(d[0]) * int(d[1]) * int(d[2])
+
+    def forward_host(self, imgs_nchw):
+        imgs = np.ascontiguousarray(imgs_nchw, np.float32)
+        n = imgs.shape[0]
+        prob = np.empty((n, self.classes), np.float32)
+        top5 = np.empty((n, 5), np.uint16)
+        self._chk(self.lib.qcnn_group_forward_host(self.h, imgs.ctypes.data, n, prob.ctypes.data, top5.ctypes.data))
+        return prob, top5

@@ -30,15 +30,17 @@ QcnnLayerDesc toDesc(const LayerInfo& li) {
 }  // namespace
 
 CaffeEva::CaffeEva(void)
-    : enblAprx(true), ctx_(nullptr), modelReady_(false), batchSize_(1), batchCnt_(100), imagesDone_(0) {}
+    : enblAprx(true), grp_(nullptr), ctx_(nullptr), modelReady_(false), batchSize_(1), batchCnt_(100),
+      inflight_(1), imagesDone_(0) {}
 
 CaffeEva::~CaffeEva(void) {
-  if (ctx_ != nullptr) qcnn_ctx_destroy(ctx_);
+  if (grp_ != nullptr) qcnn_group_destroy(grp_);   // owns the per-device contexts
 }
 
 bool CaffeEva::fail(const std::string& what) {
   lastError_ = what;
-  if (ctx_ != nullptr && *qcnn_last_error(ctx_)) lastError_ += std::string(": ") + qcnn_last_error(ctx_);
+  if (grp_ != nullptr && *qcnn_group_last_error(grp_)) lastError_ += std::string(": ") + qcnn_group_last_error(grp_);
+  else if (ctx_ != nullptr && *qcnn_last_error(ctx_)) lastError_ += std::string(": ") + qcnn_last_error(ctx_);
   printf("[ERROR] %s\n", lastError_.c_str());
   return false;
 }
@@ -88,43 +90,78 @@ bool CaffeEva::LoadCaffePara(void) {
 
   batchSize_ = envInt("QCNN_BATCH", 1);
   batchCnt_ = envInt("QCNN_BATCHES", 100);
+  // images handed to the devices at once: all of them up to QCNN_MAX_INFLIGHT (QCNN_COALESCE=0: one logical batch at a time)
+  const long long all = static_cast<long long>(batchSize_) * batchCnt_;
+  const int cap = envInt("QCNN_MAX_INFLIGHT", 1024);
+  inflight_ = (getenv("QCNN_COALESCE") != nullptr && atoi(getenv("QCNN_COALESCE")) == 0)
+                  ? batchSize_ : static_cast<int>(all < cap ? all : cap);
+  if (inflight_ < batchSize_) inflight_ = batchSize_;
   return buildDeviceModel();
 }
 
 // PrepFeatMap / PrepFeatBuf / PrepCtrdBuf / PrepAsmtBuf of the reference (src/CaffeEva.cc:328-623) happen
-// on the device side of the C-ABI; here the loaded tensors are only handed over.
+// on the device side of the C-ABI; here the loaded tensors are only handed over.  The object drives a device
+// GROUP (include/qcnn_hip.h): by default every visible GPU; parameters go to rank 0 and are broadcast with RCCL.
 bool CaffeEva::buildDeviceModel(void) {
-  if (ctx_ == nullptr) {
-    const char* dev = getenv("QCNN_DEVICE");
-    if (qcnn_ctx_create(dev ? atoi(dev) : 0, nullptr, &ctx_) != 0)
-      return fail(std::string("cannot create the device context: ") + qcnn_last_error(nullptr));
+  if (grp_ == nullptr) {
+    std::vector<int> devs;                                 // empty = every visible device
+    const char* one = getenv("QCNN_DEVICE");
+    const char* many = getenv("QCNN_DEVICES");
+    if (many != nullptr && *many != '\0' && std::string(many) != "all") {
+      for (const char* q = many; *q != '\0';) {
+        devs.push_back(atoi(q));
+        while (*q != '\0' && *q != ',') ++q;
+        if (*q == ',') ++q;
+      }
+    } else if (one != nullptr && *one != '\0') {
+      devs.push_back(atoi(one));
+    }
+    if (qcnn_group_create(devs.empty() ? nullptr : devs.data(), static_cast<int>(devs.size()), &grp_) != 0) {
+      grp_ = nullptr;
+      return fail(std::string("cannot create the device group: ") + qcnn_group_last_error(nullptr));
+    }
+    ctx_ = qcnn_group_ctx(grp_, 0);
+    printf("[INFO] device group: %d GPU(s)\n", qcnn_group_size(grp_));
   }
   const char* lut = getenv("QCNN_LUT");
-  qcnn_set_option(ctx_, QCNN_OPT_LUT_MODE, (lut && std::string(lut) == "exact") ? 0 : 1);
-  qcnn_set_option(ctx_, QCNN_OPT_KEEP_ALL, 1);
-  qcnn_set_option(ctx_, QCNN_OPT_PROFILE, 1);
+  qcnn_group_set_option(grp_, QCNN_OPT_LUT_MODE, (lut && std::string(lut) == "exact") ? 0 : 1);
+  qcnn_group_set_option(grp_, QCNN_OPT_KEEP_ALL, 1);
+  qcnn_group_set_option(grp_, QCNN_OPT_PROFILE, 1);
 
   const int L = caffeParaObj.layerCnt;
   std::vector<QcnnLayerDesc> descs(L);
   for (int l = 0; l < L; ++l) descs[l] = toDesc(caffeParaObj.layerInfoLst[l]);
-  if (qcnn_model_begin(ctx_, L, descs.data(), caffeParaObj.imgChnIn, caffeParaObj.imgHeiIn, caffeParaObj.imgWidIn))
-    return fail("qcnn_model_begin");
+  if (qcnn_group_model_begin(grp_, L, descs.data(), caffeParaObj.imgChnIn, caffeParaObj.imgHeiIn, caffeParaObj.imgWidIn))
+    return fail("qcnn_group_model_begin");
   for (int l = 0; l < L; ++l) {
     const ENUM_LyrType t = caffeParaObj.layerInfoLst[l].type;
     if (t != ENUM_LyrType::Conv && t != ENUM_LyrType::FCnt) continue;
     const Matrix<float>& ctrd = caffeParaObj.layerParaLst[l].ctrdLst;   // [M][K][Cs]
     if (ctrd.GetDimCnt() != 3) return fail("layer without a 3-D ctrdLst");
-    if (qcnn_model_set_layer_shape(ctx_, l, ctrd.GetDimLen(0), ctrd.GetDimLen(1), ctrd.GetDimLen(2)))
-      return fail("qcnn_model_set_layer_shape");
+    if (qcnn_group_model_set_layer_shape(grp_, l, ctrd.GetDimLen(0), ctrd.GetDimLen(1), ctrd.GetDimLen(2)))
+      return fail("qcnn_group_model_set_layer_shape");
   }
-  if (qcnn_model_commit(ctx_, batchSize_, nullptr)) return fail("qcnn_model_commit");
+  if (qcnn_group_model_commit(grp_, inflight_)) return fail("qcnn_group_model_commit");
   for (int l = 0; l < L; ++l) {
-    const ENUM_LyrType t = caffeParaObj.layerInfoLst[l].type;
-    if (t != ENUM_LyrType::Conv && t != ENUM_LyrType::FCnt) continue;
+    const LayerInfo& li = caffeParaObj.layerInfoLst[l];
+    if (li.type != ENUM_LyrType::Conv && li.type != ENUM_LyrType::FCnt) continue;
     const LayerPara& lp = caffeParaObj.layerParaLst[l];
-    if (qcnn_model_set_layer_params(ctx_, l, lp.biasVec.GetDataPtr(), lp.ctrdLst.GetDataPtr(), lp.asmtLst.GetDataPtr()))
-      return fail("qcnn_model_set_layer_params");
+    // the C-ABI trusts the declared (M, K, Cs) and the layer table: check what the files actually held
+    int hwc[3];
+    qcnn_fm_dims(ctx_, l + 1, hwc);
+    const size_t Ct = static_cast<size_t>(hwc[2]);
+    const size_t M = static_cast<size_t>(lp.ctrdLst.GetDimLen(0));
+    const size_t taps = (li.type == ENUM_LyrType::Conv) ? static_cast<size_t>(li.knlSiz) * li.knlSiz : 1;
+    if (static_cast<size_t>(lp.biasVec.GetEleCnt()) != Ct)
+      return fail("layer parameter files: biasVec does not have one entry per output channel");
+    if (static_cast<size_t>(lp.asmtLst.GetEleCnt()) != Ct * taps * M)
+      return fail("layer parameter files: asmtLst does not hold Ct x taps x M assignments");
+    if (qcnn_group_model_set_layer_params(grp_, l, lp.biasVec.GetDataPtr(), lp.ctrdLst.GetDataPtr(), lp.asmtLst.GetDataPtr()))
+      return fail("qcnn_group_model_set_layer_params");
   }
+  float bcastMs = 0.0f;
+  if (qcnn_group_model_broadcast(grp_, &bcastMs)) return fail("qcnn_group_model_broadcast");
+  if (qcnn_group_size(grp_) > 1) printf("[INFO] parameters broadcast to %d GPUs with RCCL in %.3f ms\n", qcnn_group_size(grp_), bcastMs);
   // the reference prints the feature-map sizes here (src/CaffeEva.cc:403-410)
   for (int l = 0; l <= L; ++l) {
     int hwc[3];
@@ -136,33 +173,55 @@ bool CaffeEva::buildDeviceModel(void) {
   return true;
 }
 
+// The reference classifies batchCnt batches of batchSize images one after the other (src/CaffeEva.cc:151-211).
+// Images are independent, so here the same images — same window rule, same prints, same results — are handed
+// to the device group in chunks of up to `inflight_` images (QCNN_MAX_INFLIGHT), each chunk sharded over the
+// GPUs: the reference's default of 100 batches of 1 image becomes ONE device batch of 100.
 void CaffeEva::ExecForwardPass(void) {
   printf("[CHECK-POINT] entering CaffeEva::ExecForwardPass()\n");
   imagesDone_ = 0;
   if (!modelReady_) { fail("ExecForwardPass() before a successful LoadCaffePara()"); return; }
   if (dataLst.GetDimCnt() != 4) { fail("ExecForwardPass() before a successful LoadDataset()"); return; }
   const int dataCnt = dataLst.GetDimLen(0);
-  const int perImg = dataLst.GetDimStp(0);
+  const size_t perImg = static_cast<size_t>(dataLst.GetDimStp(0));
   if (dataCnt < batchSize_) { fail("dataset smaller than one batch"); return; }
   lablVecPred.Create(dataCnt, kLablCntPerData, 1, 1);
   memset(lablVecPred.GetDataPtr(), 0, sizeof(uint16_t) * lablVecPred.GetEleCnt());
-  std::vector<uint16_t> top5(static_cast<size_t>(batchSize_) * kLablCntPerData);
   const int batchesInData = (dataCnt + batchSize_ - 1) / batchSize_;
-  swWall_.Resume();
+  std::vector<int> firstOf(batchCnt_);
   for (int b = 0; b < batchCnt_; ++b) {
-    printf("processing the %d-th batch\n", b + 1);
     // same window rule as the reference (src/CaffeEva.cc:170-177): the last window is right-aligned
     int first = batchSize_ * b;
     if (b >= batchesInData - 1) first = dataCnt - batchSize_;
     if (first < 0 || first + batchSize_ > dataCnt) first = dataCnt - batchSize_;
-    if (qcnn_forward_host(ctx_, dataLst.GetDataPtr() + static_cast<size_t>(first) * perImg, batchSize_, nullptr,
-                          top5.data()) != 0) {
-      fail("qcnn_forward_host");
+    firstOf[b] = first;
+  }
+  const int perChunk = inflight_ / batchSize_ > 0 ? inflight_ / batchSize_ : 1;      // logical batches per device batch
+  std::vector<float> staging;
+  std::vector<uint16_t> top5(static_cast<size_t>(perChunk) * batchSize_ * kLablCntPerData);
+  swWall_.Resume();
+  for (int b0 = 0; b0 < batchCnt_; b0 += perChunk) {
+    const int nb = (b0 + perChunk <= batchCnt_) ? perChunk : batchCnt_ - b0;
+    bool contiguous = true;
+    for (int b = 1; b < nb; ++b) contiguous = contiguous && firstOf[b0 + b] == firstOf[b0 + b - 1] + batchSize_;
+    const float* src = dataLst.GetDataPtr() + static_cast<size_t>(firstOf[b0]) * perImg;
+    if (!contiguous) {                                   // right-aligned last window: gather the chunk
+      staging.resize(static_cast<size_t>(nb) * batchSize_ * perImg);
+      for (int b = 0; b < nb; ++b)
+        memcpy(staging.data() + static_cast<size_t>(b) * batchSize_ * perImg,
+               dataLst.GetDataPtr() + static_cast<size_t>(firstOf[b0 + b]) * perImg, sizeof(float) * batchSize_ * perImg);
+      src = staging.data();
+    }
+    for (int b = 0; b < nb; ++b) printf("processing the %d-th batch\n", b0 + b + 1);
+    if (qcnn_group_forward_host(grp_, src, nb * batchSize_, nullptr, top5.data()) != 0) {
+      fail("qcnn_group_forward_host");
       break;
     }
-    for (int i = 0; i < batchSize_; ++i)
-      for (int r = 0; r < kLablCntPerData; ++r) lablVecPred.SetEleAt(top5[i * kLablCntPerData + r], first + i, r, 0, 0);
-    imagesDone_ += batchSize_;
+    for (int b = 0; b < nb; ++b)
+      for (int i = 0; i < batchSize_; ++i)
+        for (int r = 0; r < kLablCntPerData; ++r)
+          lablVecPred.SetEleAt(top5[(static_cast<size_t>(b) * batchSize_ + i) * kLablCntPerData + r], firstOf[b0 + b] + i, r, 0, 0);
+    imagesDone_ += nb * batchSize_;
   }
   swWall_.Pause();
 }
@@ -173,9 +232,11 @@ void CaffeEva::ExecForwardPass(const Matrix<float>& imgDataIn, Matrix<float>* pP
   int hwc[3];
   qcnn_fm_dims(ctx_, caffeParaObj.layerCnt, hwc);
   pProbVecOut->Resize(hwc[0] * hwc[1] * hwc[2]);
+  memset(pProbVecOut->GetDataPtr(), 0, sizeof(float) * pProbVecOut->GetEleCnt());   // never hand back uninitialised memory
+  lastError_.clear();
   swWall_.Resume();
   if (qcnn_forward_host(ctx_, imgDataIn.GetDataPtr(), 1, pProbVecOut->GetDataPtr(), nullptr) != 0)
-    fail("qcnn_forward_host");
+    fail("qcnn_forward_host");                                                      // GetErrorMsg() is non-empty: callers check it
   swWall_.Pause();
 }
 
@@ -211,13 +272,15 @@ void CaffeEva::CalcPredAccu(void) {
 
 float CaffeEva::DispElpsTime(void) {
   const int L = caffeParaObj.layerCnt;
-  std::vector<float> ms(L > 0 ? L : 1, 0.0f);
+  // HIP-event time of every launch of every forward pass since the last Init(), summed per layer (rank 0 of the
+  // device group; the ranks run concurrently on equal shares)
+  std::vector<double> ms(L > 0 ? L : 1, 0.0);
   int forwards = 0;
-  if (modelReady_) qcnn_get_layer_ms(ctx_, ms.data(), &forwards);
+  if (modelReady_) qcnn_get_layer_total_ms(ctx_, ms.data(), nullptr, &forwards);
   double byType[7] = {0, 0, 0, 0, 0, 0, 0};
   double convK = 0.0, fcK = 0.0, total = 0.0;
   for (int l = 0; l < L; ++l) {
-    const double s = ms[l] * 1e-3 * forwards;          // seconds over all recorded forward passes
+    const double s = ms[l] * 1e-3;                     // seconds over all recorded forward passes
     const int t = static_cast<int>(caffeParaObj.layerInfoLst[l].type);
     byType[t] += s;
     total += s;
@@ -238,7 +301,7 @@ float CaffeEva::DispElpsTime(void) {
   printf("swEstiInPdValFCnt: %.4f (s)\n", fcK);
   printf("swDebugTimePri: %.4f (s)\n", static_cast<double>(swWall_.GetTime()));   // host wall clock incl. H2D/D2H
   printf("swDebugTimeSec: %.4f (s)\n", 0.0);
-  for (int l = 0; l < L; ++l) printf("swIndvLayerLst #%2d: %.4f (s)\n", l + 1, ms[l] * 1e-3 * forwards);
+  for (int l = 0; l < L; ++l) printf("swIndvLayerLst #%2d: %.4f (s)\n", l + 1, ms[l] * 1e-3);
   Init(enblAprx);
   return static_cast<float>(total);
 }

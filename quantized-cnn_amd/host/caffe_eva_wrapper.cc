@@ -111,6 +111,10 @@ bool CaffeEvaWrapper::Proc(const std::string& filePathProcImg, CaffeEvaRslt* pCa
   }
   Matrix<float> prob;
   caffeEvaObj.ExecForwardPass(img, &prob);
+  if (!caffeEvaObj.GetErrorMsg().empty()) {              // the forward pass failed: do not rank a zero vector
+    errorMsg = "[CaffeEvaWrapper::Proc] forward pass failed: " + caffeEvaObj.GetErrorMsg();
+    return false;
+  }
   pCaffeEvaRslt->timeTotal = caffeEvaObj.DispElpsTime();
 
   const std::string key = baseName(filePathProcImg);

@@ -1,6 +1,7 @@
 // host_capi.cc — small C entry points into the C++ host mirror, for the pytest suite only (ctypes cannot
 // call C++ classes).  Nothing here is on the product path.
 #include "../../include/BmpImgIO.h"
+#include "../../include/CaffeEva.h"
 #include "../../include/CaffePara.h"
 #include "../../include/FileIO.h"
 #include "../../include/Matrix.h"
@@ -69,6 +70,39 @@ int qh_cbn_rewrite(const char* inPath, const char* outPath, int bits) {
   Matrix<uint8_t> m;
   if (!FileIO::ReadCbnFile(inPath, &m)) return 1;
   if (!FileIO::WriteCbnFile(outPath, m, bits)) return 2;
+  return 0;
+}
+
+// CaffeEva through its public interface on one BMP image (AlexNet, data root laid out like the reference's):
+// feature maps `layers[0..n)` of the forward pass, NHWC, written back to back into out (cap floats); sizes[] gets
+// the element counts.  Arithmetic sanity of the host mirror -> C-ABI plumbing (feature maps, not accuracy lines).
+int qh_eva_featmaps(const char* mainDir, const char* bmpPath, const int* layers, int n, float* out, int cap, int* sizes) {
+  BmpImgIOPara para;
+  para.reszType = ENUM_ReszType::Strict;
+  para.meanType = ENUM_MeanType::Full;
+  para.imgHeiFull = 256; para.imgWidFull = 256; para.imgHeiCrop = 227; para.imgWidCrop = 227;
+  para.filePathMean = std::string(mainDir) + "/AlexNet/imagenet_mean.single.bin";
+  BmpImgIO io;
+  if (!io.Init(para)) return 1;
+  Matrix<float> img;
+  if (!io.Load(bmpPath, &img)) return 2;
+  CaffeEva eva;
+  eva.Init(true);
+  eva.SetModelName("AlexNet");
+  eva.SetModelPath(std::string(mainDir) + "/AlexNet/Bin.Files", "bvlc_alexnet_aCaF");
+  if (!eva.LoadCaffePara()) return 3;
+  Matrix<float> prob;
+  eva.ExecForwardPass(img, &prob);
+  if (!eva.GetErrorMsg().empty()) return 4;
+  int used = 0;
+  for (int i = 0; i < n; ++i) {
+    Matrix<float> fm;
+    if (!eva.GetFeatMap(layers[i], 1, &fm)) return 5;
+    if (used + fm.GetEleCnt() > cap) return 6;
+    memcpy(out + used, fm.GetDataPtr(), sizeof(float) * fm.GetEleCnt());
+    sizes[i] = fm.GetEleCnt();
+    used += fm.GetEleCnt();
+  }
   return 0;
 }
 

@@ -73,6 +73,147 @@ __device__ __forceinline__ void gatherq8(f32x2* acc, uint32_t w0, uint32_t w1, u
                  "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127");
 }
 
+// four reads = 8 look-ups, temporaries v[112:127] (address in the first register of its destination quad)
+#define Q4_AD(a, w, sel) "v_xor_b32_sdwa " a ", %[" w "], %[b] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" sel " src1_sel:DWORD\n\t"
+__device__ __forceinline__ void gatherq4(f32x2* acc, uint32_t w0, uint32_t w1, uint32_t base, int validIn) {
+  int valid;
+  asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(valid) : "v"(validIn));
+  asm volatile("s_cmp_eq_u32 %[ok], 0\n\ts_cbranch_scc1 .Lqskip%=\n\t"
+               Q4_AD("v112", "w0", "WORD_0") Q4_AD("v116", "w0", "WORD_1") Q4_AD("v120", "w1", "WORD_0") Q4_AD("v124", "w1", "WORD_1")
+               Q_RD("v[112:115]", "v112") Q_RD("v[116:119]", "v116") Q_RD("v[120:123]", "v120") Q_RD("v[124:127]", "v124")
+               Q_ACC("3", "c0", "c1", "v[112:113]", "v[114:115]") Q_ACC("2", "c2", "c3", "v[116:117]", "v[118:119]")
+               Q_ACC("1", "c4", "c5", "v[120:121]", "v[122:123]") Q_ACC("0", "c6", "c7", "v[124:125]", "v[126:127]")
+               "\n.Lqskip%=:"
+               : [c0] "+v"(acc[0]), [c1] "+v"(acc[1]), [c2] "+v"(acc[2]), [c3] "+v"(acc[3]), [c4] "+v"(acc[4]),
+                 [c5] "+v"(acc[5]), [c6] "+v"(acc[6]), [c7] "+v"(acc[7])
+               : [w0] "v"(w0), [w1] "v"(w1), [b] "v"(base), [ok] "s"(valid)
+               : "scc", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123",
+                 "v124", "v125", "v126", "v127");
+}
+
+// NB builder waves (4 or 8: waves 0..NB-1) write 64 KB / NB each with ds_write_addtid_b32 and issue nmf * 4 / NB f32 MFMA
+// each; the other 16 - NB waves gather `rblocks` blocks of 8 look-ups (4 x ds_read_b128) each
+template <int NB, int M0MODE = 0>
+__global__ __launch_bounds__(1024) void kroles(float* out, uint64_t* cyc, int iters, const uint32_t* idx, int rblocks, int nmf) {
+  extern __shared__ char lds[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  for (int i = threadIdx.x; i < 160 * 1024 / 4; i += blockDim.x) reinterpret_cast<float*>(lds)[i] = 1.0f;
+  __syncthreads();
+  if (wave < NB) {
+    uint64_t t0 = __builtin_readcyclecounter();
+    f32x4 acc[4];
+    for (int j = 0; j < 4; ++j) acc[j] = f32x4{1.f * lane, 2.f, 3.f, 4.f};
+    float ma = 1.0f + lane, mb = 2.0f;
+    const int groups = 16 / NB;            // groups of four tiles per stage for this wave
+    const int mfPerGroup = nmf / 4;        // per group of four tiles: 8 = two per tile, 4 = one per tile
+    for (int it = 0; it < iters; ++it) {
+      if (M0MODE == 1) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" :: "s"(65536u * (it & 1) + wave * groups * 4096) : "m0", "memory");
+#pragma unroll
+      for (int tl = 0; tl < groups; ++tl) {
+        if (mfPerGroup >= 4) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ma, mb, acc[j], 0, 0, 0);
+        }
+        if (mfPerGroup >= 8) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(mb, ma, acc[j], 0, 0, 0);
+        }
+        const uint32_t m0v = 65536u * (it & 1) + (wave * groups + tl) * 4096;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (M0MODE == 0)
+            asm volatile("s_mov_b32 m0, %4\n\ts_nop 0\n\tds_write_addtid_b32 %0 offset:0\n\tds_write_addtid_b32 %1 offset:256\n\t"
+                         "ds_write_addtid_b32 %2 offset:512\n\tds_write_addtid_b32 %3 offset:768"
+                         :: "v"(acc[j][0]), "v"(acc[j][1]), "v"(acc[j][2]), "v"(acc[j][3]), "s"(m0v + j * 1024) : "m0", "memory");
+          else
+            asm volatile("ds_write_addtid_b32 %0 offset:%4\n\tds_write_addtid_b32 %1 offset:%5\n\t"
+                         "ds_write_addtid_b32 %2 offset:%6\n\tds_write_addtid_b32 %3 offset:%7"
+                         :: "v"(acc[j][0]), "v"(acc[j][1]), "v"(acc[j][2]), "v"(acc[j][3]), "n"(tl * 4096 + j * 1024),
+                            "n"(tl * 4096 + j * 1024 + 256), "n"(tl * 4096 + j * 1024 + 512), "n"(tl * 4096 + j * 1024 + 768) : "memory");
+        }
+        for (int j = 0; j < 4; ++j) acc[j][0] += 1.0f;
+        asm volatile("" ::: "memory");
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    uint64_t t1 = __builtin_readcyclecounter();
+    if (lane == 0) cyc[blockIdx.x * 16 + wave] = t1 - t0;
+    return;
+  }
+  f32x2 acc[48];
+  for (int j = 0; j < 48; ++j) acc[j] = f32x2{0, 0};
+  uint32_t w[12];
+  for (int j = 0; j < 12; ++j) w[j] = idx[256 + ((wave * 2 + (lane >> 5)) * 12 + j) % 700];
+  const uint32_t base = ((lane & 31) >> 2) * 8192 | ((lane & 31) >> 3) * 64 | (lane & 3) * 16;
+  uint64_t t0 = __builtin_readcyclecounter();
+  for (int it = 0; it < iters; ++it) {
+    const uint32_t st = base | 65536u * (it & 1);
+#pragma unroll
+    for (int b = 0; b < 6; ++b) gatherq4(&acc[8 * b], w[2 * b], w[2 * b + 1], st, __builtin_amdgcn_readfirstlane(b < rblocks));
+    asm volatile("s_barrier" ::: "memory");
+  }
+  uint64_t t1 = __builtin_readcyclecounter();
+  if (lane == 0) cyc[blockIdx.x * 16 + wave] = t1 - t0;
+  float s = 0; for (int j = 0; j < 48; ++j) s += acc[j].x + acc[j].y;
+  out[blockIdx.x * 1024 + threadIdx.x] = s;
+}
+
+// symmetric stage: every one of the 16 waves stores 4 result tiles (16 x ds_write_addtid_b32) of the next stage,
+// issues nmfw f32 MFMA (4 = KS 1, 8 = KS 2) for the stage after it, and gathers rblocks x 8 look-ups of the current one
+template <int ORDER>
+__global__ __launch_bounds__(1024) void ksym(float* out, uint64_t* cyc, int iters, const uint32_t* idx, int rblocks, int nmfw) {
+  extern __shared__ char lds[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  for (int i = threadIdx.x; i < 160 * 1024 / 4; i += blockDim.x) reinterpret_cast<float*>(lds)[i] = 1.0f;
+  __syncthreads();
+  f32x4 d[4];
+  for (int j = 0; j < 4; ++j) d[j] = f32x4{1.f * lane, 2.f, 3.f, 4.f};
+  float ma = 1.0f + lane, mb = 2.0f;
+  f32x2 acc[32];
+  for (int j = 0; j < 32; ++j) acc[j] = f32x2{0, 0};
+  uint32_t w[8];
+  for (int j = 0; j < 8; ++j) w[j] = idx[256 + ((wave * 2 + (lane >> 5)) * 8 + j) % 700];
+  const uint32_t base = ((lane & 31) >> 2) * 8192 | ((lane & 31) >> 3) * 64 | (lane & 3) * 16;
+  uint64_t t0 = __builtin_readcyclecounter();
+  for (int it = 0; it < iters; ++it) {
+    const uint32_t st = base | 65536u * (it & 1);
+    const uint32_t m0v = 65536u * ((it + 1) & 1) + wave * 4096;
+    auto stores = [&]() {
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" :: "s"(m0v) : "m0", "memory");
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        asm volatile("ds_write_addtid_b32 %0 offset:%4\n\tds_write_addtid_b32 %1 offset:%5\n\t"
+                     "ds_write_addtid_b32 %2 offset:%6\n\tds_write_addtid_b32 %3 offset:%7"
+                     :: "v"(d[j][0]), "v"(d[j][1]), "v"(d[j][2]), "v"(d[j][3]), "n"(j * 1024), "n"(j * 1024 + 256),
+                        "n"(j * 1024 + 512), "n"(j * 1024 + 768) : "memory");
+    };
+    auto mfmas = [&]() {
+      if (nmfw >= 4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ma, mb, d[j], 0, 0, 0);
+      }
+      if (nmfw >= 8) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(mb, ma, d[j], 0, 0, 0);
+      }
+    };
+    auto gathers = [&]() {
+#pragma unroll
+      for (int b = 0; b < 4; ++b) gatherq4(&acc[8 * b], w[2 * b], w[2 * b + 1], st, __builtin_amdgcn_readfirstlane(b < rblocks));
+    };
+    if (ORDER == 0) { stores(); __builtin_amdgcn_sched_barrier(0); mfmas(); __builtin_amdgcn_sched_barrier(0); gathers(); }
+    if (ORDER == 1) { gathers(); __builtin_amdgcn_sched_barrier(0); stores(); __builtin_amdgcn_sched_barrier(0); mfmas(); }
+    if (ORDER == 2) { stores(); __builtin_amdgcn_sched_barrier(0); gathers(); __builtin_amdgcn_sched_barrier(0); mfmas(); }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  }
+  uint64_t t1 = __builtin_readcyclecounter();
+  if (lane == 0) cyc[blockIdx.x * 16 + wave] = t1 - t0;
+  float s = 0; for (int j = 0; j < 32; ++j) s += acc[j].x + acc[j].y;
+  for (int j = 0; j < 4; ++j) s += d[j][0] + d[j][1] + d[j][2] + d[j][3];
+  out[blockIdx.x * 1024 + threadIdx.x] = s;
+}
+
 // RD: 0 = R64, 1 = R128;  WR: 0 none, 1 = W32, 2 = WADD;  nmf = f32 MFMA per builder and stage;  rblocks = look-up
 // blocks of a gather wave per stage (R64: 8 look-ups each, R128: 16 each)
 template <int RD, int WR, int BAR>
@@ -268,6 +409,63 @@ int main() {
   RUN(0, 1, 1, 12, 2, 16, "R64 + W32 + MFMA + barrier (production, conv1-like)");
   RUN(1, 2, 1, 12, 1, 16, "R128 + WADD + MFMA + barrier (candidate, conv1-like)");
   RUN(1, 2, 1, 12, 1, 0, "R128 + WADD + barrier, no MFMA");
+  // role split: 4 builders + 12 gather waves vs 8 + 8 (same total look-ups and the same 64 KB + MFMA per stage)
+#define ROLES(NB, rblocks, nmf, label)                                                                               \
+  do {                                                                                                               \
+    hipMemset(cyc, 0, sizeof(h));                                                                                    \
+    hipLaunchKernelGGL((kroles<NB>), dim3(256), dim3(1024), 163840, 0, out, cyc, iters, idx, rblocks, nmf);           \
+    hipError_t e = hipDeviceSynchronize();                                                                           \
+    maxes(cyc, mw, mr);                                                                                              \
+    printf("%-58s builders=%d lookups/gather wave=%2d mfma/stage/SIMD=%2d : %7.1f cycles/stage (%s)\n", label, NB,     \
+           8 * rblocks, nmf, (mr > mw ? mr : mw) / iters, hipGetErrorString(e));                                      \
+  } while (0)
+#define SYM(ORDER, rblocks, nmfw, label)                                                                             \
+  do {                                                                                                               \
+    hipMemset(cyc, 0, sizeof(h));                                                                                    \
+    hipLaunchKernelGGL((ksym<ORDER>), dim3(256), dim3(1024), 163840, 0, out, cyc, iters, idx, rblocks, nmfw);         \
+    hipError_t e = hipDeviceSynchronize();                                                                           \
+    maxes(cyc, mw, mr);                                                                                              \
+    printf("%-58s order=%d lookups/wave=%2d (x16) mfma/wave=%d : %7.1f cycles/stage (%s)\n", label, ORDER,           \
+           8 * rblocks, nmfw, (mr > mw ? mr : mw) / iters, hipGetErrorString(e));                                    \
+  } while (0)
+  SYM(0, 3, 8, "symmetric, conv3-like (384 look-ups, 32 MFMA/SIMD)");
+  SYM(1, 3, 8, "symmetric, conv3-like (384 look-ups, 32 MFMA/SIMD)");
+  SYM(2, 3, 8, "symmetric, conv3-like (384 look-ups, 32 MFMA/SIMD)");
+  SYM(0, 4, 8, "symmetric, 512 look-ups, 32 MFMA/SIMD");
+  SYM(0, 3, 4, "symmetric, 384 look-ups, 16 MFMA/SIMD");
+  SYM(0, 2, 4, "symmetric, conv1-like (256 look-ups, 16 MFMA/SIMD)");
+  SYM(0, 1, 4, "symmetric, 128 look-ups, 16 MFMA/SIMD");
+  SYM(0, 3, 0, "symmetric, 384 look-ups, no MFMA");
+  SYM(0, 0, 0, "symmetric, stores + barrier only");
+  SYM(0, 3, 0, "symmetric, 384 look-ups, no MFMA");
+#define ROLES1(NB, rblocks, nmf, label)                                                                              \
+  do {                                                                                                               \
+    hipMemset(cyc, 0, sizeof(h));                                                                                    \
+    hipLaunchKernelGGL((kroles<NB, 1>), dim3(256), dim3(1024), 163840, 0, out, cyc, iters, idx, rblocks, nmf);        \
+    hipError_t e = hipDeviceSynchronize();                                                                           \
+    maxes(cyc, mw, mr);                                                                                              \
+    printf("%-58s builders=%d lookups/gather wave=%2d mfma/stage/SIMD=%2d : %7.1f cycles/stage (%s)\n", label, NB,     \
+           8 * rblocks, nmf, (mr > mw ? mr : mw) / iters, hipGetErrorString(e));                                      \
+  } while (0)
+  ROLES1(4, 4, 32, "M0 once per stage: 4+12, conv3-like (384 look-ups)");
+  ROLES1(8, 6, 32, "M0 once per stage: 8+8,  conv3-like (384 look-ups)");
+  ROLES1(4, 2, 16, "M0 once per stage: 4+12, conv1-like (192 look-ups)");
+  ROLES1(8, 3, 16, "M0 once per stage: 8+8,  conv1-like (192 look-ups)");
+  ROLES1(4, 4, 0, "M0 once per stage: 4+12, no MFMA (384 look-ups)");
+  ROLES1(8, 6, 0, "M0 once per stage: 8+8,  no MFMA (384 look-ups)");
+  ROLES1(4, 0, 0, "M0 once per stage: 4 builders alone");
+  ROLES1(8, 0, 0, "M0 once per stage: 8 builders alone");
+  ROLES(4, 0, 0, "M0 per 4 stores: 4 builders alone");
+  ROLES(4, 4, 32, "4+12, conv3-like (384 look-ups)");
+  ROLES(8, 6, 32, "8+8,  conv3-like (384 look-ups)");
+  ROLES(4, 4, 16, "4+12, KS=1 (384 look-ups)");
+  ROLES(8, 6, 16, "8+8,  KS=1 (384 look-ups)");
+  ROLES(4, 2, 16, "4+12, conv1-like (192 look-ups)");
+  ROLES(8, 3, 16, "8+8,  conv1-like (192 look-ups)");
+  ROLES(4, 4, 0, "4+12, no MFMA (384 look-ups)");
+  ROLES(8, 6, 0, "8+8,  no MFMA (384 look-ups)");
+  ROLES(8, 4, 32, "8+8,  256 look-ups, 32 MFMA");
+  ROLES(8, 2, 16, "8+8,  128 look-ups, 16 MFMA");
   // probes
 #define PROBE(MODE, PK, mfw, vw, label)                                                                              \
   do {                                                                                                               \

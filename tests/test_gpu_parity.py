@@ -283,12 +283,14 @@ def test_vgg_style_channel_counts():
 
 
 # ---------------------------------------------------------------- the other topologies of src/CaffePara.cc ----
-@pytest.mark.parametrize("model,n_img", [("CaffeNet", 2), ("VggCnnS", 2), ("CaffeNetFGD", 2), ("VGG16", 1)])
+@pytest.mark.parametrize("model,n_img", [("CaffeNet", 2), ("VggCnnS", 2), ("CaffeNetFGD", 2), ("CaffeNetFGB", 2),
+                                         ("VGG16", 1)])
 def test_other_reference_topologies(model, n_img):
     """Every layer table the reference knows besides AlexNet (src/CaffePara.cc:54-237; BASELINE.json configs[3] =
     VGG-16), full size, synthetic parameters in the shipped quantisation layout: all feature maps against the
     oracle (MFMA builder, <= 1e-4) and every conv/FC layer in isolation with the exact builder (bit-identical).
-    CaffeNetFGB (518 classes, not a multiple of 4; the reference itself overruns there) is rejected by design."""
+    CaffeNetFGB's 518-way classifier is not a multiple of the reference's 8-way unroll (src/CaffeEva.cc:1008; the
+    reference over-runs its output row there); the plain-loop oracle defines the expected values."""
     in_chw, layers, _, _ = topo.MODELS[model]
     params = synth.make_params(in_chw, layers, seed=51)
     imgs = synth.make_images(n_img, in_chw, seed=52)
@@ -310,12 +312,14 @@ def test_other_reference_topologies(model, n_img):
     eng.close()
 
 
-def test_caffenet_fgb_is_rejected():
-    in_chw, layers, _, _ = topo.MODELS["CaffeNetFGB"]
-    params = synth.make_params(in_chw, layers, seed=53)
+def test_odd_channel_count_is_rejected():
+    """Output channels are handled in pairs (one per wave half): an odd count per group is refused with an error,
+    never computed wrongly."""
+    in_chw = (3, 8, 8)
+    layers = [topo.conv(0, 3, 7, 1, 1), topo.relu(), topo.fcnt(10), topo.smax()]
     eng = pkg("engine").QcnnEngine(0)
     with pytest.raises(pkg("engine").QcnnError):
-        eng.load_model(in_chw, layers, params, 1)
+        eng.configure(in_chw, layers, {0: (1, 16, 3), 2: (63, 16, 4)})
 
 
 # ---------------------------------------------------------------- device-side input pipeline ----

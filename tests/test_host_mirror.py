@@ -150,6 +150,58 @@ def test_reference_main_drives_the_hip_path(tmp_path):
 
 @pytest.mark.gpu
 @pytest.mark.skipif(not os.path.isdir(po.REF_DATA), reason="needs the staged shipped parameters")
+@pytest.mark.parametrize("lut", ["exact", "mfma"])
+def test_host_mirror_feature_maps_match_reference(golden_alex_real, lut, monkeypatch):
+    """CaffeEva (C++ host mirror -> device group -> C-ABI) on a real BMP with the shipped parameters: conv1, conv5
+    and pool5 (fm[1], fm[13], fm[15] — the deepest maps that depend on shipped files only, and not degenerate
+    like the tail behind the synthesised fc6 table) against the compiled reference's values."""
+    z = golden_alex_real
+    monkeypatch.setenv("QCNN_LUT", lut)
+    lib = host()
+    lib.qh_eva_featmaps.argtypes = [C.c_char_p, C.c_char_p, np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS"), C.c_int,
+                                    np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS"), C.c_int,
+                                    np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")]
+    want = np.array([1, 13, 15], np.int32)
+    out = np.zeros(55 * 55 * 96 + 13 * 13 * 256 + 6 * 6 * 256, np.float32)
+    sizes = np.zeros(3, np.int32)
+    bmp = os.path.join(po.REF_DATA, "Bmp.Files/ILSVRC2012_val_00000002.BMP")
+    with po._Quiet():
+        rc = lib.qh_eva_featmaps(po.REF_DATA.encode(), bmp.encode(), want, 3, out, out.size, sizes)
+    assert rc == 0
+    assert list(sizes) == [55 * 55 * 96, 13 * 13 * 256, 6 * 6 * 256]
+    off = 0
+    for l, n in zip(want, sizes):
+        fm = out[off:off + n]
+        off += n
+        fp = z["fp_%02d" % l][0]
+        scale = max(abs(fp[3]), abs(fp[4]))
+        err = np.abs(fm[::97].astype(np.float64) - z["smp_%02d" % l][0]).max() / scale
+        assert err <= 1e-4, "fm[%d] (%s): %g" % (l, lut, err)
+        assert abs(np.abs(fm.astype(np.float64)).sum() - fp[1]) <= 1e-4 * fp[1]
+    if lut == "exact":
+        assert np.array_equal(out[: 55 * 55 * 96].reshape(55, 55, 96), z["conv1_out"])
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.isdir(po.REF_DATA), reason="needs the staged shipped parameters")
+def test_reference_main_coalesced_equals_batch_by_batch(tmp_path):
+    """The unmodified Main.cc: by default the 100 logical batches of one image run as ONE device batch; with
+    QCNN_COALESCE=0 they run one at a time, as the reference does.  Same prints, same accuracy lines."""
+    exe = os.path.join(ROOT, "build", "bin", "QuanCNN_hip")
+    if not os.path.exists(exe):
+        pytest.skip("build/bin/QuanCNN_hip not built (needs /root/reference at build time)")
+    root = _make_data_root(tmp_path)
+    outs = []
+    for env in ({}, {"QCNN_COALESCE": "0"}, {"QCNN_BATCH": "7", "QCNN_BATCHES": "15", "QCNN_MAX_INFLIGHT": "32"}):
+        out = subprocess.run([exe], cwd=root, capture_output=True, text=True, timeout=600, env=dict(os.environ, **env)).stdout
+        assert out.count("processing the ") == (15 if "QCNN_BATCH" in env else 100)
+        outs.append(re.findall(r"ACCURACY@(\d): (\d+), ([0-9.]+)%", out))
+    assert len(outs[0]) == 5 and outs[0] == outs[1]
+    assert len(outs[2]) == 5
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.isdir(po.REF_DATA), reason="needs the staged shipped parameters")
 def test_single_image_mode_matches_golden_top5(golden_alex_real):
     exe = os.path.join(ROOT, "build", "bin", "qcnn_main")
     if not os.path.exists(exe):
