@@ -1,27 +1,36 @@
 #!/usr/bin/env python3
 """bench.py — images/second of the Quantized-CNN approximate forward pass on MI355X.
 
-Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched by
-torch.distributed.run with one rank per GPU.  One JSON line on stdout (rank 0).
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`.  For N > 1 the driver launches it under
+torch.distributed.run (one rank per GPU); started WITHOUT that environment, `--gpus N` re-executes itself under
+torch.distributed.run and fails loudly when fewer than N GPUs are visible.  One JSON line on stdout (rank 0).
 
-A step = one pass of the hot path (pack -> 23 AlexNet layers, LUT build + indexed accumulation for
-conv/FC, glue layers, top-5) over one batch of --batch synthetic images PER GPU, inputs already
-resident in HBM.  Images are independent: ranks share nothing on the data path; the only collective
-is the one-time RCCL broadcast of rank 0's packed parameter arena (codebooks, assignments, biases),
-outside the timed region.  Scaling is therefore "weak" (per-GPU work fixed).
+A step = one pass of the hot path (23 AlexNet layers: LUT build + indexed accumulation for conv/FC, glue layers,
+top-5) over one batch of synthetic images already resident in HBM.
+  N = 1   the batch is BASELINE.json configs[1]: 1000 images on one GPU.
+  N > 1   configs[2]: ONE 1000-image batch sharded over the N GPUs in contiguous blocks (dist.shard_bounds):
+          "scaling": "strong".  Images are independent, so there is no data-path collective; the only exchange is
+          the one-time RCCL broadcast of rank 0's packed parameter arena, outside the timed region (its time is
+          reported as `param_broadcast_ms`).  `value_weak` additionally reports 1000 images PER GPU.
 
 Extra objects on the JSON line:
-  roofline      dominant kernel (largest mean HIP-event time over the timed steps), algorithmic HBM
-                bytes per launch / its duration against 8 TB/s; `traffic` = that kernel's HBM bytes from
-                the committed rocprofv3 --pmc passes (profiles/); plus the LDS look-up rate against the
-                ds_read_b64 peak, the resource that actually bounds the kernel.
-  cpu_baseline  the reference itself (oracle/_ref/libqcnn_ref.so, kind "reference") — or the C port
-                when that was never built — timed single-threaded on this host on a bounded sample.
+  roofline      dominant kernel (largest mean HIP-event time per launch over the timed steps), algorithmic HBM bytes
+                per launch / that time against 8 TB/s; `traffic` = its HBM bytes from the committed rocprofv3 --pmc
+                passes when they were taken from THIS kernel source (hash check), else null; per conv/FC layer the
+                figures the kernels are really bounded by (stages built, rebuild factor, cycles per stage, look-ups
+                against the LDS read peak, matrix-pipe utilisation).
+  parity        the first images of the timed batch run through the CPU reference (or the C port) and compared
+                with what the GPU produced for them: probabilities, pool5 feature map, top-5.  > 1e-4 aborts.
+  cpu_baseline  the reference itself (oracle/_ref/libqcnn_ref.so, kind "reference") — or the C port when that was
+                never built — timed single-threaded on this host on a bounded sample (N = 1 only).
 """
 import argparse
+import hashlib
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import tempfile
 import time
@@ -37,27 +46,43 @@ def pkg(name=""):
 
 
 HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-LDS_B64_LOOKUPS_PER_S = 256 * 64 * 2.4e9    # 256 CU x 256 B/clk (ds_read_b64, an image pair per lane) / 4 B x 2.4 GHz
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r1_v6", "traffic.json")   # PMC HBM bytes of the dominant kernel
+TOL = 1e-4                                  # north_star tolerance, relative to the map's largest magnitude
+KERNEL_SRC = os.path.join(ROOT, "quantized-cnn_amd", "csrc", "qcnn_kernels.hip")
+
+
+def kernel_hash():
+    with open(KERNEL_SRC, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
 
 
 def pmc_traffic(layer, launches_per_forward):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
-    (FETCH_SIZE + WRITE_SIZE, separate passes, mean per dispatch), or None when no profile covers it."""
+    """HBM bytes per launch of the dominant kernel from the newest committed rocprofv3 --pmc summary
+    (profiles/*/traffic.json: FETCH_SIZE doubled per the guide's gfx950 correction + WRITE_SIZE, separate passes,
+    mean per dispatch) — only if it was taken from the kernel source that is being benchmarked."""
+    prof = os.path.join(ROOT, "profiles")
+    best = None
+    for d in sorted(os.listdir(prof)) if os.path.isdir(prof) else []:
+        p = os.path.join(prof, d, "traffic.json")
+        if os.path.exists(p):
+            best = p
+    if best is None:
+        return None, "no profiles/*/traffic.json"
     try:
-        with open(TRAFFIC_JSON) as f:
+        with open(best) as f:
             t = json.load(f)
+        rel = os.path.relpath(best, ROOT)
+        if t.get("kernel_hash") != kernel_hash():
+            return None, "%s was taken from another build of qcnn_kernels.hip (hash mismatch)" % rel
         if int(t["layer"]) != int(layer) or int(t.get("launches_per_forward", 1)) != int(launches_per_forward):
-            return None
-        return int(t["bytes"])
-    except (OSError, ValueError, KeyError):
-        return None
+            return None, "%s covers layer %s" % (rel, t["layer"])
+        return int(t["bytes"]), rel
+    except (OSError, ValueError, KeyError) as e:
+        return None, "unreadable: %s" % e
 
 
-def algorithmic_bytes(sizes, layers, params, l, batch, fused):
+def algorithmic_bytes(sizes, layers, params, l, batch):
     """HBM bytes one launch of layer l must move: read fm[l], write fm[l+1], read its parameters once
     (SURVEY.md §8d 'A_layer').  The look-up table never leaves the CU."""
-    topo = pkg("topology")
     e_in = sizes[l][0] * sizes[l][1] * sizes[l][2]
     e_out = sizes[l + 1][0] * sizes[l + 1][1] * sizes[l + 1][2]
     b = 4.0 * batch * (e_in + e_out)
@@ -67,50 +92,90 @@ def algorithmic_bytes(sizes, layers, params, l, batch, fused):
     return b
 
 
-def lookups_per_image(sizes, layers, params, l):
-    """Border-clipped table look-ups of layer l per image (the reference's trip count)."""
-    topo = pkg("topology")
-    ly = layers[l]
-    if ly["type"] == topo.FCNT:
-        return params[l]["ctrd"].shape[0] * ly["nod"]
-    if ly["type"] != topo.CONV:
-        return 0
-    h, w, _ = sizes[l]
-    ho, wo, ct = sizes[l + 1]
-    k, s, p = ly["knl"], ly["stride"], ly["pad"]
-    taps_h = sum(min(k - 1, h - 1 - (o * s - p)) - max(0, -(o * s - p)) + 1 for o in range(ho))
-    taps_w = sum(min(k - 1, w - 1 - (o * s - p)) - max(0, -(o * s - p)) + 1 for o in range(wo))
-    return taps_h * taps_w * params[l]["ctrd"].shape[0] * ct
-
-
-def cpu_baseline(in_chw, layers, params, imgs_host, sample):
-    """Time the CPU path on this host: the compiled reference if present, else the C port."""
+def cpu_side(in_chw, layers, params):
+    """The CPU checker: the compiled reference when present, else the C port.  Returns (kind, forward(img)->
+    (prob, pool-map getter), timer)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle as po
     synth = pkg("synth")
-    imgs = imgs_host[:sample]
     if po.have_ref():
         with tempfile.TemporaryDirectory() as d:
             synth.write_param_dir(d, "bench", params)
             ref = po.RefLib()
             ref.load_custom(d, "bench", in_chw, layers)
-        ref.time_forward(imgs[:2])                      # page in
-        wall, cpu = ref.time_forward(imgs)
-        return dict(value=sample / cpu, unit="images/s", cores=1, kind="reference",
-                    sample="%d images, batch 1 (the reference's own regime), single thread; %.2f s CPU time by the "
-                           "reference's swAllLayers stop-watch (clock()), %.2f s wall; g++ -O2 Makefile.native flags "
-                           "(ATLAS/OpenVML not installed)" % (sample, cpu, wall),
-                    host_cores=os.cpu_count(), ms_per_image=1000.0 * cpu / sample)
+        return "reference", ref, po
     orc = po.COracle(in_chw, layers)
     orc.set_params(params)
-    orc.forward(imgs[:1])
+    return "port", orc, po
+
+
+def parity_check(kind, cpu, layers, imgs_host, gpu_prob, gpu_top5, gpu_fm, fm_idx):
+    """Compare the GPU's outputs for imgs_host with the CPU checker's.  Error = max |a-b| / max |b| per map."""
+    worst_prob = worst_fm = 0.0
+    agree = 0
+    n = imgs_host.shape[0]
+    for i in range(n):
+        if kind == "reference":
+            prob = cpu.forward(imgs_host[i:i + 1])
+            fm = cpu.fm(fm_idx)[0]
+            top5 = cpu.top5()
+        else:
+            cpu.forward(imgs_host[i:i + 1])
+            prob = cpu.fm(len(layers)).reshape(-1)
+            fm = cpu.fm(fm_idx)[0]
+            top5 = cpu.top5(prob)
+        worst_prob = max(worst_prob, float(np.abs(gpu_prob[i] - prob).max() / max(np.abs(prob).max(), 1e-30)))
+        worst_fm = max(worst_fm, float(np.abs(gpu_fm[i] - fm).max() / max(np.abs(fm).max(), 1e-30)))
+        agree += int(np.array_equal(np.asarray(gpu_top5[i], np.uint16), np.asarray(top5, np.uint16)))
+    return dict(images=n, checker=kind, top5_agree=agree, max_rel_err_prob=worst_prob,
+                max_rel_err_fm=worst_fm, fm_checked=fm_idx, tolerance=TOL,
+                ok=bool(agree == n and worst_prob <= TOL and worst_fm <= TOL))
+
+
+def cpu_baseline(kind, cpu, imgs_host):
+    sample = imgs_host.shape[0]
+    if kind == "reference":
+        cpu.time_forward(imgs_host[:2])                      # page in
+        wall, cpu_s = cpu.time_forward(imgs_host)
+        return dict(value=sample / cpu_s, unit="images/s", cores=1, kind="reference",
+                    sample="%d images, batch 1 (the reference's own regime), single thread; %.2f s CPU time by the "
+                           "reference's swAllLayers stop-watch (clock()), %.2f s wall; g++ -O2 Makefile.native flags "
+                           "(ATLAS/OpenVML not installed)" % (sample, cpu_s, wall),
+                    host_cores=os.cpu_count(), ms_per_image=1000.0 * cpu_s / sample)
+    cpu.forward(imgs_host[:1])
     t0 = time.perf_counter()
     for i in range(sample):
-        orc.forward(imgs[i:i + 1])
+        cpu.forward(imgs_host[i:i + 1])
     dt = time.perf_counter() - t0
     return dict(value=sample / dt, unit="images/s", cores=1, kind="port",
                 sample="%d images, batch 1, single thread, oracle/qcnn_oracle.c -O2; %.2f s wall" % (sample, dt),
                 host_cores=os.cpu_count(), ms_per_image=1000.0 * dt / sample)
+
+
+def self_spawn(args):
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks ourselves."""
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < args.gpus:
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible — refusing to report a %d-GPU number"
+                         % (args.gpus, have, args.gpus))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def timed(torch, dev, fn, steps):
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize(dev)
+    return time.perf_counter() - t0
 
 
 def main():
@@ -118,16 +183,22 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=1000, help="images per GPU per step")
+    ap.add_argument("--batch", type=int, default=1000, help="images of one (global) batch")
     ap.add_argument("--model", default="AlexNet")
     ap.add_argument("--lut", default="mfma", choices=["mfma", "exact"])
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="N > 1: strong = one --batch sharded over the GPUs (BASELINE configs[2]); weak = --batch per GPU")
     ap.add_argument("--cpu-sample", type=int, default=100, help="images for the CPU baseline (0 = skip)")
-    ap.add_argument("--h2d-steps", type=int, default=2, help="extra steps timed including pinned-host H2D (0 = skip)")
+    ap.add_argument("--parity-images", type=int, default=8, help="images checked against the CPU reference (0 = skip)")
+    ap.add_argument("--extras", type=int, default=1, help="0 = only the headline measurement")
     ap.add_argument("--streams", type=int, default=1,
                     help="sub-batches of whole panels run concurrently on separate HIP streams (QCNN_OPT_STREAMS; the "
                          "library default is 2).  1 keeps one launch per layer, so that the per-kernel HIP-event "
                          "durations behind `roofline` are those of kernels that own the whole GPU")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_spawn(args)
 
     import torch
     import torch.distributed as dist
@@ -135,21 +206,26 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    if local >= torch.cuda.device_count():
+        raise SystemExit("rank %d: LOCAL_RANK %d but only %d GPU(s) visible" % (rank, local, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    topo, synth, capi = pkg("topology"), pkg("synth"), pkg("capi")
+    topo, synth, capi, dmod, perf = pkg("topology"), pkg("synth"), pkg("capi"), pkg("dist"), pkg("perfmodel")
     in_chw, layers, _, _ = topo.MODELS[args.model]
     sizes = topo.fmap_sizes(in_chw, layers)
     params = synth.make_params(in_chw, layers, seed=0)      # every rank knows the SHAPES; rank 0 owns the VALUES
     B = args.batch
+    strong = world > 1 and args.scaling == "strong"
+    lo, hi = dmod.shard_bounds(B, rank, world) if strong else (0, B)
+    n_local = hi - lo
 
     # one explicit stream for everything (torch ops, H2D copies and the engine's kernels): the default stream's
     # handle is NULL, which the C-ABI reads as "create your own stream" — the copies would then not be ordered
@@ -167,143 +243,264 @@ def main():
     eng.commit(B, arena.data_ptr())
     if rank == 0:
         eng.upload(params)
+    bcast_ms = 0.0
     if world > 1:
-        dist.broadcast(arena, src=0)                        # RCCL over xGMI: codebooks + assignments + biases
         torch.cuda.synchronize(dev)
+        dist.barrier()
+        t0 = time.perf_counter()
+        dist.broadcast(arena, src=0)                        # RCCL over xGMI: codebooks + row-offset tables + biases
+        torch.cuda.synchronize(dev)
+        bcast_ms = 1000.0 * (time.perf_counter() - t0)
     if rank != 0:
         eng.mark_loaded()
 
-    # synthetic device-resident input: 8-bit pixels minus the BGR channel means (range of BmpImgIO's output)
+    # synthetic device-resident input: 8-bit pixels minus the BGR channel means (range of BmpImgIO's output); image i of
+    # the global batch is the same whatever the number of ranks
     g = torch.Generator(device=dev)
-    g.manual_seed(1234 + rank)
-    imgs = torch.randint(0, 256, (B,) + tuple(in_chw), generator=g, device=dev, dtype=torch.int32).to(torch.float32)
+    g.manual_seed(1234)
+    full = torch.randint(0, 256, (B,) + tuple(in_chw), generator=g, device=dev, dtype=torch.int32)
+    imgs = full.to(torch.float32)
+    del full
     imgs -= torch.tensor([104.0, 117.0, 123.0], device=dev)[: in_chw[0]].view(1, -1, 1, 1)
     classes = sizes[-1][0] * sizes[-1][1] * sizes[-1][2]
     prob = torch.empty((B, classes), dtype=torch.float32, device=dev)
     top5 = torch.empty((B, 5), dtype=torch.int16, device=dev)
+    mine = imgs[lo:hi]
 
     def step():
-        eng.forward_dev(imgs.data_ptr(), B, prob.data_ptr(), top5.data_ptr())
+        if n_local > 0:
+            eng.forward_dev(mine.data_ptr(), n_local, prob[lo:hi].data_ptr(), top5[lo:hi].data_ptr())
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize(dev)
-    eng.reset_layer_ms()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    def measure(fn, steps, warmup):
+        for _ in range(warmup):
+            fn()
+        torch.cuda.synchronize(dev)
+        eng.reset_layer_ms()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
 
+    dt = measure(step, args.steps, args.warmup)
     layer_ms, recorded = eng.layer_ms()
-    ok = bool(torch.isfinite(prob).all().item())
+    ok = bool(torch.isfinite(prob[lo:hi]).all().item())
+    images_per_step = B if (strong or world == 1) else B * world
 
-    h2d = h2d_u8 = two_streams = None
-    if args.h2d_steps > 0 and rank == 0 and args.streams == 1:
-        # the library's default execution mode: two sub-batches on two streams (glue kernels of one overlap the
-        # conv tails of the other); reported next to `value`, which stays the one-launch-per-layer measurement
-        eng.set_option(capi.OPT_STREAMS, 2)
+    value_weak = None
+    if world > 1 and strong and args.extras:                 # 1000 images per GPU on top of the sharded batch
         eng.set_option(capi.OPT_PROFILE, 0)
-        step()
-        torch.cuda.synchronize(dev)
-        t3 = time.perf_counter()
-        for _ in range(max(args.h2d_steps, 3)):
+        dtw = measure(lambda: eng.forward_dev(imgs.data_ptr(), B, prob.data_ptr(), top5.data_ptr()), max(2, args.steps // 2), 1)
+        value_weak = world * B * max(2, args.steps // 2) / dtw
+        eng.set_option(capi.OPT_PROFILE, 1)
+
+    extras = {}
+    if args.extras and rank == 0 and world == 1:
+        eng.set_option(capi.OPT_PROFILE, 0)
+        if args.streams == 1:
+            # the library's default execution mode: two sub-batches on two streams
+            eng.set_option(capi.OPT_STREAMS, 2)
             step()
-        torch.cuda.synchronize(dev)
-        two_streams = B * max(args.h2d_steps, 3) / (time.perf_counter() - t3)
-        eng.set_option(capi.OPT_STREAMS, 1)
-    if args.h2d_steps > 0 and rank == 0:
+            extras["value_two_streams"] = round(B * 3 / timed(torch, dev, step, 3), 2)
+            eng.set_option(capi.OPT_STREAMS, 1)
+        # small batches: one image (the reference's own regime) and one 128-image panel (an 8-GPU shard of the batch)
+        for nb, reps, key in ((1, 20, "value_b1"), (128, 10, "value_b128")):
+            if nb <= B:
+                f = lambda nb=nb: eng.forward_dev(imgs.data_ptr(), nb, prob.data_ptr(), top5.data_ptr())
+                f()
+                extras[key] = round(nb * reps / timed(torch, dev, f, reps), 2)
+        # PCIe-inclusive rates (never `value`): every step first brings its batch from pinned host memory.
+        reps = 4
         pinned = torch.empty(imgs.shape, dtype=torch.float32, pin_memory=True)
         pinned.copy_(imgs)
         staging = torch.empty_like(imgs)
-        torch.cuda.synchronize(dev)
-        t1 = time.perf_counter()
-        for _ in range(args.h2d_steps):
+
+        def h2d_f32():
             staging.copy_(pinned, non_blocking=True)
             eng.forward_dev(staging.data_ptr(), B, prob.data_ptr(), top5.data_ptr())
-        torch.cuda.synchronize(dev)
-        h2d = B * args.h2d_steps / (time.perf_counter() - t1)
-        # same with the device-side input pipeline: 8-bit 256x256 source images + mean image, crop on the device
+        h2d_f32()
+        extras["value_incl_pinned_h2d"] = round(B * reps / timed(torch, dev, h2d_f32, reps), 2)
+        del pinned, staging
+        # device-side input pipeline (8-bit 256x256 sources, mean subtraction + crop on the GPU) with the upload of
+        # batch i+1 overlapped with the forward pass of batch i: two staging buffers, a copy stream, two events
         hs, ws = max(in_chw[1], 256), max(in_chw[2], 256)
         px = torch.randint(0, 256, (B, in_chw[0], hs, ws), dtype=torch.uint8)
         pinned_u8 = torch.empty(px.shape, dtype=torch.uint8, pin_memory=True)
         pinned_u8.copy_(px)
-        staging_u8 = torch.empty(px.shape, dtype=torch.uint8, device=dev)
+        stg = [torch.empty(px.shape, dtype=torch.uint8, device=dev) for _ in range(2)]
         mean_img = torch.full((in_chw[0], hs, ws), 110.0, dtype=torch.float32, device=dev)
+        copy_stream = torch.cuda.Stream(device=dev)
+        copied = [torch.cuda.Event() for _ in range(2)]
+        freed = [torch.cuda.Event() for _ in range(2)]
+        used = [False, False]
+
+        def upload(b):
+            with torch.cuda.stream(copy_stream):
+                if used[b % 2]:
+                    copy_stream.wait_event(freed[b % 2])
+                stg[b % 2].copy_(pinned_u8, non_blocking=True)
+                copied[b % 2].record(copy_stream)
+
+        def compute(b):
+            stream.wait_event(copied[b % 2])
+            eng.forward_u8_dev(stg[b % 2].data_ptr(), hs, ws, mean_img.data_ptr(), B, prob.data_ptr(), top5.data_ptr())
+            freed[b % 2].record(stream)
+            used[b % 2] = True
+
+        def pipeline(k):
+            upload(0)
+            for b in range(k):
+                if b + 1 < k:
+                    upload(b + 1)
+                compute(b)
+        pipeline(2)
         torch.cuda.synchronize(dev)
-        t2 = time.perf_counter()
-        for _ in range(args.h2d_steps):
-            staging_u8.copy_(pinned_u8, non_blocking=True)
-            eng.forward_u8_dev(staging_u8.data_ptr(), hs, ws, mean_img.data_ptr(), B, prob.data_ptr(), top5.data_ptr())
+        k = 6
+        t0 = time.perf_counter()
+        pipeline(k)
         torch.cuda.synchronize(dev)
-        h2d_u8 = B * args.h2d_steps / (time.perf_counter() - t2)
+        extras["value_incl_pinned_h2d_u8"] = round(B * k / (time.perf_counter() - t0), 2)
+        extras["h2d_note"] = ("u8: 8-bit sources uploaded on a copy stream while the previous batch computes (double "
+                              "buffered); f32: copy then compute on one stream")
+        del pinned_u8, stg, px
+        eng.set_option(capi.OPT_PROFILE, 1)
+
+    parity = None
+    cb = None
+    if rank == 0 and (args.parity_images > 0 or (args.cpu_sample > 0 and world == 1)):
+        kind, cpu, _ = cpu_side(in_chw, layers, params)
+        if args.parity_images > 0 and n_local > 0:
+            pn = min(args.parity_images, n_local)
+            # re-run the timed configuration on the first images' own batch (same kernels, same mode) and fetch what
+            # the reference is compared with: probabilities, top-5 and the last pooling map
+            step()
+            torch.cuda.synchronize(dev)
+            fm_idx = max(i + 1 for i, l in enumerate(layers) if l["type"] == topo.POOL)
+            parity = parity_check(kind, cpu, layers, mine[:pn].cpu().numpy(), prob[lo:lo + pn].cpu().numpy(),
+                                  top5[lo:lo + pn].cpu().numpy().view(np.uint16), eng.layer_output(fm_idx, pn), fm_idx)
+        if args.cpu_sample > 0 and world == 1:
+            cb = cpu_baseline(kind, cpu, imgs[: args.cpu_sample].cpu().numpy())
+
+    vgg = None
+    if args.extras and rank == 0 and world == 1 and args.model == "AlexNet":
+        # BASELINE.json configs[3]: VGG-16, synthetic parameters in the repo's CaffePara layout, a short run
+        eng.close()
+        del imgs, prob, top5, arena
+        torch.cuda.empty_cache()
+        v_chw, v_layers, _, _ = topo.MODELS["VGG16"]
+        v_params = synth.make_params(v_chw, v_layers, seed=0)
+        v_sizes = topo.fmap_sizes(v_chw, v_layers)
+        vb = 256
+        ve = pkg("engine").QcnnEngine(local, stream.cuda_stream)
+        ve.set_option(capi.OPT_KEEP_ALL, 0)
+        ve.set_option(capi.OPT_PROFILE, 1)
+        ve.set_option(capi.OPT_STREAMS, 1)
+        ve.load_model(v_chw, v_layers, v_params, vb)
+        vi = torch.randint(0, 256, (vb,) + tuple(v_chw), device=dev, dtype=torch.int32).to(torch.float32) - 110.0
+        vp = torch.empty((vb, 1000), dtype=torch.float32, device=dev)
+        vt = torch.empty((vb, 5), dtype=torch.int16, device=dev)
+        vf = lambda: ve.forward_dev(vi.data_ptr(), vb, vp.data_ptr(), vt.data_ptr())
+        vf()
+        torch.cuda.synchronize(dev)
+        ve.reset_layer_ms()
+        vdt = timed(torch, dev, vf, 2)
+        vms, _ = ve.layer_ms()
+        vdom = int(np.argmax(vms))
+        rep = perf.layer_report(v_sizes, v_layers, v_params, vdom, vb, float(vms[vdom]))
+        conv_total = sum(float(vms[i]) for i, l in enumerate(v_layers) if l["type"] == topo.CONV)
+        vgg = dict(value=round(vb * 2 / vdt, 2), unit="images/s", batch=vb, steps=2,
+                   outputs_finite=bool(torch.isfinite(vp).all().item()), conv_ms_per_batch=round(conv_total, 3),
+                   dominant_layer=vdom, dominant_ms=round(float(vms[vdom]), 4), dominant=rep,
+                   parameters="seeded synthetic, conv Cs=8 K=128, fc Cs=4 K=32, classifier Cs=1 K=16")
+        ve.close()
 
     if rank == 0:
         ms_step = 1000.0 * dt / args.steps
-        value = world * B * args.steps / dt
+        value = images_per_step * args.steps / dt
         dom = int(np.argmax(layer_ms))
         dom_ms = float(layer_ms[dom])
         # a layer is launched once per sub-batch (QCNN_OPT_STREAMS): layer_ms is the mean duration of ONE launch,
         # so the algorithmic bytes / look-ups are those of one launch (its share of the panels)
-        panels = (B + 127) // 128
+        panels = (n_local + 127) // 128
         ns = max(1, min(args.streams, panels))
-        launch_images = B / ns
-        abytes = algorithmic_bytes(sizes, layers, params, dom, launch_images, True)
+        launch_images = n_local / ns
+        abytes = algorithmic_bytes(sizes, layers, params, dom, launch_images)
         achieved = abytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        lk = lookups_per_image(sizes, layers, params, dom) * launch_images
-        total_lk = sum(lookups_per_image(sizes, layers, params, l) for l in range(len(layers)))
         conv_idx = [i for i, l in enumerate(layers) if l["type"] == topo.CONV]
         name = "%s%d" % (topo.TYPE_NAMES[layers[dom]["type"]], (conv_idx.index(dom) + 1) if dom in conv_idx else dom)
+        traffic, tsrc = pmc_traffic(dom, ns) if (n_local == 1000 and args.model == "AlexNet") else (None, "batch/model differ from the profiled run")
+        per_layer = {}
+        total_lk = 0
+        for i, l in enumerate(layers):
+            if l["type"] in (topo.CONV, topo.FCNT) and layer_ms[i] > 0:
+                r = perf.layer_report(sizes, layers, params, i, launch_images, float(layer_ms[i]))
+                r["ms"] = round(float(layer_ms[i]), 4)
+                per_layer["%02d_%s" % (i, topo.TYPE_NAMES[l["type"]])] = r
+        for i, l in enumerate(layers):
+            if l["type"] == topo.CONV:
+                total_lk += perf.conv_work(sizes[i], sizes[i + 1], l, *shapes[i])["lookups"]
+            elif l["type"] == topo.FCNT:
+                total_lk += shapes[i][0] * l["nod"]
+        step_bytes = sum(algorithmic_bytes(sizes, layers, params, l, n_local) for l in range(len(layers))
+                         if layer_ms[l] > 0)
         roof = dict(bound="hbm", kernel="k_%s_aprx (layer %d, %s)" % ("conv" if dom in conv_idx else "fc", dom, name),
                     achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(achieved / HBM_PEAK_GBS, 5),
-                    traffic=(pmc_traffic(dom, ns) if (B == 1000 and args.model == "AlexNet") else None),
+                    frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic, traffic_source=tsrc,
                     ms_per_launch=round(dom_ms, 4), launches_timed=recorded * ns, launches_per_step=ns,
-                    images_per_launch=launch_images,
-                    algorithmic_bytes_per_launch=int(abytes),
-                    lds_lookups_per_s=round(lk / (dom_ms * 1e-3), 0) if dom_ms > 0 else 0,
-                    lds_lookup_peak_b64=LDS_B64_LOOKUPS_PER_S,
-                    lds_frac=round(lk / (dom_ms * 1e-3) / LDS_B64_LOOKUPS_PER_S, 4) if dom_ms > 0 else 0,
+                    images_per_launch=launch_images, algorithmic_bytes_per_launch=int(abytes),
+                    whole_step_hbm_frac=round(step_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    lds_frac=per_layer.get("%02d_%s" % (dom, topo.TYPE_NAMES[layers[dom]["type"]]), {}).get("lds_frac"),
+                    lds_read_peak="256 CUs x 256 B/clk x 2.4 GHz (ds_read_b64/b128)",
+                    layers=per_layer,
                     layer_ms={"%02d_%s" % (i, topo.TYPE_NAMES[layers[i]["type"]]): round(float(m), 4)
                               for i, m in enumerate(layer_ms) if m > 0})
+        par = ("one %d-image batch sharded over %d GPU(s) in contiguous blocks, parameters replicated by one RCCL "
+               "broadcast" % (B, world)) if (strong or world == 1) else (
+            "%d images per GPU on %d GPUs, parameters replicated by one RCCL broadcast" % (B, world))
         out = {
             "metric": "images/sec AlexNet quantized forward" if args.model == "AlexNet" else "images/sec %s quantized forward" % args.model,
             "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_step, 4), "higher_is_better": True,
+            "scaling": "strong" if (strong or world == 1) else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s Q-CNN approximate forward (fp32 LUT + uint8 indices), %d synthetic %dx%d images per GPU per step, "
-                                   "device-resident" % (args.model, B, in_chw[1], in_chw[2]),
-                       "images_per_gpu": B, "global_batch": B * world, "lut_builder": args.lut,
-                       "parameters": "seeded synthetic, shipped AlexNet quantisation shapes",
-                       "streams_per_gpu": ns,
-                       "parallelism": "images sharded over %d GPU(s), parameters replicated by one RCCL broadcast" % world},
+            "config": {"workload": "%s Q-CNN approximate forward (fp32 LUT + uint8 indices), one batch of %d synthetic %dx%d "
+                                   "images per step, device-resident" % (args.model, images_per_step, in_chw[1], in_chw[2]),
+                       "global_batch": images_per_step, "images_on_rank0": n_local, "lut_builder": args.lut,
+                       "parameters": "seeded synthetic (seed 0), shipped AlexNet quantisation shapes",
+                       "streams_per_gpu": ns, "parallelism": par},
+            "rccl_ranks": world, "param_broadcast_ms": round(bcast_ms, 3),
             "outputs_finite": ok,
             "lookups_per_image": int(total_lk),
             "lookups_per_s": round(total_lk * value, 0),
             "roofline": roof,
         }
-        if h2d is not None:
-            out["value_incl_pinned_h2d"] = round(h2d, 2)
-            out["value_incl_pinned_h2d_u8"] = round(h2d_u8, 2)
-        if two_streams is not None:
-            out["value_two_streams"] = round(two_streams, 2)
-        if args.cpu_sample > 0 and world == 1:
-            imgs_host = imgs[: args.cpu_sample].cpu().numpy()
-            out["cpu_baseline"] = cpu_baseline(in_chw, layers, params, imgs_host, args.cpu_sample)
-            out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)
+        out.update(extras)
+        if value_weak is not None:
+            out["value_weak"] = round(value_weak, 2)
+        if parity is not None:
+            out["parity"] = parity
+        if vgg is not None:
+            out["value_vgg16"] = vgg["value"]
+            out["vgg16"] = vgg
+        if cb is not None:
+            out["cpu_baseline"] = cb
+            out["speedup_vs_cpu_baseline"] = round(value / cb["value"], 1)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    if rank == 0 and (not ok or (parity is not None and not parity["ok"])):
+        raise SystemExit("bench.py: outputs differ from the CPU reference beyond %g (see `parity`)" % TOL)
 
 
 if __name__ == "__main__":

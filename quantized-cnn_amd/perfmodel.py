@@ -1,0 +1,89 @@
+"""Work counts of the two hot kernels, restated from quantized-cnn_amd/csrc (qk_conv_slots / qk_conv_aprx /
+k_conv_aprx / k_fc_aprx) so that bench.py can turn a measured layer time into the figures DESIGN.md §3 argues
+with: LUT stages built, look-ups per stage, how often every source pixel's table is rebuilt, matrix-pipe and LDS
+read utilisation.  Pure arithmetic — nothing here touches a device.
+"""
+from __future__ import annotations
+
+from .topology import CONV, FCNT
+
+PANEL = 128
+GATHER_WAVES = 12
+CUS = 256
+CLOCK_HZ = 2.4e9                       # MI355X_MICROARCH.md: max shader clock
+F32_MFMA_FLOPS = 157.3e12              # dense f32 matrix peak (v_mfma_f32_16x16x4_f32: 256 FLOP/clk/CU)
+LDS_READ_BYTES_PER_CLK = 256           # per CU (ds_read_b64 / ds_read_b128)
+
+
+def conv_tile(ctg: int):
+    """(TH, TW, channels per gather wave, workgroups along the channel axis) for `ctg` output channels per group."""
+    chunks = (ctg + 383) // 384
+    per = (ctg + chunks - 1) // chunks
+    cpw = 4 if per <= 48 else 6 if per <= 72 else 8 if per <= 96 else 12 if per <= 144 else 16 if per <= 192 else 24 if per <= 288 else 32
+    th, tw = {32: (1, 1), 24: (1, 1), 16: (1, 2), 12: (1, 3), 8: (2, 2), 6: (2, 3), 4: (2, 4)}[cpw]
+    chunks = (ctg + GATHER_WAVES * cpw - 1) // (GATHER_WAVES * cpw)
+    return th, tw, cpw, chunks
+
+
+def stage_group(k: int) -> int:
+    return 128 // k if k <= 64 else 1
+
+
+def conv_work(in_hwc, out_hwc, ly, m: int, k: int, cs: int):
+    """Per 128-image panel: stages built, look-ups (border clipped), ideal stages (every (pixel, sub-space group)
+    once per group), f32 MFMA FLOP issued."""
+    h, w, cin = in_hwc
+    ho, wo, ct = out_hwc
+    knl, s, p, grp = ly["knl"], ly["stride"], ly["pad"], ly["grp"]
+    th, tw, cpw, chunks = conv_tile(ct // grp)
+    g = stage_group(k)
+    mg = (m + g - 1) // g
+    stages = 0
+    for ty in range((ho + th - 1) // th):
+        ho0, hol = ty * th, min(ty * th + th, ho) - 1
+        rows = min(h - 1, hol * s - p + knl - 1) - max(0, ho0 * s - p) + 1
+        for tx in range((wo + tw - 1) // tw):
+            wo0, wol = tx * tw, min(tx * tw + tw, wo) - 1
+            cols = min(w - 1, wol * s - p + knl - 1) - max(0, wo0 * s - p) + 1
+            stages += rows * cols * mg
+    stages *= chunks * grp
+    taps_h = sum(min(knl - 1, h - 1 - (o * s - p)) - max(0, -(o * s - p)) + 1 for o in range(ho))
+    taps_w = sum(min(knl - 1, w - 1 - (o * s - p)) - max(0, -(o * s - p)) + 1 for o in range(wo))
+    lookups = taps_h * taps_w * m * ct                      # per image
+    ideal = h * w * mg * grp
+    ks = 2 if min(cin // grp, cs) > 4 else 1
+    return dict(stages=stages, lookups=lookups, ideal_stages=ideal, mfma_flop=stages * 128 * 128 * 4 * ks * 2,
+                tile="%dx%dx%d" % (th, tw, GATHER_WAVES * cpw), ks=ks)
+
+
+def fc_work(d: int, ct: int, m: int, k: int, cs: int, msplit_chunks: int):
+    g = stage_group(k)
+    stages = (m + g - 1) // g * msplit_chunks
+    ks = 2 if min(d, cs) > 4 else 1
+    return dict(stages=stages, lookups=m * ct, ideal_stages=(m + g - 1) // g, mfma_flop=stages * 128 * 128 * 4 * ks * 2,
+                tile="fc", ks=ks)
+
+
+def layer_report(sizes, layers, params, l: int, images: float, ms: float):
+    """Roofline-style figures of conv/FC layer l for a launch over `images` images that took `ms` milliseconds."""
+    ly = layers[l]
+    mm, kk, cc = (int(x) for x in params[l]["ctrd"].shape)
+    if ly["type"] == CONV:
+        wk = conv_work(sizes[l], sizes[l + 1], ly, mm, kk, cc)
+    elif ly["type"] == FCNT:
+        e = sizes[l][0] * sizes[l][1] * sizes[l][2]
+        cpw = 32 if ly["nod"] >= 384 else (8 if ly["nod"] >= 96 else 4)
+        chunks = (ly["nod"] + GATHER_WAVES * cpw - 1) // (GATHER_WAVES * cpw)
+        wk = fc_work(e, ly["nod"], mm, kk, cc, chunks)
+    else:
+        return None
+    panels = (images + PANEL - 1) // PANEL
+    t = ms * 1e-3
+    stages = wk["stages"] * panels
+    cycles = t * CLOCK_HZ * CUS / stages if stages else 0.0
+    lookups = wk["lookups"] * images
+    return dict(tile=wk["tile"], stages_per_panel=wk["stages"], rebuild_factor=round(wk["stages"] / wk["ideal_stages"], 2),
+                lookups_per_stage=round(wk["lookups"] / wk["stages"], 1),   # row look-ups (128 images each) per built stage
+                stage_cycles=round(cycles, 0),
+                mfma_util=round(wk["mfma_flop"] * panels / t / F32_MFMA_FLOPS, 4) if t > 0 else 0.0,
+                lds_frac=round(lookups * 4 / t / (LDS_READ_BYTES_PER_CLK * CUS * CLOCK_HZ), 4) if t > 0 else 0.0)

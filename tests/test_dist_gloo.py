@@ -98,3 +98,18 @@ def test_two_ranks_equal_single_process():
         assert np.array_equal(prob, want), "rank %d" % rank
         assert np.array_equal(top5, np.stack([orc.top5(p) for p in want]))
         assert csum == params[0]["ctrd"].sum()
+
+
+def test_bench_refuses_a_multi_gpu_run_it_cannot_do():
+    """`python bench.py --gpus 2` outside torch.distributed.run must either start two ranks or fail loudly — never
+    report a one-GPU number as a two-GPU one (there is no GPU in the CPU tier, so it has to fail)."""
+    import subprocess
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs visible: the run would be legitimate")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0
+    assert "GPU(s) visible" in (r.stdout + r.stderr)
+    assert not any(line.startswith("{") for line in r.stdout.splitlines())
