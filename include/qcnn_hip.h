@@ -121,6 +121,8 @@ int qcnn_forward_host(QcnnCtx* ctx, const float* in_nchw_host, int n, float* pro
 /* Feature map l of the last forward, images [0, n), NHWC per image, to host (blocking).
  * Requires QCNN_OPT_KEEP_ALL = 1 for maps that the fast path fuses away. */
 int qcnn_get_layer_output(QcnnCtx* ctx, int l, int n, float* host_out);
+/* Same for images [first, first + n) of the last forward (e.g. one image of the last, ragged panel). */
+int qcnn_get_layer_output_range(QcnnCtx* ctx, int l, int first, int n, float* host_out);
 /* Run layer `layer` alone on n images: in_host is fm[layer] NHWC per image (FC layers: the flat
  * vector in the order the reference consumes it), out_host receives fm[layer+1] (blocking). */
 int qcnn_run_layer(QcnnCtx* ctx, int layer, const float* in_host, int n, float* out_host);

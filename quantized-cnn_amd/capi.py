@@ -68,6 +68,7 @@ def load():
     lib.qcnn_forward_u8.argtypes = [vp, u8p, i, i, f32p, i, f32p, u16p]
     lib.qcnn_forward_host.argtypes = [vp, f32p, i, f32p, u16p]
     lib.qcnn_get_layer_output.argtypes = [vp, i, i, f32p]
+    lib.qcnn_get_layer_output_range.argtypes = [vp, i, i, i, f32p]
     lib.qcnn_run_layer.argtypes = [vp, i, f32p, i, f32p]
     lib.qcnn_get_layer_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(i)]
     lib.qcnn_reset_layer_ms.argtypes = [vp]

@@ -33,6 +33,7 @@ struct FmDims { int h, w, c; };
 
 constexpr int kProfRing = 32;    // forwards whose per-layer events are kept
 constexpr int kMaxStreams = 4;   // sub-batches (streams) of one forward
+constexpr int kMaxFcSplit = 32;  // workgroups along the sub-space axis of an FC layer (partial sums reduced in fixed order)
 constexpr size_t kSlack = 64 * 1024;   // bytes of slack behind every device buffer: the MFMA operand loads are
                                         // unconditional and may read a few rows past the last dim / sub-space
 
@@ -209,20 +210,21 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
         const int stages = (s.M + G - 1) / G;
         // batch-independent choice (a given image must produce the same bits in any batch): the split count
         // that fills 256 CUs best at the design point of 8 panels (1000 images) while every workgroup keeps
-        // >= 24 stages; ties go to fewer splits.  (A grid of chunks x splits x panels workgroups runs in
+        // >= 12 stages (a single panel — one GPU's share of a sharded batch — then still spreads over ~100 CUs); ties
+        // go to fewer splits.  (A grid of chunks x splits x panels workgroups runs in
         // ceil(grid / 256) rounds: 528 workgroups cost as much as 768.)
         const int cpb = qk_fc_channels_per_block(p.Ct);
         const int chunks = (p.Ct + cpb - 1) / cpb;
         int ms = 1;
         double bestFill = 0.0;
-        for (int cand = 1; cand <= 16; ++cand) {
-          if (cand > 1 && stages / cand < 24) break;
+        for (int cand = 1; cand <= kMaxFcSplit; ++cand) {
+          if (cand > 1 && stages / cand < 12) break;
           const int grid = chunks * cand * 8;
           const double fill = (double)grid / (256.0 * ((grid + 255) / 256));
           if (fill > bestFill + 1e-9) { bestFill = fill; ms = cand; }
         }
         const size_t need = (size_t)ms * panels * p.Ct * QCNN_PANEL;
-        const size_t poff = (size_t)16 * p0 * c->fcMaxCt * QCNN_PANEL;    // every sub-batch has its own slab
+        const size_t poff = (size_t)kMaxFcSplit * p0 * c->fcMaxCt * QCNN_PANEL;    // every sub-batch has its own slab
         if (ms > 1 && poff + need <= c->fcPartialElems) { p.msplit = ms; p.partial = c->fcPartial + poff; }
       }
       e = qk_fc_aprx(p, c->lutMode, st);
@@ -494,7 +496,7 @@ int qcnn_model_commit(QcnnCtx* c, int max_batch, void* dev_arena) {
     for (int l = 0; l < c->L; ++l)
       if (c->layers[l].type == QCNN_FCNT) maxCt = std::max<size_t>(maxCt, c->dims[l + 1].c);
     c->fcMaxCt = maxCt;
-    c->fcPartialElems = (size_t)16 * c->maxPanels * maxCt * QCNN_PANEL;
+    c->fcPartialElems = (size_t)kMaxFcSplit * c->maxPanels * maxCt * QCNN_PANEL;
     if (c->fcPartialElems) HIP_TRY(c, hipMalloc(&c->fcPartial, c->fcPartialElems * sizeof(float)));
     if (c->firstFc >= 0 && c->shapes[c->firstFc].hasDmap)
       HIP_TRY(c, hipMalloc(&c->fcFlat, (size_t)c->maxPanels * fm_elems(c, c->firstFc) * QCNN_PANEL * sizeof(float) + kSlack));
@@ -648,6 +650,27 @@ int qcnn_get_layer_output(QcnnCtx* c, int l, int n, float* host_out) {
   hipError_t e = qk_unpack_rows(c->lastFm[l], c->stageOut, n, E, c->stream);
   if (e != hipSuccess) return fail(c, "unpack launch failed: %s", hipGetErrorString(e));
   HIP_TRY(c, hipMemcpyAsync(host_out, c->stageOut, (size_t)n * E * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int qcnn_get_layer_output_range(QcnnCtx* c, int l, int first, int n, float* host_out) {
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (l < 0 || l > c->L) return fail(c, "feature map %d out of range", l);
+  if (first < 0 || n <= 0 || first + n > c->lastN)
+    return fail(c, "images [%d, %d) are not inside the last forward's batch of %d", first, first + n, c->lastN);
+  if ((int)c->lastFm.size() != c->L + 1 || !c->lastFm[l]) return fail(c, "feature map %d is not available", l);
+  if (!c->keepAll && l > 0 && (c->layers[l - 1].type == QCNN_CONV || c->layers[l - 1].type == QCNN_FCNT) &&
+      l < c->L && c->layers[l].type == QCNN_RELU)
+    return fail(c, "feature map %d was fused away (QCNN_OPT_KEEP_ALL = 0)", l);
+  if (ensure_stage(c)) return 1;
+  const size_t E = fm_elems(c, l);
+  const int p0 = first / QCNN_PANEL;                       // whole panels from the one that holds `first`
+  const int cnt = first + n - p0 * QCNN_PANEL;
+  hipError_t e = qk_unpack_rows(c->lastFm[l] + (size_t)p0 * E * QCNN_PANEL, c->stageOut, cnt, (int)E, c->stream);
+  if (e != hipSuccess) return fail(c, "unpack launch failed: %s", hipGetErrorString(e));
+  HIP_TRY(c, hipMemcpyAsync(host_out, c->stageOut + (size_t)(first - p0 * QCNN_PANEL) * E, (size_t)n * E * sizeof(float),
+                            hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return 0;
 }

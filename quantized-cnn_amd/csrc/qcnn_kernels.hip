@@ -25,6 +25,9 @@
 
 #include <float.h>
 
+#include <algorithm>
+#include <atomic>
+
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -860,35 +863,39 @@ __global__ void k_relu(const float4* __restrict__ src, float4* __restrict__ dst,
 // skipped, which leaves s > 0 bit-identical).
 template <int N>
 __global__ __launch_bounds__(256) void k_lrn_stream(const float4* __restrict__ src, float4* __restrict__ dst,
-                                                    size_t pixels, int C, float coeff, float nbet, float ini) {
+                                                    size_t pixels, int C, int segLen, float coeff, float nbet, float ini) {
   constexpr int RAD = (N - 1) / 2;
   const size_t px = blockIdx.x * (size_t)(blockDim.x >> 5) + (threadIdx.x >> 5);
   if (px >= pixels) return;
+  // blockIdx.y = channel segment [cs, ce): few pixels (a single panel of a 13x13 map) would otherwise leave most of
+  // the chip idle.  segLen is a multiple of N, so channel k always lives in ring slot k % N.
+  const int cs = blockIdx.y * segLen, ce = min(C, cs + segLen);
   const int q = threadIdx.x & 31;
   const float4* __restrict__ x = src + px * (size_t)C * 32 + q;
   float4* __restrict__ y = dst + px * (size_t)C * 32 + q;
   const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-  float4 raw[N], sq[N];          // ring: slot (t % N) holds channel t
+  float4 raw[N], sq[N];          // ring: slot (t mod N) holds channel t
 #pragma unroll
   for (int j = 0; j < N; ++j) { raw[j] = zero; sq[j] = zero; }
-  // channels 0 .. RAD-1 enter the window before the first output
+  // channels cs-RAD .. cs+RAD-1 enter the window before the first output of the segment
 #pragma unroll
-  for (int t = 0; t < RAD; ++t) {
-    const float4 v = (t < C) ? x[(size_t)t * 32] : zero;
-    raw[t % N] = v;
-    sq[t % N] = make_float4(__fmul_rn(__fmul_rn(v.x, v.x), coeff), __fmul_rn(__fmul_rn(v.y, v.y), coeff),
-                            __fmul_rn(__fmul_rn(v.z, v.z), coeff), __fmul_rn(__fmul_rn(v.w, v.w), coeff));
+  for (int d = -RAD; d < RAD; ++d) {
+    const int t = cs + d;
+    const float4 v = (t >= 0 && t < C) ? x[(size_t)t * 32] : zero;
+    raw[(d + N) % N] = v;
+    sq[(d + N) % N] = make_float4(__fmul_rn(__fmul_rn(v.x, v.x), coeff), __fmul_rn(__fmul_rn(v.y, v.y), coeff),
+                                  __fmul_rn(__fmul_rn(v.z, v.z), coeff), __fmul_rn(__fmul_rn(v.w, v.w), coeff));
   }
-  for (int c0 = 0; c0 < C; c0 += N) {
+  for (int c0 = cs; c0 < ce; c0 += N) {
 #pragma unroll
     for (int u = 0; u < N; ++u) {
-      const int c = c0 + u;                 // output channel; slot of channel k is (k + N*8) % N = (u + k - c) % N
+      const int c = c0 + u;                 // output channel; slot of channel k is (u + k - c) mod N
       const int tin = c + RAD;              // channel entering the window
       const float4 v = (tin < C) ? x[(size_t)tin * 32] : zero;
       raw[(u + RAD) % N] = v;
       sq[(u + RAD) % N] = make_float4(__fmul_rn(__fmul_rn(v.x, v.x), coeff), __fmul_rn(__fmul_rn(v.y, v.y), coeff),
                                       __fmul_rn(__fmul_rn(v.z, v.z), coeff), __fmul_rn(__fmul_rn(v.w, v.w), coeff));
-      if (c < C) {
+      if (c < ce) {
         float4 sacc = make_float4(ini, ini, ini, ini);
 #pragma unroll
         for (int j = 0; j < N; ++j) {       // window channel c - RAD + j lives in slot (u - RAD + j) mod N
@@ -1202,6 +1209,27 @@ namespace {
 
 inline int panels_of(int n) { return (n + PANEL - 1) / PANEL; }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize has to be raised once per kernel and DEVICE before the 128 KB launch:
+// remember (kernel, device) pairs instead of asking the runtime on every launch.
+hipError_t allow_big_lds(const void* kern, int bytes) {
+  struct Seen { const void* k; std::atomic<unsigned long long> devMask; };
+  static Seen seen[256];
+  static std::atomic<int> used{0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const unsigned long long bit = 1ull << (dev & 63);
+  const int n = used.load(std::memory_order_acquire);
+  for (int i = 0; i < n; ++i)
+    if (seen[i].k == kern && (seen[i].devMask.load(std::memory_order_relaxed) & bit)) return hipSuccess;
+  const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) return e;
+  for (int i = 0; i < n; ++i)
+    if (seen[i].k == kern) { seen[i].devMask.fetch_or(bit); return hipSuccess; }
+  const int slot = used.fetch_add(1);
+  if (slot < 256) { seen[slot].devMask.store(bit); seen[slot].k = kern; }   // a racing duplicate only costs a repeated call
+  return hipSuccess;
+}
+
 template <int TH, int TW, int CPW>
 hipError_t launch_conv(const ConvParams& p, const QkSlots& sl, int lutMode, hipStream_t st) {
   const int tilesX = (p.Wo + TW - 1) / TW, tilesY = (p.Ho + TH - 1) / TH;
@@ -1214,8 +1242,7 @@ hipError_t launch_conv(const ConvParams& p, const QkSlots& sl, int lutMode, hipS
   if (lutMode == 1 && p.K == 64) kern = two ? k_conv_aprx<TH, TW, CPW, 4, 2> : k_conv_aprx<TH, TW, CPW, 4, 1>;
   if (lutMode == 1 && p.K == 32) kern = two ? k_conv_aprx<TH, TW, CPW, 2, 2> : k_conv_aprx<TH, TW, CPW, 2, 1>;
   if (lutMode == 1 && p.K == 16) kern = two ? k_conv_aprx<TH, TW, CPW, 1, 2> : k_conv_aprx<TH, TW, CPW, 1, 1>;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)shm);
+  hipError_t e = allow_big_lds(reinterpret_cast<const void*>(kern), (int)shm);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, grid, dim3(NW * 64), shm, st, p, tilesX, tilesY, sl.chunks, G, sl.rowStride);
   return hipGetLastError();
@@ -1234,8 +1261,7 @@ hipError_t launch_fc(const FcParams& p, const QkSlots& sl, int lutMode, hipStrea
   if (lutMode == 1 && p.K == 64) kern = two ? k_fc_aprx<CPW, 4, 2> : k_fc_aprx<CPW, 4, 1>;
   if (lutMode == 1 && p.K == 32) kern = two ? k_fc_aprx<CPW, 2, 2> : k_fc_aprx<CPW, 2, 1>;
   if (lutMode == 1 && p.K == 16) kern = two ? k_fc_aprx<CPW, 1, 2> : k_fc_aprx<CPW, 1, 1>;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)shm);
+  hipError_t e = allow_big_lds(reinterpret_cast<const void*>(kern), (int)shm);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, grid, dim3(NW * 64), shm, st, p, G, stagesPerSplit, sl.rowStride);
   return hipGetLastError();
@@ -1310,13 +1336,18 @@ hipError_t qk_lrn(const float* src, float* dst, int panels, int HW, int C, int l
   const float coeff = alp / lrnSiz;   // float / int, as src/CaffeEva.cc:1055
   if (lrnSiz == 5 || lrnSiz == 3) {   // streaming kernel: 8 pixels per block
     const size_t pixels = (size_t)panels * HW;
-    const dim3 grid((unsigned)((pixels + 7) / 8));
+    const size_t blocks = (pixels + 7) / 8;
+    // channel segments (blockIdx.y) until ~8 blocks per CU exist; a segment keeps >= 4 window lengths of channels
+    int segs = (int)std::min<size_t>((2048 + blocks - 1) / blocks, (size_t)std::max(1, C / (4 * lrnSiz)));
+    int segLen = ((C + segs - 1) / segs + lrnSiz - 1) / lrnSiz * lrnSiz;
+    segs = (C + segLen - 1) / segLen;
+    const dim3 grid((unsigned)blocks, (unsigned)segs);
     if (lrnSiz == 5)
       hipLaunchKernelGGL(k_lrn_stream<5>, grid, dim3(256), 0, st, reinterpret_cast<const float4*>(src),
-                         reinterpret_cast<float4*>(dst), pixels, C, coeff, -bet, ini);
+                         reinterpret_cast<float4*>(dst), pixels, C, segLen, coeff, -bet, ini);
     else
       hipLaunchKernelGGL(k_lrn_stream<3>, grid, dim3(256), 0, st, reinterpret_cast<const float4*>(src),
-                         reinterpret_cast<float4*>(dst), pixels, C, coeff, -bet, ini);
+                         reinterpret_cast<float4*>(dst), pixels, C, segLen, coeff, -bet, ini);
     return hipGetLastError();
   }
   const int blocks = (int)((rows + 3) / 4 < 8192 ? (rows + 3) / 4 : 8192);

@@ -130,6 +130,12 @@ class QcnnEngine:
         self._chk(self.lib.qcnn_get_layer_output(self.h, l, n, out.ctypes.data))
         return out
 
+    def layer_output_range(self, l: int, first: int, n: int):
+        h, w, c = self.fm_dims(l)
+        out = np.empty((n, h, w, c), np.float32)
+        self._chk(self.lib.qcnn_get_layer_output_range(self.h, l, first, n, out.ctypes.data))
+        return out
+
     def run_layer(self, l: int, x, n: int):
         x = np.ascontiguousarray(x, np.float32)
         h, w, c = self.fm_dims(l + 1)

@@ -4,7 +4,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/prof
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $R/bench.py --steps 5 --warmup 2 --cpu-sample 0 --h2d-steps 0 ${BENCH_EXTRA:-}"
+BENCH="python $R/bench.py --steps 5 --warmup 2 --extras 0 --cpu-sample 0 --parity-images 0 ${BENCH_EXTRA:-}"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $BENCH > $OUT/trace_bench.json 2> $OUT/trace.err
 pmc() { n=$1; shift; timeout 600 rocprofv3 --pmc "$@" --output-format csv -d $OUT/$n -o $n -- $BENCH > /dev/null 2> $OUT/$n.err; }
 pmc pmc1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU

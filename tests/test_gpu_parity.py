@@ -234,6 +234,70 @@ def test_alexnet_full_batch_properties():
         assert np.array_equal(top5[i], orc.top5(ref[j]))
 
 
+def test_alexnet_last_ragged_panel_layer_for_layer():
+    """Batch of 1000 = 7 full panels + 104 images: every feature map of an image of the LAST (ragged) panel and of
+    one in the middle, layer for layer against the oracle (layer-for-layer mode, so every map exists)."""
+    in_chw, layers, _, _ = topo.MODELS["AlexNet"]
+    params = synth.make_params(in_chw, layers, seed=7)
+    imgs = synth.make_images(1000, in_chw, seed=10)
+    eng = make_engine(in_chw, layers, params, 1000, lut=capi.LUT_MFMA, keep_all=1)
+    eng.forward_host(imgs, want_prob=False, want_top5=False)
+    orc = po.COracle(in_chw, layers)
+    orc.set_params(params)
+    pick = [999, 897, 500]
+    orc.forward(imgs[pick])
+    for l in range(len(layers) + 1):
+        for j, i in enumerate(pick):
+            e_inf, e_l2 = rel_err(eng.layer_output_range(l, i, 1)[0], orc.fm(l)[j])
+            assert e_inf <= TOL and e_l2 <= TOL, "image %d fm[%d]: %g %g" % (i, l, e_inf, e_l2)
+    eng.close()
+
+
+def test_fallback_glue_kernels():
+    """The general LRN kernel (window sizes other than 3 and 5) and the one-thread-per-image soft-max / top-5 (more
+    classes than fit an LDS tile) against the oracle."""
+    layers = [topo.conv(1, 3, 32, 1, 1), topo.relu(), topo.lorn(7, 0.0002, 0.75, 1.5), topo.pool(0, 2, 2),
+              topo.fcnt(1400), topo.smax()]
+    in_chw = (3, 8, 8)
+    params = synth.make_params(in_chw, layers, seed=77)
+    imgs = synth.make_images(131, in_chw, seed=78)
+    orc = po.COracle(in_chw, layers)
+    orc.set_params(params)
+    orc.forward(imgs)
+    eng = make_engine(in_chw, layers, params, 131, lut=capi.LUT_EXACT)
+    prob, top5 = eng.forward_host(imgs)
+    for l in range(len(layers) + 1):
+        e_inf, e_l2 = rel_err(eng.layer_output(l, 131), orc.fm(l))
+        assert e_inf <= TOL_LIBM and e_l2 <= TOL_LIBM, "fm[%d]: %g %g" % (l, e_inf, e_l2)
+    L = len(layers)
+    assert np.array_equal(top5, np.stack([orc.top5(orc.fm(L)[i]) for i in range(131)]))
+    eng.close()
+
+
+def test_vgg16_two_panel_batch():
+    """BASELINE.json configs[3] beyond one panel: 130 images (one full panel + 2).  The oracle needs ~10 s per VGG-16
+    image, so: image 129 of the batch must equal the same image run alone bit for bit (batch invariance), and that
+    single-image run is checked against the oracle."""
+    in_chw, layers, _, _ = topo.MODELS["VGG16"]
+    params = synth.make_params(in_chw, layers, seed=51)
+    imgs = synth.make_images(130, in_chw, seed=54)
+    eng = make_engine(in_chw, layers, params, 130, lut=capi.LUT_MFMA, keep_all=0)
+    prob, top5 = eng.forward_host(imgs)
+    assert np.isfinite(prob).all() and np.abs(prob.sum(axis=1) - 1.0).max() < 1e-4
+    p1, t1 = eng.forward_host(imgs[129:130])
+    assert np.array_equal(p1[0], prob[129]) and np.array_equal(t1[0], top5[129])
+    p0, t0 = eng.forward_host(imgs[0:1])
+    assert np.array_equal(p0[0], prob[0])
+    orc = po.COracle(in_chw, layers)
+    orc.set_params(params)
+    orc.forward(imgs[129:130])
+    ref = orc.fm(len(layers)).reshape(-1)
+    e_inf, e_l2 = rel_err(prob[129], ref)
+    assert e_inf <= TOL and e_l2 <= TOL, "%g %g" % (e_inf, e_l2)
+    assert np.array_equal(top5[129], orc.top5(ref))
+    eng.close()
+
+
 # ---------------------------------------------------------------- dispatch coverage ----
 def _run_vs_oracle(in_chw, layers, spec_kw, n_img, seed):
     spec = synth.quant_spec(in_chw, layers, **spec_kw)
