@@ -185,7 +185,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=1000, help="images of one (global) batch")
     ap.add_argument("--model", default="AlexNet")
-    ap.add_argument("--lut", default="mfma", choices=["mfma", "exact"])
+    ap.add_argument("--lut", default="mfma", choices=["mfma", "exact", "bf16"],
+                    help="LUT builder: f32 MFMA (default), exact VALU (bit-identical conv/FC), bf16 = opt-in bf16-pair MFMA for the 8-dim conv layers")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="N > 1: strong = one --batch sharded over the GPUs (BASELINE configs[2]); weak = --batch per GPU")
     ap.add_argument("--cpu-sample", type=int, default=100, help="images for the CPU baseline (0 = skip)")
@@ -233,7 +234,7 @@ def main():
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
     eng = pkg("engine").QcnnEngine(local, stream.cuda_stream)
-    eng.set_option(capi.OPT_LUT_MODE, capi.LUT_MFMA if args.lut == "mfma" else capi.LUT_EXACT)
+    eng.set_option(capi.OPT_LUT_MODE, {"mfma": capi.LUT_MFMA, "exact": capi.LUT_EXACT, "bf16": capi.LUT_MFMA_BF16X2}[args.lut])
     eng.set_option(capi.OPT_KEEP_ALL, 0)
     eng.set_option(capi.OPT_PROFILE, 1)
     eng.set_option(capi.OPT_STREAMS, args.streams)
@@ -306,6 +307,7 @@ def main():
         eng.set_option(capi.OPT_PROFILE, 1)
 
     extras = {}
+    bf_prob = None
     if args.extras and rank == 0 and world == 1:
         eng.set_option(capi.OPT_PROFILE, 0)
         if args.streams == 1:
@@ -314,6 +316,13 @@ def main():
             step()
             extras["value_two_streams"] = round(B * 3 / timed(torch, dev, step, 3), 2)
             eng.set_option(capi.OPT_STREAMS, 1)
+        # opt-in bf16-pair LUT builder for the 8-dim conv layers (QCNN_OPT_LUT_MODE = 3): rate and its own parity figures
+        if args.lut == "mfma":
+            eng.set_option(capi.OPT_LUT_MODE, capi.LUT_MFMA_BF16X2)
+            step()
+            extras["value_bf16_pairs"] = round(B * 3 / timed(torch, dev, step, 3), 2)
+            bf_prob = prob[: args.parity_images].cpu().numpy() if args.parity_images > 0 else None
+            eng.set_option(capi.OPT_LUT_MODE, capi.LUT_MFMA)
         # small batches: one image (the reference's own regime) and one 128-image panel (an 8-GPU shard of the batch)
         for nb, reps, key in ((1, 20, "value_b1"), (128, 10, "value_b128")):
             if nb <= B:
@@ -389,6 +398,10 @@ def main():
             fm_idx = max(i + 1 for i, l in enumerate(layers) if l["type"] == topo.POOL)
             parity = parity_check(kind, cpu, layers, mine[:pn].cpu().numpy(), prob[lo:lo + pn].cpu().numpy(),
                                   top5[lo:lo + pn].cpu().numpy().view(np.uint16), eng.layer_output(fm_idx, pn), fm_idx)
+            if bf_prob is not None:                      # the opt-in builder's probabilities against the same reference
+                ref = prob[lo:lo + pn].cpu().numpy()
+                extras["bf16_pairs_max_rel_diff_vs_f32_builder"] = float(
+                    max(np.abs(bf_prob[i] - ref[i]).max() / np.abs(ref[i]).max() for i in range(pn)))
         if args.cpu_sample > 0 and world == 1:
             cb = cpu_baseline(kind, cpu, imgs[: args.cpu_sample].cpu().numpy())
 

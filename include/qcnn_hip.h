@@ -58,7 +58,10 @@ enum {
                               bit-identical to the reference's -O2 native build); 1 = MFMA
                               (v_mfma_f32_16x16x4_f32, fused multiply-add chain; default); 2 = as 1 with every
                               table entry rounded to fp16 before it is stored (accumulation stays fp32): the
-                              tolerance study of BASELINE.json configs[4], not a faster path */
+                              tolerance study of BASELINE.json configs[4], not a faster path; 3 = as 1, but the conv
+                              layers with K = 128 and 5..8 dims per sub-space build their tables with ONE
+                              v_mfma_f32_16x16x32_bf16 per tile on operands split in two bf16 parts (16 mantissa
+                              bits per operand, fp32 accumulation and fp32 table entries): opt-in, ~1e-5 per layer */
   QCNN_OPT_KEEP_ALL = 1,   /* 1 = every layer writes its own feature map (layer-for-layer dumps, default);
                               0 = fast path: ReLU fused into the producing conv/FC epilogue */
   QCNN_OPT_PROFILE = 2,    /* 1 = bracket every layer launch with HIP events (qcnn_get_layer_ms) */

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("QCNN_HIP_LIB") or os.path.join(PKG, "libqcnn_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(PKG), "include", "qcnn_hip.h")
 
 OPT_LUT_MODE, OPT_KEEP_ALL, OPT_PROFILE, OPT_STREAMS = 0, 1, 2, 3
-LUT_EXACT, LUT_MFMA, LUT_MFMA_F16 = 0, 1, 2
+LUT_EXACT, LUT_MFMA, LUT_MFMA_F16, LUT_MFMA_BF16X2 = 0, 1, 2, 3
 
 
 class QcnnLayerDesc(C.Structure):

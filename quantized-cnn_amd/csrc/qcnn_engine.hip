@@ -24,6 +24,8 @@ std::string g_createError = "";
 struct LayerShape {
   int M = 0, K = 0, Cs = 0;
   size_t offBias = 0, offCtrd = 0, offAsmt = 0, offDmap = 0;   // byte offsets into the arena
+  size_t offCtrd2 = 0;                                         // bf16-pair split of the code book (0 bytes when not applicable)
+  bool hasCtrd2 = false;
   size_t asmtBytes = 0;
   bool hasDmap = false;
   bool loaded = false;
@@ -119,6 +121,9 @@ int plan_arena(QcnnCtx* c) {
     const int Ct = c->dims[l + 1].c;
     s.offBias = off; off = align_up(off + sizeof(float) * Ct, 256);
     s.offCtrd = off; off = align_up(off + sizeof(float) * (size_t)s.M * s.Cs * s.K, 256);
+    // conv layers with K = 128 and more than 4 dims per sub-space can run the bf16-pair builder (QCNN_OPT_LUT_MODE = 3)
+    s.hasCtrd2 = d.type == QCNN_CONV && s.K == 128 && std::min(c->dims[l].c / d.grpCnt, s.Cs) > 4;
+    if (s.hasCtrd2) { s.offCtrd2 = off; off = align_up(off + qk_ctrd2_bytes(s.M), 256); }
     // row-offset table: uint16 entries in the order the gather waves consume them (QkSlots, qcnn_kernels.h)
     const QkSlots sl = (d.type == QCNN_CONV) ? qk_conv_slots(Ct / d.grpCnt, d.grpCnt) : qk_fc_slots(Ct);
     const size_t taps = (d.type == QCNN_CONV) ? (size_t)d.knlSiz * d.knlSiz : 1;
@@ -179,6 +184,7 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
       p.src = src; p.dst = dst;
       p.bias = reinterpret_cast<const float*>(c->arena + s.offBias);
       p.ctrd = reinterpret_cast<const float*>(c->arena + s.offCtrd);
+      p.ctrd2 = s.hasCtrd2 ? c->arena + s.offCtrd2 : nullptr;
       p.rows = reinterpret_cast<const uint16_t*>(c->arena + s.offAsmt);
       p.H = a.h; p.W = a.w; p.Cin = a.c; p.Ho = b.h; p.Wo = b.w; p.Ct = b.c;
       p.knl = d.knlSiz; p.stride = d.stride; p.pad = d.padSiz; p.grp = d.grpCnt;
@@ -386,7 +392,7 @@ int qcnn_ctx_destroy(QcnnCtx* c) {
 
 int qcnn_set_option(QcnnCtx* c, int option, int value) {
   switch (option) {
-    case QCNN_OPT_LUT_MODE: if (value < 0 || value > 2) return fail(c, "LUT mode must be 0, 1 or 2"); c->lutMode = value; return 0;
+    case QCNN_OPT_LUT_MODE: if (value < 0 || value > 3) return fail(c, "LUT mode must be 0, 1, 2 or 3"); c->lutMode = value; return 0;
     case QCNN_OPT_KEEP_ALL: c->keepAll = value ? 1 : 0; return 0;
     case QCNN_OPT_PROFILE: c->profile = value ? 1 : 0; return 0;
     case QCNN_OPT_STREAMS:
@@ -558,6 +564,29 @@ int qcnn_model_set_layer_params(QcnnCtx* c, int layer, const float* bias, const 
         if (v >= K) return fail(c, "layer %d: assignment %u >= K = %d", layer, (unsigned)v, K);
         asmt[(t * M + m) * sl.rowStride + entry] = qcnn_row_offset((m % G) * K + v);
       }
+  }
+  // bf16-pair split of the code book in v_mfma_f32_16x16x32_bf16 A-operand order: [m][row tile][k-slice g][row][dim],
+  // slices 0/1 = leading part a1 = bf16(c), slices 2/3 = remainder a2 = bf16(c - a1) (round to nearest even)
+  std::vector<uint16_t> split;
+  if (s.hasCtrd2) {
+    auto toBf16 = [](float f) -> uint16_t {
+      uint32_t u; memcpy(&u, &f, 4);
+      if ((u & 0x7f800000u) == 0x7f800000u) return (uint16_t)(u >> 16);        // inf / nan: truncate
+      return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+    };
+    auto fromBf16 = [](uint16_t h) -> float { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; };
+    split.assign(qk_ctrd2_bytes(M) / sizeof(uint16_t), 0);
+    for (int m = 0; m < M; ++m)
+      for (int i = 0; i < 8; ++i)
+        for (int g4 = 0; g4 < 4; ++g4)
+          for (int row = 0; row < 16; ++row)
+            for (int dd = 0; dd < 8; ++dd) {
+              const float cv = dd < Cs ? ctrd[((size_t)m * Cs + dd) * K + i * 16 + row] : 0.0f;
+              const uint16_t a1 = toBf16(cv);
+              const uint16_t a2 = toBf16(cv - fromBf16(a1));
+              split[((((size_t)m * 8 + i) * 4 + g4) * 16 + row) * 8 + dd] = (g4 < 2) ? a1 : a2;
+            }
+    HIP_TRY(c, hipMemcpyAsync(c->arena + s.offCtrd2, split.data(), split.size() * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
   }
   HIP_TRY(c, hipMemcpyAsync(c->arena + s.offBias, bias, sizeof(float) * Ct, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipMemcpyAsync(c->arena + s.offCtrd, ctrd.data(), sizeof(float) * ctrd.size(), hipMemcpyHostToDevice, c->stream));

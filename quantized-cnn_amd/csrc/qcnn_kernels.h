@@ -79,6 +79,8 @@ struct ConvParams {
   float* dst;            // [panels][Ho*Wo*Ct][128]
   const float* bias;     // [Ct]
   const float* ctrd;     // [M][Cs][K]      (PrepCtrdBuf layout, src/CaffeEva.cc:556-557)
+  const void* ctrd2;     // [M][8 row tiles][4 k-slices][16 rows][8 bf16]: code book split in two bf16 parts (slices 0, 1:
+                         // leading part, 2, 3: remainder) in v_mfma_f32_16x16x32_bf16 operand order; K = 128 layers only, else NULL
   const uint16_t* rows;  // [kh][kw][M][rowStride] (PrepAsmtBuf order, src/CaffeEva.cc:585-586): row offsets, QkSlots order
   int H, W, Cin, Ho, Wo, Ct;
   int knl, stride, pad, grp;
@@ -102,7 +104,10 @@ struct FcParams {
   int lutF16;            // as ConvParams::lutF16
 };
 
-// lutMode: 0 exact VALU, 1 MFMA (2 = MFMA with fp16-rounded table entries, see lutF16).  Return hipError_t of the launch.
+// lutMode: 0 exact VALU, 1 f32 MFMA (2 = f32 MFMA with fp16-rounded table entries, see lutF16), 3 = bf16-pair MFMA for
+// the conv layers with K = 128 and more than 4 dims per sub-space (every other layer as mode 1).  Return hipError_t of the launch.
+// bytes of ConvParams::ctrd2 for M sub-spaces
+static inline size_t qk_ctrd2_bytes(int M) { return (size_t)M * 8 * 4 * 16 * 16; }
 hipError_t qk_conv_aprx(const ConvParams& p, int lutMode, hipStream_t st);
 hipError_t qk_fc_aprx(const FcParams& p, int lutMode, hipStream_t st);
 int qk_fc_channels_per_block(int Ct);   // output channels one k_fc_aprx workgroup covers

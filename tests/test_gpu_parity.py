@@ -447,6 +447,34 @@ def test_fp16_lut_tolerance_study(golden_alex_syn):
     assert agree >= 0.8
 
 
+@pytest.mark.parametrize("model,n_img", [("AlexNet", 2), ("VGG16", 1)])
+def test_bf16_pair_builder_within_tolerance(model, n_img):
+    """QCNN_OPT_LUT_MODE = 3: the conv layers with K = 128 and 8-dim sub-spaces build their tables with one
+    v_mfma_f32_16x16x32_bf16 per tile on operands split in two bf16 parts (opt-in).  Every feature map stays inside
+    the north-star tolerance (1e-4 relative, max-norm and l2) against the oracle; the measured errors are printed.
+    VGG-16 (13 such layers in a row) is the stress case."""
+    in_chw, layers, _, _ = topo.MODELS[model]
+    params = synth.make_params(in_chw, layers, seed=7)
+    imgs = synth.make_images(n_img, in_chw, seed=8)
+    orc = po.COracle(in_chw, layers)
+    orc.set_params(params)
+    orc.forward(imgs)
+    eng = make_engine(in_chw, layers, params, n_img, lut=capi.LUT_MFMA_BF16X2)
+    prob, top5 = eng.forward_host(imgs)
+    rows = []
+    for l in range(len(layers) + 1):
+        e_inf, e_l2 = rel_err(eng.layer_output(l, n_img), orc.fm(l))
+        rows.append((l, e_inf, e_l2))
+    print("%s, bf16-pair builder, relative error per feature map (max-norm / l2): " % model +
+          " ".join("fm%d=%.1e/%.1e" % r for r in rows if r[1] > 0))
+    assert max(r[1] for r in rows) > 2e-7                                      # the mode is really in use
+    for l, e_inf, e_l2 in rows:
+        assert e_inf <= TOL and e_l2 <= TOL, "%s fm[%d]: %g %g" % (model, l, e_inf, e_l2)
+    L = len(layers)
+    assert np.array_equal(top5, np.stack([orc.top5(orc.fm(L)[i]) for i in range(n_img)]))
+    eng.close()
+
+
 def test_result_does_not_depend_on_the_number_of_streams(golden_tiny):
     """QCNN_OPT_STREAMS cuts a forward into sub-batches of whole panels on concurrent HIP streams: same bits."""
     z = golden_tiny
