@@ -122,6 +122,10 @@ class COracle:
         self.lib.qo_top5(p, p.size, out)
         return out
 
+    def study_mode(self, lut_f16: bool, acc_f16: bool):
+        """Tolerance study switches (process-wide!): always reset to (False, False) afterwards."""
+        self.lib.qo_study_mode(int(bool(lut_f16)), int(bool(acc_f16)))
+
 
 class _Quiet:
     """Silence the reference's printf chatter (fd 1) around a call; bench.py prints ONE JSON line."""

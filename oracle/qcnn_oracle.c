@@ -19,6 +19,32 @@ int qo_pool_out(int in, int knl, int stride, int pad) {
   return (int)ceil((in + 2 * pad - knl) / (double)stride) + 1;
 }
 
+/* ---- tolerance study of BASELINE.json configs[4] (fp16 LUT storage / accumulation) -------------------------
+ * NOT part of the restatement: with both switches at 0 (the default, and the only setting the parity tests
+ * use) every function below is the reference's arithmetic.  qo_study_mode(1, 0) rounds every table entry to
+ * fp16 when it is stored (what a half-size LDS table would hold); qo_study_mode(1, 1) additionally keeps the
+ * running sums of the look-up loops in fp16 (rounded after every addition; the bias start value too). */
+static int g_lutF16 = 0, g_accF16 = 0;
+void qo_study_mode(int lutF16, int accF16) { g_lutF16 = lutF16; g_accF16 = accF16; }
+/* round-to-nearest-even to IEEE binary16 and back (gcc 11 has no _Float16 on x86-64): 10 mantissa bits for normal
+ * halves (|v| >= 2^-14), a fixed quantum of 2^-24 below that, infinity beyond 65504 + half a step */
+static float rnd16(float v) {
+  if (v != v) return v;
+  const float a = fabsf(v);
+  if (a >= 65520.0f) return v < 0 ? -INFINITY : INFINITY;
+  if (a < 6.103515625e-05f) {                       /* subnormal half range: multiples of 2^-24 */
+    const float q = 5.9604644775390625e-08f;
+    return nearbyintf(v / q) * q;                  /* default rounding mode = nearest even */
+  }
+  uint32_t u;
+  memcpy(&u, &v, 4);
+  u += 0x00000fffu + ((u >> 13) & 1u);             /* keep 10 of the 23 mantissa bits, ties to even */
+  u &= 0xffffe000u;
+  float r;
+  memcpy(&r, &u, 4);
+  return r;
+}
+
 /* src/CaffeEva.cc:1261-1296.  Table entry = ((0 + x0*c0) + x1*c1) + ... over the CsEff dims that
  * exist (:1277); saxpy is y += a*x with a rounded product (include/BlasWrapper.h:164-184). */
 void qo_lut_build(const float* data, int P, int D, const float* ctrd, int M, int Cs, int K, float* lut) {
@@ -37,6 +63,8 @@ void qo_lut_build(const float* data, int P, int D, const float* ctrd, int M, int
           y[k] = y[k] + prod;
         }
       }
+      if (g_lutF16)
+        for (int k = 0; k < K; ++k) y[k] = rnd16(y[k]);
     }
   }
 }
@@ -62,12 +90,17 @@ void qo_conv_aprx(const float* src, int B, int H, int W, int Cin, int knl, int s
         for (int b = 0; b < B; ++b) {
           float* o = dst + (((size_t)b * Ho + ho) * Wo + wo) * Ct + c0;
           memcpy(o, bias + c0, sizeof(float) * Ctg);                     /* :834 */
+          if (g_accF16)
+            for (int c = 0; c < Ctg; ++c) o[c] = rnd16(o[c]);
           for (int kh = khL; kh <= khU; ++kh) {
             for (int kw = kwL; kw <= kwU; ++kw) {
               const float* t = lutScratch + (((size_t)b * H + (hs + kh)) * W + (ws + kw)) * M * K;
               const uint8_t* a = asmt + ((size_t)(kh * knl + kw) * M) * Ct + c0;
               for (int m = 0; m < M; ++m) {
-                for (int c = 0; c < Ctg; ++c) o[c] = o[c] + t[a[c]];      /* :849-858 */
+                if (g_accF16)
+                  for (int c = 0; c < Ctg; ++c) o[c] = rnd16(o[c] + t[a[c]]);
+                else
+                  for (int c = 0; c < Ctg; ++c) o[c] = o[c] + t[a[c]];    /* :849-858 */
                 t += K;
                 a += Ct;
               }
@@ -89,8 +122,13 @@ void qo_fc_aprx(const float* src, int B, int D, int Ct, const float* bias, const
     memcpy(o, bias, sizeof(float) * Ct);
     const float* t = lutScratch + (size_t)b * M * K;
     const uint8_t* a = asmt;
+    if (g_accF16)
+      for (int c = 0; c < Ct; ++c) o[c] = rnd16(o[c]);
     for (int m = 0; m < M; ++m) {
-      for (int c = 0; c < Ct; ++c) o[c] = o[c] + t[a[c]];
+      if (g_accF16)
+        for (int c = 0; c < Ct; ++c) o[c] = rnd16(o[c] + t[a[c]]);
+      else
+        for (int c = 0; c < Ct; ++c) o[c] = o[c] + t[a[c]];
       t += K;
       a += Ct;
     }

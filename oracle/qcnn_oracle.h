@@ -27,6 +27,9 @@ typedef struct {
   float lrnAlp, lrnBet, lrnIni, drpRat;
 } QoLayer; /* field meaning = LayerInfo, include/CaffePara.h:28-44 */
 
+/* tolerance study only (BASELINE.json configs[4]): fp16-rounded table entries / fp16 running sums; (0, 0) = reference */
+void qo_study_mode(int lutF16, int accF16);
+
 /* ---- single functions (each mirrors one reference routine) ---- */
 
 /* CaffeEva::GetInPdMat, src/CaffeEva.cc:1261-1296.  data [P][D], ctrd [M][Cs][K] -> lut [P][M][K] */

@@ -1,0 +1,56 @@
+"""BASELINE.json configs[4] — "AlexNet quantized with fp16 LUT accumulate (tolerance study vs fp32 reference)".
+
+A numerical study on the CPU oracle (no GPU needed: rounding is rounding): the reference's arithmetic with (a) every
+table entry rounded to fp16 when stored, fp32 running sums, and (b) fp16 entries AND fp16 running sums (rounded
+after every addition), each against the plain fp32 forward pass, per feature map, relative to the map's largest
+magnitude.  The GPU tier measures variant (a) on the HIP path itself (QCNN_OPT_LUT_MODE = 2,
+test_fp16_lut_tolerance_study); the two agree.  Outcome: (a) is 1e-4 .. 5e-4 — outside the 1e-4
+parity bar, (b) is 1e-3 .. 1e-2 with top-5 changes; neither is offered as a fast path."""
+import numpy as np
+
+import pyoracle as po
+from conftest import pkg
+
+topo = pkg("topology")
+synth = pkg("synth")
+
+
+def _errors(a, b):
+    a = a.astype(np.float64).reshape(-1)
+    b = b.astype(np.float64).reshape(-1)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def test_fp16_storage_and_accumulate_study(capsys):
+    in_chw, layers, _, _ = topo.MODELS["AlexNet"]
+    params = synth.make_params(in_chw, layers, seed=7)
+    imgs = synth.make_images(2, in_chw, seed=8)
+    orc = po.COracle(in_chw, layers)
+    orc.set_params(params)
+    L = len(layers)
+    try:
+        orc.study_mode(False, False)
+        orc.forward(imgs)
+        ref = [orc.fm(l) for l in range(L + 1)]
+        rows = {}
+        tops = {}
+        for name, mode in (("f16 LUT, f32 sums", (True, False)), ("f16 LUT, f16 sums", (True, True))):
+            orc.study_mode(*mode)
+            orc.forward(imgs)
+            rows[name] = [_errors(orc.fm(l), ref[l]) for l in range(L + 1)]
+            tops[name] = np.mean([np.array_equal(orc.top5(orc.fm(L)[i]), orc.top5(ref[L][i])) for i in range(2)])
+    finally:
+        orc.study_mode(False, False)
+    with capsys.disabled():
+        names = ["%02d_%s" % (l, topo.TYPE_NAMES[layers[l - 1]["type"]]) if l else "00_input" for l in range(L + 1)]
+        print("\nfp16 tolerance study, AlexNet synthetic, max-norm relative error per feature map vs fp32:")
+        for l in range(1, L + 1):
+            print("  fm%-9s  %9.2e   %9.2e" % (names[l], rows["f16 LUT, f32 sums"][l], rows["f16 LUT, f16 sums"][l]))
+        print("  top-5 identical: %.2f / %.2f" % (tops["f16 LUT, f32 sums"], tops["f16 LUT, f16 sums"]))
+    a, b = rows["f16 LUT, f32 sums"], rows["f16 LUT, f16 sums"]
+    assert a[0] == 0.0 and b[0] == 0.0
+    assert 1e-5 < max(a) < 5e-3                      # storage rounding alone: a few 1e-4
+    assert max(b) > max(a) and max(b) < 0.2          # fp16 running sums are an order of magnitude worse
+    # and the switches are really off again
+    orc.forward(imgs)
+    assert np.array_equal(orc.fm(L), ref[L])
