@@ -13,6 +13,7 @@
  *                               + CaffeEva::PrepFeatMap size rule          src/CaffeEva.cc:328-411
  *   qcnn_model_set_layer_params CaffePara::LoadLayerPara result ->         src/CaffePara.cc:239-306
  *                               CaffeEva::PrepCtrdBuf / PrepAsmtBuf        src/CaffeEva.cc:534-623
+ *   qcnn_model_set_layer_params_cbn  FileIO::ReadCbnFile decode + PrepAsmtBuf   include/FileIO.h:109-178
  *   qcnn_model_commit           CaffeEva::PrepFeatBuf (buffer planning)    src/CaffeEva.cc:413-532
  *   qcnn_forward[_host]         CaffeEva::ExecForwardPass layer loop       src/CaffeEva.cc:151-261
  *                               = CalcFeatMap dispatcher                   src/CaffeEva.cc:625-670
@@ -102,6 +103,12 @@ int qcnn_model_arena_ptr(QcnnCtx* ctx, void** dev_ptr, size_t* bytes);
  * Performs the PrepCtrdBuf / PrepAsmtBuf permutations into the arena.  After commit. */
 int qcnn_model_set_layer_params(QcnnCtx* ctx, int layer, const float* bias, const float* ctrd_file,
                                 const uint8_t* asmt_file);
+/* Same, with the assignments still bit-packed as the .cbn file holds them (include/FileIO.h:128-166): `cbn_blocks` =
+ * the file's payload behind its header (4096-byte blocks of floor(32768 / bits) values, MSB first, 0-based indices in
+ * file order [Ct][kh][kw][M] / [Ct][M]), `bits` = its bitCntPerEle.  The packed stream is what crosses PCIe (AlexNet fc6:
+ * 5.9 MB instead of 9.4 MB); the decode + PrepAsmtBuf permutation run on the device. */
+int qcnn_model_set_layer_params_cbn(QcnnCtx* ctx, int layer, const float* bias, const float* ctrd_file,
+                                    const uint8_t* cbn_blocks, size_t cbn_bytes, int bits);
 /* Declare every conv/FC layer loaded without uploading: the caller filled the arena itself (e.g. the
  * receiving ranks of an RCCL broadcast of rank 0's arena).  After commit. */
 int qcnn_model_mark_loaded(QcnnCtx* ctx);

@@ -62,6 +62,7 @@ def load():
     lib.qcnn_model_arena_bytes.argtypes = [vp, C.POINTER(C.c_size_t)]
     lib.qcnn_model_commit.argtypes = [vp, i, vp]
     lib.qcnn_model_set_layer_params.argtypes = [vp, i, f32p, f32p, u8p]
+    lib.qcnn_model_set_layer_params_cbn.argtypes = [vp, i, f32p, f32p, u8p, C.c_size_t, i]
     lib.qcnn_model_mark_loaded.argtypes = [vp]
     lib.qcnn_fm_dims.argtypes = [vp, i, C.POINTER(i)]
     lib.qcnn_forward.argtypes = [vp, f32p, i, f32p, u16p]

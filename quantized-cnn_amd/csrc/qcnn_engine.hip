@@ -533,14 +533,10 @@ int qcnn_model_commit(QcnnCtx* c, int max_batch, void* dev_arena) {
   return 0;
 }
 
-int qcnn_model_set_layer_params(QcnnCtx* c, int layer, const float* bias, const float* ctrd_file,
-                                const uint8_t* asmt_file) {
-  HIP_TRY(c, hipSetDevice(c->device));
-  if (!c->committed) return fail(c, "qcnn_model_commit must precede qcnn_model_set_layer_params");
-  if (layer < 0 || layer >= c->L) return fail(c, "layer %d out of range", layer);
-  const QcnnLayerDesc& d = c->layers[layer];
+namespace {
+// bias + code book (PrepCtrdBuf permutation, and the bf16-pair split where the layer can use it) into the arena
+int upload_bias_ctrd(QcnnCtx* c, int layer, const float* bias, const float* ctrd_file) {
   LayerShape& s = c->shapes[layer];
-  if (s.K <= 0) return fail(c, "layer %d carries no parameters", layer);
   const int Ct = c->dims[layer + 1].c;
   const int M = s.M, K = s.K, Cs = s.Cs;
   // PrepCtrdBuf: [M][K][Cs] -> [M][Cs][K]  (src/CaffeEva.cc:556-557)
@@ -548,23 +544,6 @@ int qcnn_model_set_layer_params(QcnnCtx* c, int layer, const float* bias, const 
   for (int m = 0; m < M; ++m)
     for (int k = 0; k < K; ++k)
       for (int dd = 0; dd < Cs; ++dd) ctrd[((size_t)m * Cs + dd) * K + k] = ctrd_file[((size_t)m * K + k) * Cs + dd];
-  // PrepAsmtBuf: conv [Ct][kh][kw][M] -> [kh][kw][M][Ct] (:585-586); FC [Ct][M] -> [M][Ct] (:610-611).  Stored as
-  // the pre-scaled LDS offset of the code word's row inside a LUT stage (row = (m % G) * K + index < 128), with the
-  // channel axis in the order the gather waves consume it (QkSlots); padding entries point at row 0.
-  const int G = qcnn_stage_group(K);
-  const size_t taps = (d.type == QCNN_CONV) ? (size_t)d.knlSiz * d.knlSiz : 1;
-  const int groups = (d.type == QCNN_CONV) ? d.grpCnt : 1;
-  const QkSlots sl = (d.type == QCNN_CONV) ? qk_conv_slots(Ct / groups, groups) : qk_fc_slots(Ct);
-  std::vector<uint16_t> asmt(s.asmtBytes / sizeof(uint16_t) + QCNN_ROWS_PAD / sizeof(uint16_t), 0);
-  for (int ch = 0; ch < Ct; ++ch) {
-    const int entry = qk_slot_entry(sl, ch / sl.C, ch % sl.C);
-    for (size_t t = 0; t < taps; ++t)
-      for (int m = 0; m < M; ++m) {
-        const uint8_t v = asmt_file[((size_t)ch * taps + t) * M + m];
-        if (v >= K) return fail(c, "layer %d: assignment %u >= K = %d", layer, (unsigned)v, K);
-        asmt[(t * M + m) * sl.rowStride + entry] = qcnn_row_offset((m % G) * K + v);
-      }
-  }
   // bf16-pair split of the code book in v_mfma_f32_16x16x32_bf16 A-operand order: [m][row tile][k-slice g][row][dim],
   // slices 0/1 = leading part a1 = bf16(c), slices 2/3 = remainder a2 = bf16(c - a1) (round to nearest even)
   std::vector<uint16_t> split;
@@ -590,8 +569,78 @@ int qcnn_model_set_layer_params(QcnnCtx* c, int layer, const float* bias, const 
   }
   HIP_TRY(c, hipMemcpyAsync(c->arena + s.offBias, bias, sizeof(float) * Ct, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipMemcpyAsync(c->arena + s.offCtrd, ctrd.data(), sizeof(float) * ctrd.size(), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));      // the host vectors die with this scope
+  return 0;
+}
+}  // namespace
+
+int qcnn_model_set_layer_params(QcnnCtx* c, int layer, const float* bias, const float* ctrd_file,
+                                const uint8_t* asmt_file) {
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (!c->committed) return fail(c, "qcnn_model_commit must precede qcnn_model_set_layer_params");
+  if (layer < 0 || layer >= c->L) return fail(c, "layer %d out of range", layer);
+  const QcnnLayerDesc& d = c->layers[layer];
+  LayerShape& s = c->shapes[layer];
+  if (s.K <= 0) return fail(c, "layer %d carries no parameters", layer);
+  const int Ct = c->dims[layer + 1].c;
+  const int M = s.M, K = s.K;
+  // PrepAsmtBuf: conv [Ct][kh][kw][M] -> [kh][kw][M][Ct] (:585-586); FC [Ct][M] -> [M][Ct] (:610-611).  Stored as
+  // the pre-scaled LDS offset of the code word's row inside a LUT stage (row = (m % G) * K + index < 128), with the
+  // channel axis in the order the gather waves consume it (QkSlots); padding entries point at row 0.
+  const int G = qcnn_stage_group(K);
+  const size_t taps = (d.type == QCNN_CONV) ? (size_t)d.knlSiz * d.knlSiz : 1;
+  const int groups = (d.type == QCNN_CONV) ? d.grpCnt : 1;
+  const QkSlots sl = (d.type == QCNN_CONV) ? qk_conv_slots(Ct / groups, groups) : qk_fc_slots(Ct);
+  std::vector<uint16_t> asmt(s.asmtBytes / sizeof(uint16_t) + QCNN_ROWS_PAD / sizeof(uint16_t), 0);
+  for (int ch = 0; ch < Ct; ++ch) {
+    const int entry = qk_slot_entry(sl, ch / sl.C, ch % sl.C);
+    for (size_t t = 0; t < taps; ++t)
+      for (int m = 0; m < M; ++m) {
+        const uint8_t v = asmt_file[((size_t)ch * taps + t) * M + m];
+        if (v >= K) return fail(c, "layer %d: assignment %u >= K = %d", layer, (unsigned)v, K);
+        asmt[(t * M + m) * sl.rowStride + entry] = qcnn_row_offset((m % G) * K + v);
+      }
+  }
+  if (upload_bias_ctrd(c, layer, bias, ctrd_file)) return 1;
   HIP_TRY(c, hipMemcpyAsync(c->arena + s.offAsmt, asmt.data(), asmt.size() * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  s.loaded = true;
+  return 0;
+}
+
+int qcnn_model_set_layer_params_cbn(QcnnCtx* c, int layer, const float* bias, const float* ctrd_file,
+                                    const uint8_t* cbn_blocks, size_t cbn_bytes, int bits) {
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (!c->committed) return fail(c, "qcnn_model_commit must precede qcnn_model_set_layer_params_cbn");
+  if (layer < 0 || layer >= c->L) return fail(c, "layer %d out of range", layer);
+  const QcnnLayerDesc& d = c->layers[layer];
+  LayerShape& s = c->shapes[layer];
+  if (s.K <= 0) return fail(c, "layer %d carries no parameters", layer);
+  if (bits < 1 || bits > 8) return fail(c, "layer %d: %d bits per assignment (1..8 supported)", layer, bits);
+  const int Ct = c->dims[layer + 1].c;
+  const size_t taps = (d.type == QCNN_CONV) ? (size_t)d.knlSiz * d.knlSiz : 1;
+  const int groups = (d.type == QCNN_CONV) ? d.grpCnt : 1;
+  const QkSlots sl = (d.type == QCNN_CONV) ? qk_conv_slots(Ct / groups, groups) : qk_fc_slots(Ct);
+  const size_t n = (size_t)Ct * taps * s.M;
+  const size_t per = 4096 * 8 / (size_t)bits;
+  const size_t need = (n + per - 1) / per * 4096;
+  if (cbn_bytes < need) return fail(c, "layer %d: %zu bytes of packed assignments, %zu needed", layer, cbn_bytes, need);
+  if (upload_bias_ctrd(c, layer, bias, ctrd_file)) return 1;
+  uint8_t* dev = nullptr;
+  int* bad = nullptr;
+  HIP_TRY(c, hipMalloc(&dev, need + sizeof(int)));
+  bad = reinterpret_cast<int*>(dev + need);
+  hipError_t e = hipMemcpyAsync(dev, cbn_blocks, need, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(bad, 0, sizeof(int), c->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(c->arena + s.offAsmt, 0, s.asmtBytes + QCNN_ROWS_PAD, c->stream);   // padding entries -> row 0
+  if (e == hipSuccess)
+    e = qk_decode_cbn(dev, bits, n, Ct, (int)taps, s.M, s.K, sl, reinterpret_cast<uint16_t*>(c->arena + s.offAsmt), bad, c->stream);
+  int flag = 0;
+  if (e == hipSuccess) e = hipMemcpyAsync(&flag, bad, sizeof(int), hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(dev);
+  if (e != hipSuccess) return fail(c, "layer %d: device-side assignment decode failed: %s", layer, hipGetErrorString(e));
+  if (flag) return fail(c, "layer %d: an assignment >= K = %d in the packed stream", layer, s.K);
   s.loaded = true;
   return 0;
 }

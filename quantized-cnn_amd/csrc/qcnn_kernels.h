@@ -30,13 +30,13 @@
 
 // A LUT stage holds G = qcnn_stage_group(K) consecutive sub-spaces of one source pixel (conv) / of the
 // input vector (FC): G * K <= 128 rows;  stage row of a code word = (m % G) * K + assignment  (< 128).
-static inline int qcnn_stage_group(int K) { return K <= 64 ? QCNN_STAGE_ROWS / K : 1; }
+__host__ __device__ static inline int qcnn_stage_group(int K) { return K <= 64 ? QCNN_STAGE_ROWS / K : 1; }
 // Slot of stage row r inside an image tile: v_mfma_f32_16x16x4_f32 leaves row 16i + 4q + e of a result tile in
 // element e of lane group q, and ds_write_addtid_b32 of element e stores the four lane groups back to back,
 // so the row lands in slot 16i + 4e + q (the two 2-bit fields swapped).
-static inline int qcnn_row_slot(int r) { return (r & 0x70) | ((r & 3) << 2) | ((r >> 2) & 3); }
+__host__ __device__ static inline int qcnn_row_slot(int r) { return (r & 0x70) | ((r & 3) << 2) | ((r >> 2) & 3); }
 // pre-scaled LDS byte offset of a stage row inside an image tile (what the assignment tables hold)
-static inline uint16_t qcnn_row_offset(int r) { return (uint16_t)(qcnn_row_slot(r) * 64); }
+__host__ __device__ static inline uint16_t qcnn_row_offset(int r) { return (uint16_t)(qcnn_row_slot(r) * 64); }
 
 // How the 12 gather waves of a workgroup split `C` output channels (conv: the channels of one group; FC: all
 // of them), and the device layout of the row-offset table that follows from it.  A wave owns `cpw`
@@ -69,7 +69,7 @@ static inline QkSlots qk_conv_slots(int Ctg, int groups) {
 }
 static inline QkSlots qk_fc_slots(int Ct) { return qk_make_slots(Ct, 1, Ct >= 384 ? 32 : (Ct >= 96 ? 8 : 4)); }
 // table position (in uint16 entries, inside one (tap, sub-space) row) of channel c of group g, or -1
-static inline int qk_slot_entry(const QkSlots& s, int g, int c) {
+__host__ __device__ static inline int qk_slot_entry(const QkSlots& s, int g, int c) {
   if (c < 0 || c >= s.C) return -1;
   const int wave = c / s.cpw, k = c % s.cpw, hc = s.cpw / 2;
   return ((g * s.chunks * QCNN_GATHER_WAVES + wave) * 2 + k / hc) * s.hp + k % hc;
@@ -111,6 +111,12 @@ static inline size_t qk_ctrd2_bytes(int M) { return (size_t)M * 8 * 4 * 16 * 16;
 hipError_t qk_conv_aprx(const ConvParams& p, int lutMode, hipStream_t st);
 hipError_t qk_fc_aprx(const FcParams& p, int lutMode, hipStream_t st);
 int qk_fc_channels_per_block(int Ct);   // output channels one k_fc_aprx workgroup covers
+
+// Load-time decode of a bit-packed assignment stream (.cbn payload, include/FileIO.h:128-166: 4096-byte blocks of
+// floor(32768 / bits) values packed MSB first, 0-based code-word indices in FILE order [Ct][taps][M]) straight
+// into the row-offset table [taps][M][rowStride] of the arena.  *bad is set when an index >= K is met.
+hipError_t qk_decode_cbn(const uint8_t* blocks, int bits, size_t n, int Ct, int taps, int M, int K, QkSlots sl,
+                         uint16_t* rows, int* bad, hipStream_t st);
 
 // dst row e = src row map[e], rows of 128 images ([panels][D][128]); the first FC layer consumes its input
 // NCHW-flattened (src/CaffeEva.cc:187-189)

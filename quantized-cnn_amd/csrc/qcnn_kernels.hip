@@ -943,6 +943,28 @@ __global__ __launch_bounds__(NW * 64) void k_fc_aprx(FcParams p, int G, int stag
   }
 }
 
+// .cbn payload -> row-offset table: one thread per assignment.  Element e of the file order
+// [Ct][taps][M] sits in block e / per at bit (e % per) * bits, MSB first (include/FileIO.h:128-166; values never
+// straddle a block); it lands at [tap][m][slot entry of its channel] as the pre-scaled LDS offset of its stage row
+// (the same value qcnn_model_set_layer_params computes on the host).
+__global__ void k_decode_cbn(const uint8_t* __restrict__ blocks, int bits, size_t n, int Ct, int taps, int M, int K,
+                             int G, QkSlots sl, uint16_t* __restrict__ rows, int* __restrict__ bad) {
+  const int per = 4096 * 8 / bits;
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+    const size_t blk = e / per;
+    const int bit0 = (int)(e % per) * bits;
+    const uint8_t* b = blocks + blk * 4096 + (bit0 >> 3);
+    const unsigned w = ((unsigned)b[0] << 8) | (unsigned)b[(bit0 & 7) + bits > 8 ? 1 : 0];   // <= 8 bits: at most two bytes
+    const unsigned v = (w >> (16 - (bit0 & 7) - bits)) & ((1u << bits) - 1u);
+    const int m = (int)(e % M);
+    const size_t ct = e / M;
+    const int t = (int)(ct % taps), ch = (int)(ct / taps);
+    if ((int)v >= K) { atomicOr(bad, 1); continue; }
+    const int entry = qk_slot_entry(sl, ch / sl.C, ch % sl.C);
+    rows[((size_t)t * M + m) * sl.rowStride + entry] = qcnn_row_offset((m % G) * K + (int)v);
+  }
+}
+
 // dst row e = src row map[e] (the NHWC -> NCHW flatten in front of the first FC layer, src/CaffeEva.cc:187-189)
 __global__ void k_permute_rows(const float* __restrict__ src, float* __restrict__ dst, const int* __restrict__ map,
                                int D, int panels) {
@@ -1443,6 +1465,15 @@ hipError_t qk_fc_aprx(const FcParams& pIn, int lutMode, hipStream_t st) {
     case 8: return launch_fc<8>(p, sl, lutMode, st);
     default: return launch_fc<4>(p, sl, lutMode, st);
   }
+}
+
+hipError_t qk_decode_cbn(const uint8_t* blocks, int bits, size_t n, int Ct, int taps, int M, int K, QkSlots sl,
+                         uint16_t* rows, int* bad, hipStream_t st) {
+  if (bits < 1 || bits > 8) return hipErrorInvalidValue;
+  const int grid = (int)std::min<size_t>((n + 255) / 256, 8192);
+  hipLaunchKernelGGL(k_decode_cbn, dim3(grid ? grid : 1), dim3(256), 0, st, blocks, bits, n, Ct, taps, M, K,
+                     qcnn_stage_group(K), sl, rows, bad);
+  return hipGetLastError();
 }
 
 hipError_t qk_sum_partials(const float* partial, float* dst, int msplit, size_t n, int relu, hipStream_t st) {

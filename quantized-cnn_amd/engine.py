@@ -79,6 +79,16 @@ class QcnnEngine:
             self._chk(self.lib.qcnn_model_set_layer_params(self.h, i, bias.ctypes.data, ctrd.ctypes.data,
                                                            asmt.ctypes.data))
 
+    def upload_cbn(self, params):
+        """Same as upload(), but the assignments travel bit-packed (the .cbn payload) and are decoded on the device."""
+        from . import fileio
+        for i, p in params.items():
+            bias = np.ascontiguousarray(p["bias"], np.float32)
+            ctrd = np.ascontiguousarray(p["ctrd"], np.float32)
+            blocks = fileio.cbn_pack(np.ascontiguousarray(p["asmt"], np.uint8), int(p["bits"]))
+            self._chk(self.lib.qcnn_model_set_layer_params_cbn(self.h, i, bias.ctypes.data, ctrd.ctypes.data,
+                                                               blocks.ctypes.data, blocks.nbytes, int(p["bits"])))
+
     def mark_loaded(self):
         self._chk(self.lib.qcnn_model_mark_loaded(self.h))
 

@@ -61,6 +61,24 @@ def cbn_vals_per_block(bits: int) -> int:
     return (CBN_BLOCK_BYTES * 8) // bits
 
 
+def cbn_pack(idx0: np.ndarray, bits: int) -> np.ndarray:
+    """The payload of a ``.cbn`` file (everything behind the header) for 0-based indices ``idx0``: uint8 array."""
+    flat = np.ascontiguousarray(idx0, dtype=np.uint8).reshape(-1)
+    if flat.size and int(flat.max()) >= (1 << bits):
+        raise ValueError("index %d does not fit %d bits" % (int(flat.max()), bits))
+    per = cbn_vals_per_block(bits)
+    nblk = (flat.size + per - 1) // per
+    shifts = np.arange(bits - 1, -1, -1, dtype=np.uint8)
+    out = np.zeros(nblk * CBN_BLOCK_BYTES, np.uint8)
+    for b in range(nblk):
+        v = flat[b * per:(b + 1) * per]
+        bitmat = ((v[:, None] >> shifts[None, :]) & 1).astype(np.uint8).reshape(-1)
+        blk = np.zeros(CBN_BLOCK_BYTES * 8, dtype=np.uint8)
+        blk[:bitmat.size] = bitmat
+        out[b * CBN_BLOCK_BYTES:(b + 1) * CBN_BLOCK_BYTES] = np.packbits(blk)
+    return out
+
+
 def write_cbn(path: str, idx0: np.ndarray, bits: int) -> None:
     """Write 0-based indices ``idx0`` (uint8, 1..4-D) bit-packed with ``bits`` bits per element."""
     idx0 = np.ascontiguousarray(idx0, dtype=np.uint8)

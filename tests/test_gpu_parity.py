@@ -18,6 +18,7 @@ pytestmark = pytest.mark.gpu
 
 topo = pkg("topology")
 synth = pkg("synth")
+fileio = pkg("fileio")
 capi = pkg("capi")
 TOL = 1e-4          # north_star: "within 1e-4 relative"
 TOL_LIBM = 1e-6     # expf/logf differences only
@@ -384,6 +385,60 @@ def test_odd_channel_count_is_rejected():
     eng = pkg("engine").QcnnEngine(0)
     with pytest.raises(pkg("engine").QcnnError):
         eng.configure(in_chw, layers, {0: (1, 16, 3), 2: (63, 16, 4)})
+
+
+# ---------------------------------------------------------------- packed assignments decoded on the device ----
+def test_cbn_payload_decoded_on_the_device(golden_tiny):
+    """the bit-packed .cbn payload (7-bit conv, 5-/4-bit FC streams; include/FileIO.h:128-166) crosses
+    PCIe as it is and is decoded + permuted into the row-offset table by a kernel.  Same bits out as the host-side
+    PrepAsmtBuf path, for the all-layer-types network and for AlexNet's real table sizes (several 4096-byte blocks,
+    values ending right at block boundaries)."""
+    z = golden_tiny
+    in_chw, layers = topo.tiny_model()
+    params = tiny_params_from_golden(z, layers)
+    for p in params.values():
+        p["bits"] = fileio.min_bits(np.array([p["ctrd"].shape[1] - 1]))
+    a = make_engine(in_chw, layers, params, 8, lut=capi.LUT_EXACT)
+    b = pkg("engine").QcnnEngine(0)
+    b.set_option(capi.OPT_LUT_MODE, capi.LUT_EXACT)
+    shapes = {i: tuple(int(x) for x in p["ctrd"].shape) for i, p in params.items()}
+    b.configure(in_chw, layers, shapes)
+    b.commit(8)
+    b.upload_cbn(params)
+    pa, ta = a.forward_host(z["imgs"])
+    pb, tb = b.forward_host(z["imgs"])
+    assert np.array_equal(pa, pb) and np.array_equal(ta, tb)
+    for l in range(len(layers) + 1):
+        assert np.array_equal(a.layer_output(l, 3), b.layer_output(l, 3)), l
+    a.close(); b.close()
+    # AlexNet sizes: conv2 (7 bits, 230 400 values = 49.2 blocks), fc7 (5 bits), fc8 (4 bits) as single layers
+    in_chw, layers, _, _ = topo.MODELS["AlexNet"]
+    params = synth.make_params(in_chw, layers, seed=21)
+    shapes = {i: tuple(int(x) for x in p["ctrd"].shape) for i, p in params.items()}
+    e1 = make_engine(in_chw, layers, params, 2, lut=capi.LUT_MFMA)
+    e2 = pkg("engine").QcnnEngine(0)
+    e2.configure(in_chw, layers, shapes)
+    e2.commit(2)
+    e2.upload_cbn(params)
+    imgs = synth.make_images(2, in_chw, seed=22)
+    p1, t1 = e1.forward_host(imgs)
+    p2, t2 = e2.forward_host(imgs)
+    assert np.array_equal(p1, p2) and np.array_equal(t1, t2)
+    e1.close(); e2.close()
+
+
+def test_cbn_payload_with_an_index_beyond_k_is_rejected():
+    in_chw = (3, 8, 8)
+    layers = [topo.conv(0, 3, 8, 1, 1), topo.relu(), topo.fcnt(10), topo.smax()]
+    spec = synth.quant_spec(in_chw, layers, conv_k=24, fc_k=24)
+    params = synth.make_params(in_chw, layers, seed=5, spec=spec)
+    params[0] = dict(params[0], asmt=np.full_like(params[0]["asmt"], 30), bits=5)      # 30 fits 5 bits but K = 24
+    params[2]["bits"] = 5
+    eng = pkg("engine").QcnnEngine(0)
+    eng.configure(in_chw, layers, {i: tuple(int(x) for x in p["ctrd"].shape) for i, p in params.items()})
+    eng.commit(2)
+    with pytest.raises(pkg("engine").QcnnError):
+        eng.upload_cbn(params)
 
 
 # ---------------------------------------------------------------- device-side input pipeline ----
