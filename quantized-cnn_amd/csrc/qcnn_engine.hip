@@ -171,7 +171,7 @@ int ensure_stage(QcnnCtx* c) {
 // in consumption order (qcnn_run_layer), so the NCHW-flatten map is not applied.
 // p0: first panel of the sub-batch (offsets into the scratch buffers), st: the stream it runs on
 int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bool fuseRelu, bool flatFcInput,
-                 int p0, hipStream_t st) {
+                 int p0, hipStream_t st, const float* inNchw = nullptr, int nImages = 0) {
   const QcnnLayerDesc& d = c->layers[l];
   const FmDims& a = c->dims[l];
   const FmDims& b = c->dims[l + 1];
@@ -182,6 +182,8 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
       if (!s.loaded) return fail(c, "layer %d: parameters not uploaded", l);
       ConvParams p;
       p.src = src; p.dst = dst;
+      p.srcNchw = 0; p.nImages = 0; p.panel0 = 0;
+      if (inNchw) { p.src = inNchw; p.srcNchw = 1; p.nImages = nImages; p.panel0 = p0; }   // network input read in place
       p.bias = reinterpret_cast<const float*>(c->arena + s.offBias);
       p.ctrd = reinterpret_cast<const float*>(c->arena + s.offCtrd);
       p.ctrd2 = s.hasCtrd2 ? c->arena + s.offCtrd2 : nullptr;
@@ -216,19 +218,24 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
         const int stages = (s.M + G - 1) / G;
         // batch-independent choice (a given image must produce the same bits in any batch): the split count
         // that fills 256 CUs best at the design point of 8 panels (1000 images) while every workgroup keeps
-        // >= 12 stages (a single panel — one GPU's share of a sharded batch — then still spreads over ~100 CUs); ties
-        // go to fewer splits.  (A grid of chunks x splits x panels workgroups runs in
+        // >= 24 stages (>= 12 when that leaves a single panel — one GPU's share of a sharded batch — on fewer than 64
+        // CUs); ties go to fewer splits.  (A grid of chunks x splits x panels workgroups runs in
         // ceil(grid / 256) rounds: 528 workgroups cost as much as 768.)
         const int cpb = qk_fc_channels_per_block(p.Ct);
         const int chunks = (p.Ct + cpb - 1) / cpb;
-        int ms = 1;
-        double bestFill = 0.0;
-        for (int cand = 1; cand <= kMaxFcSplit; ++cand) {
-          if (cand > 1 && stages / cand < 12) break;
-          const int grid = chunks * cand * 8;
-          const double fill = (double)grid / (256.0 * ((grid + 255) / 256));
-          if (fill > bestFill + 1e-9) { bestFill = fill; ms = cand; }
-        }
+        auto pick = [&](int minStages) {
+          int best = 1;
+          double bestFill = 0.0;
+          for (int cand = 1; cand <= kMaxFcSplit; ++cand) {
+            if (cand > 1 && stages / cand < minStages) break;
+            const int grid = chunks * cand * 8;
+            const double fill = (double)grid / (256.0 * ((grid + 255) / 256));
+            if (fill > bestFill + 1e-9) { bestFill = fill; best = cand; }
+          }
+          return best;
+        };
+        int ms = pick(24);
+        if (chunks * ms < 64) ms = pick(12);     // few channel chunks (a 1000-way classifier): a single panel would sit on < 64 CUs
         const size_t need = (size_t)ms * panels * p.Ct * QCNN_PANEL;
         const size_t poff = (size_t)kMaxFcSplit * p0 * c->fcMaxCt * QCNN_PANEL;    // every sub-batch has its own slab
         if (ms > 1 && poff + need <= c->fcPartialElems) { p.msplit = ms; p.partial = c->fcPartial + poff; }
@@ -282,13 +289,22 @@ int drain_profile(QcnnCtx* c) {
 // that the LDS-bound conv/FC kernels of one sub-batch overlap the HBM-bound glue kernels of another and the
 // last dispatch round of one kernel is filled by the next.  Every image still sees exactly the same
 // arithmetic (panels are independent), so results do not depend on the number of streams.
-int run_layers(QcnnCtx* c, int n) {
+// Can the first layer's builders read the NCHW network input in place (no pack kernel, no packed copy of the input)?
+// Fast path only (layer-for-layer mode keeps fm[0] for dumps); a conv layer with <= 4 input channels per group (one
+// sub-space of <= 4 dims: exactly what the operand loads of one stage touch) and K = 128 or the exact builder.
+bool direct_input(const QcnnCtx* c) {
+  if (c->keepAll || c->L == 0 || c->layers[0].type != QCNN_CONV) return false;
+  const QcnnLayerDesc& d = c->layers[0];
+  return c->inC / d.grpCnt <= 4 && (c->lutMode == 0 || c->shapes[0].K == 128);
+}
+
+int run_layers(QcnnCtx* c, int n, const float* inNchw = nullptr) {
   const int panels = (n + QCNN_PANEL - 1) / QCNN_PANEL;
   const int ns = std::max(1, std::min(std::min(c->nStreams, kMaxStreams), panels));
   if (c->profile && c->profCount == kProfRing && drain_profile(c)) return 1;   // ring full: fold it into the sums
   const bool prof = c->profile != 0;
   c->lastFm.assign(c->L + 1, nullptr);
-  c->lastFm[0] = c->fmBuf[0];
+  c->lastFm[0] = inNchw ? nullptr : c->fmBuf[0];
   for (int l = 0; l < c->L; ++l) {              // pointer table (aliases) — identical for every sub-batch
     const int type = c->layers[l].type;
     const bool prevFused = l > 0 && !c->keepAll && type == QCNN_RELU &&
@@ -301,14 +317,15 @@ int run_layers(QcnnCtx* c, int n) {
   }
   for (int l = 0; l < c->L; ++l) {              // layer-major issue order: the streams advance together
     const int type = c->layers[l].type;
-    if (c->lastFm[l + 1] == c->lastFm[l]) continue;          // alias: copy semantics, no traffic
+    if (c->lastFm[l + 1] == c->lastFm[l] && c->lastFm[l] != nullptr) continue;   // alias: copy semantics, no traffic
     const bool fuse = !c->keepAll && (type == QCNN_CONV || type == QCNN_FCNT) && l + 1 < c->L &&
                       c->layers[l + 1].type == QCNN_RELU;
     for (int k = 0; k < ns; ++k) {
       const int p0 = (int)((long long)panels * k / ns), p1 = (int)((long long)panels * (k + 1) / ns);
       if (p1 <= p0) continue;
       hipStream_t st = k == 0 ? c->stream : c->aux[k - 1];
-      const float* src = c->lastFm[l] + (size_t)p0 * fm_elems(c, l) * QCNN_PANEL;
+      const bool direct = l == 0 && inNchw != nullptr;
+      const float* src = direct ? nullptr : c->lastFm[l] + (size_t)p0 * fm_elems(c, l) * QCNN_PANEL;
       float* dst = c->lastFm[l + 1] + (size_t)p0 * fm_elems(c, l + 1) * QCNN_PANEL;
       hipEvent_t e0 = nullptr, e1 = nullptr;
       if (prof) {
@@ -316,7 +333,7 @@ int run_layers(QcnnCtx* c, int n) {
         e0 = c->ev[slot]; e1 = c->ev[slot + 1];
         HIP_TRY(c, hipEventRecord(e0, st));
       }
-      if (launch_layer(c, l, src, dst, p1 - p0, fuse, false, p0, st)) return 1;
+      if (launch_layer(c, l, src, dst, p1 - p0, fuse, false, p0, st, direct ? inNchw : nullptr, n)) return 1;
       if (prof) {
         HIP_TRY(c, hipEventRecord(e1, st));
         c->profPending.push_back(QcnnCtx::ProfRec{(((size_t)c->profCount * kMaxStreams + k) * c->L + l) * 2, l});
@@ -661,8 +678,8 @@ int qcnn_fm_dims(QcnnCtx* c, int l, int* hwc3) {
 
 namespace {
 // layers + output conversion of a forward whose input panel (fmBuf[0]) has just been enqueued
-int forward_tail(QcnnCtx* c, int n, float* prob_dev, uint16_t* top5_dev) {
-  if (run_layers(c, n)) return 1;
+int forward_tail(QcnnCtx* c, int n, float* prob_dev, uint16_t* top5_dev, const float* inNchw = nullptr) {
+  if (run_layers(c, n, inNchw)) return 1;
   const int classes = (int)fm_elems(c, c->L);
   hipError_t e;
   if (prob_dev) {
@@ -681,6 +698,7 @@ int qcnn_forward(QcnnCtx* c, const float* in_nchw_dev, int n, float* prob_dev, u
   HIP_TRY(c, hipSetDevice(c->device));
   if (!c->committed) return fail(c, "model not committed");
   if (n <= 0 || n > c->maxBatch) return fail(c, "batch %d outside (0, %d]", n, c->maxBatch);
+  if (direct_input(c)) return forward_tail(c, n, prob_dev, top5_dev, in_nchw_dev);   // conv1's builders read it in place
   hipError_t e = qk_pack_nchw(in_nchw_dev, c->fmBuf[0], n, c->inC, c->inH, c->inW, c->stream);
   if (e != hipSuccess) return fail(c, "input pack launch failed: %s", hipGetErrorString(e));
   return forward_tail(c, n, prob_dev, top5_dev);

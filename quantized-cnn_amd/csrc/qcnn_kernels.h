@@ -75,6 +75,9 @@ __host__ __device__ static inline int qk_slot_entry(const QkSlots& s, int g, int
   return ((g * s.chunks * QCNN_GATHER_WAVES + wave) * 2 + k / hc) * s.hp + k % hc;
 }
 struct ConvParams {
+  int srcNchw;           // 1: src is the network input [nImages][Cin][H][W] read in place by the builders (first layer with
+  int nImages;           //    <= 4 channels per group, K = 128 or the exact builder); 0: src is a panel map
+  int panel0;            // srcNchw: index of the launch's first panel inside the batch (sub-batches on several streams)
   const float* src;      // [panels][H*W*Cin][128]
   float* dst;            // [panels][Ho*Wo*Ct][128]
   const float* bias;     // [Ct]

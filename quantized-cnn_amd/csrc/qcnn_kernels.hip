@@ -255,13 +255,44 @@ __device__ __forceinline__ void gather_apply(f32x2 (&acc)[CPW], const Idx<idx_dw
 // xbase + xoff0 + (m*Cs + d) * 512 bytes.
 // ------------------------------------------------------------------------------------------------
 
+// Where a builder lane finds its activations.  Panels (every layer but possibly the first): dim d of a pixel is a
+// 512-byte row of the 128 images.  NCHW (the network input read in place, ConvParams::srcNchw: no pack kernel, one
+// HBM round trip less): dim d is a channel plane, an image is C*H*W floats away from the next; lanes of images past
+// the end of the batch re-read the last image (their results are never unpacked).
+struct XAddr {
+  uint32_t dimStride;     // bytes from dim d to dim d+1 of the same pixel and image
+  uint32_t mfmaLane[2];   // MFMA builder: byte offset of (image tile it of the wave, image lane & 15, dim lane >> 4)
+  uint32_t pairLane[2];   // exact builder: byte offset of images 2*lane and 2*lane+1
+};
+__device__ __forceinline__ XAddr xaddr_panel(int bw, int lane) {
+  XAddr a;
+  a.dimStride = XROWB;
+  a.mfmaLane[0] = (uint32_t)(lane >> 4) * XROWB + bw * 128 + (lane & 15) * 4;
+  a.mfmaLane[1] = a.mfmaLane[0] + 64;
+  a.pairLane[0] = lane * 8;
+  a.pairLane[1] = lane * 8 + 4;
+  return a;
+}
+// first image of the panel = img0, n images in the batch, C*H*W floats per image, dims (channels) per group Cg <= 4
+__device__ __forceinline__ XAddr xaddr_nchw(int bw, int lane, int img0, int n, uint32_t imgBytes, uint32_t planeBytes, int Cg) {
+  XAddr a;
+  a.dimStride = planeBytes;
+  const uint32_t dim = min(lane >> 4, Cg - 1);          // a dim the group does not have is clamped (and zeroed at use)
+#pragma unroll
+  for (int it = 0; it < 2; ++it)
+    a.mfmaLane[it] = dim * planeBytes + (uint32_t)min(img0 + bw * 32 + it * 16 + (lane & 15), n - 1) * imgBytes;
+  a.pairLane[0] = (uint32_t)min(img0 + 2 * lane, n - 1) * imgBytes;
+  a.pairLane[1] = (uint32_t)min(img0 + 2 * lane + 1, n - 1) * imgBytes;
+  return a;
+}
+
 // LDS slot of a stage row (device copy of qcnn_row_slot)
 __device__ __forceinline__ int row_slot(int r) { return (r & 0x70) | ((r & 3) << 2) | ((r >> 2) & 3); }
 
 // exact: y = ((0 + x0*c0) + x1*c1) + ...  with separately rounded product and sum, the order of the
 // reference's saxpy chain (src/CaffeEva.cc:1284-1289, include/BlasWrapper.h:164-184).  Any K <= 128.
 // Builder wave bw computes rows bw*ceil(K/4) .. of every sub-space; a lane carries an image pair.
-__device__ __forceinline__ void build_stage_exact(char* stage, const char* __restrict__ xbase, uint32_t xoff0,
+__device__ __forceinline__ void build_stage_exact(char* stage, const char* __restrict__ xbase, uint32_t xoff0, const XAddr& xa,
                                                   const float* __restrict__ ctrd, int K, int Cs, int D, int G, int m0,
                                                   int mEnd, int bw, int lane) {
   const int kpw = (K + NBW - 1) / NBW;
@@ -273,12 +304,14 @@ __device__ __forceinline__ void build_stage_exact(char* stage, const char* __res
     const int m = m0 + g;
     if (m >= mEnd) break;
     const int dsel = min(D - m * Cs, Cs);
-    const char* __restrict__ xm = xbase + xoff0 + (uint32_t)(m * Cs) * (uint32_t)XROWB + lane * 8;
+    const char* __restrict__ xm = xbase + xoff0 + (uint32_t)(m * Cs) * xa.dimStride;
     f32x2 xv[QCNN_MAX_CS];
 #pragma unroll
     for (int d = 0; d < QCNN_MAX_CS; ++d) {
       xv[d] = f32x2{0.0f, 0.0f};
-      if (d < dsel) xv[d] = *reinterpret_cast<const f32x2*>(xm + d * XROWB);
+      if (d < dsel)
+        xv[d] = f32x2{*reinterpret_cast<const float*>(xm + d * xa.dimStride + xa.pairLane[0]),
+                      *reinterpret_cast<const float*>(xm + d * xa.dimStride + xa.pairLane[1])};
     }
     const float* __restrict__ cm = ctrd + (size_t)m * Cs * K;
     for (int k = k0; k < k1; ++k) {
@@ -312,15 +345,14 @@ struct MfmaOps {
 };
 
 template <int KT, int KS>
-__device__ __forceinline__ void mfma_load(MfmaOps<KT, KS>& o, const char* __restrict__ xbase, uint32_t xoff0,
+__device__ __forceinline__ void mfma_load(MfmaOps<KT, KS>& o, const char* __restrict__ xbase, uint32_t xoff0, const XAddr& xa,
                                           const float* __restrict__ ctrd, int Cs, int m0, int bw, int lane) {
   constexpr int K = KT * 16;
   constexpr int SUBS = MfmaOps<KT, KS>::SUBS;
   const uint32_t li = lane & 15, lk = lane >> 4;
   const uint32_t laneA = lk * K + (li ^ ((uint32_t)bw << 2));           // floats; rows pre-swizzled for the wave's tiles (mfma_pair)
-  const uint32_t laneB = lk * XROWB + li * 4;                            // bytes
   const float* __restrict__ cbU = ctrd + (size_t)m0 * Cs * K;            // uniform
-  const char* __restrict__ xbU = xbase + xoff0 + (uint32_t)(m0 * Cs) * (uint32_t)XROWB + bw * 128;   // uniform
+  const char* __restrict__ xbU = xbase + xoff0 + (uint32_t)(m0 * Cs) * xa.dimStride;   // uniform
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
@@ -332,7 +364,7 @@ __device__ __forceinline__ void mfma_load(MfmaOps<KT, KS>& o, const char* __rest
     for (int it = 0; it < 2; ++it)
 #pragma unroll
       for (int sub = 0; sub < SUBS; ++sub)
-        o.b[it][sub][ks] = *reinterpret_cast<const float*>(xbU + ((sub * Cs + ks * 4) * XROWB + it * 64) + laneB);
+        o.b[it][sub][ks] = *reinterpret_cast<const float*>(xbU + (uint32_t)(sub * Cs + ks * 4) * xa.dimStride + xa.mfmaLane[it]);
   }
 }
 
@@ -518,6 +550,7 @@ __device__ __forceinline__ void bf_store(BfSet& o, int bw) {
 // ------------------------------------------------------------------------------------------------
 struct ConvGeom {
   int W, Cin, knl, M, MG, G, wiL, wiU;
+  uint32_t pixStride;   // bytes from one source pixel to the next: Cin * 512 (panels) or 4 (NCHW input read in place)
   uint32_t rowStride;   // uint16 entries of one (tap, sub-space) row of the offset table
 };
 // Workgroups are dispatched in linear order, so the tiles are numbered heaviest first: interior tiles
@@ -551,7 +584,7 @@ __device__ __forceinline__ StagePos next_pos(const StagePos& c, const ConvGeom& 
   return n;
 }
 __device__ __forceinline__ uint32_t pixel_off(const StagePos& c, const ConvGeom& g) {
-  return (uint32_t)(c.hi * g.W + c.wi) * (uint32_t)g.Cin * (uint32_t)XROWB;
+  return (uint32_t)(c.hi * g.W + c.wi) * g.pixStride;
 }
 
 // offsets of the first sub-space of stage c for every position of the tile (taps that do not exist are
@@ -621,6 +654,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
   const int hiL = max(0, ho0 * p.stride - p.pad), hiU = min(p.H - 1, hoL * p.stride - p.pad + p.knl - 1);
   ConvGeom g;
   g.W = p.W; g.Cin = p.Cin; g.knl = p.knl; g.M = M; g.G = G; g.rowStride = (uint32_t)rowStride;
+  g.pixStride = p.srcNchw ? 4u : (uint32_t)p.Cin * (uint32_t)XROWB;
   g.MG = (M + G - 1) / G;                           // stages per source pixel
   g.wiL = max(0, wo0 * p.stride - p.pad);
   g.wiU = min(p.W - 1, woL * p.stride - p.pad + p.knl - 1);
@@ -636,8 +670,13 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
     const int bw = role.idx;
     const int K = p.K, Cs = p.Cs;
     __builtin_amdgcn_s_setprio(QCNN_PRIO_BUILDER);
-    const char* __restrict__ xbase =
-        reinterpret_cast<const char*>(p.src + ((size_t)panel * p.H * p.W * p.Cin + (size_t)grp * Cg) * PANEL);
+    // activations: this panel's rows — or, for a first layer reading the NCHW network input in place, the batch itself
+    const char* __restrict__ xbase = p.srcNchw
+        ? reinterpret_cast<const char*>(p.src + (size_t)grp * Cg * p.H * p.W)
+        : reinterpret_cast<const char*>(p.src + ((size_t)panel * p.H * p.W * p.Cin + (size_t)grp * Cg) * PANEL);
+    const XAddr xa = p.srcNchw ? xaddr_nchw(bw, lane, (p.panel0 + panel) * PANEL, p.nImages, (uint32_t)p.Cin * p.H * p.W * 4u,
+                                            (uint32_t)p.H * p.W * 4u, Cg)
+                               : xaddr_panel(bw, lane);
     if constexpr (KS == 3) {
       // bf16-pair builder (K = 128, one sub-space of up to 8 dims per stage).  Per stage period: issue the raw
       // activation loads of the stage after next, multiply the next stage out of one operand set, refill that set's
@@ -698,16 +737,16 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
     StagePos q2 = next_pos(q1, g);
     StagePos q3 = next_pos(q2, g);
     if (KT > 0) {
-      mfma_load<KTT, KS>(opsA, xbase, pixel_off(first, g), p.ctrd, Cs, 0, bw, lane);
+      mfma_load<KTT, KS>(opsA, xbase, pixel_off(first, g), xa, p.ctrd, Cs, 0, bw, lane);
       mfma_store<KTT, KS, 0>(opsA, Cs, Cg, 0, M, bw, lane, p.lutF16);
       {
         const StagePos qa = (q1.hi > hiU) ? first : q1, qb = (q2.hi > hiU) ? first : q2;
-        mfma_load<KTT, KS>(opsA, xbase, pixel_off(qa, g), p.ctrd, Cs, qa.mg * G, bw, lane);
+        mfma_load<KTT, KS>(opsA, xbase, pixel_off(qa, g), xa, p.ctrd, Cs, qa.mg * G, bw, lane);
         __builtin_amdgcn_sched_barrier(0);             // keep set A's loads older than set B's (vmcnt accounting)
-        mfma_load<KTT, KS>(opsB, xbase, pixel_off(qb, g), p.ctrd, Cs, qb.mg * G, bw, lane);
+        mfma_load<KTT, KS>(opsB, xbase, pixel_off(qb, g), xa, p.ctrd, Cs, qb.mg * G, bw, lane);
       }
     } else {
-      build_stage_exact(lds, xbase, pixel_off(first, g), p.ctrd, K, Cs, Cg, G, 0, M, bw, lane);
+      build_stage_exact(lds, xbase, pixel_off(first, g), xa, p.ctrd, K, Cs, Cg, G, 0, M, bw, lane);
     }
     barrier_after_lds_writes();
     // Straight-line body (no VMEM operation under a condition), so that the compiler's vmcnt waits are
@@ -717,9 +756,9 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
       if (KT > 0) {                                    // stage s+1 -> buffer 1, from set A
         mfma_store<KTT, KS, 1>(opsA, Cs, Cg, q1.mg * G, M, bw, lane, p.lutF16);
         const StagePos qf = (q3.hi > hiU) ? first : q3;
-        mfma_load<KTT, KS>(opsA, xbase, pixel_off(qf, g), p.ctrd, Cs, qf.mg * G, bw, lane);
+        mfma_load<KTT, KS>(opsA, xbase, pixel_off(qf, g), xa, p.ctrd, Cs, qf.mg * G, bw, lane);
       } else if (s + 1 < S) {
-        build_stage_exact(lds + STAGE_BYTES, xbase, pixel_off(q1, g), p.ctrd, K, Cs, Cg, G, q1.mg * G, M, bw, lane);
+        build_stage_exact(lds + STAGE_BYTES, xbase, pixel_off(q1, g), xa, p.ctrd, K, Cs, Cg, G, q1.mg * G, M, bw, lane);
       }
       TR_ARRIVE(s);
       barrier_after_lds_writes();
@@ -728,9 +767,9 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
       if (KT > 0) {                                    // stage s+2 -> buffer 0, from set B
         mfma_store<KTT, KS, 0>(opsB, Cs, Cg, q1.mg * G, M, bw, lane, p.lutF16);
         const StagePos qf = (q3.hi > hiU) ? first : q3;
-        mfma_load<KTT, KS>(opsB, xbase, pixel_off(qf, g), p.ctrd, Cs, qf.mg * G, bw, lane);
+        mfma_load<KTT, KS>(opsB, xbase, pixel_off(qf, g), xa, p.ctrd, Cs, qf.mg * G, bw, lane);
       } else if (s + 2 < S) {
-        build_stage_exact(lds, xbase, pixel_off(q1, g), p.ctrd, K, Cs, Cg, G, q1.mg * G, M, bw, lane);
+        build_stage_exact(lds, xbase, pixel_off(q1, g), xa, p.ctrd, K, Cs, Cg, G, q1.mg * G, M, bw, lane);
       }
       TR_ARRIVE(s + 1);
       barrier_after_lds_writes();
@@ -845,17 +884,18 @@ __global__ __launch_bounds__(NW * 64) void k_fc_aprx(FcParams p, int G, int stag
     const int K = p.K, Cs = p.Cs;
     __builtin_amdgcn_s_setprio(QCNN_PRIO_BUILDER);
     const char* __restrict__ xbase = reinterpret_cast<const char*>(p.src + (size_t)panel * p.D * PANEL);
+    const XAddr xa = xaddr_panel(bw, lane);
     MfmaOps<KTT, KS> opsA, opsB;                          // two operand sets, see k_conv_aprx
     const int mLastStage = mBeg + max(S - 1, 0) * G;  // operand prefetches past the end re-fetch the last stage
     if (S > 0) {
       if (KT > 0) {
-        mfma_load<KTT, KS>(opsA, xbase, 0u, p.ctrd, Cs, mBeg, bw, lane);
+        mfma_load<KTT, KS>(opsA, xbase, 0u, xa, p.ctrd, Cs, mBeg, bw, lane);
         mfma_store<KTT, KS, 0>(opsA, Cs, p.D, mBeg, mEnd, bw, lane, p.lutF16);
-        mfma_load<KTT, KS>(opsA, xbase, 0u, p.ctrd, Cs, min(mBeg + G, mLastStage), bw, lane);
+        mfma_load<KTT, KS>(opsA, xbase, 0u, xa, p.ctrd, Cs, min(mBeg + G, mLastStage), bw, lane);
         __builtin_amdgcn_sched_barrier(0);
-        mfma_load<KTT, KS>(opsB, xbase, 0u, p.ctrd, Cs, min(mBeg + 2 * G, mLastStage), bw, lane);
+        mfma_load<KTT, KS>(opsB, xbase, 0u, xa, p.ctrd, Cs, min(mBeg + 2 * G, mLastStage), bw, lane);
       } else {
-        build_stage_exact(lds, xbase, 0u, p.ctrd, K, Cs, p.D, G, mBeg, mEnd, bw, lane);
+        build_stage_exact(lds, xbase, 0u, xa, p.ctrd, K, Cs, p.D, G, mBeg, mEnd, bw, lane);
       }
     }
     barrier_after_lds_writes();
@@ -863,16 +903,16 @@ __global__ __launch_bounds__(NW * 64) void k_fc_aprx(FcParams p, int G, int stag
       const int m0 = mBeg + s * G;
       if (KT > 0) {
         mfma_store<KTT, KS, 1>(opsA, Cs, p.D, min(m0 + G, mLastStage), mEnd, bw, lane, p.lutF16);
-        mfma_load<KTT, KS>(opsA, xbase, 0u, p.ctrd, Cs, min(m0 + 3 * G, mLastStage), bw, lane);
+        mfma_load<KTT, KS>(opsA, xbase, 0u, xa, p.ctrd, Cs, min(m0 + 3 * G, mLastStage), bw, lane);
       } else if (s + 1 < S) {
-        build_stage_exact(lds + STAGE_BYTES, xbase, 0u, p.ctrd, K, Cs, p.D, G, m0 + G, mEnd, bw, lane);
+        build_stage_exact(lds + STAGE_BYTES, xbase, 0u, xa, p.ctrd, K, Cs, p.D, G, m0 + G, mEnd, bw, lane);
       }
       barrier_after_lds_writes();
       if (KT > 0) {
         mfma_store<KTT, KS, 0>(opsB, Cs, p.D, min(m0 + 2 * G, mLastStage), mEnd, bw, lane, p.lutF16);
-        mfma_load<KTT, KS>(opsB, xbase, 0u, p.ctrd, Cs, min(m0 + 4 * G, mLastStage), bw, lane);
+        mfma_load<KTT, KS>(opsB, xbase, 0u, xa, p.ctrd, Cs, min(m0 + 4 * G, mLastStage), bw, lane);
       } else if (s + 2 < S) {
-        build_stage_exact(lds, xbase, 0u, p.ctrd, K, Cs, p.D, G, m0 + 2 * G, mEnd, bw, lane);
+        build_stage_exact(lds, xbase, 0u, xa, p.ctrd, K, Cs, p.D, G, m0 + 2 * G, mEnd, bw, lane);
       }
       barrier_after_lds_writes();
     }
