@@ -66,6 +66,11 @@ enum {
   QCNN_OPT_KEEP_ALL = 1,   /* 1 = every layer writes its own feature map (layer-for-layer dumps, default);
                               0 = fast path: ReLU fused into the producing conv/FC epilogue */
   QCNN_OPT_PROFILE = 2,    /* 1 = bracket every layer launch with HIP events (qcnn_get_layer_ms) */
+  QCNN_OPT_SMALL_BATCH = 4, /* 1 (default): batches of one or two images run the conv/FC layers with the few-image kernels
+                              (lanes = output channels; one image no longer costs a 128-image panel).  Their sums
+                              run over sub-space chunks first: equal to the panel kernels to rounding (~1e-6), not bit
+                              for bit; 0 = panel kernels for every batch size (batch-size-invariant bits).  The exact
+                              builder (QCNN_OPT_LUT_MODE = 0) always uses the panel kernels. */
   QCNN_OPT_STREAMS = 3     /* 1..4 (default 2): a forward is cut into that many sub-batches of whole 128-image
                               panels which run concurrently on separate HIP streams (LDS-bound conv/FC kernels
                               of one overlap HBM-bound glue kernels of another); results do not depend on it */

@@ -35,6 +35,8 @@ struct FmDims { int h, w, c; };
 
 constexpr int kProfRing = 32;    // forwards whose per-layer events are kept
 constexpr int kMaxStreams = 4;   // sub-batches (streams) of one forward
+constexpr int kSmallBatchMax = 2;  // batches up to this size run the few-image kernels (QCNN_OPT_SMALL_BATCH): beyond, a
+                                   // 128-image panel is cheaper (measured: 2 images 1.6 ms, 4 images 3.3 ms, a panel 2.8 ms)
 constexpr int kMaxFcSplit = 32;  // workgroups along the sub-space axis of an FC layer (partial sums reduced in fixed order)
 constexpr size_t kSlack = 64 * 1024;   // bytes of slack behind every device buffer: the MFMA operand loads are
                                         // unconditional and may read a few rows past the last dim / sub-space
@@ -48,6 +50,7 @@ struct QcnnCtx {
   std::string err;
   int lutMode = 1, keepAll = 1, profile = 0;
   int nStreams = 2;                  // QCNN_OPT_STREAMS: sub-batches of whole panels run concurrently
+  int smallBatch = 1;                // QCNN_OPT_SMALL_BATCH: few-image kernels for batches <= kSmallBatchMax
   hipStream_t aux[3] = {nullptr, nullptr, nullptr};
   hipEvent_t evFork = nullptr, evJoin[3] = {nullptr, nullptr, nullptr};
 
@@ -170,8 +173,11 @@ int ensure_stage(QcnnCtx* c) {
 // One layer on `panels` panels: src/dst in panel layout.  flatFcInput: the FC input rows are already
 // in consumption order (qcnn_run_layer), so the NCHW-flatten map is not applied.
 // p0: first panel of the sub-batch (offsets into the scratch buffers), st: the stream it runs on
+// live: images every panel of this launch holds (128, or the batch size of a single-panel forward); small: the
+// few-image kernels (qcnn_small.hip) run the conv/FC layers
 int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bool fuseRelu, bool flatFcInput,
-                 int p0, hipStream_t st, const float* inNchw = nullptr, int nImages = 0) {
+                 int p0, hipStream_t st, const float* inNchw = nullptr, int nImages = 0, int live = QCNN_PANEL,
+                 bool small = false) {
   const QcnnLayerDesc& d = c->layers[l];
   const FmDims& a = c->dims[l];
   const FmDims& b = c->dims[l + 1];
@@ -191,7 +197,7 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
       p.H = a.h; p.W = a.w; p.Cin = a.c; p.Ho = b.h; p.Wo = b.w; p.Ct = b.c;
       p.knl = d.knlSiz; p.stride = d.stride; p.pad = d.padSiz; p.grp = d.grpCnt;
       p.M = s.M; p.Cs = s.Cs; p.K = s.K; p.relu = fuseRelu ? 1 : 0; p.panels = panels;
-      e = qk_conv_aprx(p, c->lutMode, st);
+      e = small ? qk_conv_small(p, live, st) : qk_conv_aprx(p, c->lutMode, st);
       break;
     }
     case QCNN_FCNT: {
@@ -204,7 +210,7 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
       if (s.hasDmap && !flatFcInput) {   // NHWC -> consumption order (NCHW flatten) into the scratch map
         float* flat = c->fcFlat + (size_t)p0 * fm_elems(c, l) * QCNN_PANEL;
         e = qk_permute_rows(src, flat, reinterpret_cast<const int*>(c->arena + s.offDmap), a.h * a.w * a.c,
-                            panels, st);
+                            panels, live, st);
         if (e != hipSuccess) break;
         p.src = flat;
       }
@@ -213,6 +219,13 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
       // Split the sub-space axis over workgroups when the (channel chunk x panel) grid cannot fill the
       // chip; the exact builder keeps one pass so that the summation order stays the reference's.
       p.msplit = 1; p.partial = nullptr;
+      if (small) {                       // few images: the tables are materialised in the partial-sum scratch
+        if ((size_t)live * s.M * s.K > c->fcPartialElems)
+          return fail(c, "layer %d: the small-batch table scratch is too small", l);
+        p.partial = c->fcPartial;
+        e = qk_fc_small(p, live, st);
+        break;
+      }
       if (c->lutMode >= 1) {
         const int G = qcnn_stage_group(s.K);
         const int stages = (s.M + G - 1) / G;
@@ -246,20 +259,20 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
       break;
     }
     case QCNN_POOL:
-      e = qk_pool(src, dst, panels, a.h, a.w, a.c, b.h, b.w, d.knlSiz, d.stride, d.padSiz, st);
+      e = qk_pool(src, dst, panels, a.h, a.w, a.c, b.h, b.w, d.knlSiz, d.stride, d.padSiz, live, st);
       break;
     case QCNN_RELU:
       e = qk_relu(src, dst, (size_t)panels * fm_elems(c, l) * QCNN_PANEL, st);
       break;
     case QCNN_LORN:
-      e = qk_lrn(src, dst, panels, a.h * a.w, a.c, d.lrnSiz, d.lrnAlp, d.lrnBet, d.lrnIni, st);
+      e = qk_lrn(src, dst, panels, a.h * a.w, a.c, d.lrnSiz, d.lrnAlp, d.lrnBet, d.lrnIni, live, st);
       break;
     case QCNN_DRPT:   // test-time dropout is a copy (src/CaffeEva.cc:1091-1096); only reached by qcnn_run_layer
       e = hipMemcpyAsync(dst, src, (size_t)panels * fm_elems(c, l) * QCNN_PANEL * sizeof(float),
                          hipMemcpyDeviceToDevice, st);
       break;
     case QCNN_SMAX:
-      e = qk_softmax(src, dst, panels, a.h * a.w * a.c, st);
+      e = qk_softmax(src, dst, panels, a.h * a.w * a.c, live, st);
       break;
     default:
       return fail(c, "layer %d: invalid layer type %d", l, d.type);
@@ -301,6 +314,11 @@ bool direct_input(const QcnnCtx* c) {
 int run_layers(QcnnCtx* c, int n, const float* inNchw = nullptr) {
   const int panels = (n + QCNN_PANEL - 1) / QCNN_PANEL;
   const int ns = std::max(1, std::min(std::min(c->nStreams, kMaxStreams), panels));
+  // A batch of a few images: conv/FC by the channel-lane kernels, glue kernels on the live lanes only.  Only in the
+  // default f32 mode: the exact builder's point is the reference's summation order (which only the panel kernels
+  // keep), and modes 2 / 3 study properties of the panel kernels' table builders.
+  const bool small = c->smallBatch && c->lutMode == 1 && n <= kSmallBatchMax;
+  const int live = panels == 1 ? n : QCNN_PANEL;
   if (c->profile && c->profCount == kProfRing && drain_profile(c)) return 1;   // ring full: fold it into the sums
   const bool prof = c->profile != 0;
   c->lastFm.assign(c->L + 1, nullptr);
@@ -333,7 +351,7 @@ int run_layers(QcnnCtx* c, int n, const float* inNchw = nullptr) {
         e0 = c->ev[slot]; e1 = c->ev[slot + 1];
         HIP_TRY(c, hipEventRecord(e0, st));
       }
-      if (launch_layer(c, l, src, dst, p1 - p0, fuse, false, p0, st, direct ? inNchw : nullptr, n)) return 1;
+      if (launch_layer(c, l, src, dst, p1 - p0, fuse, false, p0, st, direct ? inNchw : nullptr, n, live, small)) return 1;
       if (prof) {
         HIP_TRY(c, hipEventRecord(e1, st));
         c->profPending.push_back(QcnnCtx::ProfRec{(((size_t)c->profCount * kMaxStreams + k) * c->L + l) * 2, l});
@@ -412,6 +430,7 @@ int qcnn_set_option(QcnnCtx* c, int option, int value) {
     case QCNN_OPT_LUT_MODE: if (value < 0 || value > 3) return fail(c, "LUT mode must be 0, 1, 2 or 3"); c->lutMode = value; return 0;
     case QCNN_OPT_KEEP_ALL: c->keepAll = value ? 1 : 0; return 0;
     case QCNN_OPT_PROFILE: c->profile = value ? 1 : 0; return 0;
+    case QCNN_OPT_SMALL_BATCH: c->smallBatch = value ? 1 : 0; return 0;
     case QCNN_OPT_STREAMS:
       if (value < 1 || value > kMaxStreams) return fail(c, "streams must be in [1, %d]", kMaxStreams);
       c->nStreams = value; return 0;

@@ -114,6 +114,11 @@ static inline size_t qk_ctrd2_bytes(int M) { return (size_t)M * 8 * 4 * 16 * 16;
 hipError_t qk_conv_aprx(const ConvParams& p, int lutMode, hipStream_t st);
 hipError_t qk_fc_aprx(const FcParams& p, int lutMode, hipStream_t st);
 int qk_fc_channels_per_block(int Ct);   // output channels one k_fc_aprx workgroup covers
+// The same two layers for a batch of a few images (qcnn_small.hip): lanes = output channels, one workgroup per (output
+// tile, channel chunk, image); n = images of the launch (all inside the panels src/dst point at); f32 arithmetic,
+// results equal to the panel kernels' to rounding.  p.rows / p.ctrd / p.bias as above; msplit / partial unused.
+hipError_t qk_conv_small(const ConvParams& p, int n, hipStream_t st);
+hipError_t qk_fc_small(const FcParams& p, int n, hipStream_t st);
 
 // Load-time decode of a bit-packed assignment stream (.cbn payload, include/FileIO.h:128-166: 4096-byte blocks of
 // floor(32768 / bits) values packed MSB first, 0-based code-word indices in FILE order [Ct][taps][M]) straight
@@ -123,16 +128,18 @@ hipError_t qk_decode_cbn(const uint8_t* blocks, int bits, size_t n, int Ct, int 
 
 // dst row e = src row map[e], rows of 128 images ([panels][D][128]); the first FC layer consumes its input
 // NCHW-flattened (src/CaffeEva.cc:187-189)
-hipError_t qk_permute_rows(const float* src, float* dst, const int* map, int D, int panels, hipStream_t st);
+// `live` (here and in the glue wrappers below): images every panel of the launch really holds — 128, or the batch size
+// of a single-panel launch, whose other lanes are then not touched at all
+hipError_t qk_permute_rows(const float* src, float* dst, const int* map, int D, int panels, int live, hipStream_t st);
 // dst[e] = sum_z partial[z][e] (z ascending), optional ReLU; n floats per partial slab
 hipError_t qk_sum_partials(const float* partial, float* dst, int msplit, size_t n, int relu, hipStream_t st);
 
 hipError_t qk_relu(const float* src, float* dst, size_t n, hipStream_t st);
 hipError_t qk_lrn(const float* src, float* dst, int panels, int HW, int C, int lrnSiz, float alp, float bet,
-                  float ini, hipStream_t st);
+                  float ini, int live, hipStream_t st);
 hipError_t qk_pool(const float* src, float* dst, int panels, int H, int W, int C, int Ho, int Wo, int knl,
-                   int stride, int pad, hipStream_t st);
-hipError_t qk_softmax(const float* src, float* dst, int panels, int C, hipStream_t st);
+                   int stride, int pad, int live, hipStream_t st);
+hipError_t qk_softmax(const float* src, float* dst, int panels, int C, int live, hipStream_t st);
 hipError_t qk_top5(const float* prob, uint16_t* out, int n, int C, hipStream_t st);   // prob panel layout -> [n][5]
 
 // [n][C][H][W] -> panels [H*W*C][128] (lanes >= n zero-filled)

@@ -1007,8 +1007,9 @@ __global__ void k_decode_cbn(const uint8_t* __restrict__ blocks, int bits, size_
 
 // dst row e = src row map[e] (the NHWC -> NCHW flatten in front of the first FC layer, src/CaffeEva.cc:187-189)
 __global__ void k_permute_rows(const float* __restrict__ src, float* __restrict__ dst, const int* __restrict__ map,
-                               int D, int panels) {
+                               int D, int panels, int livePairs) {
   const int lane = threadIdx.x & 63;
+  if (lane >= livePairs) return;
   const size_t rows = (size_t)panels * D;
   for (size_t r = blockIdx.x * (size_t)(blockDim.x >> 6) + (threadIdx.x >> 6); r < rows;
        r += (size_t)gridDim.x * (blockDim.x >> 6)) {
@@ -1059,10 +1060,11 @@ __global__ void k_relu(const float4* __restrict__ src, float4* __restrict__ dst,
 // skipped, which leaves s > 0 bit-identical).
 template <int N>
 __global__ __launch_bounds__(256) void k_lrn_stream(const float4* __restrict__ src, float4* __restrict__ dst,
-                                                    size_t pixels, int C, int segLen, float coeff, float nbet, float ini) {
+                                                    size_t pixels, int C, int segLen, float coeff, float nbet, float ini,
+                                                    int liveQuads) {
   constexpr int RAD = (N - 1) / 2;
   const size_t px = blockIdx.x * (size_t)(blockDim.x >> 5) + (threadIdx.x >> 5);
-  if (px >= pixels) return;
+  if (px >= pixels || (int)(threadIdx.x & 31) >= liveQuads) return;   // lanes of images a small batch does not have
   // blockIdx.y = channel segment [cs, ce): few pixels (a single panel of a 13x13 map) would otherwise leave most of
   // the chip idle.  segLen is a multiple of N, so channel k always lives in ring slot k % N.
   const int cs = blockIdx.y * segLen, ce = min(C, cs + segLen);
@@ -1173,10 +1175,11 @@ __global__ void k_pool(const float* __restrict__ src, float* __restrict__ dst, i
 
 // max-pool, four images per thread (32 lanes = one row, a wave = two adjacent channels): same window rule
 __global__ __launch_bounds__(256) void k_pool4(const float4* __restrict__ src, float4* __restrict__ dst, int panels,
-                                               int H, int W, int C, int Ho, int Wo, int knl, int stride, int pad) {
+                                               int H, int W, int C, int Ho, int Wo, int knl, int stride, int pad,
+                                               int liveQuads) {
   const size_t rows = (size_t)panels * Ho * Wo * C;
   const size_t r = blockIdx.x * (size_t)(blockDim.x >> 5) + (threadIdx.x >> 5);
-  if (r >= rows) return;
+  if (r >= rows || (int)(threadIdx.x & 31) >= liveQuads) return;
   const int q = threadIdx.x & 31;
   const int c = (int)(r % C);
   size_t t = r / C;
@@ -1524,10 +1527,10 @@ hipError_t qk_sum_partials(const float* partial, float* dst, int msplit, size_t 
   return hipGetLastError();
 }
 
-hipError_t qk_permute_rows(const float* src, float* dst, const int* map, int D, int panels, hipStream_t st) {
+hipError_t qk_permute_rows(const float* src, float* dst, const int* map, int D, int panels, int live, hipStream_t st) {
   const size_t rows = (size_t)panels * D;
   const int blocks = (int)((rows + 3) / 4 < 8192 ? (rows + 3) / 4 : 8192);
-  hipLaunchKernelGGL(k_permute_rows, dim3(blocks ? blocks : 1), dim3(256), 0, st, src, dst, map, D, panels);
+  hipLaunchKernelGGL(k_permute_rows, dim3(blocks ? blocks : 1), dim3(256), 0, st, src, dst, map, D, panels, (live + 1) / 2);
   return hipGetLastError();
 }
 
@@ -1540,7 +1543,7 @@ hipError_t qk_relu(const float* src, float* dst, size_t n, hipStream_t st) {
 }
 
 hipError_t qk_lrn(const float* src, float* dst, int panels, int HW, int C, int lrnSiz, float alp, float bet, float ini,
-                  hipStream_t st) {
+                  int live, hipStream_t st) {
   const size_t rows = (size_t)panels * HW * C;
   const float coeff = alp / lrnSiz;   // float / int, as src/CaffeEva.cc:1055
   if (lrnSiz == 5 || lrnSiz == 3) {   // streaming kernel: 8 pixels per block
@@ -1553,10 +1556,10 @@ hipError_t qk_lrn(const float* src, float* dst, int panels, int HW, int C, int l
     const dim3 grid((unsigned)blocks, (unsigned)segs);
     if (lrnSiz == 5)
       hipLaunchKernelGGL(k_lrn_stream<5>, grid, dim3(256), 0, st, reinterpret_cast<const float4*>(src),
-                         reinterpret_cast<float4*>(dst), pixels, C, segLen, coeff, -bet, ini);
+                         reinterpret_cast<float4*>(dst), pixels, C, segLen, coeff, -bet, ini, (live + 3) / 4);
     else
       hipLaunchKernelGGL(k_lrn_stream<3>, grid, dim3(256), 0, st, reinterpret_cast<const float4*>(src),
-                         reinterpret_cast<float4*>(dst), pixels, C, segLen, coeff, -bet, ini);
+                         reinterpret_cast<float4*>(dst), pixels, C, segLen, coeff, -bet, ini, (live + 3) / 4);
     return hipGetLastError();
   }
   const int blocks = (int)((rows + 3) / 4 < 8192 ? (rows + 3) / 4 : 8192);
@@ -1565,11 +1568,11 @@ hipError_t qk_lrn(const float* src, float* dst, int panels, int HW, int C, int l
 }
 
 hipError_t qk_pool(const float* src, float* dst, int panels, int H, int W, int C, int Ho, int Wo, int knl, int stride,
-                   int pad, hipStream_t st) {
+                   int pad, int live, hipStream_t st) {
   const size_t rows = (size_t)panels * Ho * Wo * C;
   if ((rows + 7) / 8 < (size_t)1 << 31) {
     hipLaunchKernelGGL(k_pool4, dim3((unsigned)((rows + 7) / 8)), dim3(256), 0, st, reinterpret_cast<const float4*>(src),
-                       reinterpret_cast<float4*>(dst), panels, H, W, C, Ho, Wo, knl, stride, pad);
+                       reinterpret_cast<float4*>(dst), panels, H, W, C, Ho, Wo, knl, stride, pad, (live + 3) / 4);
     return hipGetLastError();
   }
   const int blocks = (int)((rows + 3) / 4 < 8192 ? (rows + 3) / 4 : 8192);
@@ -1578,13 +1581,13 @@ hipError_t qk_pool(const float* src, float* dst, int panels, int H, int W, int C
   return hipGetLastError();
 }
 
-hipError_t qk_softmax(const float* src, float* dst, int panels, int C, hipStream_t st) {
+hipError_t qk_softmax(const float* src, float* dst, int panels, int C, int live, hipStream_t st) {
   const size_t shm = ((size_t)C * 32 + 32) * sizeof(float);
   if (shm <= 160 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_softmax_lds),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_softmax_lds, dim3(PANEL / 32, panels), dim3(256), shm, st, src, dst, C);
+    hipLaunchKernelGGL(k_softmax_lds, dim3((live + 31) / 32, panels), dim3(256), shm, st, src, dst, C);
     return hipGetLastError();
   }
   hipLaunchKernelGGL(k_softmax, dim3((panels * PANEL + 63) / 64), dim3(64), 0, st, src, dst, panels, C);
@@ -1597,7 +1600,7 @@ hipError_t qk_top5(const float* prob, uint16_t* out, int n, int C, hipStream_t s
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_top5_lds),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_top5_lds, dim3(PANEL / 32, panels_of(n)), dim3(256), shm, st, prob, out, n, C);
+    hipLaunchKernelGGL(k_top5_lds, dim3(n <= PANEL ? (n + 31) / 32 : PANEL / 32, panels_of(n)), dim3(256), shm, st, prob, out, n, C);
     return hipGetLastError();
   }
   hipLaunchKernelGGL(k_top5, dim3((n + 63) / 64), dim3(64), 0, st, prob, out, n, C);

@@ -86,6 +86,7 @@ def test_tiny_ragged_multi_panel_batch(golden_tiny):
     imgs = synth.make_images(130, in_chw, seed=31)
     imgs[:3] = z["imgs"]
     eng = make_engine(in_chw, layers, params, 130)
+    eng.set_option(capi.OPT_SMALL_BATCH, 0)      # the batch-size invariance below is a property of the panel kernels
     prob, top5 = eng.forward_host(imgs)
     orc = po.COracle(in_chw, layers)
     orc.set_params(params)
@@ -283,6 +284,7 @@ def test_vgg16_two_panel_batch():
     params = synth.make_params(in_chw, layers, seed=51)
     imgs = synth.make_images(130, in_chw, seed=54)
     eng = make_engine(in_chw, layers, params, 130, lut=capi.LUT_MFMA, keep_all=0)
+    eng.set_option(capi.OPT_SMALL_BATCH, 0)      # bit-for-bit batch invariance: panel kernels for every batch size
     prob, top5 = eng.forward_host(imgs)
     assert np.isfinite(prob).all() and np.abs(prob.sum(axis=1) - 1.0).max() < 1e-4
     p1, t1 = eng.forward_host(imgs[129:130])
@@ -385,6 +387,48 @@ def test_odd_channel_count_is_rejected():
     eng = pkg("engine").QcnnEngine(0)
     with pytest.raises(pkg("engine").QcnnError):
         eng.configure(in_chw, layers, {0: (1, 16, 3), 2: (63, 16, 4)})
+
+
+# ---------------------------------------------------------------- batches of a few images ----
+@pytest.mark.parametrize("model,n_img", [("AlexNet", 1), ("AlexNet", 2), ("CaffeNetFGB", 2), ("VggCnnS", 2), ("VGG16", 1)])
+def test_small_batch_kernels_vs_oracle(model, n_img):
+    """Batches of one or two images run the conv/FC layers with the few-image kernels (qcnn_small.hip: lanes = output
+    channels, QCNN_OPT_SMALL_BATCH = 1, the default).  Every feature map against the oracle, and the same batch through
+    the panel kernels: equal to rounding."""
+    in_chw, layers, _, _ = topo.MODELS[model]
+    params = synth.make_params(in_chw, layers, seed=7)
+    imgs = synth.make_images(n_img, in_chw, seed=9)
+    orc = po.COracle(in_chw, layers)
+    orc.set_params(params)
+    orc.forward(imgs)
+    L = len(layers)
+    eng = make_engine(in_chw, layers, params, 64, lut=capi.LUT_MFMA)
+    prob, top5 = eng.forward_host(imgs)
+    for l in range(L + 1):
+        e_inf, e_l2 = rel_err(eng.layer_output(l, n_img), orc.fm(l))
+        assert e_inf <= TOL and e_l2 <= TOL, "%s fm[%d]: %g %g" % (model, l, e_inf, e_l2)
+    assert np.array_equal(top5, np.stack([orc.top5(orc.fm(L)[i]) for i in range(n_img)]))
+    eng.set_option(capi.OPT_SMALL_BATCH, 0)
+    prob_panel, top5_panel = eng.forward_host(imgs)
+    assert np.array_equal(top5, top5_panel)
+    assert np.abs(prob - prob_panel).max() <= 1e-5 * np.abs(prob_panel).max()
+    eng.set_option(capi.OPT_KEEP_ALL, 0)                                  # fast path: ReLU fused, input read in place
+    eng.set_option(capi.OPT_SMALL_BATCH, 1)
+    prob_fast, top5_fast = eng.forward_host(imgs)
+    assert np.array_equal(prob_fast, prob) and np.array_equal(top5_fast, top5)
+    eng.close()
+
+
+def test_small_batch_tiny_model_all_layer_types(golden_tiny):
+    z = golden_tiny
+    in_chw, layers = topo.tiny_model()
+    eng = make_engine(in_chw, layers, tiny_params_from_golden(z, layers), 8, lut=capi.LUT_MFMA)
+    B = 2
+    prob, top5 = eng.forward_host(z["imgs"][:B])
+    for l in range(len(layers) + 1):
+        e_inf, e_l2 = rel_err(eng.layer_output(l, B), z["fm_%02d" % l][:B])
+        assert e_inf <= TOL and e_l2 <= TOL, "fm[%d]: %g %g" % (l, e_inf, e_l2)
+    assert np.array_equal(top5, z["top5"][:B])
 
 
 # ---------------------------------------------------------------- packed assignments decoded on the device ----
@@ -514,7 +558,7 @@ def test_bf16_pair_builder_within_tolerance(model, n_img):
     orc = po.COracle(in_chw, layers)
     orc.set_params(params)
     orc.forward(imgs)
-    eng = make_engine(in_chw, layers, params, n_img, lut=capi.LUT_MFMA_BF16X2)
+    eng = make_engine(in_chw, layers, params, n_img, lut=capi.LUT_MFMA_BF16X2)     # (a study mode: always the panel kernels)
     prob, top5 = eng.forward_host(imgs)
     rows = []
     for l in range(len(layers) + 1):
