@@ -511,6 +511,7 @@ def main():
             out["speedup_vs_cpu_baseline"] = round(value / cb["value"], 1)
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()                      # rank 0 may still have been busy with the CPU reference
         dist.destroy_process_group()
     if rank == 0 and (not ok or (parity is not None and not parity["ok"])):
         raise SystemExit("bench.py: outputs differ from the CPU reference beyond %g (see `parity`)" % TOL)
