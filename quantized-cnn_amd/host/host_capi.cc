@@ -1,7 +1,9 @@
 // host_capi.cc — small C entry points into the C++ host mirror, for the pytest suite only (ctypes cannot
 // call C++ classes).  Nothing here is on the product path.
 #include "../../include/BmpImgIO.h"
+#ifndef QH_NO_DEVICE          // the sanitizer build (tests/test_host_sanitizers.py) covers the device-free classes only
 #include "../../include/CaffeEva.h"
+#endif
 #include "../../include/CaffePara.h"
 #include "../../include/FileIO.h"
 #include "../../include/Matrix.h"
@@ -73,6 +75,7 @@ int qh_cbn_rewrite(const char* inPath, const char* outPath, int bits) {
   return 0;
 }
 
+#ifndef QH_NO_DEVICE
 // CaffeEva through its public interface on one BMP image (AlexNet, data root laid out like the reference's):
 // feature maps `layers[0..n)` of the forward pass, NHWC, written back to back into out (cap floats); sizes[] gets
 // the element counts.  Arithmetic sanity of the host mirror -> C-ABI plumbing (feature maps, not accuracy lines).
@@ -105,6 +108,8 @@ int qh_eva_featmaps(const char* mainDir, const char* bmpPath, const int* layers,
   }
   return 0;
 }
+
+#endif  // QH_NO_DEVICE
 
 // Matrix semantics the reference relies on; returns the number of failed checks
 int qh_matrix_selftest(void) {
