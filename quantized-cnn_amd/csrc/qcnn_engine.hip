@@ -27,6 +27,7 @@ struct LayerShape {
   size_t offCtrd2 = 0;                                         // bf16-pair split of the code book (0 bytes when not applicable)
   bool hasCtrd2 = false;
   size_t asmtBytes = 0;
+  size_t offProg = 0, progBytes = 0;                           // conv with K = 128: offsets in consumption order (QkProgram)
   bool hasDmap = false;
   bool loaded = false;
 };
@@ -132,6 +133,12 @@ int plan_arena(QcnnCtx* c) {
     const size_t taps = (d.type == QCNN_CONV) ? (size_t)d.knlSiz * d.knlSiz : 1;
     s.asmtBytes = taps * s.M * sl.rowStride * sizeof(uint16_t);
     s.offAsmt = off; off = align_up(off + s.asmtBytes + QCNN_ROWS_PAD, 256);
+    s.progBytes = 0;
+    if (d.type == QCNN_CONV && s.K == 128) {     // the MFMA panel kernel reads its offsets through the program table
+      const QkProgram pg = qk_conv_program(sl, d.knlSiz, d.stride);
+      s.progBytes = (size_t)pg.rfH * pg.rfW * s.M * pg.rowU16 * sizeof(uint16_t);
+      s.offProg = off; off = align_up(off + s.progBytes + QCNN_ROWS_PAD, 256);
+    }
     s.hasDmap = (d.type == QCNN_FCNT && l == c->firstFc && c->dims[l].h * c->dims[l].w > 1);
     if (s.hasDmap) { s.offDmap = off; off = align_up(off + sizeof(int) * fm_elems(c, l), 256); }
   }
@@ -194,6 +201,7 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
       p.ctrd = reinterpret_cast<const float*>(c->arena + s.offCtrd);
       p.ctrd2 = s.hasCtrd2 ? c->arena + s.offCtrd2 : nullptr;
       p.rows = reinterpret_cast<const uint16_t*>(c->arena + s.offAsmt);
+      p.prog = s.progBytes ? reinterpret_cast<const uint16_t*>(c->arena + s.offProg) : nullptr;
       p.H = a.h; p.W = a.w; p.Cin = a.c; p.Ho = b.h; p.Wo = b.w; p.Ct = b.c;
       p.knl = d.knlSiz; p.stride = d.stride; p.pad = d.padSiz; p.grp = d.grpCnt;
       p.M = s.M; p.Cs = s.Cs; p.K = s.K; p.relu = fuseRelu ? 1 : 0; p.panels = panels;
@@ -610,6 +618,18 @@ int upload_bias_ctrd(QcnnCtx* c, int layer, const float* bias, const float* ctrd
 }
 }  // namespace
 
+namespace {
+// rows table of a conv layer (already in the arena, same stream) -> program table
+hipError_t build_program(QcnnCtx* c, int layer, const QkSlots& sl) {
+  const QcnnLayerDesc& d = c->layers[layer];
+  const LayerShape& s = c->shapes[layer];
+  if (!s.progBytes) return hipSuccess;
+  return qk_build_program(reinterpret_cast<const uint16_t*>(c->arena + s.offAsmt),
+                          reinterpret_cast<uint16_t*>(c->arena + s.offProg), sl, qk_conv_program(sl, d.knlSiz, d.stride),
+                          d.knlSiz, d.stride, s.M, c->stream);
+}
+}  // namespace
+
 int qcnn_model_set_layer_params(QcnnCtx* c, int layer, const float* bias, const float* ctrd_file,
                                 const uint8_t* asmt_file) {
   HIP_TRY(c, hipSetDevice(c->device));
@@ -639,6 +659,7 @@ int qcnn_model_set_layer_params(QcnnCtx* c, int layer, const float* bias, const 
   }
   if (upload_bias_ctrd(c, layer, bias, ctrd_file)) return 1;
   HIP_TRY(c, hipMemcpyAsync(c->arena + s.offAsmt, asmt.data(), asmt.size() * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, build_program(c, layer, sl));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   s.loaded = true;
   return 0;
@@ -671,6 +692,7 @@ int qcnn_model_set_layer_params_cbn(QcnnCtx* c, int layer, const float* bias, co
   if (e == hipSuccess) e = hipMemsetAsync(c->arena + s.offAsmt, 0, s.asmtBytes + QCNN_ROWS_PAD, c->stream);   // padding entries -> row 0
   if (e == hipSuccess)
     e = qk_decode_cbn(dev, bits, n, Ct, (int)taps, s.M, s.K, sl, reinterpret_cast<uint16_t*>(c->arena + s.offAsmt), bad, c->stream);
+  if (e == hipSuccess) e = build_program(c, layer, sl);
   int flag = 0;
   if (e == hipSuccess) e = hipMemcpyAsync(&flag, bad, sizeof(int), hipMemcpyDeviceToHost, c->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);

@@ -67,6 +67,42 @@ static inline QkSlots qk_conv_slots(int Ctg, int groups) {
   const int cpw = per <= 48 ? 4 : per <= 72 ? 6 : per <= 96 ? 8 : per <= 144 ? 12 : per <= 192 ? 16 : per <= 288 ? 24 : 32;
   return qk_make_slots(Ctg, groups, cpw);
 }
+// output tile (positions per workgroup) that goes with a conv layer's channels per wave: as many positions as 64-72
+// accumulator registers allow
+__host__ __device__ static inline void qk_conv_tile(int cpw, int* th, int* tw) {
+  switch (cpw) {
+    case 32: case 24: *th = 1; *tw = 1; break;
+    case 16: *th = 1; *tw = 2; break;
+    case 12: *th = 1; *tw = 3; break;
+    case 8: *th = 2; *tw = 2; break;
+    case 6: *th = 2; *tw = 3; break;
+    default: *th = 2; *tw = 4; break;
+  }
+}
+// "Program" of a conv layer: the row offsets in the order a workgroup consumes them.  Entry (ry, rx, m) — a source
+// pixel RELATIVE to the tile's unclipped receptive field ((TH-1)*stride + knl rows) and a sub-space — holds, for every
+// workgroup slice (group, chunk), wave and wave half, ONE contiguous block with the offsets of ALL positions of the
+// tile: [pos][hp] uint16 padded to a multiple of 8.  Position (dy, dx) looks at tap (ry - dy*stride, rx - dx*stride);
+// taps that do not exist hold 0 (the gather skips them).  One table serves every tile: border tiles just never visit
+// the clipped pixels.  A stage then costs ONE contiguous row read for the whole workgroup (it is fetched by one wave
+// and handed to the others through LDS) instead of one table row per position and wave.
+struct QkProgram {
+  int th, tw, np, rfH, rfW;
+  int blkU16;      // uint16 per wave half and entry (np * hp rounded up to a multiple of 8)
+  int wgRowU16;    // per workgroup slice and entry = 12 * 2 * blkU16
+  int rowU16;      // per entry = groups * chunks * wgRowU16
+};
+__host__ __device__ static inline QkProgram qk_conv_program(const QkSlots& sl, int knl, int stride) {
+  QkProgram g;
+  qk_conv_tile(sl.cpw, &g.th, &g.tw);
+  g.np = g.th * g.tw;
+  g.rfH = (g.th - 1) * stride + knl;
+  g.rfW = (g.tw - 1) * stride + knl;
+  g.blkU16 = (g.np * sl.hp + 7) / 8 * 8;
+  g.wgRowU16 = QCNN_GATHER_WAVES * 2 * g.blkU16;
+  g.rowU16 = sl.groups * sl.chunks * g.wgRowU16;
+  return g;
+}
 static inline QkSlots qk_fc_slots(int Ct) { return qk_make_slots(Ct, 1, Ct >= 384 ? 32 : (Ct >= 96 ? 8 : 4)); }
 // table position (in uint16 entries, inside one (tap, sub-space) row) of channel c of group g, or -1
 __host__ __device__ static inline int qk_slot_entry(const QkSlots& s, int g, int c) {
@@ -85,6 +121,7 @@ struct ConvParams {
   const void* ctrd2;     // [M][8 row tiles][4 k-slices][16 rows][8 bf16]: code book split in two bf16 parts (slices 0, 1:
                          // leading part, 2, 3: remainder) in v_mfma_f32_16x16x32_bf16 operand order; K = 128 layers only, else NULL
   const uint16_t* rows;  // [kh][kw][M][rowStride] (PrepAsmtBuf order, src/CaffeEva.cc:585-586): row offsets, QkSlots order
+  const uint16_t* prog;  // [rfH][rfW][M][rowU16]: the same offsets in consumption order (QkProgram); panel kernels only
   int H, W, Cin, Ho, Wo, Ct;
   int knl, stride, pad, grp;
   int M, Cs, K;
@@ -125,6 +162,10 @@ hipError_t qk_fc_small(const FcParams& p, int n, hipStream_t st);
 // into the row-offset table [taps][M][rowStride] of the arena.  *bad is set when an index >= K is met.
 hipError_t qk_decode_cbn(const uint8_t* blocks, int bits, size_t n, int Ct, int taps, int M, int K, QkSlots sl,
                          uint16_t* rows, int* bad, hipStream_t st);
+
+// rows (plain table of a conv layer) -> prog (QkProgram order); one thread per program entry
+hipError_t qk_build_program(const uint16_t* rows, uint16_t* prog, QkSlots sl, QkProgram pg, int knl, int stride, int M,
+                            hipStream_t st);
 
 // dst row e = src row map[e], rows of 128 images ([panels][D][128]); the first FC layer consumes its input
 // NCHW-flattened (src/CaffeEva.cc:187-189)

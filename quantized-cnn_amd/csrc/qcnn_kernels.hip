@@ -64,16 +64,19 @@ __device__ __forceinline__ void barrier_plain() { asm volatile("s_barrier" ::: "
 #ifdef QCNN_TRACE
 // Debug build only (scripts/trace_stage.py): workgroup `qcnn_trace_block` records, for every wave and the first
 // 64 stage periods, the cycle at which it arrives at the stage barrier and the cycle at which it leaves it.
-__device__ unsigned long long qcnn_trace_buf[16 * 64 * 2 + 16];
+__device__ unsigned long long qcnn_trace_buf[16 * 64 * 2 + 16 + 16 * 64];
 __device__ int qcnn_trace_block = 0;
 #define TR_ARRIVE(s) do { if ((int)blockIdx.x == qcnn_trace_block && blockIdx.y == 0 && blockIdx.z == 0 && (s) < 64 && (threadIdx.x & 63) == 0) \
     qcnn_trace_buf[((threadIdx.x >> 6) * 64 + (s)) * 2] = __builtin_readcyclecounter(); } while (0)
 #define TR_LEAVE(s) do { if ((int)blockIdx.x == qcnn_trace_block && blockIdx.y == 0 && blockIdx.z == 0 && (s) < 64 && (threadIdx.x & 63) == 0) \
     qcnn_trace_buf[((threadIdx.x >> 6) * 64 + (s)) * 2 + 1] = __builtin_readcyclecounter(); } while (0)
+#define TR_MID(s) do { if ((int)blockIdx.x == qcnn_trace_block && blockIdx.y == 0 && blockIdx.z == 0 && (s) < 64 && (threadIdx.x & 63) == 0) \
+    qcnn_trace_buf[16 * 64 * 2 + 16 + (threadIdx.x >> 6) * 64 + (s)] = __builtin_readcyclecounter(); } while (0)
 #define TR_ROLE(r) do { if ((int)blockIdx.x == qcnn_trace_block && blockIdx.y == 0 && blockIdx.z == 0 && (threadIdx.x & 63) == 0) \
     qcnn_trace_buf[16 * 64 * 2 + (threadIdx.x >> 6)] = (r).builder ? 100 + (r).idx : (r).idx; } while (0)
 #else
 #define TR_ARRIVE(s) do {} while (0)
+#define TR_MID(s) do {} while (0)
 #define TR_LEAVE(s) do {} while (0)
 #define TR_ROLE(r) do {} while (0)
 #endif
@@ -132,6 +135,7 @@ struct Idx {
 
 template <int DW>
 __device__ __forceinline__ void vload_idx(Idx<DW>& o, const uint16_t* __restrict__ ap, uint32_t laneOff) {
+
   const uint32_t* __restrict__ ap4 =
       reinterpret_cast<const uint32_t*>(__builtin_assume_aligned(reinterpret_cast<const char*>(ap) + laneOff, 4));
 #pragma unroll
@@ -631,6 +635,63 @@ __device__ __forceinline__ void conv_gather(f32x2 (&acc)[TH * TW][CPW], const Id
   }
 }
 
+
+// ---- offsets through the program table (QkProgram, qcnn_kernels.h): K = 128 panel kernels ----
+// One wave fetches the workgroup's contiguous row of the stage after next straight into LDS (LDS-DMA: no registers,
+// no ds_write); every gather wave then picks its block for the NEXT stage with one or two ds_read_b128 while it
+// gathers the current one.  Measured before the change: the per-position table reads and their address arithmetic
+// kept a gather wave busy for 565-1270 cycles per stage (profiles/r2_v7/trace); dropping them altogether (wrong
+// results, timing only) was worth 11 % of the whole forward pass.
+constexpr uint32_t IDX_LDS = 2u * STAGE_BYTES;     // two row buffers behind the two LUT stages
+constexpr uint32_t IDX_BUF = 2048u;
+template <int NB>
+struct IdxBlk {
+  uint32_t w[NB];
+};
+template <int NB>
+__device__ __forceinline__ void blk_load(IdxBlk<NB>& o, const char* __restrict__ src) {
+  const uint4* __restrict__ q = reinterpret_cast<const uint4*>(__builtin_assume_aligned(src, 16));
+#pragma unroll
+  for (int i = 0; i < NB / 4; ++i) {
+    const uint4 v = q[i];
+    o.w[4 * i] = v.x; o.w[4 * i + 1] = v.y; o.w[4 * i + 2] = v.z; o.w[4 * i + 3] = v.w;
+  }
+}
+// 16 bytes per lane from gsrc (per lane) to LDS byte ldsDst + 16 * lane (ldsDst wave-uniform); completion = vmcnt
+__device__ __forceinline__ void glds16(const char* gsrc, uint32_t ldsDst) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(ldsDst) : "memory");
+}
+template <int BYTES>
+__device__ __forceinline__ void idx_row_to_lds(const char* __restrict__ row, uint32_t ldsDst, int lane) {
+  static_assert(BYTES <= (int)IDX_BUF && BYTES % 16 == 0, "a workgroup row fits one buffer");
+  if (lane * 16 < BYTES) glds16(row + lane * 16, ldsDst);
+  if (BYTES > 1024 && lane * 16 < BYTES - 1024) glds16(row + 1024 + lane * 16, ldsDst + 1024u);
+}
+__device__ __forceinline__ void barrier_after_lds_dma() {
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <int TH, int TW, int CPW, int NB>
+__device__ __forceinline__ void conv_gather_prog(f32x2 (&acc)[TH * TW][CPW], const IdxBlk<NB>& blk, const StagePos& c,
+                                                 const ConvGeom& g, const int (&rowStart)[TH], const int (&colStart)[TW],
+                                                 uint32_t stage, bool live) {
+  constexpr int DW = idx_dwords(CPW);
+#pragma unroll
+  for (int dy = 0; dy < TH; ++dy) {
+    const bool rowOk = live && (unsigned)(c.hi - rowStart[dy]) < (unsigned)g.knl;
+#pragma unroll
+    for (int dx = 0; dx < TW; ++dx) {
+      const int valid = uni((rowOk && (unsigned)(c.wi - colStart[dx]) < (unsigned)g.knl) ? 1 : 0);
+      Idx<DW> o;
+#pragma unroll
+      for (int j = 0; j < DW; ++j) o.w[j] = blk.w[(dy * TW + dx) * DW + j];
+      gather_apply<CPW>(acc[dy * TW + dx], o, stage, valid);
+    }
+  }
+}
+
 template <int TH, int TW, int CPW, int KT, int KS>
 __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX, int tilesY, int chunksPerGrp, int G,
                                                         int rowStride) {
@@ -755,6 +816,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
     for (int s = 0; s < Sp; s += 2) {
       if (KT > 0) {                                    // stage s+1 -> buffer 1, from set A
         mfma_store<KTT, KS, 1>(opsA, Cs, Cg, q1.mg * G, M, bw, lane, p.lutF16);
+        TR_MID(s);
         const StagePos qf = (q3.hi > hiU) ? first : q3;
         mfma_load<KTT, KS>(opsA, xbase, pixel_off(qf, g), xa, p.ctrd, Cs, qf.mg * G, bw, lane);
       } else if (s + 1 < S) {
@@ -766,6 +828,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
       q1 = q2; q2 = q3; q3 = next_pos(q3, g);
       if (KT > 0) {                                    // stage s+2 -> buffer 0, from set B
         mfma_store<KTT, KS, 0>(opsB, Cs, Cg, q1.mg * G, M, bw, lane, p.lutF16);
+        TR_MID(s + 1);
         const StagePos qf = (q3.hi > hiU) ? first : q3;
         mfma_load<KTT, KS>(opsB, xbase, pixel_off(qf, g), xa, p.ctrd, Cs, qf.mg * G, bw, lane);
       } else if (s + 2 < S) {
@@ -809,27 +872,72 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
 #pragma unroll
   for (int dx = 0; dx < TW; ++dx) colStart[dx] = (wo0 + dx < p.Wo) ? (wo0 + dx) * p.stride - p.pad : -(1 << 28);
 
-  // Per stage: [prefetch the offsets of stage s+1][gather stage s][barrier]; two offset sets alternate.
-  Idx<DW> ia[NP], ib[NP];
-  StagePos c0p = first;
-  StagePos c1p = next_pos(c0p, g);
-  conv_prefetch_idx<TH, TW, CPW>(ia, c0p, g, rowsW, rowStart, colStart, laneOff);
   __builtin_amdgcn_s_setprio(QCNN_PRIO_GATHER);
-  barrier_plain();
-  for (int s = 0; s < Sp; s += 2) {
-    conv_prefetch_idx<TH, TW, CPW>(ib, c1p, g, rowsW, rowStart, colStart, laneOff);    // stage s+1 (past the end: clamped, unused)
-    conv_gather<TH, TW, CPW, KT == 8>(acc, ia, c0p, g, rowsW, rowStart, colStart, laneLds, laneOff, active);
-    c0p = c1p; c1p = next_pos(c1p, g);
-    TR_ARRIVE(s);
+  if constexpr (KT == 8) {
+    // Offsets through the program table.  Per stage: [pick the block of stage s+1 from LDS][wave 0: DMA the row of
+    // stage s+2 into the other row buffer][gather stage s][barrier].
+    constexpr int NB = (NP * DW + 3) / 4 * 4;          // dwords of one wave half's block
+    constexpr int WGROW = NGW * 2 * NB * 4;            // bytes of the workgroup's row of one program entry
+    const int rfW = (TW - 1) * p.stride + p.knl;
+    const int ry0 = ho0 * p.stride - p.pad, rx0 = wo0 * p.stride - p.pad;   // origin of the unclipped receptive field
+    const uint32_t entryB = (uint32_t)(p.grp * chunksPerGrp) * WGROW;
+    const char* __restrict__ progWg = reinterpret_cast<const char*>(p.prog) + (size_t)(grp * chunksPerGrp + chunk) * WGROW;
+    auto rowOf = [&](const StagePos& q) {              // stages past the end: any existing row
+      const StagePos c = (q.hi > hiU) ? first : q;
+      return progWg + (size_t)(uint32_t)(((c.hi - ry0) * rfW + (c.wi - rx0)) * M + c.mg) * entryB;
+    };
+    const uint32_t myBlk = (uint32_t)(gw * 2 + half) * NB * 4;
+    const bool loader = gw == 0;
+    IdxBlk<NB> ba, bb;
+    StagePos c0p = first;
+    StagePos c1p = next_pos(c0p, g);
+    StagePos c2p = next_pos(c1p, g);
+    blk_load(ba, rowOf(c0p) + myBlk);
+    if (loader) idx_row_to_lds<WGROW>(rowOf(c1p), IDX_LDS + IDX_BUF, lane);
+    barrier_after_lds_dma();
+    for (int s = 0; s < Sp; s += 2) {
+      blk_load(bb, lds + IDX_LDS + IDX_BUF + myBlk);                      // stage s+1
+      if (loader) idx_row_to_lds<WGROW>(rowOf(c2p), IDX_LDS, lane);       // stage s+2
+      TR_MID(s);
+      conv_gather_prog<TH, TW, CPW, NB>(acc, ba, c0p, g, rowStart, colStart, laneLds, active);
+      c0p = c1p; c1p = c2p; c2p = next_pos(c2p, g);
+      TR_ARRIVE(s);
+      barrier_after_lds_dma();
+      TR_LEAVE(s);
+      blk_load(ba, lds + IDX_LDS + myBlk);                                // stage s+2
+      if (loader) idx_row_to_lds<WGROW>(rowOf(c2p), IDX_LDS + IDX_BUF, lane);   // stage s+3
+      TR_MID(s + 1);
+      conv_gather_prog<TH, TW, CPW, NB>(acc, bb, c0p, g, rowStart, colStart, laneLds | STAGE_BYTES, active && s + 1 < S);
+      c0p = c1p; c1p = c2p; c2p = next_pos(c2p, g);
+      TR_ARRIVE(s + 1);
+      barrier_after_lds_dma();
+      TR_LEAVE(s + 1);
+    }
+  } else {
+    // Offsets from the plain table.  Per stage: [prefetch the offsets of stage s+1][gather stage s][barrier]; two
+    // offset sets alternate.
+    Idx<DW> ia[NP], ib[NP];
+    StagePos c0p = first;
+    StagePos c1p = next_pos(c0p, g);
+    conv_prefetch_idx<TH, TW, CPW>(ia, c0p, g, rowsW, rowStart, colStart, laneOff);
     barrier_plain();
-    TR_LEAVE(s);
-    conv_prefetch_idx<TH, TW, CPW>(ia, c1p, g, rowsW, rowStart, colStart, laneOff);    // stage s+2
-    conv_gather<TH, TW, CPW, KT == 8>(acc, ib, c0p, g, rowsW, rowStart, colStart, laneLds | STAGE_BYTES, laneOff,
+    for (int s = 0; s < Sp; s += 2) {
+      conv_prefetch_idx<TH, TW, CPW>(ib, c1p, g, rowsW, rowStart, colStart, laneOff);    // stage s+1 (past the end: clamped, unused)
+      TR_MID(s);
+      conv_gather<TH, TW, CPW, false>(acc, ia, c0p, g, rowsW, rowStart, colStart, laneLds, laneOff, active);
+      c0p = c1p; c1p = next_pos(c1p, g);
+      TR_ARRIVE(s);
+      barrier_plain();
+      TR_LEAVE(s);
+      conv_prefetch_idx<TH, TW, CPW>(ia, c1p, g, rowsW, rowStart, colStart, laneOff);    // stage s+2
+      TR_MID(s + 1);
+      conv_gather<TH, TW, CPW, false>(acc, ib, c0p, g, rowsW, rowStart, colStart, laneLds | STAGE_BYTES, laneOff,
                                       active && s + 1 < S);
-    c0p = c1p; c1p = next_pos(c1p, g);
-    TR_ARRIVE(s + 1);
-    barrier_plain();
-    TR_LEAVE(s + 1);
+      c0p = c1p; c1p = next_pos(c1p, g);
+      TR_ARRIVE(s + 1);
+      barrier_plain();
+      TR_LEAVE(s + 1);
+    }
   }
 
   if (active) {
@@ -1398,7 +1506,7 @@ __global__ __launch_bounds__(256) void k_unpack(const float* __restrict__ src, f
 #ifdef QCNN_TRACE
 }  // namespace
 extern "C" int qcnn_debug_trace_read(unsigned long long* host, int block) {
-  hipError_t e = hipMemcpyFromSymbol(host, HIP_SYMBOL(qcnn_trace_buf), sizeof(unsigned long long) * (16 * 64 * 2 + 16));
+  hipError_t e = hipMemcpyFromSymbol(host, HIP_SYMBOL(qcnn_trace_buf), sizeof(unsigned long long) * (16 * 64 * 2 + 16 + 16 * 64));
   if (e != hipSuccess) return 1;
   e = hipMemcpyToSymbol(HIP_SYMBOL(qcnn_trace_block), &block, sizeof(int));
   return e == hipSuccess ? 0 : 1;
@@ -1429,13 +1537,33 @@ hipError_t allow_big_lds(const void* kern, int bytes) {
   return hipSuccess;
 }
 
+// rows (plain table, [kh][kw][M][rowStride]) -> program table ([ry][rx][M][rowU16], QkProgram): one thread per entry
+__global__ __launch_bounds__(256) void k_build_program(const uint16_t* __restrict__ rows, uint16_t* __restrict__ prog,
+                                                       QkSlots sl, QkProgram pg, int knl, int stride, int M, size_t n) {
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
+    const int r = (int)(e % (size_t)pg.rowU16);
+    const int row = (int)(e / (size_t)pg.rowU16);
+    const int m = row % M, pix = row / M;
+    const int ry = pix / pg.rfW, rx = pix % pg.rfW;
+    const int wh = r / pg.blkU16, r3 = r % pg.blkU16;       // (workgroup slice, wave, half) and the place inside its block
+    const int pos = r3 / sl.hp, j = r3 % sl.hp;
+    uint16_t v = 0;
+    if (pos < pg.np) {
+      const int kh = ry - (pos / pg.tw) * stride, kw = rx - (pos % pg.tw) * stride;
+      if ((unsigned)kh < (unsigned)knl && (unsigned)kw < (unsigned)knl)
+        v = rows[(size_t)((kh * knl + kw) * M + m) * sl.rowStride + wh * sl.hp + j];
+    }
+    prog[e] = v;
+  }
+}
+
 template <int TH, int TW, int CPW>
 hipError_t launch_conv(const ConvParams& p, const QkSlots& sl, int lutMode, hipStream_t st) {
   const bool bf16Pairs = lutMode == 3;
   if (lutMode == 3) lutMode = 1;
   const int tilesX = (p.Wo + TW - 1) / TW, tilesY = (p.Ho + TH - 1) / TH;
   const dim3 grid(tilesX * tilesY * p.panels, sl.chunks * p.grp, 1);
-  const size_t shm = (size_t)2 * STAGE_BYTES;
+  const size_t shm = (size_t)2 * STAGE_BYTES + 2 * IDX_BUF;
   const int G = qcnn_stage_group(p.K);
   const bool two = min(p.Cin / p.grp, p.Cs) > 4;      // MFMA k-steps (4 dims each) that carry data
   auto kern = k_conv_aprx<TH, TW, CPW, 0, 1>;
@@ -1516,6 +1644,14 @@ hipError_t qk_decode_cbn(const uint8_t* blocks, int bits, size_t n, int Ct, int 
   const int grid = (int)std::min<size_t>((n + 255) / 256, 8192);
   hipLaunchKernelGGL(k_decode_cbn, dim3(grid ? grid : 1), dim3(256), 0, st, blocks, bits, n, Ct, taps, M, K,
                      qcnn_stage_group(K), sl, rows, bad);
+  return hipGetLastError();
+}
+
+hipError_t qk_build_program(const uint16_t* rows, uint16_t* prog, QkSlots sl, QkProgram pg, int knl, int stride, int M,
+                            hipStream_t st) {
+  const size_t n = (size_t)pg.rfH * pg.rfW * M * pg.rowU16;
+  const int grid = (int)std::min<size_t>((n + 255) / 256, 8192);
+  hipLaunchKernelGGL(k_build_program, dim3(grid ? grid : 1), dim3(256), 0, st, rows, prog, sl, pg, knl, stride, M, n);
   return hipGetLastError();
 }
 

@@ -38,8 +38,8 @@ def main():
     eng.load_model(in_chw, layers, params, batch)
     sizes = topo.fmap_sizes(in_chw, layers)
     h, w, c = sizes[layer]
-    x = synth.make_images(batch, (c, h, w), seed=1).transpose(0, 2, 3, 1).copy() if layer else None
-    buf = (C.c_ulonglong * (16 * 64 * 2 + 16))()
+    x = (np.random.default_rng(1).standard_normal((batch, h, w, c)).astype(np.float32)) if layer else None
+    buf = (C.c_ulonglong * (16 * 64 * 2 + 16 + 16 * 64))()
     lib = eng.lib
     lib.qcnn_debug_trace_read.argtypes = [C.c_void_p, C.c_int]
     lib.qcnn_debug_trace_read(buf, block)            # select the block
@@ -50,7 +50,8 @@ def main():
         eng.run_layer(layer, x, batch)
     lib.qcnn_debug_trace_read(buf, block)
     t = np.array(buf[: 16 * 64 * 2], dtype=np.float64).reshape(16, 64, 2)
-    role = np.array(buf[16 * 64 * 2:], dtype=np.int64)
+    role = np.array(buf[16 * 64 * 2: 16 * 64 * 2 + 16], dtype=np.int64)
+    mid = np.array(buf[16 * 64 * 2 + 16:], dtype=np.float64).reshape(16, 64)
     arrive, leave = t[:, :, 0], t[:, :, 1]
     ok = (arrive[0] > 0).sum()
     print("layer %d block %d batch %d: %d stages traced; roles (100+ = builder): %s" % (layer, block, batch, ok, role.tolist()))
@@ -63,6 +64,13 @@ def main():
     for wv in order:
         print("  wave %2d role %3d : wait %7.0f   busy %7.0f" % (wv, role[wv], slack[wv, 1:].mean(),
                                                                  (arrive[wv, 1:ok] - leave[wv, :ok - 1]).mean()))
+    # builders: leave -> [MFMA + stores] -> mid -> [operand loads of the stage after next] -> arrive
+    # gather waves: leave -> [offset prefetch issue] -> mid -> [look-ups] -> arrive
+    print("split of the busy time at the mid-point (builders: multiply+store | operand loads; gather: prefetch | look-ups):")
+    for wv in order:
+        a = (mid[wv, 1:ok] - leave[wv, :ok - 1]).mean()
+        b2 = (arrive[wv, 1:ok] - mid[wv, 1:ok]).mean()
+        print("  wave %2d role %3d : %7.0f | %7.0f" % (wv, role[wv], a, b2))
     print("per stage (first 24): period, slowest gather busy, slowest builder busy")
     for s in range(1, min(ok, 25)):
         busy = arrive[:, s] - leave[:, s - 1]
