@@ -231,8 +231,9 @@ __host__ __device__ constexpr int idx_dwords(int CPW) { return (CPW / 2 + 1) / 2
 // the CPW look-ups (CPW/2 reads) of one position / sub-space; `stage` = LDS byte address of the lane's four
 // images in slot 0 of the stage
 template <int CPW>
-__device__ __forceinline__ void gather_apply(f32x2 (&acc)[CPW], const Idx<idx_dwords(CPW)>& o, uint32_t stage, int valid) {
+__device__ __forceinline__ void gather_apply(f32x2 (&acc)[CPW], const Idx<idx_dwords(CPW)>& o, uint32_t stage, int validIn) {
   static_assert(CPW == 4 || CPW == 6 || CPW == 8 || CPW == 12 || CPW == 16 || CPW == 24 || CPW == 32, "channel slices");
+  const int valid = uni(validIn);       // an "s" operand of the blocks; free when the value already lives in an SGPR
   if constexpr (CPW == 32) {
     gq8(&acc[0], o.w[0], o.w[1], o.w[2], o.w[3], stage, valid);
     gq8(&acc[16], o.w[4], o.w[5], o.w[6], o.w[7], stage, valid);
@@ -673,21 +674,28 @@ __device__ __forceinline__ void barrier_after_lds_dma() {
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// 1 when 0 <= d < n, else 0 — in integer arithmetic only: a comparison would make hipcc carry the (wave-uniform)
+// result as a lane mask and turn it into the asm blocks' scalar operand through v_cndmask + v_readfirstlane, once per
+// position and stage (measured: the validity logic of the four positions of conv1 alone cost 30 % of the layer)
+__device__ __forceinline__ int in_range(int d, int n) { return (int)(~(uint32_t)(d | (n - 1 - d)) >> 31); }
+
 template <int TH, int TW, int CPW, int NB>
 __device__ __forceinline__ void conv_gather_prog(f32x2 (&acc)[TH * TW][CPW], const IdxBlk<NB>& blk, const StagePos& c,
                                                  const ConvGeom& g, const int (&rowStart)[TH], const int (&colStart)[TW],
-                                                 uint32_t stage, bool live) {
+                                                 uint32_t stage, int live) {
   constexpr int DW = idx_dwords(CPW);
+  int colOk[TW];
+#pragma unroll
+  for (int dx = 0; dx < TW; ++dx) colOk[dx] = in_range(c.wi - colStart[dx], g.knl);
 #pragma unroll
   for (int dy = 0; dy < TH; ++dy) {
-    const bool rowOk = live && (unsigned)(c.hi - rowStart[dy]) < (unsigned)g.knl;
+    const int rowOk = live & in_range(c.hi - rowStart[dy], g.knl);
 #pragma unroll
     for (int dx = 0; dx < TW; ++dx) {
-      const int valid = uni((rowOk && (unsigned)(c.wi - colStart[dx]) < (unsigned)g.knl) ? 1 : 0);
       Idx<DW> o;
 #pragma unroll
       for (int j = 0; j < DW; ++j) o.w[j] = blk.w[(dy * TW + dx) * DW + j];
-      gather_apply<CPW>(acc[dy * TW + dx], o, stage, valid);
+      gather_apply<CPW>(acc[dy * TW + dx], o, stage, rowOk & colOk[dx]);
     }
   }
 }
@@ -889,6 +897,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
     const uint32_t myBlk = (uint32_t)(gw * 2 + half) * NB * 4;
     const bool loader = gw == 0;
     IdxBlk<NB> ba, bb;
+    const int activeI = in_range(cw0, Ctg);            // `active` as an integer (see in_range)
     StagePos c0p = first;
     StagePos c1p = next_pos(c0p, g);
     StagePos c2p = next_pos(c1p, g);
@@ -899,7 +908,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
       blk_load(bb, lds + IDX_LDS + IDX_BUF + myBlk);                      // stage s+1
       if (loader) idx_row_to_lds<WGROW>(rowOf(c2p), IDX_LDS, lane);       // stage s+2
       TR_MID(s);
-      conv_gather_prog<TH, TW, CPW, NB>(acc, ba, c0p, g, rowStart, colStart, laneLds, active);
+      conv_gather_prog<TH, TW, CPW, NB>(acc, ba, c0p, g, rowStart, colStart, laneLds, activeI);
       c0p = c1p; c1p = c2p; c2p = next_pos(c2p, g);
       TR_ARRIVE(s);
       barrier_after_lds_dma();
@@ -907,7 +916,8 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
       blk_load(ba, lds + IDX_LDS + myBlk);                                // stage s+2
       if (loader) idx_row_to_lds<WGROW>(rowOf(c2p), IDX_LDS + IDX_BUF, lane);   // stage s+3
       TR_MID(s + 1);
-      conv_gather_prog<TH, TW, CPW, NB>(acc, bb, c0p, g, rowStart, colStart, laneLds | STAGE_BYTES, active && s + 1 < S);
+      conv_gather_prog<TH, TW, CPW, NB>(acc, bb, c0p, g, rowStart, colStart, laneLds | STAGE_BYTES,
+                                        activeI & in_range(s + 1, S));
       c0p = c1p; c1p = c2p; c2p = next_pos(c2p, g);
       TR_ARRIVE(s + 1);
       barrier_after_lds_dma();
@@ -1054,6 +1064,7 @@ __global__ __launch_bounds__(NW * 64) void k_fc_aprx(FcParams p, int G, int stag
   // stage) are skipped inside the look-up blocks; the stream is padded to Sp stages so that every wave meets
   // the same barriers.
   Idx<DW> ia, ib;
+  const int activeI = in_range(cw0, p.Ct);             // `active` as an integer (see in_range)
   const int mClamp = max(mEnd - 1, mBeg);
   vload_idx(ia, rowsW + (size_t)mBeg * rowStride, laneOff);
   vload_idx(ib, rowsW + (size_t)min(mBeg + 1, mClamp) * rowStride, laneOff);
@@ -1065,10 +1076,10 @@ __global__ __launch_bounds__(NW * 64) void k_fc_aprx(FcParams p, int G, int stag
     const int T = Sp * G;           // sub-space slots incl. padding (even)
     for (int k = 0; k < T; k += 2) {
       const int m = mBeg + k;
-      gather_apply<CPW>(acc, ia, stage, uni(active && m < mEnd));
+      gather_apply<CPW>(acc, ia, stage, activeI & in_range(m, mEnd));
       vload_idx(ia, rowsW + (size_t)min(m + 2, mClamp) * rowStride, laneOff);
       if (++r == G) { r = 0; stage ^= STAGE_BYTES; barrier_plain(); }
-      gather_apply<CPW>(acc, ib, stage, uni(active && m + 1 < mEnd));
+      gather_apply<CPW>(acc, ib, stage, activeI & in_range(m + 1, mEnd));
       vload_idx(ib, rowsW + (size_t)min(m + 3, mClamp) * rowStride, laneOff);
       if (++r == G) { r = 0; stage ^= STAGE_BYTES; barrier_plain(); }
     }
