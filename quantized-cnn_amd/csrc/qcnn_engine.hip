@@ -331,11 +331,22 @@ int run_layers(QcnnCtx* c, int n, const float* inNchw = nullptr) {
   const bool prof = c->profile != 0;
   c->lastFm.assign(c->L + 1, nullptr);
   c->lastFm[0] = inNchw ? nullptr : c->fmBuf[0];
+  // LRN + the 3x3 / stride 2 / pad 0 max-pool behind it run as one kernel on the fast path when every sub-batch
+  // fills the chip with it; the normalised map is then not materialised (qcnn_get_feature_map reports it missing)
+  auto lrn_pool = [&](int l) {
+    if (c->keepAll || small || l + 1 >= c->L) return false;
+    const QcnnLayerDesc& a = c->layers[l];
+    const QcnnLayerDesc& b = c->layers[l + 1];
+    if (a.type != QCNN_LORN || b.type != QCNN_POOL || (a.lrnSiz != 5 && a.lrnSiz != 3)) return false;
+    if (b.knlSiz != 3 || b.stride != 2 || b.padSiz != 0) return false;
+    return (long long)qk_lrn_pool_blocks(c->dims[l + 2].h, c->dims[l + 2].w) * (panels / ns) >= 256;
+  };
   for (int l = 0; l < c->L; ++l) {              // pointer table (aliases) — identical for every sub-batch
     const int type = c->layers[l].type;
     const bool prevFused = l > 0 && !c->keepAll && type == QCNN_RELU &&
                            (c->layers[l - 1].type == QCNN_CONV || c->layers[l - 1].type == QCNN_FCNT);
     c->lastFm[l + 1] = (type == QCNN_DRPT || prevFused) ? c->lastFm[l] : c->fmBuf[l + 1];
+    if (lrn_pool(l)) c->lastFm[l + 1] = nullptr;
   }
   if (ns > 1) {
     HIP_TRY(c, hipEventRecord(c->evFork, c->stream));
@@ -344,6 +355,8 @@ int run_layers(QcnnCtx* c, int n, const float* inNchw = nullptr) {
   for (int l = 0; l < c->L; ++l) {              // layer-major issue order: the streams advance together
     const int type = c->layers[l].type;
     if (c->lastFm[l + 1] == c->lastFm[l] && c->lastFm[l] != nullptr) continue;   // alias: copy semantics, no traffic
+    if (c->lastFm[l] == nullptr && l > 0) continue;                               // the pool of a fused LRN + pool pair
+    const bool lrnPool = c->lastFm[l + 1] == nullptr;
     const bool fuse = !c->keepAll && (type == QCNN_CONV || type == QCNN_FCNT) && l + 1 < c->L &&
                       c->layers[l + 1].type == QCNN_RELU;
     for (int k = 0; k < ns; ++k) {
@@ -352,14 +365,22 @@ int run_layers(QcnnCtx* c, int n, const float* inNchw = nullptr) {
       hipStream_t st = k == 0 ? c->stream : c->aux[k - 1];
       const bool direct = l == 0 && inNchw != nullptr;
       const float* src = direct ? nullptr : c->lastFm[l] + (size_t)p0 * fm_elems(c, l) * QCNN_PANEL;
-      float* dst = c->lastFm[l + 1] + (size_t)p0 * fm_elems(c, l + 1) * QCNN_PANEL;
+      float* dst = lrnPool ? c->lastFm[l + 2] + (size_t)p0 * fm_elems(c, l + 2) * QCNN_PANEL
+                           : c->lastFm[l + 1] + (size_t)p0 * fm_elems(c, l + 1) * QCNN_PANEL;
       hipEvent_t e0 = nullptr, e1 = nullptr;
       if (prof) {
         const size_t slot = (((size_t)c->profCount * kMaxStreams + k) * c->L + l) * 2;
         e0 = c->ev[slot]; e1 = c->ev[slot + 1];
         HIP_TRY(c, hipEventRecord(e0, st));
       }
-      if (launch_layer(c, l, src, dst, p1 - p0, fuse, false, p0, st, direct ? inNchw : nullptr, n, live, small)) return 1;
+      if (lrnPool) {
+        const QcnnLayerDesc& d = c->layers[l];
+        const hipError_t e = qk_lrn_pool(src, dst, p1 - p0, c->dims[l].h, c->dims[l].w, c->dims[l].c, c->dims[l + 2].h,
+                                         c->dims[l + 2].w, d.lrnSiz, d.lrnAlp, d.lrnBet, d.lrnIni, live, st);
+        if (e != hipSuccess) return fail(c, "layer %d (LRN + pool): %s", l, hipGetErrorString(e));
+      } else if (launch_layer(c, l, src, dst, p1 - p0, fuse, false, p0, st, direct ? inNchw : nullptr, n, live, small)) {
+        return 1;
+      }
       if (prof) {
         HIP_TRY(c, hipEventRecord(e1, st));
         c->profPending.push_back(QcnnCtx::ProfRec{(((size_t)c->profCount * kMaxStreams + k) * c->L + l) * 2, l});

@@ -178,6 +178,10 @@ hipError_t qk_sum_partials(const float* partial, float* dst, int msplit, size_t 
 hipError_t qk_relu(const float* src, float* dst, size_t n, hipStream_t st);
 hipError_t qk_lrn(const float* src, float* dst, int panels, int HW, int C, int lrnSiz, float alp, float bet,
                   float ini, int live, hipStream_t st);
+// LRN and the 3x3 / stride 2 / pad 0 max-pool behind it in one pass (the normalised map is not written)
+int qk_lrn_pool_blocks(int Ho, int Wo);          // workgroups per panel
+hipError_t qk_lrn_pool(const float* src, float* dst, int panels, int H, int W, int C, int Ho, int Wo, int lrnSiz, float alp,
+                       float bet, float ini, int live, hipStream_t st);
 hipError_t qk_pool(const float* src, float* dst, int panels, int H, int W, int C, int Ho, int Wo, int knl,
                    int stride, int pad, int live, hipStream_t st);
 hipError_t qk_softmax(const float* src, float* dst, int panels, int C, int live, hipStream_t st);

@@ -1327,6 +1327,106 @@ __global__ __launch_bounds__(256) void k_pool4(const float4* __restrict__ src, f
   dst[r * 32 + q] = v;
 }
 
+// LRN followed by a 3x3 / stride 2 / pad 0 max-pool in one pass (fast path only: the normalised map is never
+// materialised).  A block = a 4x4 tile of pool outputs = 9x9 source pixels, 32 images (8 float4 lanes), all channels.
+// Thread (pixel, image quad) walks the channels exactly like k_lrn_stream (same arithmetic, same order) but parks N
+// normalised channels at a time in an LDS slab [N][81 pixels][8 quads]; then thread (pool output, channel of the
+// chunk, quad) takes the maximum of its window out of the slab (k_pool4's order and comparison) and stores it.
+// Every normalised value is evaluated once per block (the one-pixel halo between tiles: 81/64 = 1.27x) instead of
+// once per window that contains it (2.25x: that version lost to the two separate kernels), and the
+// map takes one HBM read instead of write + read.
+constexpr int LP_PT = 4;                        // pool outputs per tile side
+constexpr int LP_IT = (LP_PT - 1) * 2 + 3;      // source pixels per tile side
+constexpr int LP_PIX = LP_IT * LP_IT;
+constexpr int LP_Q = 8;                         // float4 lanes (4 images each) per block
+constexpr int LP_THREADS = 704;                 // >= LP_PIX * LP_Q, >= 16 * 5 * LP_Q
+template <int N>
+__global__ __launch_bounds__(LP_THREADS) void k_lrn_pool(const float4* __restrict__ src, float4* __restrict__ dst, int H,
+                                                         int W, int C, int Ho, int Wo, int tilesX, float coeff, float nbet,
+                                                         float ini, int liveQuads) {
+  constexpr int RAD = (N - 1) / 2;
+  __shared__ float4 slab[N * LP_PIX * LP_Q];
+  const int q = threadIdx.x & (LP_Q - 1), rest = threadIdx.x >> 3;
+  const int slices = 32 / LP_Q;
+  const int slice = blockIdx.x % slices, tile = blockIdx.x / slices;
+  const int panel = blockIdx.y;
+  const int qg = slice * LP_Q + q;                               // float4 lane inside the 128-image row
+  const bool qlive = qg < liveQuads;
+  const int ty = tile / tilesX, tx = tile % tilesX;
+  // LRN role: source pixel `rest` of the tile
+  const int ph = ty * LP_PT * 2 + rest / LP_IT, pw = tx * LP_PT * 2 + rest % LP_IT;
+  const bool lrnOn = rest < LP_PIX && ph < H && pw < W && qlive;
+  const float4* __restrict__ x = src + ((size_t)panel * H * W + (size_t)(lrnOn ? ph * W + pw : 0)) * C * 32 + qg;
+  // pool role: output `rest / N` of the tile, channel `rest % N` of the chunk
+  const int pu = rest % N, po = rest / N;
+  const int ho = ty * LP_PT + po / LP_PT, wo = tx * LP_PT + po % LP_PT;
+  const bool poolOn = po < LP_PT * LP_PT && ho < Ho && wo < Wo && qlive;
+  const int hU = min(H, ho * 2 + 3) - 1 - ty * LP_PT * 2, wU = min(W, wo * 2 + 3) - 1 - tx * LP_PT * 2;   // tile-relative, inclusive
+  const int hL = (po / LP_PT) * 2, wL = (po % LP_PT) * 2;
+  float4* __restrict__ y = dst + ((size_t)panel * Ho * Wo + (size_t)(poolOn ? ho * Wo + wo : 0)) * C * 32 + qg;
+
+  const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  float4 raw[N], sq[N];          // ring: slot (t mod N) holds channel t (k_lrn_stream)
+#pragma unroll
+  for (int j = 0; j < N; ++j) { raw[j] = zero; sq[j] = zero; }
+#pragma unroll
+  for (int d = -RAD; d < RAD; ++d) {
+    const float4 v = (lrnOn && d >= 0 && d < C) ? x[(size_t)d * 32] : zero;
+    raw[(d + N) % N] = v;
+    sq[(d + N) % N] = make_float4(__fmul_rn(__fmul_rn(v.x, v.x), coeff), __fmul_rn(__fmul_rn(v.y, v.y), coeff),
+                                  __fmul_rn(__fmul_rn(v.z, v.z), coeff), __fmul_rn(__fmul_rn(v.w, v.w), coeff));
+  }
+  for (int c0 = 0; c0 < C; c0 += N) {
+    if (lrnOn) {
+#pragma unroll
+      for (int u = 0; u < N; ++u) {
+        const int c = c0 + u;
+        const int tin = c + RAD;
+        const float4 v = (tin < C) ? x[(size_t)tin * 32] : zero;
+        raw[(u + RAD) % N] = v;
+        sq[(u + RAD) % N] = make_float4(__fmul_rn(__fmul_rn(v.x, v.x), coeff), __fmul_rn(__fmul_rn(v.y, v.y), coeff),
+                                        __fmul_rn(__fmul_rn(v.z, v.z), coeff), __fmul_rn(__fmul_rn(v.w, v.w), coeff));
+        if (c < C) {
+          float4 sacc = make_float4(ini, ini, ini, ini);
+#pragma unroll
+          for (int j = 0; j < N; ++j) {
+            const float4 w = sq[(u - RAD + j + N) % N];
+            sacc.x = __fadd_rn(sacc.x, w.x); sacc.y = __fadd_rn(sacc.y, w.y);
+            sacc.z = __fadd_rn(sacc.z, w.z); sacc.w = __fadd_rn(sacc.w, w.w);
+          }
+          const float4 xc = raw[u % N];
+          float4 o;
+          o.x = __fmul_rn(xc.x, expf(__fmul_rn(nbet, logf(sacc.x))));
+          o.y = __fmul_rn(xc.y, expf(__fmul_rn(nbet, logf(sacc.y))));
+          o.z = __fmul_rn(xc.z, expf(__fmul_rn(nbet, logf(sacc.z))));
+          o.w = __fmul_rn(xc.w, expf(__fmul_rn(nbet, logf(sacc.w))));
+          slab[(u * LP_PIX + rest) * LP_Q + q] = o;
+        }
+      }
+    }
+    __syncthreads();
+    if (poolOn && c0 + pu < C) {
+      float4 v = zero;
+      bool first = true;
+      for (int h = hL; h <= hU; ++h)
+        for (int w = wL; w <= wU; ++w) {
+          const float4 sv = slab[(pu * LP_PIX + h * LP_IT + w) * LP_Q + q];
+          if (first) {
+            v = sv;
+          } else {
+            v.x = (sv.x < v.x) ? v.x : sv.x;
+            v.y = (sv.y < v.y) ? v.y : sv.y;
+            v.z = (sv.z < v.z) ? v.z : sv.z;
+            v.w = (sv.w < v.w) ? v.w : sv.w;
+          }
+          first = false;
+        }
+      y[(size_t)(c0 + pu) * 32] = v;
+    }
+    __syncthreads();
+  }
+}
+
 // Softmax through LDS: a block = 32 images x 8 class lanes.  expf of every logit in parallel into an
 // LDS tile [C][32], the reference's SEQUENTIAL float sum over the classes (src/CaffeEva.cc:1107-1114) by
 // one thread per image out of LDS, then the division in parallel.  Same values as k_softmax.
@@ -1711,6 +1811,24 @@ hipError_t qk_lrn(const float* src, float* dst, int panels, int HW, int C, int l
   }
   const int blocks = (int)((rows + 3) / 4 < 8192 ? (rows + 3) / 4 : 8192);
   hipLaunchKernelGGL(k_lrn, dim3(blocks ? blocks : 1), dim3(256), 0, st, src, dst, rows, C, lrnSiz, coeff, -bet, ini);
+  return hipGetLastError();
+}
+
+int qk_lrn_pool_blocks(int Ho, int Wo) { return ((Ho + LP_PT - 1) / LP_PT) * ((Wo + LP_PT - 1) / LP_PT) * (32 / LP_Q); }
+
+// LRN + the 3x3 / stride 2 / pad 0 max-pool behind it; the caller checked the window (qk_lrn_pool_blocks per panel)
+hipError_t qk_lrn_pool(const float* src, float* dst, int panels, int H, int W, int C, int Ho, int Wo, int lrnSiz, float alp,
+                       float bet, float ini, int live, hipStream_t st) {
+  if (lrnSiz != 5 && lrnSiz != 3) return hipErrorInvalidValue;
+  const float coeff = alp / lrnSiz;   // float / int, as src/CaffeEva.cc:1055
+  const int tilesX = (Wo + LP_PT - 1) / LP_PT;
+  const dim3 grid((unsigned)qk_lrn_pool_blocks(Ho, Wo), (unsigned)panels);
+  if (lrnSiz == 5)
+    hipLaunchKernelGGL(k_lrn_pool<5>, grid, dim3(LP_THREADS), 0, st, reinterpret_cast<const float4*>(src),
+                       reinterpret_cast<float4*>(dst), H, W, C, Ho, Wo, tilesX, coeff, -bet, ini, (live + 3) / 4);
+  else
+    hipLaunchKernelGGL(k_lrn_pool<3>, grid, dim3(LP_THREADS), 0, st, reinterpret_cast<const float4*>(src),
+                       reinterpret_cast<float4*>(dst), H, W, C, Ho, Wo, tilesX, coeff, -bet, ini, (live + 3) / 4);
   return hipGetLastError();
 }
 

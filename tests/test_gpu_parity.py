@@ -255,6 +255,32 @@ def test_alexnet_last_ragged_panel_layer_for_layer():
     eng.close()
 
 
+def test_lrn_pool_fused_equals_separate_kernels():
+    """Fast path: LRN + 3x3/2 max-pool run as one kernel once a sub-batch fills the chip (here 17 panels, one stream;
+    23x23 and 11x11 maps give partial pool tiles and clipped ceil-mode windows, the last panel is ragged).  The
+    pooled map must equal the layer-for-layer run bit for bit; the normalised map is reported as not materialised."""
+    layers = [topo.conv(1, 3, 16, 1, 2), topo.relu(), topo.lorn(5, 0.0001, 0.75, 1.0), topo.pool(0, 3, 2),
+              topo.conv(1, 3, 24, 1, 1), topo.relu(), topo.lorn(3, 0.0002, 0.75, 2.0), topo.pool(0, 3, 2),
+              topo.fcnt(40), topo.smax()]
+    in_chw = (3, 46, 46)
+    params = synth.make_params(in_chw, layers, seed=31)
+    n = 16 * 128 + 77
+    imgs = synth.make_images(n, in_chw, seed=32)
+    sep = make_engine(in_chw, layers, params, n, lut=capi.LUT_MFMA, keep_all=1)
+    sep.forward_host(imgs, want_prob=False, want_top5=False)
+    fus = make_engine(in_chw, layers, params, n, lut=capi.LUT_MFMA, keep_all=0)
+    fus.set_option(capi.OPT_STREAMS, 1)
+    p_f, t_f = fus.forward_host(imgs)
+    for l in (4, 8):
+        for first in (0, 500, n - 3):
+            assert np.array_equal(fus.layer_output_range(l, first, 3), sep.layer_output_range(l, first, 3)), (l, first)
+    with pytest.raises(RuntimeError):
+        fus.layer_output_range(3, 0, 1)          # the LRN output of a fused pair does not exist
+    p_s, t_s = sep.forward_host(imgs)
+    assert np.array_equal(p_f, p_s) and np.array_equal(t_f, t_s)
+    sep.close(); fus.close()
+
+
 def test_fallback_glue_kernels():
     """The general LRN kernel (window sizes other than 3 and 5) and the one-thread-per-image soft-max / top-5 (more
     classes than fit an LDS tile) against the oracle."""
