@@ -52,7 +52,7 @@ __device__ __forceinline__ void lane_unit(int lane, int& unit, int& place) {
 }
 
 // NW waves per workgroup, NB of them builders; STAGE = bytes of one stage (NW * 4 KB: 64 KB or 32 KB)
-template <int NW, int NB, int KSTEPS>
+template <int NW, int NB, int KSTEPS, int HALF = 0>
 __global__ __launch_bounds__(NW * 64, 16 / NW) void kwg(float* out, uint64_t* cyc, int iters, const uint32_t* idx, int reads8,
                                                           int bar) {
   extern __shared__ char lds[];
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(NW * 64, 16 / NW) void kwg(float* out, uint64_t* cy
     uint64_t t0 = __builtin_readcyclecounter();
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
-      for (int tl = 0; tl < 4; ++tl) {            // 4 groups of 4 result tiles = 2 image tiles x 8 row tiles
+      for (int tl = 0; tl < (HALF ? 2 : 4); ++tl) {   // 4 groups of 4 result tiles = 2 image tiles x 8 row tiles (HALF: one image tile)
         const uint32_t m0v = STAGE * (it & 1) + (uint32_t)(2 * wave + (tl >> 1)) * 8192u + (tl & 1) * 4096u;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(NW * 64, 16 / NW) void kwg(float* out, uint64_t* cy
   for (int j = 0; j < 32; ++j) acc[j] = f32x2{0, 0};
   uint32_t w[8];
   uint32_t base;
-  if (NW == 16) {       // lanes 0-31 one row, lanes 32-63 another: 8 image tiles x 4 quarters
+  if (NW == 16 && !HALF) {       // lanes 0-31 one row, lanes 32-63 another: 8 image tiles x 4 quarters
     const int quad = lane & 31;
     base = (uint32_t)(quad >> 2) * 8192u | (uint32_t)(quad >> 3) * 64u | (uint32_t)(quad & 3) * 16u;
     for (int j = 0; j < 8; ++j) w[j] = idx[((wave * 2 + (lane >> 5)) * 8 + j) % 768];
@@ -112,6 +112,7 @@ __global__ __launch_bounds__(NW * 64, 16 / NW) void kwg(float* out, uint64_t* cy
     const uint32_t st = base | STAGE * (it & 1);
     gq8(&acc[0], w[0], w[1], w[2], w[3], st, __builtin_amdgcn_readfirstlane(reads8 > 0));
     gq8(&acc[16], w[4], w[5], w[6], w[7], st, __builtin_amdgcn_readfirstlane(reads8 > 1));
+    if (HALF) gq8(&acc[0], w[1], w[2], w[5], w[6], st, __builtin_amdgcn_readfirstlane(reads8 > 2));
     if (bar) asm volatile("s_barrier" ::: "memory");
   }
   uint64_t t1 = __builtin_readcyclecounter();
@@ -121,17 +122,17 @@ __global__ __launch_bounds__(NW * 64, 16 / NW) void kwg(float* out, uint64_t* cy
 }
 
 static uint64_t h[512 * 16];
-template <int NW, int NB, int KSTEPS>
+template <int NW, int NB, int KSTEPS, int HALF = 0>
 static void run(float* out, uint64_t* cyc, const uint32_t* idx, int reads8, int bar, const char* label) {
   const int iters = 1000, blocks = 256 * 16 / NW;
   const size_t shm = 2 * NW * 4096;
-  hipFuncSetAttribute(reinterpret_cast<const void*>(kwg<NW, NB, KSTEPS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+  hipFuncSetAttribute(reinterpret_cast<const void*>(kwg<NW, NB, KSTEPS, HALF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
   int occ = 0;
-  hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kwg<NW, NB, KSTEPS>, NW * 64, shm);
+  hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kwg<NW, NB, KSTEPS, HALF>, NW * 64, shm);
   hipMemset(cyc, 0, sizeof(h));
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   hipEventRecord(e0);
-  hipLaunchKernelGGL((kwg<NW, NB, KSTEPS>), dim3(blocks), dim3(NW * 64), shm, 0, out, cyc, iters, idx, reads8, bar);
+  hipLaunchKernelGGL((kwg<NW, NB, KSTEPS, HALF>), dim3(blocks), dim3(NW * 64), shm, 0, out, cyc, iters, idx, reads8, bar);
   hipEventRecord(e1);
   hipError_t e = hipDeviceSynchronize();
   float ms = 0; hipEventElapsedTime(&ms, e0, e1);
@@ -155,6 +156,10 @@ int main() {
     run<8, 2, 2>(out, cyc, idx, 2, 1, "conv3-like, two 8-wave WGs per CU");
     run<16, 4, 1>(out, cyc, idx, 1, 1, "conv1-like, one 16-wave WG per CU");
     run<8, 2, 1>(out, cyc, idx, 1, 1, "conv1-like, two 8-wave WGs per CU");
+    run<16, 4, 2, 1>(out, cyc, idx, 2, 1, "64-image half panel, 16 waves, 16 reads/wave");
+    run<16, 4, 2, 1>(out, cyc, idx, 3, 1, "64-image half panel, 16 waves, 24 reads/wave");
+    run<16, 4, 1, 1>(out, cyc, idx, 1, 1, "64-image half panel, conv1-like (KS 1, 8 reads)");
+    run<16, 4, 1, 1>(out, cyc, idx, 2, 1, "64-image half panel, conv1-like (KS 1, 16 reads)");
     run<16, 4, 2>(out, cyc, idx, 2, 0, "conv3-like, 16 waves, no barrier");
     run<8, 2, 2>(out, cyc, idx, 2, 0, "conv3-like, 8 waves x 2, no barrier");
   }
