@@ -11,14 +11,20 @@
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-#define Q_AD(a, w, sel) "v_xor_b32_sdwa " a ", %[" w "], %[b] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" sel " src1_sel:DWORD\n\t"
+#ifdef ADDR_MAD   // address = offset halfword + lane base by v_mad_u32_u16 with op_sel instead of an SDWA xor
+#define Q_SEL_WORD_0 "0"
+#define Q_SEL_WORD_1 "1"
+#define Q_AD(a, w, sel) "v_mad_u32_u16 " a ", %[" w "], 1, %[b] op_sel:[" Q_SEL_##sel ",0,0,0]\n\t"
+#else
+#define Q_AD(a, w, sel) "v_xor_b32_sdwa " a ", %[" w "], %[b] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" #sel " src1_sel:DWORD\n\t"
+#endif
 #define Q_RD(v, a) "ds_read_b128 " v ", " a "\n\t"
 #define Q_ACC(n, c0, c1, lo, hi) \
   "s_waitcnt lgkmcnt(" n ")\n\tv_pk_add_f32 %[" c0 "], " lo ", %[" c0 "]\n\tv_pk_add_f32 %[" c1 "], " hi ", %[" c1 "]\n\t"
 __device__ __forceinline__ void gq8(f32x2* acc, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t base, int valid) {
   asm volatile("s_cmp_eq_u32 %[ok], 0\n\ts_cbranch_scc1 .Lqskip%=\n\t"
-               Q_AD("v96", "w0", "WORD_0") Q_AD("v100", "w0", "WORD_1") Q_AD("v104", "w1", "WORD_0") Q_AD("v108", "w1", "WORD_1")
-               Q_AD("v112", "w2", "WORD_0") Q_AD("v116", "w2", "WORD_1") Q_AD("v120", "w3", "WORD_0") Q_AD("v124", "w3", "WORD_1")
+               Q_AD("v96", "w0", WORD_0) Q_AD("v100", "w0", WORD_1) Q_AD("v104", "w1", WORD_0) Q_AD("v108", "w1", WORD_1)
+               Q_AD("v112", "w2", WORD_0) Q_AD("v116", "w2", WORD_1) Q_AD("v120", "w3", WORD_0) Q_AD("v124", "w3", WORD_1)
                Q_RD("v[96:99]", "v96") Q_RD("v[100:103]", "v100") Q_RD("v[104:107]", "v104") Q_RD("v[108:111]", "v108")
                Q_RD("v[112:115]", "v112") Q_RD("v[116:119]", "v116") Q_RD("v[120:123]", "v120") Q_RD("v[124:127]", "v124")
                Q_ACC("7", "c0", "c1", "v[96:97]", "v[98:99]") Q_ACC("6", "c2", "c3", "v[100:101]", "v[102:103]")
