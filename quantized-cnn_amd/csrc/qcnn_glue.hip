@@ -67,10 +67,25 @@ __global__ void k_relu(const float4* __restrict__ src, float4* __restrict__ dst,
 
 // LRN, streaming form.  A thread owns one pixel and four images (float4: 32 lanes = one 512-byte row, a
 // wave = two pixels) and walks the channels once, keeping the window of N scaled squares and raw values
-// in registers: every element is read exactly once.  Same arithmetic and the same summation order as
-// k_lrn below (window j ascending; channels outside [0, C) contribute an exact +0.0f instead of being
-// skipped, which leaves s > 0 bit-identical).
-template <int N>
+// in registers: every element is read exactly once.  Same summation order as k_lrn below (window j ascending;
+// channels outside [0, C) contribute an exact +0.0f instead of being skipped, which leaves s > 0 bit-identical);
+// the power goes through lrn_scale.
+// s^(-beta) of the LRN scale.  The reference's native build evaluates exp(-beta * log(s)) in float
+// (include/BlasWrapper.h:142-144), its OpenVML build calls vsPowx: the specification is the power, not one libm's way
+// to it.  For beta = 0.75 — every shipped topology (src/CaffePara.cc:31,35) — the power is rsqrt(s) * sqrt(rsqrt(s)):
+// v_rsq_f32 and v_sqrt_f32 are accurate to 1 ulp each, the product to <= 3.5 ulp (2e-7, the size of the error
+// exp(b * log(a)) itself makes for s ~ 1..10), at 3 instructions instead of ~40.  With expf/logf the LRN kernels were
+// bound by these two calls (fused LRN + pool: 0.63 ms), not by HBM.  Any other beta takes expf/logf.
+template <bool B34>
+__device__ __forceinline__ float lrn_scale(float s, float nbet) {
+  if (B34) {
+    const float r = __builtin_amdgcn_rsqf(s);
+    return __fmul_rn(r, __builtin_amdgcn_sqrtf(r));
+  }
+  return expf(__fmul_rn(nbet, logf(s)));
+}
+
+template <int N, bool B34>
 __global__ __launch_bounds__(256) void k_lrn_stream(const float4* __restrict__ src, float4* __restrict__ dst,
                                                     size_t pixels, int C, int segLen, float coeff, float nbet, float ini,
                                                     int liveQuads) {
@@ -115,10 +130,10 @@ __global__ __launch_bounds__(256) void k_lrn_stream(const float4* __restrict__ s
         }
         const float4 xc = raw[u % N];
         float4 o;
-        o.x = __fmul_rn(xc.x, expf(__fmul_rn(nbet, logf(sacc.x))));
-        o.y = __fmul_rn(xc.y, expf(__fmul_rn(nbet, logf(sacc.y))));
-        o.z = __fmul_rn(xc.z, expf(__fmul_rn(nbet, logf(sacc.z))));
-        o.w = __fmul_rn(xc.w, expf(__fmul_rn(nbet, logf(sacc.w))));
+        o.x = __fmul_rn(xc.x, lrn_scale<B34>(sacc.x, nbet));
+        o.y = __fmul_rn(xc.y, lrn_scale<B34>(sacc.y, nbet));
+        o.z = __fmul_rn(xc.z, lrn_scale<B34>(sacc.z, nbet));
+        o.w = __fmul_rn(xc.w, lrn_scale<B34>(sacc.w, nbet));
         y[(size_t)c * 32] = o;
       }
     }
@@ -233,7 +248,7 @@ constexpr int LP_IT = (LP_PT - 1) * 2 + 3;      // source pixels per tile side
 constexpr int LP_PIX = LP_IT * LP_IT;
 constexpr int LP_Q = 8;                         // float4 lanes (4 images each) per block
 constexpr int LP_THREADS = 704;                 // >= LP_PIX * LP_Q, >= 16 * 5 * LP_Q
-template <int N>
+template <int N, bool B34>
 __global__ __launch_bounds__(LP_THREADS) void k_lrn_pool(const float4* __restrict__ src, float4* __restrict__ dst, int H,
                                                          int W, int C, int Ho, int Wo, int tilesX, float coeff, float nbet,
                                                          float ini, int liveQuads) {
@@ -289,10 +304,10 @@ __global__ __launch_bounds__(LP_THREADS) void k_lrn_pool(const float4* __restric
           }
           const float4 xc = raw[u % N];
           float4 o;
-          o.x = __fmul_rn(xc.x, expf(__fmul_rn(nbet, logf(sacc.x))));
-          o.y = __fmul_rn(xc.y, expf(__fmul_rn(nbet, logf(sacc.y))));
-          o.z = __fmul_rn(xc.z, expf(__fmul_rn(nbet, logf(sacc.z))));
-          o.w = __fmul_rn(xc.w, expf(__fmul_rn(nbet, logf(sacc.w))));
+          o.x = __fmul_rn(xc.x, lrn_scale<B34>(sacc.x, nbet));
+          o.y = __fmul_rn(xc.y, lrn_scale<B34>(sacc.y, nbet));
+          o.z = __fmul_rn(xc.z, lrn_scale<B34>(sacc.z, nbet));
+          o.w = __fmul_rn(xc.w, lrn_scale<B34>(sacc.w, nbet));
           slab[(u * LP_PIX + rest) * LP_Q + q] = o;
         }
       }
@@ -546,12 +561,11 @@ hipError_t qk_lrn(const float* src, float* dst, int panels, int HW, int C, int l
     int segLen = ((C + segs - 1) / segs + lrnSiz - 1) / lrnSiz * lrnSiz;
     segs = (C + segLen - 1) / segLen;
     const dim3 grid((unsigned)blocks, (unsigned)segs);
-    if (lrnSiz == 5)
-      hipLaunchKernelGGL(k_lrn_stream<5>, grid, dim3(256), 0, st, reinterpret_cast<const float4*>(src),
-                         reinterpret_cast<float4*>(dst), pixels, C, segLen, coeff, -bet, ini, (live + 3) / 4);
-    else
-      hipLaunchKernelGGL(k_lrn_stream<3>, grid, dim3(256), 0, st, reinterpret_cast<const float4*>(src),
-                         reinterpret_cast<float4*>(dst), pixels, C, segLen, coeff, -bet, ini, (live + 3) / 4);
+    auto kern = k_lrn_stream<5, false>;
+    if (lrnSiz == 5) kern = (bet == 0.75f) ? k_lrn_stream<5, true> : k_lrn_stream<5, false>;
+    else kern = (bet == 0.75f) ? k_lrn_stream<3, true> : k_lrn_stream<3, false>;
+    hipLaunchKernelGGL(kern, grid, dim3(256), 0, st, reinterpret_cast<const float4*>(src),
+                       reinterpret_cast<float4*>(dst), pixels, C, segLen, coeff, -bet, ini, (live + 3) / 4);
     return hipGetLastError();
   }
   const int blocks = (int)((rows + 3) / 4 < 8192 ? (rows + 3) / 4 : 8192);
@@ -568,12 +582,11 @@ hipError_t qk_lrn_pool(const float* src, float* dst, int panels, int H, int W, i
   const float coeff = alp / lrnSiz;   // float / int, as src/CaffeEva.cc:1055
   const int tilesX = (Wo + LP_PT - 1) / LP_PT;
   const dim3 grid((unsigned)qk_lrn_pool_blocks(Ho, Wo), (unsigned)panels);
-  if (lrnSiz == 5)
-    hipLaunchKernelGGL(k_lrn_pool<5>, grid, dim3(LP_THREADS), 0, st, reinterpret_cast<const float4*>(src),
-                       reinterpret_cast<float4*>(dst), H, W, C, Ho, Wo, tilesX, coeff, -bet, ini, (live + 3) / 4);
-  else
-    hipLaunchKernelGGL(k_lrn_pool<3>, grid, dim3(LP_THREADS), 0, st, reinterpret_cast<const float4*>(src),
-                       reinterpret_cast<float4*>(dst), H, W, C, Ho, Wo, tilesX, coeff, -bet, ini, (live + 3) / 4);
+  auto kern = k_lrn_pool<5, false>;
+  if (lrnSiz == 5) kern = (bet == 0.75f) ? k_lrn_pool<5, true> : k_lrn_pool<5, false>;
+  else kern = (bet == 0.75f) ? k_lrn_pool<3, true> : k_lrn_pool<3, false>;
+  hipLaunchKernelGGL(kern, grid, dim3(LP_THREADS), 0, st, reinterpret_cast<const float4*>(src),
+                     reinterpret_cast<float4*>(dst), H, W, C, Ho, Wo, tilesX, coeff, -bet, ini, (live + 3) / 4);
   return hipGetLastError();
 }
 
