@@ -64,7 +64,10 @@ enum {
                               v_mfma_f32_16x16x32_bf16 per tile on operands split in two bf16 parts (16 mantissa
                               bits per operand, fp32 accumulation and fp32 table entries): opt-in, ~1e-5 per layer */
   QCNN_OPT_KEEP_ALL = 1,   /* 1 = every layer writes its own feature map (layer-for-layer dumps, default);
-                              0 = fast path: ReLU fused into the producing conv/FC epilogue */
+                              0 = fast path: ReLU fused into the producing conv/FC epilogue, the first conv layer
+                              reads the NCHW input in place, and an LRN layer followed by a 3x3 / stride 2 / pad 0
+                              max-pool runs as one kernel with it once a sub-batch is large enough to fill the chip
+                              (the normalised map then does not exist: qcnn_get_layer_output fails for it) */
   QCNN_OPT_PROFILE = 2,    /* 1 = bracket every layer launch with HIP events (qcnn_get_layer_ms) */
   QCNN_OPT_SMALL_BATCH = 4, /* 1 (default): batches of one or two images run the conv/FC layers with the few-image kernels
                               (lanes = output channels; one image no longer costs a 128-image panel).  Their sums
