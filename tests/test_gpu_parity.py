@@ -375,6 +375,16 @@ def test_vgg_style_channel_counts():
     _run_vs_oracle((3, 12, 12), layers, {}, 3, seed=43)
 
 
+def test_conv_geometries_on_a_rectangular_map():
+    """Kernel / stride / pad combinations and a non-square input the shipped models do not have (7x7/3 pad 3,
+    5x5/2 pad 0 in two groups, 1x1/2, 3x3/1 pad 2 wider than its map edge): the receptive-field geometry of the
+    offset program tables (QkProgram) for every one of them, K = 128, against the oracle."""
+    layers = [topo.conv(3, 7, 24, 1, 3), topo.relu(), topo.conv(0, 5, 96, 2, 2), topo.relu(),
+              topo.conv(0, 1, 16, 1, 2), topo.relu(), topo.conv(2, 3, 200, 1, 1), topo.relu(),
+              topo.fcnt(48), topo.smax()]
+    _run_vs_oracle((3, 61, 85), layers, {}, 3, seed=47)
+
+
 # ---------------------------------------------------------------- the other topologies of src/CaffePara.cc ----
 @pytest.mark.parametrize("model,n_img", [("CaffeNet", 2), ("VggCnnS", 2), ("CaffeNetFGD", 2), ("CaffeNetFGB", 2),
                                          ("VGG16", 1)])
