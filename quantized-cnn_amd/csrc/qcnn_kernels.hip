@@ -353,7 +353,7 @@ struct MfmaOps {
 
 template <int KT, int KS>
 __device__ __forceinline__ void mfma_load(MfmaOps<KT, KS>& o, const char* __restrict__ xbase, uint32_t xoff0, const XAddr& xa,
-                                          const float* __restrict__ ctrd, int Cs, int m0, int bw, int lane) {
+                                          const float* __restrict__ ctrd, int Cs, int m0, int bw, int lane, bool loadA = true) {
   constexpr int K = KT * 16;
   constexpr int SUBS = MfmaOps<KT, KS>::SUBS;
   const uint32_t li = lane & 15, lk = lane >> 4;
@@ -362,10 +362,12 @@ __device__ __forceinline__ void mfma_load(MfmaOps<KT, KS>& o, const char* __rest
   const char* __restrict__ xbU = xbase + xoff0 + (uint32_t)(m0 * Cs) * xa.dimStride;   // uniform
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
+    if (loadA) {                                             // a layer with one stage per pixel keeps its code book tiles
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int mi = i / KT, kk = (i % KT) * 16;             // compile-time
-      o.a[i][ks] = (cbU + ((mi * Cs + ks * 4) * K + kk))[laneA];
+      for (int i = 0; i < 8; ++i) {
+        const int mi = i / KT, kk = (i % KT) * 16;           // compile-time
+        o.a[i][ks] = (cbU + ((mi * Cs + ks * 4) * K + kk))[laneA];
+      }
     }
 #pragma unroll
     for (int it = 0; it < 2; ++it)
@@ -398,18 +400,45 @@ template <int I>
 __device__ __forceinline__ void store_tile_lo(const f32x4& v, uint32_t m0v) { QCNN_WR2("e0", "e1", "o0", "o1"); }
 template <int I>
 __device__ __forceinline__ void store_tile_hi(const f32x4& v, uint32_t m0v) { QCNN_WR2("e2", "e3", "o2", "o3"); }
+// all four registers of a tile behind ONE M0 write (4-dim first layers: half the scalar instructions of the split form)
+template <int I>
+__device__ __forceinline__ void store_tile_all(const f32x4& v, uint32_t m0v) {
+  asm volatile("s_mov_b32 m0, %[m]\n\ts_nop 0\n\tds_write_addtid_b32 %[e0] offset:%[o0]\n\t"
+               "ds_write_addtid_b32 %[e1] offset:%[o1]\n\tds_write_addtid_b32 %[e2] offset:%[o2]\n\t"
+               "ds_write_addtid_b32 %[e3] offset:%[o3]"
+               :: [m] "s"(m0v), [e0] "v"(v[0]), [e1] "v"(v[1]), [e2] "v"(v[2]), [e3] "v"(v[3]),
+                  [o0] "n"(I * 1024), [o1] "n"(I * 1024 + 256), [o2] "n"(I * 1024 + 512), [o3] "n"(I * 1024 + 768)
+               : "m0", "memory");
+}
 
 // Multiply the stage `o` was loaded for (m0, mEnd, D, Cs) out into stage buffer BUF.  The 16 tiles of the wave
 // are walked in pairs with a hand-made software pipeline: MFMA(pair n) is interleaved instruction by
 // instruction with the LDS writes of pair n-1, so that a write (which a single wave can only issue every ~15
 // cycles) sits in the shadow of a matrix instruction and never waits for its own result.
-template <int KT, int KS, int BUF, int N>
+// F16: -1 = test the run-time flag after every pair (8-dim layers: removing those uniform branches from the MFMA
+// stream made the layers 3 % SLOWER), 0 / 1 = compile-time (4-dim first layers, whose builder chain is the pole of the
+// stage: every instruction less counts, -1 %)
+template <int KT, int KS, int BUF, int N, int F16 = -1>
 __device__ __forceinline__ void mfma_pair(MfmaOps<KT, KS>& o, f32x4& pa, f32x4& pb, int bw, int f16) {
   constexpr int it = (N < 8 ? N : 0) / 4, i = 2 * ((N < 8 ? N : 0) % 4);          // this pair: tiles (it, i), (it, i+1)
   constexpr int pit = (N > 0 ? N - 1 : 0) / 4, pi = 2 * ((N > 0 ? N - 1 : 0) % 4);  // previous pair (results in pa, pb)
   const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
   const uint32_t m0v = (uint32_t)BUF * STAGE_BYTES + (uint32_t)(2 * bw + pit) * TILEB;
   f32x4 ca = zero, cb = zero;
+  if constexpr (KS == 1) {        // one k-step: MFMA, the four stores of one tile, MFMA, the four stores of the other
+    __builtin_amdgcn_sched_barrier(0);
+    if (N < 8) ca = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a[i][0], o.b[it][i / KT][0], zero, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (N > 0) store_tile_all<pi>(pa, m0v);
+    __builtin_amdgcn_sched_barrier(0);
+    if (N < 8) cb = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a[i + 1][0], o.b[it][(i + 1) / KT][0], zero, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (N > 0) store_tile_all<pi + 1>(pb, m0v);
+    __builtin_amdgcn_sched_barrier(0);
+    pa = ca; pb = cb;
+    if (F16 < 0 ? f16 != 0 : F16 == 1) { pa = round_f16(pa); pb = round_f16(pb); }
+    return;
+  }
   __builtin_amdgcn_sched_barrier(0);
   if (N < 8) ca = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a[i][0], o.b[it][i / KT][0], zero, 0, 0, 0);
   __builtin_amdgcn_sched_barrier(0);
@@ -429,11 +458,27 @@ __device__ __forceinline__ void mfma_pair(MfmaOps<KT, KS>& o, f32x4& pa, f32x4& 
   if (N > 0) store_tile_hi<pi + 1>(pb, m0v);
   __builtin_amdgcn_sched_barrier(0);
   pa = ca; pb = cb;
-  if (f16) { pa = round_f16(pa); pb = round_f16(pb); }   // tolerance study only (uniform branch)
+  if (F16 < 0 ? f16 != 0 : F16 == 1) { pa = round_f16(pa); pb = round_f16(pb); }   // tolerance study only
 }
 
-template <int KT, int KS, int BUF>
-__device__ __forceinline__ void mfma_store(MfmaOps<KT, KS>& o, int Cs, int D, int m0, int mEnd, int bw, int lane, int f16) {
+template <int KT, int KS, int BUF, int F16>
+__device__ __forceinline__ void mfma_multiply(MfmaOps<KT, KS>& o, int bw, int f16) {
+  f32x4 pa = {0.0f, 0.0f, 0.0f, 0.0f}, pb = pa;   // results of the previous pair, still to be written
+  mfma_pair<KT, KS, BUF, 0, F16>(o, pa, pb, bw, f16);
+  mfma_pair<KT, KS, BUF, 1, F16>(o, pa, pb, bw, f16);
+  mfma_pair<KT, KS, BUF, 2, F16>(o, pa, pb, bw, f16);
+  mfma_pair<KT, KS, BUF, 3, F16>(o, pa, pb, bw, f16);
+  mfma_pair<KT, KS, BUF, 4, F16>(o, pa, pb, bw, f16);
+  mfma_pair<KT, KS, BUF, 5, F16>(o, pa, pb, bw, f16);
+  mfma_pair<KT, KS, BUF, 6, F16>(o, pa, pb, bw, f16);
+  mfma_pair<KT, KS, BUF, 7, F16>(o, pa, pb, bw, f16);
+  mfma_pair<KT, KS, BUF, 8, F16>(o, pa, pb, bw, f16);
+}
+
+// zero what must not contribute: dims a sub-space does not have, sub-spaces past the end.  maskA = false leaves the
+// code-book operands alone (they were masked when they were loaded and are kept in registers: mfma_load's loadA)
+template <int KT, int KS>
+__device__ __forceinline__ void mfma_mask(MfmaOps<KT, KS>& o, int Cs, int D, int m0, int mEnd, int lane, bool maskA, bool maskB) {
   constexpr int SUBS = MfmaOps<KT, KS>::SUBS;
   const int lk = lane >> 4;
   // plain: every sub-space of the stage exists and has all 4*KS dims -> nothing to zero
@@ -444,23 +489,34 @@ __device__ __forceinline__ void mfma_store(MfmaOps<KT, KS>& o, int Cs, int D, in
 #pragma unroll
       for (int sub = 0; sub < SUBS; ++sub) {
         const bool ok = (m0 + sub < mEnd) && (ks * 4 + lk < min(D - (m0 + sub) * Cs, Cs));
+        if (maskB) {
 #pragma unroll
-        for (int it = 0; it < 2; ++it) o.b[it][sub][ks] = ok ? o.b[it][sub][ks] : 0.0f;
+          for (int it = 0; it < 2; ++it) o.b[it][sub][ks] = ok ? o.b[it][sub][ks] : 0.0f;
+        }
+        if (maskA) {
 #pragma unroll
-        for (int i = sub * KT; i < (sub + 1) * KT; ++i) o.a[i][ks] = ok ? o.a[i][ks] : 0.0f;
+          for (int i = sub * KT; i < (sub + 1) * KT; ++i) o.a[i][ks] = ok ? o.a[i][ks] : 0.0f;
+        }
       }
     }
   }
-  f32x4 pa = {0.0f, 0.0f, 0.0f, 0.0f}, pb = pa;   // results of the previous pair, still to be written
-  mfma_pair<KT, KS, BUF, 0>(o, pa, pb, bw, f16);
-  mfma_pair<KT, KS, BUF, 1>(o, pa, pb, bw, f16);
-  mfma_pair<KT, KS, BUF, 2>(o, pa, pb, bw, f16);
-  mfma_pair<KT, KS, BUF, 3>(o, pa, pb, bw, f16);
-  mfma_pair<KT, KS, BUF, 4>(o, pa, pb, bw, f16);
-  mfma_pair<KT, KS, BUF, 5>(o, pa, pb, bw, f16);
-  mfma_pair<KT, KS, BUF, 6>(o, pa, pb, bw, f16);
-  mfma_pair<KT, KS, BUF, 7>(o, pa, pb, bw, f16);
-  mfma_pair<KT, KS, BUF, 8>(o, pa, pb, bw, f16);
+}
+
+template <int KT, int KS, int BUF>
+__device__ __forceinline__ void mfma_store(MfmaOps<KT, KS>& o, int Cs, int D, int m0, int mEnd, int bw, int lane, int f16,
+                                           bool maskA = true) {
+  if (maskA) {
+    mfma_mask<KT, KS>(o, Cs, D, m0, mEnd, lane, true, true);
+  } else {                        // kept operands: one sub-space, always the same -> the activation mask is lane-constant
+    const bool ok = (lane >> 4) < min(D, Cs);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) o.b[it][0][0] = ok ? o.b[it][0][0] : 0.0f;
+  }
+  if constexpr (KS == 1) {
+    if (f16) mfma_multiply<KT, KS, BUF, 1>(o, bw, f16); else mfma_multiply<KT, KS, BUF, 0>(o, bw, f16);
+  } else {
+    mfma_multiply<KT, KS, BUF, -1>(o, bw, f16);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -804,6 +860,10 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
     // receiving) stage s+2, and the loads of stage s+3 are issued as soon as the first is consumed, so
     // an operand fetch has a whole stage period to land.
     MfmaOps<KTT, KS> opsA, opsB;
+    // One stage per source pixel (a first layer: M = 1, <= 4 input channels): the code book operands never change and
+    // stay in registers (conv1 -3 %).  Only the KS = 1 instantiations carry the test: as a run-time branch in every
+    // kernel it cost the 8-dim layers 2-5 % (the operand loads are no longer straight-line code).
+    const bool reloadA = KS != 1 || g.MG > 1;
     StagePos q1 = next_pos(first, g);
     StagePos q2 = next_pos(q1, g);
     StagePos q3 = next_pos(q2, g);
@@ -815,6 +875,10 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
         mfma_load<KTT, KS>(opsA, xbase, pixel_off(qa, g), xa, p.ctrd, Cs, qa.mg * G, bw, lane);
         __builtin_amdgcn_sched_barrier(0);             // keep set A's loads older than set B's (vmcnt accounting)
         mfma_load<KTT, KS>(opsB, xbase, pixel_off(qb, g), xa, p.ctrd, Cs, qb.mg * G, bw, lane);
+        if (!reloadA) {                                  // kept code-book operands are masked here, once
+          mfma_mask<KTT, KS>(opsA, Cs, Cg, 0, M, lane, true, false);
+          mfma_mask<KTT, KS>(opsB, Cs, Cg, 0, M, lane, true, false);
+        }
       }
     } else {
       build_stage_exact(lds, xbase, pixel_off(first, g), xa, p.ctrd, K, Cs, Cg, G, 0, M, bw, lane);
@@ -825,10 +889,10 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
     // from re-fetched operands into a buffer nobody reads.
     for (int s = 0; s < Sp; s += 2) {
       if (KT > 0) {                                    // stage s+1 -> buffer 1, from set A
-        mfma_store<KTT, KS, 1>(opsA, Cs, Cg, q1.mg * G, M, bw, lane, p.lutF16);
+        mfma_store<KTT, KS, 1>(opsA, Cs, Cg, reloadA ? q1.mg * G : 0, M, bw, lane, p.lutF16, reloadA);
         TR_MID(s);
         const StagePos qf = (q3.hi > hiU) ? first : q3;
-        mfma_load<KTT, KS>(opsA, xbase, pixel_off(qf, g), xa, p.ctrd, Cs, qf.mg * G, bw, lane);
+        mfma_load<KTT, KS>(opsA, xbase, pixel_off(qf, g), xa, p.ctrd, Cs, qf.mg * G, bw, lane, reloadA);
       } else if (s + 1 < S) {
         build_stage_exact(lds + STAGE_BYTES, xbase, pixel_off(q1, g), xa, p.ctrd, K, Cs, Cg, G, q1.mg * G, M, bw, lane);
       }
@@ -837,10 +901,10 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
       TR_LEAVE(s);
       q1 = q2; q2 = q3; q3 = next_pos(q3, g);
       if (KT > 0) {                                    // stage s+2 -> buffer 0, from set B
-        mfma_store<KTT, KS, 0>(opsB, Cs, Cg, q1.mg * G, M, bw, lane, p.lutF16);
+        mfma_store<KTT, KS, 0>(opsB, Cs, Cg, reloadA ? q1.mg * G : 0, M, bw, lane, p.lutF16, reloadA);
         TR_MID(s + 1);
         const StagePos qf = (q3.hi > hiU) ? first : q3;
-        mfma_load<KTT, KS>(opsB, xbase, pixel_off(qf, g), xa, p.ctrd, Cs, qf.mg * G, bw, lane);
+        mfma_load<KTT, KS>(opsB, xbase, pixel_off(qf, g), xa, p.ctrd, Cs, qf.mg * G, bw, lane, reloadA);
       } else if (s + 2 < S) {
         build_stage_exact(lds, xbase, pixel_off(q1, g), xa, p.ctrd, K, Cs, Cg, G, q1.mg * G, M, bw, lane);
       }
