@@ -215,6 +215,27 @@ __device__ __forceinline__ void gq3(f32x2* acc, uint32_t w0, uint32_t w1, uint32
                  : Q_CLOB4);
   }
 }
+// six reads = 12 look-ups (CPW = 12: all channels of a position in one block instead of two blocks of three — a
+// block is a round trip to the LDS, and a wave of a 128-channel layer made up to six of them per stage); temporaries
+// v[104:127]
+#define Q_CLOB6 "scc", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115",   \
+                "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127"
+__device__ __forceinline__ void gq6(f32x2* acc, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t base, int valid) {
+  asm volatile(Q_SKIP
+               Q_AD("v104", "w0", "WORD_0") Q_AD("v108", "w0", "WORD_1") Q_AD("v112", "w1", "WORD_0") Q_AD("v116", "w1", "WORD_1")
+               Q_AD("v120", "w2", "WORD_0") Q_AD("v124", "w2", "WORD_1")
+               Q_RD("v[104:107]", "v104") Q_RD("v[108:111]", "v108") Q_RD("v[112:115]", "v112") Q_RD("v[116:119]", "v116")
+               Q_RD("v[120:123]", "v120") Q_RD("v[124:127]", "v124")
+               Q_ACC("5", "c0", "c1", "v[104:105]", "v[106:107]") Q_ACC("4", "c2", "c3", "v[108:109]", "v[110:111]")
+               Q_ACC("3", "c4", "c5", "v[112:113]", "v[114:115]") Q_ACC("2", "c6", "c7", "v[116:117]", "v[118:119]")
+               Q_ACC("1", "c8", "c9", "v[120:121]", "v[122:123]") Q_ACC("0", "c10", "c11", "v[124:125]", "v[126:127]")
+               "\n.Lqskip%=:"
+               : [c0] "+v"(acc[0]), [c1] "+v"(acc[1]), [c2] "+v"(acc[2]), [c3] "+v"(acc[3]), [c4] "+v"(acc[4]),
+                 [c5] "+v"(acc[5]), [c6] "+v"(acc[6]), [c7] "+v"(acc[7]), [c8] "+v"(acc[8]), [c9] "+v"(acc[9]),
+                 [c10] "+v"(acc[10]), [c11] "+v"(acc[11])
+               : [w0] "v"(w0), [w1] "v"(w1), [w2] "v"(w2), [b] "v"(base), [ok] "s"(valid)
+               : Q_CLOB6);
+}
 // two reads = 4 look-ups
 __device__ __forceinline__ void gq2(f32x2* acc, uint32_t w0, uint32_t base, int valid) {
   asm volatile(Q_SKIP
@@ -245,8 +266,7 @@ __device__ __forceinline__ void gather_apply(f32x2 (&acc)[CPW], const Idx<idx_dw
   } else if constexpr (CPW == 16) {
     gq8(&acc[0], o.w[0], o.w[1], o.w[2], o.w[3], stage, valid);
   } else if constexpr (CPW == 12) {
-    gq3<1>(&acc[0], o.w[0], o.w[1], stage, valid);
-    gq3<0>(&acc[6], o.w[1], o.w[2], stage, valid);
+    gq6(&acc[0], o.w[0], o.w[1], o.w[2], stage, valid);   // (two blocks of three reads: conv2 +4 %, conv5 +5 %)
   } else if constexpr (CPW == 8) {
     gq4(&acc[0], o.w[0], o.w[1], stage, valid);
   } else if constexpr (CPW == 6) {
