@@ -19,6 +19,17 @@
 //                      QCNN_BATCHES x QCNN_BATCH images to the GPUs in chunks of that size — the same images,
 //                      prints and results as one batch at a time (QCNN_COALESCE=0 restores that)
 //        QCNN_LUT      "mfma" (default) | "exact"    look-up-table builder (exact = bit-identical conv/FC)
+//        QCNN_KEEP_ALL 0 (default) | 1               1 = every layer writes its own feature map (GetFeatMap() of maps the
+//                      fast path fuses away: pre-ReLU conv/FC outputs, LRN maps in front of a pool)
+//        QCNN_WARMUP   1 (default) | 0               LoadCaffePara() ends with two one-panel forward passes on zeros
+//                      (code objects loaded, staging buffers and streams created before the first timed pass)
+//        QCNN_PIN_DATASET copy (default) | register | 0   where the image block lives: a pinned buffer of the HIP runtime
+//                      (uploads are DMA transfers at the full PCIe rate, overlapped with the previous batch's layers),
+//                      dataLst's own storage registered with the runtime (no second copy, about half the rate), or
+//                      plain pageable memory
+//  * ExecForwardPass(void) hands ALL its device batches to the group in one call: the upload of a batch runs under
+//    the layers of the one before it; every image goes through the panel kernels.  ExecForwardPass(img, prob) is the
+//    latency mode: the few-image kernels (results equal to rounding, ~1e-6).
 //  * DispElpsTime() prints the reference's stop-watch names; the values are HIP-event times of the
 //    layers (LUT build and look-up are one fused kernel, so swCompLkupTbl* report 0 and swEstiInPdVal*
 //    carry the fused time).
@@ -79,11 +90,16 @@ class CaffeEva {
   int batchCnt_;                    // QCNN_BATCHES
   int inflight_;                    // images handed to the device group at once
   int imagesDone_;                  // images classified by the last ExecForwardPass(void)
+  bool keepAll_;                    // QCNN_KEEP_ALL: layer-for-layer mode (every feature map materialised)
+  float* pinned_;                   // dataLst storage registered with the HIP runtime (qcnn_host_register), or NULL
+  float* pinnedCopy_;               // the images in a pinned buffer of the HIP runtime (qcnn_host_alloc), or NULL
   std::string lastError_;
   StopWatch swWall_;                // wall clock around the forward passes (host view)
 
   bool fail(const std::string& what);
   bool buildDeviceModel(void);
+  void pinDataset(void);
+  void unpinDataset(void);
 };
 
 #endif  // QCNN_HOST_CAFFEEVA_H_

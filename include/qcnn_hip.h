@@ -22,6 +22,9 @@
  *                               -> GetInPdMat (look-up-table build)        src/CaffeEva.cc:1261-1296
  *                               -> _ReLu/_LoRN/_Pool/_Drpt/_SMax           src/CaffeEva.cc:870-921,1027-1116
  *                               + CvtFeatMapToLablVec (top-5)              src/CaffeEva.cc:1162-1190
+ *   qcnn_forward_host_batches   the batch loop itself (one batch after the  src/CaffeEva.cc:168-206
+ *                               other), uploads overlapped with compute
+ *   qcnn_host_register          pins CaffeEva::dataLst (LoadDataset)       src/CaffeEva.cc:95-107
  *   qcnn_forward_u8             BmpImgIO::RmMeanImg + CropImg in front     src/BmpImgIO.cc:180-224
  *   qcnn_run_layer              CaffeEva::CalcFeatMap on one layer         src/CaffeEva.cc:625-670
  *   qcnn_get_layer_output       featMapLst[l] read-back (parity dumps)     include/CaffeEva.h:109
@@ -39,7 +42,9 @@
 extern "C" {
 #endif
 
-#define QCNN_ABI_VERSION 2
+#define QCNN_ABI_VERSION 3
+
+#define QCNN_SMALL_BATCH_MAX 2   /* batches up to this size can take the few-image kernels (QCNN_OPT_SMALL_BATCH) */
 
 typedef struct QcnnCtx QcnnCtx;
 
@@ -69,11 +74,21 @@ enum {
                               max-pool runs as one kernel with it once a sub-batch is large enough to fill the chip
                               (the normalised map then does not exist: qcnn_get_layer_output fails for it) */
   QCNN_OPT_PROFILE = 2,    /* 1 = bracket every layer launch with HIP events (qcnn_get_layer_ms) */
-  QCNN_OPT_SMALL_BATCH = 4, /* 1 (default): batches of one or two images run the conv/FC layers with the few-image kernels
+  QCNN_OPT_SMALL_BATCH = 4, /* 1 (default): batches of up to QCNN_SMALL_BATCH_MAX images run the conv/FC layers with the few-image kernels
                               (lanes = output channels; one image no longer costs a 128-image panel).  Their sums
                               run over sub-space chunks first: equal to the panel kernels to rounding (~1e-6), not bit
                               for bit; 0 = panel kernels for every batch size (batch-size-invariant bits).  The exact
                               builder (QCNN_OPT_LUT_MODE = 0) always uses the panel kernels. */
+  QCNN_OPT_SPLIT = 5,      /* 1 (default): a conv/FC launch that cannot fill the 256 CUs with whole tiles (a few panels, i.e.
+                              one GPU's share of a batch sharded over the GPUs of a node) cuts the look-up sequences of the
+                              tail of its tiles into slices run by separate workgroups and adds the partial sums in a
+                              fixed order; FC layers pick their sub-space split for the panel count of the launch.  Results
+                              then depend on the batch size to rounding (~1e-6).  Never applied with the exact builder
+                              (QCNN_OPT_LUT_MODE = 0).  0 = one workgroup per tile, batch-size-invariant bits. */
+  QCNN_OPT_HOST_CHUNK = 6, /* panels per chunk (default 2) of a qcnn_forward_host batch of at least two chunks: every chunk is
+                              uploaded on a copy stream and its layers start when it has arrived, so the upload of chunk
+                              k + 1 runs under the layers of chunk k; all chunks fill the same whole-batch feature maps.
+                              0 = always one launch per layer for the whole batch */
   QCNN_OPT_STREAMS = 3     /* 1..4 (default 2): a forward is cut into that many sub-batches of whole 128-image
                               panels which run concurrently on separate HIP streams (LDS-bound conv/FC kernels
                               of one overlap HBM-bound glue kernels of another); results do not depend on it */
@@ -134,8 +149,23 @@ int qcnn_forward(QcnnCtx* ctx, const float* in_nchw_dev, int n, float* prob_dev,
  * a quarter of the host-to-device bytes. */
 int qcnn_forward_u8(QcnnCtx* ctx, const uint8_t* in_u8_dev, int src_h, int src_w, const float* mean_dev, int n,
                     float* prob_dev, uint16_t* top5_dev);
-/* Blocking convenience: host in, host out (H2D + forward + D2H + sync). */
+/* Blocking convenience: host in, host out (H2D + forward + D2H + sync).  A batch of at least two chunks
+ * (QCNN_OPT_HOST_CHUNK) goes through chunk by chunk, uploads overlapped with the previous chunk's layers. */
 int qcnn_forward_host(QcnnCtx* ctx, const float* in_nchw_host, int n, float* prob_host, uint16_t* top5_host);
+/* Blocking: nb batches one after the other — batch b = n[b] <= max_batch images at in_host[b]; prob_host / top5_host
+ * (either may be NULL, and so may single entries) receive the results per batch.  The upload of batch b + 1 runs on a
+ * copy stream under the layers of batch b (two device input buffers), results return through pinned buffers: with
+ * registered (qcnn_host_register) or pinned input memory the kernels never wait for PCIe. */
+int qcnn_forward_host_batches(QcnnCtx* ctx, const float* const* in_host, const int* n, int nb, float* const* prob_host,
+                              uint16_t* const* top5_host);
+/* Pin / unpin caller memory (hipHostRegister, portable across devices) so that uploads from it are asynchronous DMA
+ * transfers.  Errors are reported through qcnn_last_error(NULL). */
+int qcnn_host_register(void* ptr, size_t bytes);
+int qcnn_host_unregister(void* ptr);
+/* Pinned host memory from the HIP runtime (hipHostMalloc, portable): the fastest source / destination of a transfer
+ * (measured on MI355X: uploads from it run at about twice the rate of uploads from registered pageable memory). */
+int qcnn_host_alloc(size_t bytes, void** out);
+int qcnn_host_free(void* ptr);
 /* Feature map l of the last forward, images [0, n), NHWC per image, to host (blocking).
  * Requires QCNN_OPT_KEEP_ALL = 1 for maps that the fast path fuses away. */
 int qcnn_get_layer_output(QcnnCtx* ctx, int l, int n, float* host_out);
@@ -144,6 +174,10 @@ int qcnn_get_layer_output_range(QcnnCtx* ctx, int l, int first, int n, float* ho
 /* Run layer `layer` alone on n images: in_host is fm[layer] NHWC per image (FC layers: the flat
  * vector in the order the reference consumes it), out_host receives fm[layer+1] (blocking). */
 int qcnn_run_layer(QcnnCtx* ctx, int layer, const float* in_host, int n, float* out_host);
+
+/* How the last launch of conv layer `layer` was cut (QCNN_OPT_SPLIT): *slices = workgroups per split tile (1 = no tile
+ * was split), *tiles_unsplit = tiles of the heaviest-first order that ran whole (-1 when nothing was split). */
+int qcnn_get_layer_split(QcnnCtx* ctx, int layer, int* tiles_unsplit, int* slices);
 
 /* ---- timing (QCNN_OPT_PROFILE = 1) ---- */
 /* Mean milliseconds of one LAUNCH per layer (a forward issues QCNN_OPT_STREAMS launches per layer, each over
@@ -159,7 +193,10 @@ int qcnn_reset_layer_ms(QcnnCtx* ctx);
  * a batch of n goes to rank i * G / n (contiguous blocks); the only collective is the one-time ncclBroadcast of
  * rank 0's parameter arena over xGMI.  Model calls mirror the per-context ones and apply to every rank. */
 typedef struct QcnnGroup QcnnGroup;
-/* device_ids == NULL or n_dev <= 0: every visible device */
+/* device_ids == NULL or n_dev <= 0: every visible device.  A device may be listed once; with QCNN_GROUP_ALLOW_DUP=1 in
+ * the environment (test rigs with fewer GPUs than ranks) it may repeat: such a group has no RCCL communicator — RCCL
+ * refuses two ranks on one device — and "broadcasts" rank 0's arena with device-to-device / peer copies instead; the
+ * per-rank contexts, host threads and shard arithmetic are the production ones. */
 int qcnn_group_create(const int* device_ids, int n_dev, QcnnGroup** out);
 int qcnn_group_destroy(QcnnGroup* grp);
 const char* qcnn_group_last_error(const QcnnGroup* grp);   /* grp == NULL: error of qcnn_group_create */
@@ -177,6 +214,10 @@ int qcnn_group_model_set_layer_params(QcnnGroup* grp, int layer, const float* bi
 int qcnn_group_model_broadcast(QcnnGroup* grp, float* elapsed_ms);
 /* Blocking: host in, host out; one host thread per GPU runs its block on its own context and stream. */
 int qcnn_group_forward_host(QcnnGroup* grp, const float* in_nchw_host, int n, float* prob_host, uint16_t* top5_host);
+/* Blocking: nb global batches of n[b] images each, every one sharded over the ranks like qcnn_group_forward_host; a
+ * rank's uploads overlap its layers as in qcnn_forward_host_batches. */
+int qcnn_group_forward_host_batches(QcnnGroup* grp, const float* const* in_host, const int* n, int nb,
+                                    float* const* prob_host, uint16_t* const* top5_host);
 int qcnn_group_sync(QcnnGroup* grp);
 
 #ifdef __cplusplus

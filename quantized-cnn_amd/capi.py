@@ -13,7 +13,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("QCNN_HIP_LIB") or os.path.join(PKG, "libqcnn_hip.so")   # QCNN_HIP_LIB: an experimental build of the same library
 HEADER_PATH = os.path.join(os.path.dirname(PKG), "include", "qcnn_hip.h")
 
-OPT_LUT_MODE, OPT_KEEP_ALL, OPT_PROFILE, OPT_STREAMS, OPT_SMALL_BATCH = 0, 1, 2, 3, 4
+OPT_LUT_MODE, OPT_KEEP_ALL, OPT_PROFILE, OPT_STREAMS, OPT_SMALL_BATCH, OPT_SPLIT, OPT_HOST_CHUNK = 0, 1, 2, 3, 4, 5, 6
 LUT_EXACT, LUT_MFMA, LUT_MFMA_F16, LUT_MFMA_BF16X2 = 0, 1, 2, 3
 
 
@@ -68,9 +68,15 @@ def load():
     lib.qcnn_forward.argtypes = [vp, f32p, i, f32p, u16p]
     lib.qcnn_forward_u8.argtypes = [vp, u8p, i, i, f32p, i, f32p, u16p]
     lib.qcnn_forward_host.argtypes = [vp, f32p, i, f32p, u16p]
+    lib.qcnn_forward_host_batches.argtypes = [vp, C.POINTER(vp), C.POINTER(i), i, C.POINTER(vp), C.POINTER(vp)]
+    lib.qcnn_host_register.argtypes = [vp, C.c_size_t]
+    lib.qcnn_host_unregister.argtypes = [vp]
+    lib.qcnn_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
+    lib.qcnn_host_free.argtypes = [vp]
     lib.qcnn_get_layer_output.argtypes = [vp, i, i, f32p]
     lib.qcnn_get_layer_output_range.argtypes = [vp, i, i, i, f32p]
     lib.qcnn_run_layer.argtypes = [vp, i, f32p, i, f32p]
+    lib.qcnn_get_layer_split.argtypes = [vp, i, C.POINTER(i), C.POINTER(i)]
     lib.qcnn_get_layer_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(i)]
     lib.qcnn_reset_layer_ms.argtypes = [vp]
     lib.qcnn_get_layer_total_ms.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(i)]
@@ -94,6 +100,7 @@ def load():
     lib.qcnn_group_model_set_layer_params.argtypes = [vp, i, f32p, f32p, u8p]
     lib.qcnn_group_model_broadcast.argtypes = [vp, C.POINTER(C.c_float)]
     lib.qcnn_group_forward_host.argtypes = [vp, f32p, i, f32p, u16p]
+    lib.qcnn_group_forward_host_batches.argtypes = [vp, C.POINTER(vp), C.POINTER(i), i, C.POINTER(vp), C.POINTER(vp)]
     lib.qcnn_group_sync.argtypes = [vp]
     _lib = lib
     return lib

@@ -8,6 +8,7 @@
 
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -30,15 +31,19 @@ struct LayerShape {
   size_t offProg = 0, progBytes = 0;                           // conv with K = 128: offsets in consumption order (QkProgram)
   bool hasDmap = false;
   bool loaded = false;
+  int planKey = -1;                                            // conv: split plan of the last planned launch geometry (qk_conv_plan)
+  QkSplitPlan plan = {0, 1, 0};
+  int lastFrom = -1, lastZ = 1;                                // how the last launch was actually cut
 };
 
 struct FmDims { int h, w, c; };
 
 constexpr int kProfRing = 32;    // forwards whose per-layer events are kept
 constexpr int kMaxStreams = 4;   // sub-batches (streams) of one forward
-constexpr int kSmallBatchMax = 2;  // batches up to this size run the few-image kernels (QCNN_OPT_SMALL_BATCH): beyond, a
+constexpr int kSmallBatchMax = QCNN_SMALL_BATCH_MAX;  // batches up to this size run the few-image kernels (QCNN_OPT_SMALL_BATCH): beyond, a
                                    // 128-image panel is cheaper (measured: 2 images 1.6 ms, 4 images 3.3 ms, a panel 2.8 ms)
 constexpr int kMaxFcSplit = 32;  // workgroups along the sub-space axis of an FC layer (partial sums reduced in fixed order)
+constexpr size_t kConvPartialFloats = (size_t)64 << 20;   // 256 MB of partial sums for split conv tiles (all sub-batches)
 constexpr size_t kSlack = 64 * 1024;   // bytes of slack behind every device buffer: the MFMA operand loads are
                                         // unconditional and may read a few rows past the last dim / sub-space
 
@@ -52,6 +57,8 @@ struct QcnnCtx {
   int lutMode = 1, keepAll = 1, profile = 0;
   int nStreams = 2;                  // QCNN_OPT_STREAMS: sub-batches of whole panels run concurrently
   int smallBatch = 1;                // QCNN_OPT_SMALL_BATCH: few-image kernels for batches <= kSmallBatchMax
+  int hostChunk = 2;                 // QCNN_OPT_HOST_CHUNK: panels per chunk of a large qcnn_forward_host batch (0: one launch)
+  int split = 1;                     // QCNN_OPT_SPLIT: launches that do not fill the chip split their tail (MFMA builders only)
   hipStream_t aux[3] = {nullptr, nullptr, nullptr};
   hipEvent_t evFork = nullptr, evJoin[3] = {nullptr, nullptr, nullptr};
 
@@ -71,8 +78,18 @@ struct QcnnCtx {
   float* stageOut = nullptr;
   size_t stageElems = 0;
   uint16_t* stageTop5 = nullptr;
+  // pipelined host path (qcnn_forward_host_batches): the upload of batch b+1 runs on its own stream under the layers of
+  // batch b; two device input buffers (stageIn and stageIn1), two pinned host result buffers
+  hipStream_t copyStream = nullptr;
+  float* stageIn1 = nullptr;         // [maxBatch][inC*inH*inW]
+  float* pinProb[2] = {nullptr, nullptr};
+  uint16_t* pinTop5[2] = {nullptr, nullptr};
+  hipEvent_t evCopied[2] = {nullptr, nullptr}, evFreed[2] = {nullptr, nullptr}, evDone[2] = {nullptr, nullptr};
+  bool freedValid[2] = {false, false};
+  std::vector<hipEvent_t> evChunk;   // chunked single batch (qcnn_forward_host): "chunk k is on the device"
   float* fcFlat = nullptr;           // first FC layer's input in consumption order
   float* fcPartial = nullptr;        // split-M partial sums of the FC layers
+  float* convPartial = nullptr;      // partial sums of split conv tiles (kConvPartialFloats)
   size_t fcPartialElems = 0;
   size_t fcMaxCt = 0;
   int lastN = 0;
@@ -154,7 +171,16 @@ void free_model(QcnnCtx* c) {
   if (c->stageIn) (void)hipFree(c->stageIn);
   if (c->stageOut) (void)hipFree(c->stageOut);
   if (c->stageTop5) (void)hipFree(c->stageTop5);
+  if (c->stageIn1) (void)hipFree(c->stageIn1);
+  c->stageIn1 = nullptr;
+  for (int k = 0; k < 2; ++k) {
+    if (c->pinProb[k]) (void)hipHostFree(c->pinProb[k]);
+    if (c->pinTop5[k]) (void)hipHostFree(c->pinTop5[k]);
+    c->pinProb[k] = nullptr; c->pinTop5[k] = nullptr; c->freedValid[k] = false;
+  }
   if (c->fcPartial) (void)hipFree(c->fcPartial);
+  if (c->convPartial) (void)hipFree(c->convPartial);
+  c->convPartial = nullptr;
   if (c->fcFlat) (void)hipFree(c->fcFlat);
   c->fcFlat = nullptr;
   c->stageIn = c->stageOut = nullptr; c->stageTop5 = nullptr; c->stageElems = 0;
@@ -177,18 +203,37 @@ int ensure_stage(QcnnCtx* c) {
   return 0;
 }
 
+// buffers, stream and events of the pipelined host path
+int ensure_pipeline(QcnnCtx* c) {
+  if (ensure_stage(c)) return 1;
+  if (c->stageIn1) return 0;
+  const size_t inElems = fm_elems(c, 0) * c->maxBatch;
+  const size_t classes = fm_elems(c, c->L);
+  for (int k = 0; k < 2; ++k) {
+    if (!c->evCopied[k]) HIP_TRY(c, hipEventCreateWithFlags(&c->evCopied[k], hipEventDisableTiming));
+    if (!c->evFreed[k]) HIP_TRY(c, hipEventCreateWithFlags(&c->evFreed[k], hipEventDisableTiming));
+    if (!c->evDone[k]) HIP_TRY(c, hipEventCreateWithFlags(&c->evDone[k], hipEventDisableTiming));
+    HIP_TRY(c, hipHostMalloc(&c->pinProb[k], (size_t)c->maxBatch * classes * sizeof(float), hipHostMallocPortable));
+    HIP_TRY(c, hipHostMalloc(&c->pinTop5[k], (size_t)c->maxBatch * 5 * sizeof(uint16_t), hipHostMallocPortable));
+    c->freedValid[k] = false;
+  }
+  HIP_TRY(c, hipMalloc(&c->stageIn1, inElems * sizeof(float) + kSlack));
+  return 0;
+}
+
 // One layer on `panels` panels: src/dst in panel layout.  flatFcInput: the FC input rows are already
 // in consumption order (qcnn_run_layer), so the NCHW-flatten map is not applied.
 // p0: first panel of the sub-batch (offsets into the scratch buffers), st: the stream it runs on
 // live: images every panel of this launch holds (128, or the batch size of a single-panel forward); small: the
 // few-image kernels (qcnn_small.hip) run the conv/FC layers
+// sub / nsub: index and number of the sub-batches (streams) of this forward: each has its own share of the scratch
 int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bool fuseRelu, bool flatFcInput,
                  int p0, hipStream_t st, const float* inNchw = nullptr, int nImages = 0, int live = QCNN_PANEL,
-                 bool small = false) {
+                 bool small = false, int sub = 0, int nsub = 1) {
   const QcnnLayerDesc& d = c->layers[l];
   const FmDims& a = c->dims[l];
   const FmDims& b = c->dims[l + 1];
-  const LayerShape& s = c->shapes[l];
+  LayerShape& s = c->shapes[l];
   hipError_t e = hipSuccess;
   switch (d.type) {
     case QCNN_CONV: {
@@ -205,7 +250,25 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
       p.H = a.h; p.W = a.w; p.Cin = a.c; p.Ho = b.h; p.Wo = b.w; p.Ct = b.c;
       p.knl = d.knlSiz; p.stride = d.stride; p.pad = d.padSiz; p.grp = d.grpCnt;
       p.M = s.M; p.Cs = s.Cs; p.K = s.K; p.relu = fuseRelu ? 1 : 0; p.panels = panels;
-      e = small ? qk_conv_small(p, live, st) : qk_conv_aprx(p, c->lutMode, st);
+      // few-image kernel unless the layer's shape is outside what it covers (a tap window x K that does not fit its LDS
+      // table): the panel kernel handles every shape set_layer_shape accepts
+      p.splitFrom = 0; p.splitZ = 1; p.partial = nullptr;
+      s.lastFrom = -1; s.lastZ = 1;
+      e = small ? qk_conv_small(p, live, st) : hipErrorInvalidValue;
+      if (e == hipErrorInvalidValue) {
+        // A launch of a few hundred workgroups (one GPU's share of a sharded batch) splits the tail of its tiles over
+        // several workgroups (qk_conv_plan).  MFMA builders only: the exact builder keeps the reference's summation order.
+        if (c->split && c->lutMode >= 1 && c->convPartial) {
+          const size_t share = kConvPartialFloats / (size_t)nsub;
+          const int key = panels * 8 + nsub;
+          if (s.planKey != key) { s.plan = qk_conv_plan(p, share); s.planKey = key; }
+          if (s.plan.Z > 1) {
+            p.splitFrom = s.plan.splitFrom; p.splitZ = s.plan.Z; p.partial = c->convPartial + share * sub;
+            s.lastFrom = s.plan.splitFrom; s.lastZ = s.plan.Z;
+          }
+        }
+        e = qk_conv_aprx(p, c->lutMode, st);
+      }
       break;
     }
     case QCNN_FCNT: {
@@ -227,12 +290,11 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
       // Split the sub-space axis over workgroups when the (channel chunk x panel) grid cannot fill the
       // chip; the exact builder keeps one pass so that the summation order stays the reference's.
       p.msplit = 1; p.partial = nullptr;
-      if (small) {                       // few images: the tables are materialised in the partial-sum scratch
-        if ((size_t)live * s.M * s.K > c->fcPartialElems)
-          return fail(c, "layer %d: the small-batch table scratch is too small", l);
-        p.partial = c->fcPartial;
-        e = qk_fc_small(p, live, st);
-        break;
+      if (small && s.K % 4 == 0 && (size_t)live * s.M * s.K <= c->fcPartialElems) {
+        p.partial = c->fcPartial;          // few images: the tables are materialised in the partial-sum scratch
+        e = qk_fc_small(p, live, st);      // (K not a multiple of 4: the panel kernel below)
+        if (e != hipErrorInvalidValue) break;
+        p.partial = nullptr;
       }
       if (c->lutMode >= 1) {
         const int G = qcnn_stage_group(s.K);
@@ -257,6 +319,20 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
         };
         int ms = pick(24);
         if (chunks * ms < 64) ms = pick(12);     // few channel chunks (a 1000-way classifier): a single panel would sit on < 64 CUs
+        if (c->split && chunks * ms * panels < 2 * 256) {
+          // QCNN_OPT_SPLIT: a launch of a few panels (one GPU's share of a sharded batch) picks the split for ITS panel
+          // count (the bits of an image then depend on the batch size, to rounding): >= 8 stages per workgroup, fewest
+          // rounds of 256 workgroups x stages each, ties to fewer splits
+          int best = ms;
+          double bestT = 1e30;
+          for (int cand = 1; cand <= kMaxFcSplit; ++cand) {
+            if (cand > 1 && stages / cand < 8) break;
+            const int grid = chunks * cand * panels;
+            const double t = (double)((grid + 255) / 256) * ((double)((stages + cand - 1) / cand) + 10.0) + 0.5 * cand;
+            if (t < bestT - 1e-9) { bestT = t; best = cand; }
+          }
+          ms = best;
+        }
         const size_t need = (size_t)ms * panels * p.Ct * QCNN_PANEL;
         const size_t poff = (size_t)kMaxFcSplit * p0 * c->fcMaxCt * QCNN_PANEL;    // every sub-batch has its own slab
         if (ms > 1 && poff + need <= c->fcPartialElems) { p.msplit = ms; p.partial = c->fcPartial + poff; }
@@ -313,24 +389,40 @@ int drain_profile(QcnnCtx* c) {
 // Can the first layer's builders read the NCHW network input in place (no pack kernel, no packed copy of the input)?
 // Fast path only (layer-for-layer mode keeps fm[0] for dumps); a conv layer with <= 4 input channels per group (one
 // sub-space of <= 4 dims: exactly what the operand loads of one stage touch) and K = 128 or the exact builder.
+// workgroups a fused LRN + pool launch must have (QCNN_LRNPOOL_MIN overrides it for experiments)
+int lrn_pool_min_blocks() {
+  static const int v = [] { const char* e = getenv("QCNN_LRNPOOL_MIN"); return (e && atoi(e) > 0) ? atoi(e) : 256; }();
+  return v;
+}
+
 bool direct_input(const QcnnCtx* c) {
   if (c->keepAll || c->L == 0 || c->layers[0].type != QCNN_CONV) return false;
   const QcnnLayerDesc& d = c->layers[0];
+  // ONE sub-space (a second one would be fetched from channel planes past the group's own, for the last image past the
+  // caller's buffer), and the whole batch inside 4 GiB: the builders keep per-lane image offsets in 32 bits
+  if (c->shapes[0].M != 1) return false;
+  if ((unsigned long long)c->maxBatch * c->inC * c->inH * c->inW * sizeof(float) >= (1ull << 32)) return false;
   return c->inC / d.grpCnt <= 4 && (c->lutMode == 0 || c->shapes[0].K == 128);
 }
 
-int run_layers(QcnnCtx* c, int n, const float* inNchw = nullptr) {
-  const int panels = (n + QCNN_PANEL - 1) / QCNN_PANEL;
+// pa / pb: the panels [pa, pb) of the batch this call runs (pb < 0: all of them) — a large host batch goes through in
+// chunks whose uploads overlap the previous chunk's layers, all chunks writing into the same whole-batch feature maps
+int run_layers(QcnnCtx* c, int n, const float* inNchw = nullptr, int pa = 0, int pb = -1) {
+  const int panelsAll = (n + QCNN_PANEL - 1) / QCNN_PANEL;
+  if (pb < 0) pb = panelsAll;
+  const int panels = pb - pa;
   const int ns = std::max(1, std::min(std::min(c->nStreams, kMaxStreams), panels));
   // A batch of a few images: conv/FC by the channel-lane kernels, glue kernels on the live lanes only.  Only in the
   // default f32 mode: the exact builder's point is the reference's summation order (which only the panel kernels
   // keep), and modes 2 / 3 study properties of the panel kernels' table builders.
   const bool small = c->smallBatch && c->lutMode == 1 && n <= kSmallBatchMax;
-  const int live = panels == 1 ? n : QCNN_PANEL;
+  const int live = panelsAll == 1 ? n : QCNN_PANEL;
   if (c->profile && c->profCount == kProfRing && drain_profile(c)) return 1;   // ring full: fold it into the sums
   const bool prof = c->profile != 0;
-  c->lastFm.assign(c->L + 1, nullptr);
-  c->lastFm[0] = inNchw ? nullptr : c->fmBuf[0];
+  // pointer table of THIS call (aliases; nullptr = not materialised by this call: the network input read in place, the
+  // normalised map of a fused LRN + pool pair); it becomes / is merged into the context's table at the end
+  std::vector<float*> fm(c->L + 1, nullptr);
+  fm[0] = inNchw ? nullptr : c->fmBuf[0];
   // LRN + the 3x3 / stride 2 / pad 0 max-pool behind it run as one kernel on the fast path when every sub-batch
   // fills the chip with it; the normalised map is then not materialised (qcnn_get_feature_map reports it missing)
   auto lrn_pool = [&](int l) {
@@ -339,14 +431,18 @@ int run_layers(QcnnCtx* c, int n, const float* inNchw = nullptr) {
     const QcnnLayerDesc& b = c->layers[l + 1];
     if (a.type != QCNN_LORN || b.type != QCNN_POOL || (a.lrnSiz != 5 && a.lrnSiz != 3)) return false;
     if (b.knlSiz != 3 || b.stride != 2 || b.padSiz != 0) return false;
-    return (long long)qk_lrn_pool_blocks(c->dims[l + 2].h, c->dims[l + 2].w) * (panels / ns) >= 256;
+    return (long long)qk_lrn_pool_blocks(c->dims[l + 2].h, c->dims[l + 2].w) * (panels / ns) >= lrn_pool_min_blocks();
   };
   for (int l = 0; l < c->L; ++l) {              // pointer table (aliases) — identical for every sub-batch
     const int type = c->layers[l].type;
     const bool prevFused = l > 0 && !c->keepAll && type == QCNN_RELU &&
                            (c->layers[l - 1].type == QCNN_CONV || c->layers[l - 1].type == QCNN_FCNT);
-    c->lastFm[l + 1] = (type == QCNN_DRPT || prevFused) ? c->lastFm[l] : c->fmBuf[l + 1];
-    if (lrn_pool(l)) c->lastFm[l + 1] = nullptr;
+    fm[l + 1] = (type == QCNN_DRPT || prevFused) ? fm[l] : c->fmBuf[l + 1];
+    if (lrn_pool(l)) fm[l + 1] = nullptr;
+  }
+  for (int k = 0; k < ns - 1; ++k) {                 // auxiliary streams of the sub-batches, created when first needed
+    if (!c->aux[k]) HIP_TRY(c, hipStreamCreateWithFlags(&c->aux[k], hipStreamNonBlocking));
+    if (!c->evJoin[k]) HIP_TRY(c, hipEventCreateWithFlags(&c->evJoin[k], hipEventDisableTiming));
   }
   if (ns > 1) {
     HIP_TRY(c, hipEventRecord(c->evFork, c->stream));
@@ -354,19 +450,19 @@ int run_layers(QcnnCtx* c, int n, const float* inNchw = nullptr) {
   }
   for (int l = 0; l < c->L; ++l) {              // layer-major issue order: the streams advance together
     const int type = c->layers[l].type;
-    if (c->lastFm[l + 1] == c->lastFm[l] && c->lastFm[l] != nullptr) continue;   // alias: copy semantics, no traffic
-    if (c->lastFm[l] == nullptr && l > 0) continue;                               // the pool of a fused LRN + pool pair
-    const bool lrnPool = c->lastFm[l + 1] == nullptr;
+    if (fm[l + 1] == fm[l] && fm[l] != nullptr) continue;   // alias: copy semantics, no traffic
+    if (fm[l] == nullptr && l > 0) continue;                               // the pool of a fused LRN + pool pair
+    const bool lrnPool = fm[l + 1] == nullptr;
     const bool fuse = !c->keepAll && (type == QCNN_CONV || type == QCNN_FCNT) && l + 1 < c->L &&
                       c->layers[l + 1].type == QCNN_RELU;
     for (int k = 0; k < ns; ++k) {
-      const int p0 = (int)((long long)panels * k / ns), p1 = (int)((long long)panels * (k + 1) / ns);
+      const int p0 = pa + (int)((long long)panels * k / ns), p1 = pa + (int)((long long)panels * (k + 1) / ns);
       if (p1 <= p0) continue;
       hipStream_t st = k == 0 ? c->stream : c->aux[k - 1];
       const bool direct = l == 0 && inNchw != nullptr;
-      const float* src = direct ? nullptr : c->lastFm[l] + (size_t)p0 * fm_elems(c, l) * QCNN_PANEL;
-      float* dst = lrnPool ? c->lastFm[l + 2] + (size_t)p0 * fm_elems(c, l + 2) * QCNN_PANEL
-                           : c->lastFm[l + 1] + (size_t)p0 * fm_elems(c, l + 1) * QCNN_PANEL;
+      const float* src = direct ? nullptr : fm[l] + (size_t)p0 * fm_elems(c, l) * QCNN_PANEL;
+      float* dst = lrnPool ? fm[l + 2] + (size_t)p0 * fm_elems(c, l + 2) * QCNN_PANEL
+                           : fm[l + 1] + (size_t)p0 * fm_elems(c, l + 1) * QCNN_PANEL;
       hipEvent_t e0 = nullptr, e1 = nullptr;
       if (prof) {
         const size_t slot = (((size_t)c->profCount * kMaxStreams + k) * c->L + l) * 2;
@@ -378,7 +474,7 @@ int run_layers(QcnnCtx* c, int n, const float* inNchw = nullptr) {
         const hipError_t e = qk_lrn_pool(src, dst, p1 - p0, c->dims[l].h, c->dims[l].w, c->dims[l].c, c->dims[l + 2].h,
                                          c->dims[l + 2].w, d.lrnSiz, d.lrnAlp, d.lrnBet, d.lrnIni, live, st);
         if (e != hipSuccess) return fail(c, "layer %d (LRN + pool): %s", l, hipGetErrorString(e));
-      } else if (launch_layer(c, l, src, dst, p1 - p0, fuse, false, p0, st, direct ? inNchw : nullptr, n, live, small)) {
+      } else if (launch_layer(c, l, src, dst, p1 - p0, fuse, false, p0, st, direct ? inNchw : nullptr, n, live, small, k, ns)) {
         return 1;
       }
       if (prof) {
@@ -392,6 +488,13 @@ int run_layers(QcnnCtx* c, int n, const float* inNchw = nullptr) {
     HIP_TRY(c, hipStreamWaitEvent(c->stream, c->evJoin[k - 1], 0));
   }
   if (prof) c->profCount++;
+  // what can be read back afterwards: a map exists only if every chunk of the batch materialised it
+  if (pa == 0 || (int)c->lastFm.size() != c->L + 1) {
+    c->lastFm = fm;
+  } else {
+    for (int l = 0; l <= c->L; ++l)
+      if (fm[l] == nullptr) c->lastFm[l] = nullptr;
+  }
   c->lastN = n;
   return 0;
 }
@@ -435,6 +538,16 @@ int qcnn_ctx_create(int device_id, void* stream, QcnnCtx** out) {
     if (e != hipSuccess) { delete c; return fail(nullptr, "hipStreamCreate -> %s", hipGetErrorString(e)); }
     c->ownStream = true;
   }
+  // The copy stream is created HERE, second: the runtime spreads a process's streams over a handful of hardware queues
+  // (four by default) in creation order, and a copy stream that shares its queue with the compute stream serialises
+  // "upload batch b + 1" in front of "layers of batch b" (measured: 25 ms instead of 15 ms per 1000-image batch).  The
+  // auxiliary compute streams are created on demand (run_layers), so the default two-stream set-up uses three queues.
+  e = hipStreamCreateWithFlags(&c->copyStream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    if (c->ownStream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return fail(nullptr, "hipStreamCreate (copy stream) -> %s", hipGetErrorString(e));
+  }
   *out = c;
   return 0;
 }
@@ -449,6 +562,13 @@ int qcnn_ctx_destroy(QcnnCtx* c) {
     if (c->evJoin[k]) (void)hipEventDestroy(c->evJoin[k]);
   }
   if (c->evFork) (void)hipEventDestroy(c->evFork);
+  for (int k = 0; k < 2; ++k) {
+    if (c->evCopied[k]) (void)hipEventDestroy(c->evCopied[k]);
+    if (c->evFreed[k]) (void)hipEventDestroy(c->evFreed[k]);
+    if (c->evDone[k]) (void)hipEventDestroy(c->evDone[k]);
+  }
+  for (hipEvent_t e : c->evChunk) (void)hipEventDestroy(e);
+  if (c->copyStream) (void)hipStreamDestroy(c->copyStream);
   if (c->ownStream) (void)hipStreamDestroy(c->stream);
   delete c;
   return 0;
@@ -460,6 +580,10 @@ int qcnn_set_option(QcnnCtx* c, int option, int value) {
     case QCNN_OPT_KEEP_ALL: c->keepAll = value ? 1 : 0; return 0;
     case QCNN_OPT_PROFILE: c->profile = value ? 1 : 0; return 0;
     case QCNN_OPT_SMALL_BATCH: c->smallBatch = value ? 1 : 0; return 0;
+    case QCNN_OPT_SPLIT: c->split = value ? 1 : 0; return 0;
+    case QCNN_OPT_HOST_CHUNK:
+      if (value < 0) return fail(c, "host chunk must be >= 0 panels");
+      c->hostChunk = value; return 0;
     case QCNN_OPT_STREAMS:
       if (value < 1 || value > kMaxStreams) return fail(c, "streams must be in [1, %d]", kMaxStreams);
       c->nStreams = value; return 0;
@@ -569,6 +693,7 @@ int qcnn_model_commit(QcnnCtx* c, int max_batch, void* dev_arena) {
     c->fcMaxCt = maxCt;
     c->fcPartialElems = (size_t)kMaxFcSplit * c->maxPanels * maxCt * QCNN_PANEL;
     if (c->fcPartialElems) HIP_TRY(c, hipMalloc(&c->fcPartial, c->fcPartialElems * sizeof(float)));
+    HIP_TRY(c, hipMalloc(&c->convPartial, kConvPartialFloats * sizeof(float)));
     if (c->firstFc >= 0 && c->shapes[c->firstFc].hasDmap)
       HIP_TRY(c, hipMalloc(&c->fcFlat, (size_t)c->maxPanels * fm_elems(c, c->firstFc) * QCNN_PANEL * sizeof(float) + kSlack));
   }
@@ -577,11 +702,7 @@ int qcnn_model_commit(QcnnCtx* c, int max_batch, void* dev_arena) {
   c->profSum.assign(c->L, 0.0);
   c->profLaunches.assign(c->L, 0);
   c->profCount = 0; c->profForwards = 0; c->profPending.clear();
-  for (int k = 0; k < kMaxStreams - 1; ++k) {
-    if (!c->aux[k]) HIP_TRY(c, hipStreamCreateWithFlags(&c->aux[k], hipStreamNonBlocking));
-    if (!c->evJoin[k]) HIP_TRY(c, hipEventCreateWithFlags(&c->evJoin[k], hipEventDisableTiming));
-  }
-  if (!c->evFork) HIP_TRY(c, hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming));
+  if (!c->evFork) HIP_TRY(c, hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming));   // aux streams: on demand (run_layers)
   // first-FC flatten map: consumption index d = (ch*H + y)*W + x  ->  NHWC row (y*W + x)*C + ch  (src/CaffeEva.cc:187-189)
   for (int l = 0; l < c->L; ++l) {
     const LayerShape& s = c->shapes[l];
@@ -740,8 +861,8 @@ int qcnn_fm_dims(QcnnCtx* c, int l, int* hwc3) {
 
 namespace {
 // layers + output conversion of a forward whose input panel (fmBuf[0]) has just been enqueued
-int forward_tail(QcnnCtx* c, int n, float* prob_dev, uint16_t* top5_dev, const float* inNchw = nullptr) {
-  if (run_layers(c, n, inNchw)) return 1;
+// output conversion of a finished layer loop: probabilities [n][classes], top-5 [n][5]
+int forward_outputs(QcnnCtx* c, int n, float* prob_dev, uint16_t* top5_dev) {
   const int classes = (int)fm_elems(c, c->L);
   hipError_t e;
   if (prob_dev) {
@@ -753,6 +874,10 @@ int forward_tail(QcnnCtx* c, int n, float* prob_dev, uint16_t* top5_dev, const f
     if (e != hipSuccess) return fail(c, "top-5 launch failed: %s", hipGetErrorString(e));
   }
   return 0;
+}
+int forward_tail(QcnnCtx* c, int n, float* prob_dev, uint16_t* top5_dev, const float* inNchw = nullptr) {
+  if (run_layers(c, n, inNchw)) return 1;
+  return forward_outputs(c, n, prob_dev, top5_dev);
 }
 }  // namespace
 
@@ -778,14 +903,166 @@ int qcnn_forward_u8(QcnnCtx* c, const uint8_t* in_u8_dev, int src_h, int src_w, 
   return forward_tail(c, n, prob_dev, top5_dev);
 }
 
+int qcnn_host_register(void* ptr, size_t bytes) {
+  if (!ptr || !bytes) return fail(nullptr, "qcnn_host_register: empty range");
+  const hipError_t e = hipHostRegister(ptr, bytes, hipHostRegisterPortable);
+  if (e != hipSuccess) { (void)hipGetLastError(); return fail(nullptr, "hipHostRegister(%zu bytes) -> %s", bytes, hipGetErrorString(e)); }
+  return 0;
+}
+
+int qcnn_host_alloc(size_t bytes, void** out) {
+  if (!out || !bytes) return fail(nullptr, "qcnn_host_alloc: empty request");
+  *out = nullptr;
+  const hipError_t e = hipHostMalloc(out, bytes, hipHostMallocPortable);
+  if (e != hipSuccess) { (void)hipGetLastError(); *out = nullptr; return fail(nullptr, "hipHostMalloc(%zu bytes) -> %s", bytes, hipGetErrorString(e)); }
+  return 0;
+}
+
+int qcnn_host_free(void* ptr) {
+  if (!ptr) return 0;
+  const hipError_t e = hipHostFree(ptr);
+  if (e != hipSuccess) { (void)hipGetLastError(); return fail(nullptr, "hipHostFree -> %s", hipGetErrorString(e)); }
+  return 0;
+}
+
+int qcnn_host_unregister(void* ptr) {
+  if (!ptr) return 0;
+  const hipError_t e = hipHostUnregister(ptr);
+  if (e != hipSuccess) { (void)hipGetLastError(); return fail(nullptr, "hipHostUnregister -> %s", hipGetErrorString(e)); }
+  return 0;
+}
+
+// The reference's image loop (src/CaffeEva.cc:151-211) classifies one batch after the other; here the upload of batch
+// b + 1 (copy stream, second input buffer) runs under the layers of batch b, and the results come back through pinned
+// buffers one batch late, so that neither direction of PCIe is ever waited for by the kernels.
+int qcnn_forward_host_batches(QcnnCtx* c, const float* const* in_host, const int* n, int nb, float* const* prob_host,
+                              uint16_t* const* top5_host) {
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (!c->committed) return fail(c, "model not committed");
+  if (nb <= 0 || !in_host || !n) return fail(c, "qcnn_forward_host_batches: no batches");
+  for (int b = 0; b < nb; ++b)
+    if (n[b] <= 0 || n[b] > c->maxBatch || !in_host[b]) return fail(c, "batch %d: %d images outside (0, %d]", b, n[b], c->maxBatch);
+  if (ensure_pipeline(c)) return 1;
+  const size_t inE = fm_elems(c, 0);
+  const size_t classes = fm_elems(c, c->L);
+  float* const dIn[2] = {c->stageIn, c->stageIn1};
+  // the copy stream may not touch an input buffer before everything already enqueued on the compute stream has read it
+  for (int k = 0; k < 2; ++k) { HIP_TRY(c, hipEventRecord(c->evFreed[k], c->stream)); c->freedValid[k] = true; }
+  auto upload = [&](int b) -> int {
+    const int k = b & 1;
+    if (c->freedValid[k]) HIP_TRY(c, hipStreamWaitEvent(c->copyStream, c->evFreed[k], 0));
+    HIP_TRY(c, hipMemcpyAsync(dIn[k], in_host[b], inE * n[b] * sizeof(float), hipMemcpyHostToDevice, c->copyStream));
+    HIP_TRY(c, hipEventRecord(c->evCopied[k], c->copyStream));
+    return 0;
+  };
+  auto collect = [&](int b) -> int {
+    const int k = b & 1;
+    HIP_TRY(c, hipEventSynchronize(c->evDone[k]));
+    if (prob_host && prob_host[b]) memcpy(prob_host[b], c->pinProb[k], (size_t)n[b] * classes * sizeof(float));
+    if (top5_host && top5_host[b]) memcpy(top5_host[b], c->pinTop5[k], (size_t)n[b] * 5 * sizeof(uint16_t));
+    return 0;
+  };
+  // QCNN_DEBUG_PIPELINE=1: time every upload and every batch's kernels with events and print the schedule afterwards
+  static const bool dbg = [] { const char* e = getenv("QCNN_DEBUG_PIPELINE"); return e && atoi(e) != 0; }();
+  std::vector<hipEvent_t> dbgEv;
+  if (dbg) {
+    dbgEv.resize((size_t)nb * 4 + 1);
+    for (hipEvent_t& e : dbgEv) HIP_TRY(c, hipEventCreate(&e));
+    HIP_TRY(c, hipEventRecord(dbgEv[(size_t)nb * 4], c->stream));
+  }
+  auto uploadT = [&](int b) -> int {
+    if (!dbg) return upload(b);
+    const int k = b & 1;
+    if (c->freedValid[k]) HIP_TRY(c, hipStreamWaitEvent(c->copyStream, c->evFreed[k], 0));
+    HIP_TRY(c, hipEventRecord(dbgEv[(size_t)b * 4], c->copyStream));
+    HIP_TRY(c, hipMemcpyAsync(dIn[k], in_host[b], inE * n[b] * sizeof(float), hipMemcpyHostToDevice, c->copyStream));
+    HIP_TRY(c, hipEventRecord(dbgEv[(size_t)b * 4 + 1], c->copyStream));
+    HIP_TRY(c, hipEventRecord(c->evCopied[k], c->copyStream));
+    return 0;
+  };
+  if (uploadT(0)) return 1;
+  for (int b = 0; b < nb; ++b) {
+    const int k = b & 1;
+    if (b + 1 < nb && uploadT(b + 1)) return 1;
+    const bool wantProb = prob_host && prob_host[b], wantTop5 = top5_host && top5_host[b];
+    HIP_TRY(c, hipStreamWaitEvent(c->stream, c->evCopied[k], 0));
+    if (dbg) HIP_TRY(c, hipEventRecord(dbgEv[(size_t)b * 4 + 2], c->stream));
+    if (qcnn_forward(c, dIn[k], n[b], wantProb ? c->stageOut : nullptr, wantTop5 ? c->stageTop5 : nullptr)) return 1;
+    if (dbg) HIP_TRY(c, hipEventRecord(dbgEv[(size_t)b * 4 + 3], c->stream));
+    HIP_TRY(c, hipEventRecord(c->evFreed[k], c->stream));
+    if (wantProb)
+      HIP_TRY(c, hipMemcpyAsync(c->pinProb[k], c->stageOut, (size_t)n[b] * classes * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    if (wantTop5)
+      HIP_TRY(c, hipMemcpyAsync(c->pinTop5[k], c->stageTop5, (size_t)n[b] * 5 * sizeof(uint16_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipEventRecord(c->evDone[k], c->stream));
+    if (b >= 1 && collect(b - 1)) return 1;
+  }
+  if (collect(nb - 1)) return 1;
+  HIP_TRY(c, hipStreamSynchronize(c->copyStream));
+  if (dbg) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (int b = 0; b < nb; ++b) {
+      float t[4];
+      for (int j = 0; j < 4; ++j) HIP_TRY(c, hipEventElapsedTime(&t[j], dbgEv[(size_t)nb * 4], dbgEv[(size_t)b * 4 + j]));
+      fprintf(stderr, "[qcnn pipeline] batch %d (%d images): upload %.2f -> %.2f ms, layers %.2f -> %.2f ms\n", b, n[b], t[0], t[1],
+              t[2], t[3]);
+    }
+    for (hipEvent_t e : dbgEv) (void)hipEventDestroy(e);
+  }
+  return 0;
+}
+
 int qcnn_forward_host(QcnnCtx* c, const float* in_nchw_host, int n, float* prob_host, uint16_t* top5_host) {
   HIP_TRY(c, hipSetDevice(c->device));
   if (!c->committed) return fail(c, "model not committed");
   if (n <= 0 || n > c->maxBatch) return fail(c, "batch %d outside (0, %d]", n, c->maxBatch);
-  if (ensure_stage(c)) return 1;
-  const size_t inElems = fm_elems(c, 0) * n;
+  const size_t inE = fm_elems(c, 0);
   const int classes = (int)fm_elems(c, c->L);
-  HIP_TRY(c, hipMemcpyAsync(c->stageIn, in_nchw_host, inElems * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  if (c->hostChunk > 0 && n >= 2 * c->hostChunk * QCNN_PANEL) {
+    // A batch of at least two chunks (QCNN_OPT_HOST_CHUNK panels each, default two) goes through chunk by chunk: every chunk is uploaded on the copy stream
+    // into its place of the batch's input buffer, and its layers start as soon as it has arrived — the upload of chunk
+    // k + 1 (a DMA transfer from pinned / registered memory, a staged copy otherwise) runs under the layers of chunk k.
+    // All chunks write into the same whole-batch feature maps, so dumps and results are those of one launch.
+    if (ensure_pipeline(c)) return 1;
+    const int panelsAll = (n + QCNN_PANEL - 1) / QCNN_PANEL;
+    const int chunkPanels = c->hostChunk;
+    const int nc = (panelsAll + chunkPanels - 1) / chunkPanels;
+    while ((int)c->evChunk.size() < nc) {
+      hipEvent_t ev;
+      HIP_TRY(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+      c->evChunk.push_back(ev);
+    }
+    const bool direct = direct_input(c);
+    HIP_TRY(c, hipEventRecord(c->evFreed[0], c->stream));            // the buffer may still feed an earlier forward
+    HIP_TRY(c, hipStreamWaitEvent(c->copyStream, c->evFreed[0], 0));
+    for (int k = 0; k < nc; ++k) {
+      const size_t first = (size_t)k * chunkPanels * QCNN_PANEL;
+      const size_t cnt = std::min<size_t>((size_t)chunkPanels * QCNN_PANEL, (size_t)n - first);
+      HIP_TRY(c, hipMemcpyAsync(c->stageIn + first * inE, in_nchw_host + first * inE, cnt * inE * sizeof(float),
+                                hipMemcpyHostToDevice, c->copyStream));
+      HIP_TRY(c, hipEventRecord(c->evChunk[k], c->copyStream));
+    }
+    for (int k = 0; k < nc; ++k) {
+      const int pa = k * chunkPanels, pb = std::min(panelsAll, pa + chunkPanels);
+      const size_t first = (size_t)pa * QCNN_PANEL;
+      const int cnt = (int)std::min<size_t>((size_t)(pb - pa) * QCNN_PANEL, (size_t)n - first);
+      HIP_TRY(c, hipStreamWaitEvent(c->stream, c->evChunk[k], 0));
+      if (!direct) {
+        const hipError_t e = qk_pack_nchw(c->stageIn + first * inE, c->fmBuf[0] + first * inE, cnt, c->inC, c->inH, c->inW, c->stream);
+        if (e != hipSuccess) return fail(c, "input pack launch failed: %s", hipGetErrorString(e));
+      }
+      if (run_layers(c, n, direct ? c->stageIn : nullptr, pa, pb)) return 1;
+    }
+    if (forward_outputs(c, n, prob_host ? c->stageOut : nullptr, top5_host ? c->stageTop5 : nullptr)) return 1;
+    if (prob_host)
+      HIP_TRY(c, hipMemcpyAsync(prob_host, c->stageOut, (size_t)n * classes * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    if (top5_host)
+      HIP_TRY(c, hipMemcpyAsync(top5_host, c->stageTop5, (size_t)n * 5 * sizeof(uint16_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return 0;
+  }
+  if (ensure_stage(c)) return 1;
+  HIP_TRY(c, hipMemcpyAsync(c->stageIn, in_nchw_host, inE * n * sizeof(float), hipMemcpyHostToDevice, c->stream));
   if (qcnn_forward(c, c->stageIn, n, prob_host ? c->stageOut : nullptr, top5_host ? c->stageTop5 : nullptr)) return 1;
   if (prob_host)
     HIP_TRY(c, hipMemcpyAsync(prob_host, c->stageOut, (size_t)n * classes * sizeof(float), hipMemcpyDeviceToHost, c->stream));
@@ -857,6 +1134,14 @@ int qcnn_run_layer(QcnnCtx* c, int layer, const float* in_host, int n, float* ou
   if (e != hipSuccess) return fail(c, "unpack launch failed: %s", hipGetErrorString(e));
   HIP_TRY(c, hipMemcpyAsync(out_host, c->stageOut, (size_t)n * Eout * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int qcnn_get_layer_split(QcnnCtx* c, int layer, int* tiles_unsplit, int* slices) {
+  if (layer < 0 || layer >= c->L) return fail(c, "layer %d out of range", layer);
+  const LayerShape& s = c->shapes[layer];
+  if (tiles_unsplit) *tiles_unsplit = s.lastFrom;
+  if (slices) *slices = s.lastZ;
   return 0;
 }
 

@@ -11,6 +11,7 @@
 
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <chrono>
@@ -29,6 +30,8 @@ struct QcnnGroup {
   size_t inElems = 0;
   float bcastMs = 0.0f;
   bool broadcastDone = false;
+  bool dupDevices = false;      // QCNN_GROUP_ALLOW_DUP: several ranks on one device, no RCCL communicator
+  int smallBatch = 1;           // QCNN_OPT_SMALL_BATCH as the caller set it; applied per forward by the GLOBAL batch size
 };
 
 namespace {
@@ -76,9 +79,14 @@ int qcnn_group_create(const int* device_ids, int n_dev, QcnnGroup** out) {
   if (!device_ids || n_dev <= 0) {
     for (int d = 0; d < visible; ++d) g->devs.push_back(d);
   } else {
+    const char* dup = getenv("QCNN_GROUP_ALLOW_DUP");
+    const bool allowDup = dup != nullptr && atoi(dup) != 0;
     for (int i = 0; i < n_dev; ++i) {
       for (int j = 0; j < i; ++j)
-        if (device_ids[j] == device_ids[i]) { delete g; return gfail(nullptr, "device %d listed twice", device_ids[i]); }
+        if (device_ids[j] == device_ids[i]) {
+          if (!allowDup) { delete g; return gfail(nullptr, "device %d listed twice", device_ids[i]); }
+          g->dupDevices = true;
+        }
       g->devs.push_back(device_ids[i]);
     }
   }
@@ -93,7 +101,8 @@ int qcnn_group_create(const int* device_ids, int n_dev, QcnnGroup** out) {
     g->ctx.push_back(c);
   }
   g->comm.assign(g->devs.size(), nullptr);
-  const ncclResult_t nr = ncclCommInitAll(g->comm.data(), (int)g->devs.size(), g->devs.data());
+  const ncclResult_t nr = g->dupDevices ? ncclSuccess
+                                        : ncclCommInitAll(g->comm.data(), (int)g->devs.size(), g->devs.data());
   if (nr != ncclSuccess) {
     gfail(nullptr, "ncclCommInitAll over %zu device(s) -> %s", g->devs.size(), ncclGetErrorString(nr));
     for (QcnnCtx* k : g->ctx) qcnn_ctx_destroy(k);
@@ -126,6 +135,7 @@ int qcnn_group_shard_bounds(const QcnnGroup* g, int n, int rank, int* first, int
 }
 
 int qcnn_group_set_option(QcnnGroup* g, int option, int value) {
+  if (option == QCNN_OPT_SMALL_BATCH) g->smallBatch = value ? 1 : 0;
   FOR_ALL(g, qcnn_set_option(c, option, value));
   return 0;
 }
@@ -174,16 +184,28 @@ int qcnn_group_model_broadcast(QcnnGroup* g, float* elapsed_ms) {
   for (int r = 0; r < G; ++r)
     if (qcnn_sync(g->ctx[r])) return gfail(g, "rank %d: %s", r, qcnn_last_error(g->ctx[r]));
   const auto t0 = std::chrono::steady_clock::now();
-  ncclResult_t nr = ncclGroupStart();
-  for (int r = 0; r < G && nr == ncclSuccess; ++r) {
-    (void)hipSetDevice(g->devs[r]);
-    nr = ncclBroadcast(arena[r], arena[r], bytes, ncclUint8, 0, g->comm[r],
-                       static_cast<hipStream_t>(qcnn_ctx_stream(g->ctx[r])));
+  if (g->dupDevices) {
+    // test rig (QCNN_GROUP_ALLOW_DUP): ranks share devices, RCCL cannot span them — copy rank 0's arena instead
+    for (int r = 1; r < G; ++r) {
+      (void)hipSetDevice(g->devs[r]);
+      hipStream_t st = static_cast<hipStream_t>(qcnn_ctx_stream(g->ctx[r]));
+      const hipError_t e = (g->devs[r] == g->devs[0])
+                               ? hipMemcpyAsync(arena[r], arena[0], bytes, hipMemcpyDeviceToDevice, st)
+                               : hipMemcpyPeerAsync(arena[r], g->devs[r], arena[0], g->devs[0], bytes, st);
+      if (e != hipSuccess) return gfail(g, "arena copy to rank %d -> %s", r, hipGetErrorString(e));
+    }
+  } else {
+    ncclResult_t nr = ncclGroupStart();
+    for (int r = 0; r < G && nr == ncclSuccess; ++r) {
+      (void)hipSetDevice(g->devs[r]);
+      nr = ncclBroadcast(arena[r], arena[r], bytes, ncclUint8, 0, g->comm[r],
+                         static_cast<hipStream_t>(qcnn_ctx_stream(g->ctx[r])));
+    }
+    const ncclResult_t ne = ncclGroupEnd();
+    if (nr != ncclSuccess || ne != ncclSuccess)
+      return gfail(g, "ncclBroadcast of the %zu-byte parameter arena -> %s", bytes,
+                   ncclGetErrorString(nr != ncclSuccess ? nr : ne));
   }
-  const ncclResult_t ne = ncclGroupEnd();
-  if (nr != ncclSuccess || ne != ncclSuccess)
-    return gfail(g, "ncclBroadcast of the %zu-byte parameter arena -> %s", bytes,
-                 ncclGetErrorString(nr != ncclSuccess ? nr : ne));
   for (int r = 0; r < G; ++r)
     if (qcnn_sync(g->ctx[r])) return gfail(g, "rank %d: %s", r, qcnn_last_error(g->ctx[r]));
   g->bcastMs = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -194,18 +216,39 @@ int qcnn_group_model_broadcast(QcnnGroup* g, float* elapsed_ms) {
   return 0;
 }
 
-int qcnn_group_forward_host(QcnnGroup* g, const float* in_nchw_host, int n, float* prob_host, uint16_t* top5_host) {
+int qcnn_group_forward_host_batches(QcnnGroup* g, const float* const* in_host, const int* n, int nb,
+                                    float* const* prob_host, uint16_t* const* top5_host) {
   const int G = (int)g->ctx.size();
-  if (n <= 0) return gfail(g, "batch %d must be positive", n);
+  if (nb <= 0 || !in_host || !n) return gfail(g, "no batches");
+  int nMax = 0;
+  for (int b = 0; b < nb; ++b) {
+    if (n[b] <= 0 || !in_host[b]) return gfail(g, "batch %d: %d images", b, n[b]);
+    nMax = n[b] > nMax ? n[b] : nMax;
+  }
   if (G > 1 && !g->broadcastDone) return gfail(g, "qcnn_group_model_broadcast must follow the parameter upload");
+  // The kernel family follows the GLOBAL batch, not the shard: an image must not change bits with the number of GPUs
+  // (a shard of one or two images of a larger batch would otherwise take the few-image kernels).
+  for (int r = 0; r < G; ++r)
+    if (qcnn_set_option(g->ctx[r], QCNN_OPT_SMALL_BATCH, (g->smallBatch && nMax <= QCNN_SMALL_BATCH_MAX) ? 1 : 0))
+      return gfail(g, "rank %d: %s", r, qcnn_last_error(g->ctx[r]));
   std::vector<int> rc(G, 0);
   auto work = [&](int r) {
-    int first = 0, count = 0;
-    shard(n, r, G, &first, &count);
-    if (count == 0) return;
-    rc[r] = qcnn_forward_host(g->ctx[r], in_nchw_host + (size_t)first * g->inElems, count,
-                              prob_host ? prob_host + (size_t)first * g->classes : nullptr,
-                              top5_host ? top5_host + (size_t)first * 5 : nullptr);
+    std::vector<const float*> in;
+    std::vector<int> cnt;
+    std::vector<float*> pr;
+    std::vector<uint16_t*> t5;
+    for (int b = 0; b < nb; ++b) {                    // this rank's block of every batch; empty blocks are skipped
+      int first = 0, count = 0;
+      shard(n[b], r, G, &first, &count);
+      if (count == 0) continue;
+      in.push_back(in_host[b] + (size_t)first * g->inElems);
+      cnt.push_back(count);
+      pr.push_back((prob_host && prob_host[b]) ? prob_host[b] + (size_t)first * g->classes : nullptr);
+      t5.push_back((top5_host && top5_host[b]) ? top5_host[b] + (size_t)first * 5 : nullptr);
+    }
+    if (in.empty()) return;
+    rc[r] = (in.size() == 1) ? qcnn_forward_host(g->ctx[r], in[0], cnt[0], pr[0], t5[0])
+                             : qcnn_forward_host_batches(g->ctx[r], in.data(), cnt.data(), (int)in.size(), pr.data(), t5.data());
   };
   if (G == 1) {
     work(0);
@@ -218,6 +261,11 @@ int qcnn_group_forward_host(QcnnGroup* g, const float* in_nchw_host, int n, floa
   for (int r = 0; r < G; ++r)
     if (rc[r]) return gfail(g, "rank %d (device %d): %s", r, g->devs[r], qcnn_last_error(g->ctx[r]));
   return 0;
+}
+
+int qcnn_group_forward_host(QcnnGroup* g, const float* in_nchw_host, int n, float* prob_host, uint16_t* top5_host) {
+  if (n <= 0) return gfail(g, "batch %d must be positive", n);
+  return qcnn_group_forward_host_batches(g, &in_nchw_host, &n, 1, &prob_host, &top5_host);
 }
 
 int qcnn_group_sync(QcnnGroup* g) {

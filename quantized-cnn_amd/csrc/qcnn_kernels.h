@@ -128,7 +128,22 @@ struct ConvParams {
   int relu;              // fuse max(0, x) into the store
   int panels;
   int lutF16;            // tolerance study (BASELINE configs[4]): table entries rounded to fp16 before they are stored
+  // A launch that does not fill the chip (one GPU's share of a sharded batch): the tiles from rank splitFrom on (the
+  // tail of the heaviest-first order) are cut into splitZ workgroups each, which take consecutive slices of the tile's
+  // stage sequence and leave partial sums in `partial` ([tile - splitFrom][slice][panel][position][Ct][128]); k_conv_sum
+  // adds the slices in order (bias sits in slice 0, ReLU is applied there).  splitZ <= 1: no tile is split.  Chosen by
+  // qk_conv_plan; the summation order of a split tile differs from the reference's, so the exact builder never splits.
+  int splitFrom, splitZ;
+  float* partial;
 };
+struct QkSplitPlan {
+  int splitFrom;         // first split tile rank (= number of tiles: nothing is split)
+  int Z;                 // slices per split tile
+  size_t partialFloats;  // scratch the launch needs
+};
+// decide the split of a conv launch over p.panels panels (p.partial / splitFrom / splitZ are ignored); scratchFloats =
+// what the caller can offer for partial sums
+QkSplitPlan qk_conv_plan(const ConvParams& p, size_t scratchFloats);
 
 struct FcParams {
   float* partial;        // [msplit][panels][Ct][128] scratch for split-M partial sums (msplit > 1)

@@ -29,6 +29,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <functional>
+#include <vector>
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -660,7 +662,7 @@ struct ConvGeom {
 // Workgroups are dispatched in linear order, so the tiles are numbered heaviest first: interior tiles
 // (full receptive field = most stages), then the four edges, then the corners.  With a few workgroups per
 // CU the last dispatch round is then made of the short border tiles (longest-processing-time-first).
-__device__ __forceinline__ void tile_of_rank(int r, int tilesY, int tilesX, int& ty, int& tx) {
+__host__ __device__ __forceinline__ void tile_of_rank(int r, int tilesY, int tilesX, int& ty, int& tx) {
   if (tilesY < 3 || tilesX < 3) { ty = r / tilesX; tx = r % tilesX; return; }
   const int iy = tilesY - 2, ix = tilesX - 2;
   if (r < iy * ix) { ty = 1 + r / ix; tx = 1 + r % ix; return; }
@@ -810,9 +812,26 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
   static_assert(KS != 3 || KT == 8, "the bf16-pair builder exists for K = 128");
   const int lane = threadIdx.x & 63;
   const int wave = uni(threadIdx.x >> 6);
-  int ty, tx;                                       // blockIdx.x = tile rank (heaviest first) * panels + panel
-  tile_of_rank((int)(blockIdx.x / (unsigned)p.panels), tilesY, tilesX, ty, tx);
-  const int panel = (int)(blockIdx.x % (unsigned)p.panels);
+  // blockIdx.x = tile rank (heaviest first) * panels + panel for the tiles a single workgroup runs from end to end; the
+  // ranks from p.splitFrom on (the tail of a launch that does not fill the chip: ConvParams::splitZ) follow, each cut into
+  // splitZ workgroups that take consecutive slices of the tile's stage sequence and write partial sums
+  int ty, tx, panel, slice = 0, slices = 1, tailTile = 0;
+  {
+    const unsigned bx = blockIdx.x, nBody = (unsigned)p.splitFrom * (unsigned)p.panels;
+    int rank;
+    if (bx < nBody) {
+      rank = (int)(bx / (unsigned)p.panels);
+      panel = (int)(bx % (unsigned)p.panels);
+    } else {
+      const unsigned r = bx - nBody;
+      slices = p.splitZ;
+      panel = (int)(r % (unsigned)p.panels);
+      slice = (int)((r / (unsigned)p.panels) % (unsigned)slices);
+      tailTile = (int)(r / (unsigned)(p.panels * slices));
+      rank = p.splitFrom + tailTile;
+    }
+    tile_of_rank(rank, tilesY, tilesX, ty, tx);
+  }
   const int grp = blockIdx.y / chunksPerGrp, chunk = blockIdx.y % chunksPerGrp;
   const int Cg = p.Cin / p.grp, Ctg = p.Ct / p.grp;
   const int M = p.M;
@@ -826,16 +845,19 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
   g.MG = (M + G - 1) / G;                           // stages per source pixel
   g.wiL = max(0, wo0 * p.stride - p.pad);
   g.wiU = min(p.W - 1, woL * p.stride - p.pad + p.knl - 1);
-  const int S = (hiU - hiL + 1) * (g.wiU - g.wiL + 1) * g.MG;
+  const int cols = g.wiU - g.wiL + 1;
+  const int Stot = (hiU - hiL + 1) * cols * g.MG;   // stages of the whole tile; this workgroup runs [sBeg, sBeg + S)
+  const int sBeg = (int)((long long)Stot * slice / slices);
+  const int S = (int)((long long)Stot * (slice + 1) / slices) - sBeg;
   const int Sp = (S + 1) & ~1;                      // every wave runs Sp stage periods (barriers)
-  const StagePos first = {hiL, g.wiL, 0};
+  const StagePos first = {hiL + (sBeg / g.MG) / cols, g.wiL + (sBeg / g.MG) % cols, sBeg % g.MG};
   if ((uint32_t)(uintptr_t)lds != 0u) __builtin_trap();   // the stage addressing assumes the dynamic segment starts at LDS byte 0
 
   const WaveRole role = assign_roles(lds, wave, lane);
   TR_ROLE(role);
   if (role.builder) {
     // ---------------------------------------------------------------- builder wave ----
-    const int bw = role.idx;
+    const int bw = uni(role.idx);                   // kept in an SGPR: it feeds the M0 operand of the add-TID stores
     const int K = p.K, Cs = p.Cs;
     __builtin_amdgcn_s_setprio(QCNN_PRIO_BUILDER);
     // activations: this panel's rows — or, for a first layer reading the NCHW network input in place, the batch itself
@@ -855,13 +877,13 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
       StagePos q1 = next_pos(first, g);
       StagePos q2 = next_pos(q1, g);
       auto dselOf = [&](const StagePos& q) { return min(Cg - q.mg * Cs, Cs); };
-      auto clampPos = [&](const StagePos& q) { return (q.hi > hiU) ? first : q; };
-      bf_load_a(sa, c2, 0, bw, lane);
-      bf_issue_x(raw, xbase, pixel_off(first, g), Cs, 0, bw, lane);
+      auto clampPos = [&](const StagePos& q, int idx) { return (idx < S) ? q : first; };   // stages past the end re-fetch the first
+      bf_load_a(sa, c2, first.mg, bw, lane);
+      bf_issue_x(raw, xbase, pixel_off(first, g), Cs, first.mg, bw, lane);
       bf_convert(sa, raw, dselOf(first), lane);
       bf_store<0>(sa, bw);
       {
-        const StagePos qa = clampPos(q1), qb = clampPos(q2);
+        const StagePos qa = clampPos(q1, 1), qb = clampPos(q2, 2);
         bf_load_a(sa, c2, qa.mg, bw, lane);
         bf_issue_x(raw, xbase, pixel_off(qa, g), Cs, qa.mg, bw, lane);
         bf_convert(sa, raw, dselOf(qa), lane);
@@ -873,7 +895,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
       barrier_after_lds_writes();
       for (int s = 0; s < Sp; s += 2) {
         {                                                // stage s+1 -> buffer 1 from set A; set A then receives stage s+3
-          const StagePos qf = clampPos(q3);
+          const StagePos qf = clampPos(q3, s + 3);
           bf_issue_x(raw, xbase, pixel_off(qf, g), Cs, qf.mg, bw, lane);
           bf_store<1>(sa, bw);
           bf_load_a(sa, c2, qf.mg, bw, lane);
@@ -884,7 +906,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
         TR_LEAVE(s);
         q1 = q2; q2 = q3; q3 = next_pos(q3, g);
         {                                                // stage s+2 -> buffer 0 from set B; set B then receives stage s+4
-          const StagePos qf = clampPos(q3);
+          const StagePos qf = clampPos(q3, s + 4);
           bf_issue_x(raw, xbase, pixel_off(qf, g), Cs, qf.mg, bw, lane);
           bf_store<0>(sb, bw);
           bf_load_a(sb, c2, qf.mg, bw, lane);
@@ -909,10 +931,10 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
     StagePos q2 = next_pos(q1, g);
     StagePos q3 = next_pos(q2, g);
     if (KT > 0) {
-      mfma_load<KTT, KS>(opsA, xbase, pixel_off(first, g), xa, p.ctrd, Cs, 0, bw, lane);
-      mfma_store<KTT, KS, 0>(opsA, Cs, Cg, 0, M, bw, lane, p.lutF16);
+      mfma_load<KTT, KS>(opsA, xbase, pixel_off(first, g), xa, p.ctrd, Cs, first.mg * G, bw, lane);
+      mfma_store<KTT, KS, 0>(opsA, Cs, Cg, first.mg * G, M, bw, lane, p.lutF16);
       {
-        const StagePos qa = (q1.hi > hiU) ? first : q1, qb = (q2.hi > hiU) ? first : q2;
+        const StagePos qa = (1 < S) ? q1 : first, qb = (2 < S) ? q2 : first;   // stages past the end re-fetch the first
         mfma_load<KTT, KS>(opsA, xbase, pixel_off(qa, g), xa, p.ctrd, Cs, qa.mg * G, bw, lane);
         __builtin_amdgcn_sched_barrier(0);             // keep set A's loads older than set B's (vmcnt accounting)
         mfma_load<KTT, KS>(opsB, xbase, pixel_off(qb, g), xa, p.ctrd, Cs, qb.mg * G, bw, lane);
@@ -922,7 +944,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
         }
       }
     } else {
-      build_stage_exact(lds, xbase, pixel_off(first, g), xa, p.ctrd, K, Cs, Cg, G, 0, M, bw, lane);
+      build_stage_exact(lds, xbase, pixel_off(first, g), xa, p.ctrd, K, Cs, Cg, G, first.mg * G, M, bw, lane);
     }
     barrier_after_lds_writes();
     // Straight-line body (no VMEM operation under a condition), so that the compiler's vmcnt waits are
@@ -932,7 +954,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
       if (KT > 0) {                                    // stage s+1 -> buffer 1, from set A
         mfma_store<KTT, KS, 1>(opsA, Cs, Cg, reloadA ? q1.mg * G : 0, M, bw, lane, p.lutF16, reloadA);
         TR_MID(s);
-        const StagePos qf = (q3.hi > hiU) ? first : q3;
+        const StagePos qf = (s + 3 < S) ? q3 : first;
         mfma_load<KTT, KS>(opsA, xbase, pixel_off(qf, g), xa, p.ctrd, Cs, qf.mg * G, bw, lane, reloadA);
       } else if (s + 1 < S) {
         build_stage_exact(lds + STAGE_BYTES, xbase, pixel_off(q1, g), xa, p.ctrd, K, Cs, Cg, G, q1.mg * G, M, bw, lane);
@@ -944,7 +966,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
       if (KT > 0) {                                    // stage s+2 -> buffer 0, from set B
         mfma_store<KTT, KS, 0>(opsB, Cs, Cg, reloadA ? q1.mg * G : 0, M, bw, lane, p.lutF16, reloadA);
         TR_MID(s + 1);
-        const StagePos qf = (q3.hi > hiU) ? first : q3;
+        const StagePos qf = (s + 4 < S) ? q3 : first;
         mfma_load<KTT, KS>(opsB, xbase, pixel_off(qf, g), xa, p.ctrd, Cs, qf.mg * G, bw, lane, reloadA);
       } else if (s + 2 < S) {
         build_stage_exact(lds, xbase, pixel_off(q1, g), xa, p.ctrd, K, Cs, Cg, G, q1.mg * G, M, bw, lane);
@@ -975,7 +997,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
     const float* __restrict__ bp = p.bias + grp * Ctg + (active ? cl0 : 0);   // reads past the last channel stay inside the arena
 #pragma unroll
     for (int j = 0; j < HC; ++j) {
-      const float b = bp[j];
+      const float b = (slice == 0) ? bp[j] : 0.0f;       // the bias enters the first slice's partial sum only
 #pragma unroll
       for (int q = 0; q < NP; ++q) { acc[q][2 * j] = f32x2{b, b}; acc[q][2 * j + 1] = f32x2{b, b}; }
     }
@@ -997,8 +1019,8 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
     const int ry0 = ho0 * p.stride - p.pad, rx0 = wo0 * p.stride - p.pad;   // origin of the unclipped receptive field
     const uint32_t entryB = (uint32_t)(p.grp * chunksPerGrp) * WGROW;
     const char* __restrict__ progWg = reinterpret_cast<const char*>(p.prog) + (size_t)(grp * chunksPerGrp + chunk) * WGROW;
-    auto rowOf = [&](const StagePos& q) {              // stages past the end: any existing row
-      const StagePos c = (q.hi > hiU) ? first : q;
+    auto rowOf = [&](const StagePos& q, int idx) {     // stages past the end: any existing row
+      const StagePos c = (idx < S) ? q : first;
       return progWg + (size_t)(uint32_t)(((c.hi - ry0) * rfW + (c.wi - rx0)) * M + c.mg) * entryB;
     };
     const uint32_t myBlk = (uint32_t)(gw * 2 + half) * NB * 4;
@@ -1008,20 +1030,20 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
     StagePos c0p = first;
     StagePos c1p = next_pos(c0p, g);
     StagePos c2p = next_pos(c1p, g);
-    blk_load(ba, rowOf(c0p) + myBlk);
-    if (loader) idx_row_to_lds<WGROW>(rowOf(c1p), IDX_LDS + IDX_BUF, lane);
+    blk_load(ba, rowOf(c0p, 0) + myBlk);
+    if (loader) idx_row_to_lds<WGROW>(rowOf(c1p, 1), IDX_LDS + IDX_BUF, lane);
     barrier_after_lds_dma();
     for (int s = 0; s < Sp; s += 2) {
       blk_load(bb, lds + IDX_LDS + IDX_BUF + myBlk);                      // stage s+1
-      if (loader) idx_row_to_lds<WGROW>(rowOf(c2p), IDX_LDS, lane);       // stage s+2
+      if (loader) idx_row_to_lds<WGROW>(rowOf(c2p, s + 2), IDX_LDS, lane);       // stage s+2
       TR_MID(s);
-      conv_gather_prog<TH, TW, CPW, NB>(acc, ba, c0p, g, rowStart, colStart, laneLds, activeI);
+      conv_gather_prog<TH, TW, CPW, NB>(acc, ba, c0p, g, rowStart, colStart, laneLds, activeI);   // S >= 1: stage s exists
       c0p = c1p; c1p = c2p; c2p = next_pos(c2p, g);
       TR_ARRIVE(s);
       barrier_after_lds_dma();
       TR_LEAVE(s);
       blk_load(ba, lds + IDX_LDS + myBlk);                                // stage s+2
-      if (loader) idx_row_to_lds<WGROW>(rowOf(c2p), IDX_LDS + IDX_BUF, lane);   // stage s+3
+      if (loader) idx_row_to_lds<WGROW>(rowOf(c2p, s + 3), IDX_LDS + IDX_BUF, lane);   // stage s+3
       TR_MID(s + 1);
       conv_gather_prog<TH, TW, CPW, NB>(acc, bb, c0p, g, rowStart, colStart, laneLds | STAGE_BYTES,
                                         activeI & in_range(s + 1, S));
@@ -1058,17 +1080,21 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
   }
 
   if (active) {
-    float* __restrict__ dst = p.dst + (size_t)panel * p.Ho * p.Wo * p.Ct * PANEL;
+    // final map, or — a slice of a split tile — this slice's slab of partial sums [tail tile][slice][panel][position]
+    // [Ct][128], which k_conv_sum adds up in slice order (ReLU there)
+    const bool part = slices > 1;
+    float* __restrict__ dst = part ? p.partial + ((size_t)(tailTile * slices + slice) * p.panels + panel) * NP * p.Ct * PANEL
+                                   : p.dst + (size_t)panel * p.Ho * p.Wo * p.Ct * PANEL;
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
       const int ho = ho0 + q / TW, wo = wo0 + q % TW;
       if (ho < p.Ho && wo < p.Wo) {
-        float* o = dst + ((size_t)(ho * p.Wo + wo) * p.Ct + grp * Ctg + cl0) * PANEL + 4 * quad;
+        float* o = dst + ((size_t)(part ? q : ho * p.Wo + wo) * p.Ct + grp * Ctg + cl0) * PANEL + 4 * quad;
 #pragma unroll
         for (int j = 0; j < HC; ++j) {
           if (cl0 + j < Ctg) {
             f32x4 v = {acc[q][2 * j].x, acc[q][2 * j].y, acc[q][2 * j + 1].x, acc[q][2 * j + 1].y};
-            if (p.relu) {
+            if (p.relu && !part) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[e] = (0.0f < v[e]) ? v[e] : 0.0f;
             }
@@ -1105,7 +1131,7 @@ __global__ __launch_bounds__(NW * 64) void k_fc_aprx(FcParams p, int G, int stag
 
   const WaveRole role = assign_roles(lds, wave, lane);
   if (role.builder) {
-    const int bw = role.idx;
+    const int bw = uni(role.idx);                   // kept in an SGPR: it feeds the M0 operand of the add-TID stores
     const int K = p.K, Cs = p.Cs;
     __builtin_amdgcn_s_setprio(QCNN_PRIO_BUILDER);
     const char* __restrict__ xbase = reinterpret_cast<const char*>(p.src + (size_t)panel * p.D * PANEL);
@@ -1284,12 +1310,51 @@ __global__ __launch_bounds__(256) void k_build_program(const uint16_t* __restric
   }
 }
 
+// Split tiles (ConvParams::splitZ): dst = sum over the slices, in slice order, of the partial sums; optional ReLU.
+// grid (tail tiles * positions per tile, panels, chunks of 1024 float4), 256 threads x 4 float4.
+__global__ __launch_bounds__(256) void k_conv_sum(const f32x4* __restrict__ partial, f32x4* __restrict__ dst, int splitFrom,
+                                                  int Z, int panels, int tilesX, int tilesY, int TH, int TW, int Ho, int Wo,
+                                                  int Ct, int relu) {
+  const int NP = TH * TW;
+  const int tailTile = blockIdx.x / NP, q = blockIdx.x % NP, panel = blockIdx.y;
+  int ty, tx;
+  tile_of_rank(splitFrom + tailTile, tilesY, tilesX, ty, tx);
+  const int ho = ty * TH + q / TW, wo = tx * TW + q % TW;
+  if (ho >= Ho || wo >= Wo) return;
+  const size_t rowQuads = (size_t)Ct * (PANEL / 4);                       // float4 of one position
+  const f32x4* __restrict__ src = partial + (((size_t)tailTile * Z * panels + panel) * NP + q) * rowQuads;
+  const size_t sliceStride = (size_t)panels * NP * rowQuads;
+  f32x4* __restrict__ out = dst + ((size_t)panel * Ho * Wo + (size_t)ho * Wo + wo) * rowQuads;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const size_t e = ((size_t)blockIdx.z * 4 + k) * 256 + threadIdx.x;
+    if (e < rowQuads) {
+      f32x4 v = src[e];
+      for (int z = 1; z < Z; ++z) {
+        const f32x4 w = src[z * sliceStride + e];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = __fadd_rn(v[c], w[c]);
+      }
+      if (relu) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = (0.0f < v[c]) ? v[c] : 0.0f;
+      }
+      out[e] = v;
+    }
+  }
+}
+
 template <int TH, int TW, int CPW>
 hipError_t launch_conv(const ConvParams& p, const QkSlots& sl, int lutMode, hipStream_t st) {
   const bool bf16Pairs = lutMode == 3;
   if (lutMode == 3) lutMode = 1;
   const int tilesX = (p.Wo + TW - 1) / TW, tilesY = (p.Ho + TH - 1) / TH;
-  const dim3 grid(tilesX * tilesY * p.panels, sl.chunks * p.grp, 1);
+  const int tiles = tilesX * tilesY;
+  const bool split = p.splitZ > 1 && p.splitFrom >= 0 && p.splitFrom < tiles && p.partial != nullptr;
+  ConvParams q = p;
+  if (!split) { q.splitFrom = tiles; q.splitZ = 1; q.partial = nullptr; }
+  const int tailTiles = tiles - q.splitFrom;
+  const dim3 grid((q.splitFrom + tailTiles * q.splitZ) * p.panels, sl.chunks * p.grp, 1);
   const size_t shm = (size_t)2 * STAGE_BYTES + 2 * IDX_BUF;
   const int G = qcnn_stage_group(p.K);
   const bool two = min(p.Cin / p.grp, p.Cs) > 4;      // MFMA k-steps (4 dims each) that carry data
@@ -1301,7 +1366,13 @@ hipError_t launch_conv(const ConvParams& p, const QkSlots& sl, int lutMode, hipS
   if (bf16Pairs && p.K == 128 && two && p.ctrd2 != nullptr) kern = k_conv_aprx<TH, TW, CPW, 8, 3>;
   hipError_t e = allow_big_lds(reinterpret_cast<const void*>(kern), (int)shm);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, grid, dim3(NW * 64), shm, st, p, tilesX, tilesY, sl.chunks, G, sl.rowStride);
+  hipLaunchKernelGGL(kern, grid, dim3(NW * 64), shm, st, q, tilesX, tilesY, sl.chunks, G, sl.rowStride);
+  e = hipGetLastError();
+  if (e != hipSuccess || !split) return e;
+  const int rowQuads = p.Ct * (PANEL / 4);
+  hipLaunchKernelGGL(k_conv_sum, dim3(tailTiles * TH * TW, p.panels, (rowQuads + 1023) / 1024), dim3(256), 0, st,
+                     reinterpret_cast<const f32x4*>(q.partial), reinterpret_cast<f32x4*>(p.dst), q.splitFrom, q.splitZ,
+                     p.panels, tilesX, tilesY, TH, TW, p.Ho, p.Wo, p.Ct, p.relu);
   return hipGetLastError();
 }
 
@@ -1347,6 +1418,80 @@ hipError_t qk_conv_aprx(const ConvParams& pIn, int lutMode, hipStream_t st) {
     case 6: return launch_conv<2, 3, 6>(p, sl, lutMode, st);     // 6 positions x 12 x 6
     default: return launch_conv<2, 4, 4>(p, sl, lutMode, st);    // 8 positions x 12 x 4
   }
+}
+
+// Split plan of a conv launch (ConvParams::splitZ).  A workgroup occupies a CU for its tile's whole stage sequence
+// (0.1 - 0.4 ms), so a launch of a few hundred workgroups — one GPU's share of a batch sharded over 4 - 8 GPUs — leaves
+// CUs idle for whole tile durations.  List-schedule the launch (dispatch order, 256 CUs, cost = stages + a fixed part)
+// for a few candidate splits — none; the last `r` tiles, r = what exceeds whole rounds of 256 workgroups; all tiles —
+// and slice counts, add the cost of writing and re-reading the partial sums, keep the cheapest.
+QkSplitPlan qk_conv_plan(const ConvParams& p, size_t scratchFloats) {
+  const int Ctg = p.Ct / p.grp;
+  const QkSlots sl = qk_conv_slots(Ctg, p.grp);
+  int TH, TW;
+  qk_conv_tile(sl.cpw, &TH, &TW);
+  const int tilesX = (p.Wo + TW - 1) / TW, tilesY = (p.Ho + TH - 1) / TH, tiles = tilesX * tilesY;
+  const int ny = sl.chunks * p.grp;
+  const int G = qcnn_stage_group(p.K), MG = (p.M + G - 1) / G;
+  QkSplitPlan none = {tiles, 1, 0};
+  if ((long long)tiles * p.panels * ny >= 8 * 256) return none;          // enough workgroups for the tail not to matter
+  std::vector<int> S(tiles);
+  for (int r = 0; r < tiles; ++r) {
+    int ty, tx;
+    tile_of_rank(r, tilesY, tilesX, ty, tx);
+    const int ho0 = ty * TH, wo0 = tx * TW;
+    const int hoL = std::min(ho0 + TH, p.Ho) - 1, woL = std::min(wo0 + TW, p.Wo) - 1;
+    const int rows = std::min(p.H - 1, hoL * p.stride - p.pad + p.knl - 1) - std::max(0, ho0 * p.stride - p.pad) + 1;
+    const int cols = std::min(p.W - 1, woL * p.stride - p.pad + p.knl - 1) - std::max(0, wo0 * p.stride - p.pad) + 1;
+    S[r] = std::max(rows, 0) * std::max(cols, 0) * MG;
+  }
+  const double kFixed = 10.0;          // stage-times a workgroup spends outside its stage loop (roles, first stage, stores)
+  const double kStageUs = 1.1;         // ~2700 cycles
+  std::vector<double> cu(256);
+  auto makespan = [&](int splitFrom, int Z) {
+    std::fill(cu.begin(), cu.end(), 0.0);
+    std::make_heap(cu.begin(), cu.end(), std::greater<double>());
+    auto run = [&](double cost) {
+      std::pop_heap(cu.begin(), cu.end(), std::greater<double>());
+      cu.back() += cost;
+      std::push_heap(cu.begin(), cu.end(), std::greater<double>());
+    };
+    for (int y = 0; y < ny; ++y) {               // dispatch order: x fastest
+      for (int r = 0; r < splitFrom; ++r)
+        for (int pn = 0; pn < p.panels; ++pn) run(S[r] + kFixed);
+      for (int r = splitFrom; r < tiles; ++r)
+        for (int z = 0; z < Z; ++z)
+          for (int pn = 0; pn < p.panels; ++pn) run((double)S[r] / Z + kFixed);
+    }
+    return *std::max_element(cu.begin(), cu.end());
+  };
+  // stage-times of the reduction: k_conv_sum reads Z slabs and writes one at ~4 TB/s behind a launch; the Z slab stores of
+  // the conv kernel itself mostly hide under other workgroups' stages (calibrated on conv3 / conv5 of AlexNet, one panel:
+  // predicted 36 / 24 stage-times, measured 35 / 27)
+  auto reduceCost = [&](int splitFrom, int Z) {
+    const double slab = (double)(tiles - splitFrom) * p.panels * TH * TW * p.Ct * PANEL * 4.0;
+    return (slab * (Z + 1.0) / 4.0e6 + slab * Z / 10.0e6 + 5.0) / kStageUs;
+  };
+  QkSplitPlan best = none;
+  double bestCost = makespan(tiles, 1);
+  const long long wgs = (long long)tiles * p.panels * ny;
+  const int rem = (int)(wgs % 256);                 // workgroups beyond whole rounds
+  int cand[2] = {0, tiles};
+  if (rem > 0 && wgs > 256) cand[1] = std::max(0, tiles - (rem + p.panels * ny - 1) / (p.panels * ny));
+  for (int ci = 0; ci < 2; ++ci) {
+    const int from = cand[ci];
+    if (from >= tiles) continue;
+    int minS = S[from];
+    for (int r = from; r < tiles; ++r) minS = std::min(minS, S[r]);
+    for (int Z = 2; Z <= 8; ++Z) {
+      if (minS < 6 * Z) break;                      // a slice keeps at least six stages
+      const size_t need = (size_t)(tiles - from) * Z * p.panels * TH * TW * p.Ct * PANEL;
+      if (need > scratchFloats) break;
+      const double c = makespan(from, Z) + reduceCost(from, Z);
+      if (c < bestCost * 0.97) { bestCost = c; best.splitFrom = from; best.Z = Z; best.partialFloats = need; }
+    }
+  }
+  return best;
 }
 
 int qk_fc_channels_per_block(int Ct) { return NGW * qk_fc_slots(Ct).cpw; }

@@ -134,6 +134,11 @@ class QcnnEngine:
                                              top5.ctypes.data if want_top5 else None))
         return prob, top5
 
+    def forward_host_batches(self, batches, want_prob=True, want_top5=True):
+        """Blocking: a list of [n_b, C, H, W] float32 arrays, one batch after the other with the upload of batch b + 1
+        overlapped with the layers of batch b (qcnn_forward_host_batches).  Returns ([prob_b], [top5_b])."""
+        return _host_batches(self.lib.qcnn_forward_host_batches, self, batches, self.fm_dims(self.L), want_prob, want_top5)
+
     def layer_output(self, l: int, n: int):
         h, w, c = self.fm_dims(l)
         out = np.empty((n, h, w, c), np.float32)
@@ -153,6 +158,12 @@ class QcnnEngine:
         self._chk(self.lib.qcnn_run_layer(self.h, l, x.ctypes.data, n, out.ctypes.data))
         return out
 
+    def layer_split(self, l: int):
+        """(tiles run whole, slices per split tile) of the last launch of conv layer l (QCNN_OPT_SPLIT); slices = 1: no split."""
+        a, b = C.c_int(0), C.c_int(0)
+        self._chk(self.lib.qcnn_get_layer_split(self.h, l, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     # -- timing ---------------------------------------------------------------------------------
     def layer_ms(self):
         ms = (C.c_float * self.L)()
@@ -170,6 +181,34 @@ class QcnnEngine:
 
     def reset_layer_ms(self):
         self._chk(self.lib.qcnn_reset_layer_ms(self.h))
+
+
+def _host_batches(fn, obj, batches, out_hwc, want_prob, want_top5):
+    imgs = [np.ascontiguousarray(b, np.float32) for b in batches]
+    nb = len(imgs)
+    classes = out_hwc[0] * out_hwc[1] * out_hwc[2]
+    prob = [np.empty((b.shape[0], classes), np.float32) for b in imgs] if want_prob else None
+    top5 = [np.empty((b.shape[0], 5), np.uint16) for b in imgs] if want_top5 else None
+    vp = C.c_void_p
+    a_in = (vp * nb)(*[b.ctypes.data for b in imgs])
+    a_n = (C.c_int * nb)(*[b.shape[0] for b in imgs])
+    a_p = (vp * nb)(*[p.ctypes.data for p in prob]) if want_prob else None
+    a_t = (vp * nb)(*[t.ctypes.data for t in top5]) if want_top5 else None
+    obj._chk(fn(obj.h, a_in, a_n, nb, a_p, a_t))
+    return prob, top5
+
+
+def host_register(arr) -> None:
+    """Pin a numpy array's storage (hipHostRegister): uploads from it become asynchronous DMA transfers."""
+    lib = capi.load()
+    if lib.qcnn_host_register(C.c_void_p(arr.ctypes.data), arr.nbytes):
+        raise QcnnError(lib.qcnn_last_error(None).decode())
+
+
+def host_unregister(arr) -> None:
+    lib = capi.load()
+    if lib.qcnn_host_unregister(C.c_void_p(arr.ctypes.data)):
+        raise QcnnError(lib.qcnn_last_error(None).decode())
 
 
 class QcnnDeviceGroup:
@@ -243,3 +282,9 @@ class QcnnDeviceGroup:
         top5 = np.empty((n, 5), np.uint16)
         self._chk(self.lib.qcnn_group_forward_host(self.h, imgs.ctypes.data, n, prob.ctypes.data, top5.ctypes.data))
         return prob, top5
+
+    def forward_host_batches(self, batches, want_prob=True, want_top5=True):
+        d = (C.c_int * 3)()
+        self.lib.qcnn_fm_dims(self.lib.qcnn_group_ctx(self.h, 0), self.L, d)
+        return _host_batches(self.lib.qcnn_group_forward_host_batches, self, batches, (int(d[0]), int(d[1]), int(d[2])),
+                             want_prob, want_top5)

@@ -31,10 +31,43 @@ QcnnLayerDesc toDesc(const LayerInfo& li) {
 
 CaffeEva::CaffeEva(void)
     : enblAprx(true), grp_(nullptr), ctx_(nullptr), modelReady_(false), batchSize_(1), batchCnt_(100),
-      inflight_(1), imagesDone_(0) {}
+      inflight_(1), imagesDone_(0), keepAll_(false), pinned_(nullptr), pinnedCopy_(nullptr) {}
 
 CaffeEva::~CaffeEva(void) {
   if (grp_ != nullptr) qcnn_group_destroy(grp_);   // owns the per-device contexts
+  unpinDataset();
+}
+
+// Where the image block lives while it is classified.  QCNN_PIN_DATASET = "copy" (default): a pinned buffer from the HIP
+// runtime (qcnn_host_alloc) that takes over the images from dataLst — uploads from it are DMA transfers at the full
+// PCIe rate which run under the previous batch's kernels; "register": dataLst's own storage registered with the runtime
+// (no second copy, about half the transfer rate); "0": plain pageable memory (uploads are staged copies).
+void CaffeEva::pinDataset(void) {
+  unpinDataset();
+  if (dataLst.GetEleCnt() <= 0) return;
+  const char* env = getenv("QCNN_PIN_DATASET");
+  const std::string mode = (env != nullptr && *env != '\0') ? env : "copy";
+  const size_t bytes = sizeof(float) * static_cast<size_t>(dataLst.GetEleCnt());
+  if (mode == "0" || mode == "off") return;
+  if (mode == "register") {
+    if (qcnn_host_register(dataLst.GetDataPtr(), bytes) == 0) pinned_ = dataLst.GetDataPtr();
+    else printf("[INFO] dataset not pinned (%s): uploads are staged copies\n", qcnn_last_error(nullptr));
+    return;
+  }
+  void* buf = nullptr;
+  if (qcnn_host_alloc(bytes, &buf) != 0) {
+    printf("[INFO] no pinned buffer for the dataset (%s): uploads are staged copies\n", qcnn_last_error(nullptr));
+    return;
+  }
+  memcpy(buf, dataLst.GetDataPtr(), bytes);
+  pinnedCopy_ = static_cast<float*>(buf);
+}
+
+void CaffeEva::unpinDataset(void) {
+  if (pinned_ != nullptr) qcnn_host_unregister(pinned_);
+  if (pinnedCopy_ != nullptr) qcnn_host_free(pinnedCopy_);
+  pinned_ = nullptr;
+  pinnedCopy_ = nullptr;
 }
 
 bool CaffeEva::fail(const std::string& what) {
@@ -64,8 +97,10 @@ void CaffeEva::SetModelPath(const std::string& dirPathMainSrc, const std::string
 
 bool CaffeEva::LoadDataset(const std::string& dirPathData) {
   printf("[CHECK-POINT] entering CaffeEva::LoadDataset()\n");
+  unpinDataset();
   if (!FileIO::ReadBinFile(dirPathData + "/dataMatTst.single.bin", &dataLst)) return false;
   if (!FileIO::ReadBinFile(dirPathData + "/lablVecTst.uint16.bin", &lablVecGrth)) return false;
+  if (grp_ != nullptr) pinDataset();     // else: once the device group exists (LoadCaffePara)
   return true;
 }
 
@@ -125,8 +160,13 @@ bool CaffeEva::buildDeviceModel(void) {
   }
   const char* lut = getenv("QCNN_LUT");
   qcnn_group_set_option(grp_, QCNN_OPT_LUT_MODE, (lut && std::string(lut) == "exact") ? 0 : 1);
-  qcnn_group_set_option(grp_, QCNN_OPT_KEEP_ALL, 1);
+  // fast path by default (ReLU fused into the producing layer, first layer reads the batch in place, LRN + pool fused);
+  // QCNN_KEEP_ALL=1 makes every layer write its own map, which is what GetFeatMap() needs for the fused ones
+  const char* keep = getenv("QCNN_KEEP_ALL");
+  keepAll_ = keep != nullptr && atoi(keep) != 0;
+  qcnn_group_set_option(grp_, QCNN_OPT_KEEP_ALL, keepAll_ ? 1 : 0);
   qcnn_group_set_option(grp_, QCNN_OPT_PROFILE, 1);
+  if (pinned_ == nullptr && pinnedCopy_ == nullptr) pinDataset();
 
   const int L = caffeParaObj.layerCnt;
   std::vector<QcnnLayerDesc> descs(L);
@@ -169,6 +209,21 @@ bool CaffeEva::buildDeviceModel(void) {
     printf("layer #%2d: %4d x %4d x %4d x %4d (%6.2f MB)\n", l, batchSize_, hwc[0], hwc[1], hwc[2],
            batchSize_ * hwc[0] * hwc[1] * hwc[2] * 4 / 1024.0 / 1024.0);
   }
+  // Warm-up (QCNN_WARMUP=0 skips it): two one-panel batches of zeros through the pipelined path, so that code objects,
+  // staging buffers, streams and events exist before the first timed forward pass; the timers start from zero after it.
+  const char* warm = getenv("QCNN_WARMUP");
+  if (warm == nullptr || atoi(warm) != 0) {
+    const int wn = inflight_ < 128 ? inflight_ : 128;
+    const size_t perImg = static_cast<size_t>(caffeParaObj.imgChnIn) * caffeParaObj.imgHeiIn * caffeParaObj.imgWidIn;
+    std::vector<float> zeros(perImg * wn, 0.0f);
+    std::vector<uint16_t> t5(static_cast<size_t>(wn) * kLablCntPerData);
+    const float* in[2] = {zeros.data(), zeros.data()};
+    const int cnt[2] = {wn, wn};
+    uint16_t* out[2] = {t5.data(), t5.data()};
+    qcnn_group_set_option(grp_, QCNN_OPT_SMALL_BATCH, 0);
+    if (qcnn_group_forward_host_batches(grp_, in, cnt, 2, nullptr, out)) return fail("warm-up forward pass");
+    for (int r = 0; r < qcnn_group_size(grp_); ++r) qcnn_reset_layer_ms(qcnn_group_ctx(grp_, r));
+  }
   modelReady_ = true;
   return true;
 }
@@ -184,6 +239,7 @@ void CaffeEva::ExecForwardPass(void) {
   if (dataLst.GetDimCnt() != 4) { fail("ExecForwardPass() before a successful LoadDataset()"); return; }
   const int dataCnt = dataLst.GetDimLen(0);
   const size_t perImg = static_cast<size_t>(dataLst.GetDimStp(0));
+  const float* images = pinnedCopy_ != nullptr ? pinnedCopy_ : dataLst.GetDataPtr();   // same values, pinned storage
   if (dataCnt < batchSize_) { fail("dataset smaller than one batch"); return; }
   lablVecPred.Create(dataCnt, kLablCntPerData, 1, 1);
   memset(lablVecPred.GetDataPtr(), 0, sizeof(uint16_t) * lablVecPred.GetEleCnt());
@@ -196,34 +252,43 @@ void CaffeEva::ExecForwardPass(void) {
     if (first < 0 || first + batchSize_ > dataCnt) first = dataCnt - batchSize_;
     firstOf[b] = first;
   }
+  // Device batches: chunks of up to `inflight_` images = whole logical batches.  All of them are handed over in ONE call,
+  // so that the upload of a chunk runs under the layers of the one before it (qcnn_group_forward_host_batches).
   const int perChunk = inflight_ / batchSize_ > 0 ? inflight_ / batchSize_ : 1;      // logical batches per device batch
-  std::vector<float> staging;
-  std::vector<uint16_t> top5(static_cast<size_t>(perChunk) * batchSize_ * kLablCntPerData);
-  swWall_.Resume();
-  for (int b0 = 0; b0 < batchCnt_; b0 += perChunk) {
+  const int chunks = (batchCnt_ + perChunk - 1) / perChunk;
+  std::vector<const float*> in(chunks);
+  std::vector<int> cnt(chunks);
+  std::vector<uint16_t*> t5(chunks);
+  std::vector<std::vector<float> > staging(chunks);
+  std::vector<uint16_t> top5(static_cast<size_t>(batchCnt_) * batchSize_ * kLablCntPerData);
+  for (int k = 0; k < chunks; ++k) {
+    const int b0 = k * perChunk;
     const int nb = (b0 + perChunk <= batchCnt_) ? perChunk : batchCnt_ - b0;
     bool contiguous = true;
     for (int b = 1; b < nb; ++b) contiguous = contiguous && firstOf[b0 + b] == firstOf[b0 + b - 1] + batchSize_;
-    const float* src = dataLst.GetDataPtr() + static_cast<size_t>(firstOf[b0]) * perImg;
+    in[k] = images + static_cast<size_t>(firstOf[b0]) * perImg;
     if (!contiguous) {                                   // right-aligned last window: gather the chunk
-      staging.resize(static_cast<size_t>(nb) * batchSize_ * perImg);
+      staging[k].resize(static_cast<size_t>(nb) * batchSize_ * perImg);
       for (int b = 0; b < nb; ++b)
-        memcpy(staging.data() + static_cast<size_t>(b) * batchSize_ * perImg,
-               dataLst.GetDataPtr() + static_cast<size_t>(firstOf[b0 + b]) * perImg, sizeof(float) * batchSize_ * perImg);
-      src = staging.data();
+        memcpy(staging[k].data() + static_cast<size_t>(b) * batchSize_ * perImg,
+               images + static_cast<size_t>(firstOf[b0 + b]) * perImg, sizeof(float) * batchSize_ * perImg);
+      in[k] = staging[k].data();
     }
-    for (int b = 0; b < nb; ++b) printf("processing the %d-th batch\n", b0 + b + 1);
-    if (qcnn_group_forward_host(grp_, src, nb * batchSize_, nullptr, top5.data()) != 0) {
-      fail("qcnn_group_forward_host");
-      break;
-    }
-    for (int b = 0; b < nb; ++b)
-      for (int i = 0; i < batchSize_; ++i)
-        for (int r = 0; r < kLablCntPerData; ++r)
-          lablVecPred.SetEleAt(top5[(static_cast<size_t>(b) * batchSize_ + i) * kLablCntPerData + r], firstOf[b0 + b] + i, r, 0, 0);
-    imagesDone_ += nb * batchSize_;
+    cnt[k] = nb * batchSize_;
+    t5[k] = top5.data() + static_cast<size_t>(b0) * batchSize_ * kLablCntPerData;
   }
+  for (int b = 0; b < batchCnt_; ++b) printf("processing the %d-th batch\n", b + 1);
+  // every image through the panel kernels, whatever the chunking: coalesced and batch-by-batch runs give the same bits
+  qcnn_group_set_option(grp_, QCNN_OPT_SMALL_BATCH, 0);
+  swWall_.Resume();
+  const bool ok = qcnn_group_forward_host_batches(grp_, in.data(), cnt.data(), chunks, nullptr, t5.data()) == 0;
   swWall_.Pause();
+  if (!ok) { fail("qcnn_group_forward_host_batches"); return; }
+  for (int b = 0; b < batchCnt_; ++b)
+    for (int i = 0; i < batchSize_; ++i)
+      for (int r = 0; r < kLablCntPerData; ++r)
+        lablVecPred.SetEleAt(top5[(static_cast<size_t>(b) * batchSize_ + i) * kLablCntPerData + r], firstOf[b] + i, r, 0, 0);
+  imagesDone_ = batchCnt_ * batchSize_;
 }
 
 void CaffeEva::ExecForwardPass(const Matrix<float>& imgDataIn, Matrix<float>* pProbVecOut) {
@@ -234,6 +299,7 @@ void CaffeEva::ExecForwardPass(const Matrix<float>& imgDataIn, Matrix<float>* pP
   pProbVecOut->Resize(hwc[0] * hwc[1] * hwc[2]);
   memset(pProbVecOut->GetDataPtr(), 0, sizeof(float) * pProbVecOut->GetEleCnt());   // never hand back uninitialised memory
   lastError_.clear();
+  qcnn_group_set_option(grp_, QCNN_OPT_SMALL_BATCH, 1);     // latency mode: the few-image kernels
   swWall_.Resume();
   if (qcnn_forward_host(ctx_, imgDataIn.GetDataPtr(), 1, pProbVecOut->GetDataPtr(), nullptr) != 0)
     fail("qcnn_forward_host");                                                      // GetErrorMsg() is non-empty: callers check it
@@ -245,7 +311,8 @@ bool CaffeEva::GetFeatMap(const int layerInd, const int dataCnt, Matrix<float>* 
   int hwc[3];
   if (qcnn_fm_dims(ctx_, layerInd, hwc)) return fail("qcnn_fm_dims");
   pFeatMap->Create(dataCnt, hwc[0], hwc[1], hwc[2]);
-  if (qcnn_get_layer_output(ctx_, layerInd, dataCnt, pFeatMap->GetDataPtr())) return fail("qcnn_get_layer_output");
+  if (qcnn_get_layer_output(ctx_, layerInd, dataCnt, pFeatMap->GetDataPtr()))
+    return fail(keepAll_ ? "qcnn_get_layer_output" : "qcnn_get_layer_output (maps the fast path fuses away need QCNN_KEEP_ALL=1)");
   return true;
 }
 

@@ -3,6 +3,7 @@
 usage: layer_times.py [batch=128] [steps=20] [streams=1]"""
 import importlib, os, sys
 import numpy as np
+import torch   # before libqcnn_hip.so: both must bind to the HIP runtime torch ships
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 pkg = lambda n: importlib.import_module("quantized-cnn_amd." + n)
@@ -18,6 +19,8 @@ def main():
     eng = pkg("engine").QcnnEngine(0)
     eng.set_option(capi.OPT_KEEP_ALL, 0)
     eng.set_option(capi.OPT_STREAMS, streams)
+    split = int(os.environ.get("QCNN_SPLIT", "1"))
+    eng.set_option(capi.OPT_SPLIT, split)
     eng.load_model(in_chw, layers, params, batch)
     imgs = synth.make_images(batch, in_chw, seed=2)
     import time
@@ -31,7 +34,20 @@ def main():
     tot, _, fw = eng.layer_total_ms()
     ms = tot / max(fw, 1)
     names = [topo.TYPE_NAMES[l["type"]] for l in layers]
-    print("batch %d streams %d: %.3f ms per forward_host (incl. H2D/D2H), layers sum %.3f ms" % (batch, streams, wall, ms.sum()))
+    x = torch.from_numpy(imgs).cuda()
+    top5 = torch.empty((batch, 5), dtype=torch.int16, device="cuda")
+    eng.set_option(capi.OPT_PROFILE, 0)
+    for _ in range(3):
+        eng.forward_dev(x.data_ptr(), batch, None, top5.data_ptr())
+    eng.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.forward_dev(x.data_ptr(), batch, None, top5.data_ptr())
+    eng.sync()
+    dev = (time.perf_counter() - t0) / steps * 1e3
+    cuts = " ".join("%d:%dx%d" % ((l,) + eng.layer_split(l)) for l in (0, 4, 8, 10, 12))
+    print("batch %d streams %d split %d: resident %.3f ms (%.0f img/s), forward_host %.3f ms, layers sum %.3f ms, cuts %s"
+          % (batch, streams, split, dev, batch / dev * 1e3, wall, ms.sum(), cuts))
     print("  " + "  ".join("%02d_%s %.3f" % (i, names[i], ms[i]) for i in range(len(layers)) if ms[i] > 0.0005))
 
 

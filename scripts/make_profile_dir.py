@@ -36,7 +36,9 @@ def main():
     dom = max((r for r in table if r["kernel"].startswith("k_conv_aprx") or r["kernel"].startswith("k_fc_aprx")),
               key=lambda r: float(r["SQ_WAVE_CYCLES"] or 0))
     fetch_kib, write_kib = float(dom["FETCH_SIZE"]), float(dom["WRITE_SIZE"])
-    h = hashlib.sha256(open(os.path.join(ROOT, "quantized-cnn_amd", "csrc", "qcnn_kernels.hip"), "rb").read()).hexdigest()[:16]
+    sys.path.insert(0, ROOT)
+    import bench as bench_mod
+    h = bench_mod.kernel_hash()          # every device source under quantized-cnn_amd/csrc
     json.dump({"kernel": dom["kernel"], "layer": dom_layer, "launches_per_forward": 1,
                "bytes": int((2.0 * fetch_kib + write_kib) * 1024),
                "fetch_size_kib_raw": fetch_kib, "write_size_kib_raw": write_kib, "kernel_hash": h,

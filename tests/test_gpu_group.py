@@ -18,7 +18,8 @@ engine = pkg("engine")
 def _single(in_chw, layers, params, imgs):
     eng = engine.QcnnEngine(0)
     eng.set_option(capi.OPT_KEEP_ALL, 0)
-    eng.set_option(capi.OPT_SMALL_BATCH, 0)      # bit-for-bit comparisons across block sizes: panel kernels everywhere
+    eng.set_option(capi.OPT_SMALL_BATCH, 0)      # bit-for-bit comparisons across block sizes: panel kernels everywhere,
+    eng.set_option(capi.OPT_SPLIT, 0)            # one workgroup per tile
     eng.load_model(in_chw, layers, params, imgs.shape[0])
     out = eng.forward_host(imgs)
     eng.close()
@@ -35,6 +36,7 @@ def test_group_over_all_visible_devices_equals_single_context():
     assert grp.size == torch.cuda.device_count()
     grp.set_option(capi.OPT_KEEP_ALL, 0)
     grp.set_option(capi.OPT_SMALL_BATCH, 0)
+    grp.set_option(capi.OPT_SPLIT, 0)
     grp.load_model(in_chw, layers, params, imgs.shape[0])
     assert grp.broadcast_ms is not None and grp.broadcast_ms >= 0.0
     blocks = [grp.shard_bounds(imgs.shape[0], r) for r in range(grp.size)]
@@ -58,6 +60,7 @@ def test_two_ranks_when_two_devices_are_visible():
     want_prob, want_top5 = _single(in_chw, layers, params, imgs)
     grp = engine.QcnnDeviceGroup([0, 1])
     grp.set_option(capi.OPT_SMALL_BATCH, 0)
+    grp.set_option(capi.OPT_SPLIT, 0)
     grp.load_model(in_chw, layers, params, 300)
     prob, top5 = grp.forward_host(imgs)
     assert grp.shard_bounds(300, 1) == (150, 300)
@@ -65,7 +68,8 @@ def test_two_ranks_when_two_devices_are_visible():
     grp.close()
 
 
-def test_group_rejects_duplicate_devices():
+def test_group_rejects_duplicate_devices(monkeypatch):
+    monkeypatch.delenv("QCNN_GROUP_ALLOW_DUP", raising=False)         # the test-rig allowance is opt-in
     with pytest.raises(engine.QcnnError):
         engine.QcnnDeviceGroup([0, 0])
 

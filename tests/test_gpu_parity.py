@@ -26,10 +26,13 @@ SAMPLE_STRIDE = 97
 BITWISE_TYPES = (topo.CONV, topo.FCNT, topo.RELU, topo.POOL, topo.DRPT)
 
 
-def make_engine(in_chw, layers, params, max_batch, lut=capi.LUT_EXACT, keep_all=1):
+def make_engine(in_chw, layers, params, max_batch, lut=capi.LUT_EXACT, keep_all=1, split=0):
+    """split = 0: one workgroup per tile whatever the batch size (QCNN_OPT_SPLIT off) — the setting under which an image's
+    bits do not depend on its batch, which many tests below rely on; the split itself has its own tests."""
     eng = pkg("engine").QcnnEngine(0)
     eng.set_option(capi.OPT_LUT_MODE, lut)
     eng.set_option(capi.OPT_KEEP_ALL, keep_all)
+    eng.set_option(capi.OPT_SPLIT, split)
     eng.load_model(in_chw, layers, params, max_batch)
     return eng
 
@@ -270,6 +273,7 @@ def test_lrn_pool_fused_equals_separate_kernels():
     sep.forward_host(imgs, want_prob=False, want_top5=False)
     fus = make_engine(in_chw, layers, params, n, lut=capi.LUT_MFMA, keep_all=0)
     fus.set_option(capi.OPT_STREAMS, 1)
+    fus.set_option(capi.OPT_HOST_CHUNK, 0)      # one launch per layer: the 17 panels together fill the chip with the fused kernel
     p_f, t_f = fus.forward_host(imgs)
     for l in (4, 8):
         for first in (0, 500, n - 3):
@@ -497,6 +501,7 @@ def test_cbn_payload_decoded_on_the_device(golden_tiny):
     shapes = {i: tuple(int(x) for x in p["ctrd"].shape) for i, p in params.items()}
     e1 = make_engine(in_chw, layers, params, 2, lut=capi.LUT_MFMA)
     e2 = pkg("engine").QcnnEngine(0)
+    e2.set_option(capi.OPT_SPLIT, 0)
     e2.configure(in_chw, layers, shapes)
     e2.commit(2)
     e2.upload_cbn(params)
@@ -630,3 +635,62 @@ def test_result_does_not_depend_on_the_number_of_streams(golden_tiny):
     with pytest.raises(pkg("engine").QcnnError):
         eng2 = pkg("engine").QcnnEngine(0)
         eng2.set_option(capi.OPT_STREAMS, 9)
+
+
+# ---------------------------------------------------------------- launches that do not fill the chip: split tiles ----
+@pytest.mark.parametrize("n_img", [125, 250])
+def test_split_tiles_of_a_sharded_batch(n_img):
+    """QCNN_OPT_SPLIT (default on): one GPU's share of a 1000-image batch at 8 / 4 GPUs.  conv3-5 of AlexNet launch fewer
+    workgroups than fit whole rounds of 256 CUs, so the tail of their tiles is cut into slices with a fixed-order
+    reduction (k_conv_sum) and the FC layers pick their split for the panel count.  Against the same batch without the
+    split: every materialised map within 1e-5 (summation order only), same top-5; against the oracle on sampled images:
+    within 1e-4.  The exact builder never splits: bit-identical with the option on."""
+    in_chw, layers, _, _ = topo.MODELS["AlexNet"]
+    params = synth.make_params(in_chw, layers, seed=0)
+    imgs = synth.make_images(n_img, in_chw, seed=77)
+    base = make_engine(in_chw, layers, params, n_img, lut=capi.LUT_MFMA, keep_all=1, split=0)
+    p0, t0 = base.forward_host(imgs)
+    fm0 = {l: base.layer_output(l, n_img) for l in (9, 11, 13, 15, 16, 19, 22)}
+    base.close()
+    eng = make_engine(in_chw, layers, params, n_img, lut=capi.LUT_MFMA, keep_all=1, split=1)
+    eng.set_option(capi.OPT_STREAMS, 1)
+    p1, t1 = eng.forward_host(imgs)
+    cut = {l: eng.layer_split(l) for l in (0, 4, 8, 10, 12)}
+    assert any(z > 1 for _, z in cut.values()), cut                      # something was actually split
+    for l, want in fm0.items():
+        e_inf, _ = rel_err(eng.layer_output(l, n_img), want)
+        assert e_inf <= 1e-5, "fm[%d]: %g (split %r)" % (l, e_inf, cut)
+    assert np.array_equal(t0, t1)
+    assert np.abs(p1 - p0).max() <= 1e-5 * np.abs(p0).max()
+    orc = po.COracle(in_chw, layers)
+    orc.set_params(params)
+    for i in (0, n_img - 1):
+        orc.forward(imgs[i:i + 1])
+        e_inf, e_l2 = rel_err(p1[i], orc.fm(len(layers)).reshape(-1))
+        assert e_inf <= TOL and e_l2 <= TOL
+        e_inf, e_l2 = rel_err(eng.layer_output_range(13, i, 1), orc.fm(13))
+        assert e_inf <= TOL and e_l2 <= TOL
+    eng.set_option(capi.OPT_LUT_MODE, capi.LUT_EXACT)
+    pe, _ = eng.forward_host(imgs[:3])
+    assert all(z == 1 for _, z in (eng.layer_split(l) for l in (0, 4, 8, 10, 12)))
+    eng.close()
+
+
+def test_split_tiles_small_geometries():
+    """The split on small maps and odd shapes (tiny model, conv geometries with borders, K < 128 program-less kernels):
+    every slice boundary falls somewhere inside a tile's (pixel, sub-space) sequence; results within 1e-5 of the unsplit run."""
+    cases = [(topo.tiny_model(), {}),
+             (((3, 61, 85), [topo.conv(3, 7, 24, 1, 3), topo.relu(), topo.conv(0, 5, 96, 2, 2), topo.relu(),
+                             topo.conv(2, 3, 200, 1, 1), topo.relu(), topo.fcnt(48), topo.smax()]), {}),
+             (topo.tiny_model(), dict(conv_k=32, conv_cs=4, fc_k=128, fc_cs=8, last_k=16, last_cs=2))]
+    for (in_chw, layers), spec_kw in cases:
+        spec = synth.quant_spec(in_chw, layers, **spec_kw)
+        params = synth.make_params(in_chw, layers, seed=91, spec=spec)
+        imgs = synth.make_images(130, in_chw, seed=92)
+        outs = []
+        for split in (0, 1):
+            eng = make_engine(in_chw, layers, params, 130, lut=capi.LUT_MFMA, keep_all=0, split=split)
+            outs.append(eng.forward_host(imgs))
+            eng.close()
+        assert np.array_equal(outs[0][1], outs[1][1])
+        assert np.abs(outs[0][0] - outs[1][0]).max() <= 1e-5 * np.abs(outs[0][0]).max()

@@ -157,6 +157,7 @@ def test_host_mirror_feature_maps_match_reference(golden_alex_real, lut, monkeyp
     like the tail behind the synthesised fc6 table) against the compiled reference's values."""
     z = golden_alex_real
     monkeypatch.setenv("QCNN_LUT", lut)
+    monkeypatch.setenv("QCNN_KEEP_ALL", "1")          # conv1 / conv5 before their ReLU exist in layer-for-layer mode only
     lib = host()
     lib.qh_eva_featmaps.argtypes = [C.c_char_p, C.c_char_p, np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS"), C.c_int,
                                     np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS"), C.c_int,
@@ -180,6 +181,54 @@ def test_host_mirror_feature_maps_match_reference(golden_alex_real, lut, monkeyp
         assert abs(np.abs(fm.astype(np.float64)).sum() - fp[1]) <= 1e-4 * fp[1]
     if lut == "exact":
         assert np.array_equal(out[: 55 * 55 * 96].reshape(55, 55, 96), z["conv1_out"])
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.isdir(po.REF_DATA), reason="needs the staged shipped parameters")
+def test_host_mirror_fast_path_pool5_matches_reference(golden_alex_real, monkeypatch):
+    """The host mirror's DEFAULT mode is the fast path (QCNN_KEEP_ALL unset: fused ReLU, input read in place): pool5
+    (fm[15], materialised on both paths) of the real BMP against the compiled reference's values; a map the fast path
+    fuses away is refused with an error, not invented."""
+    z = golden_alex_real
+    monkeypatch.delenv("QCNN_KEEP_ALL", raising=False)
+    monkeypatch.setenv("QCNN_LUT", "mfma")
+    lib = host()
+    lib.qh_eva_featmaps.argtypes = [C.c_char_p, C.c_char_p, np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS"), C.c_int,
+                                    np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS"), C.c_int,
+                                    np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")]
+    bmp = os.path.join(po.REF_DATA, "Bmp.Files/ILSVRC2012_val_00000002.BMP")
+    out = np.zeros(6 * 6 * 256, np.float32)
+    sizes = np.zeros(1, np.int32)
+    with po._Quiet():
+        rc = lib.qh_eva_featmaps(po.REF_DATA.encode(), bmp.encode(), np.array([15], np.int32), 1, out, out.size, sizes)
+    assert rc == 0 and sizes[0] == 6 * 6 * 256
+    fp = z["fp_15"][0]
+    err = np.abs(out[::97].astype(np.float64) - z["smp_15"][0]).max() / max(abs(fp[3]), abs(fp[4]))
+    assert err <= 1e-4
+    big = np.zeros(55 * 55 * 96, np.float32)
+    with po._Quiet():
+        rc = lib.qh_eva_featmaps(po.REF_DATA.encode(), bmp.encode(), np.array([1], np.int32), 1, big, big.size, sizes)
+    assert rc == 5                                     # GetFeatMap(conv1 before ReLU) fails on the fast path
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.isdir(po.REF_DATA), reason="needs the staged shipped parameters")
+def test_reference_main_pipelined_batches(tmp_path):
+    """Unmodified Main.cc with several device batches in flight (QCNN_BATCH x QCNN_BATCHES > QCNN_MAX_INFLIGHT): the
+    uploads of the later chunks run under the layers of the earlier ones; same accuracy lines as one chunk."""
+    exe = os.path.join(ROOT, "build", "bin", "QuanCNN_hip")
+    if not os.path.exists(exe):
+        pytest.skip("build/bin/QuanCNN_hip not built (needs /root/reference at build time)")
+    root = _make_data_root(tmp_path, n_images=260)
+    outs = []
+    for env in ({"QCNN_BATCH": "130", "QCNN_BATCHES": "2", "QCNN_MAX_INFLIGHT": "1024"},
+                {"QCNN_BATCH": "130", "QCNN_BATCHES": "2", "QCNN_MAX_INFLIGHT": "130"},
+                {"QCNN_BATCH": "130", "QCNN_BATCHES": "2", "QCNN_MAX_INFLIGHT": "130", "QCNN_PIN_DATASET": "0"},
+                {"QCNN_BATCH": "130", "QCNN_BATCHES": "2", "QCNN_MAX_INFLIGHT": "130", "QCNN_PIN_DATASET": "register"}):
+        out = subprocess.run([exe], cwd=root, capture_output=True, text=True, timeout=600, env=dict(os.environ, **env)).stdout
+        assert out.count("processing the ") == 2, out[-1500:]
+        outs.append(re.findall(r"ACCURACY@(\d): (\d+), ([0-9.]+)%", out))
+    assert len(outs[0]) == 5 and outs[0] == outs[1] == outs[2] == outs[3]
 
 
 @pytest.mark.gpu
