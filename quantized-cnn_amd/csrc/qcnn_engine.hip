@@ -145,10 +145,10 @@ int plan_arena(QcnnCtx* c) {
     // conv layers with K = 128 and more than 4 dims per sub-space can run the bf16-pair builder (QCNN_OPT_LUT_MODE = 3)
     s.hasCtrd2 = d.type == QCNN_CONV && s.K == 128 && std::min(c->dims[l].c / d.grpCnt, s.Cs) > 4;
     if (s.hasCtrd2) { s.offCtrd2 = off; off = align_up(off + qk_ctrd2_bytes(s.M), 256); }
-    // row-offset table: uint16 entries in the order the gather waves consume them (QkSlots, qcnn_kernels.h)
+    // assignment table: one-byte row slots in the order the gather waves consume them (QkSlots, qcnn_kernels.h)
     const QkSlots sl = (d.type == QCNN_CONV) ? qk_conv_slots(Ct / d.grpCnt, d.grpCnt) : qk_fc_slots(Ct);
     const size_t taps = (d.type == QCNN_CONV) ? (size_t)d.knlSiz * d.knlSiz : 1;
-    s.asmtBytes = taps * s.M * sl.rowStride * sizeof(uint16_t);
+    s.asmtBytes = taps * s.M * sl.rowStride;
     s.offAsmt = off; off = align_up(off + s.asmtBytes + QCNN_ROWS_PAD, 256);
     s.progBytes = 0;
     if (d.type == QCNN_CONV && s.K == 128) {     // the MFMA panel kernel reads its offsets through the program table
@@ -245,7 +245,7 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
       p.bias = reinterpret_cast<const float*>(c->arena + s.offBias);
       p.ctrd = reinterpret_cast<const float*>(c->arena + s.offCtrd);
       p.ctrd2 = s.hasCtrd2 ? c->arena + s.offCtrd2 : nullptr;
-      p.rows = reinterpret_cast<const uint16_t*>(c->arena + s.offAsmt);
+      p.rows = reinterpret_cast<const uint8_t*>(c->arena + s.offAsmt);
       p.prog = s.progBytes ? reinterpret_cast<const uint16_t*>(c->arena + s.offProg) : nullptr;
       p.H = a.h; p.W = a.w; p.Cin = a.c; p.Ho = b.h; p.Wo = b.w; p.Ct = b.c;
       p.knl = d.knlSiz; p.stride = d.stride; p.pad = d.padSiz; p.grp = d.grpCnt;
@@ -277,7 +277,7 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
       p.src = src; p.dst = dst;
       p.bias = reinterpret_cast<const float*>(c->arena + s.offBias);
       p.ctrd = reinterpret_cast<const float*>(c->arena + s.offCtrd);
-      p.rows = reinterpret_cast<const uint16_t*>(c->arena + s.offAsmt);
+      p.rows = reinterpret_cast<const uint8_t*>(c->arena + s.offAsmt);
       if (s.hasDmap && !flatFcInput) {   // NHWC -> consumption order (NCHW flatten) into the scratch map
         float* flat = c->fcFlat + (size_t)p0 * fm_elems(c, l) * QCNN_PANEL;
         e = qk_permute_rows(src, flat, reinterpret_cast<const int*>(c->arena + s.offDmap), a.h * a.w * a.c,
@@ -766,7 +766,7 @@ hipError_t build_program(QcnnCtx* c, int layer, const QkSlots& sl) {
   const QcnnLayerDesc& d = c->layers[layer];
   const LayerShape& s = c->shapes[layer];
   if (!s.progBytes) return hipSuccess;
-  return qk_build_program(reinterpret_cast<const uint16_t*>(c->arena + s.offAsmt),
+  return qk_build_program(reinterpret_cast<const uint8_t*>(c->arena + s.offAsmt),
                           reinterpret_cast<uint16_t*>(c->arena + s.offProg), sl, qk_conv_program(sl, d.knlSiz, d.stride),
                           d.knlSiz, d.stride, s.M, c->stream);
 }
@@ -783,24 +783,24 @@ int qcnn_model_set_layer_params(QcnnCtx* c, int layer, const float* bias, const 
   const int Ct = c->dims[layer + 1].c;
   const int M = s.M, K = s.K;
   // PrepAsmtBuf: conv [Ct][kh][kw][M] -> [kh][kw][M][Ct] (:585-586); FC [Ct][M] -> [M][Ct] (:610-611).  Stored as
-  // the pre-scaled LDS offset of the code word's row inside a LUT stage (row = (m % G) * K + index < 128), with the
-  // channel axis in the order the gather waves consume it (QkSlots); padding entries point at row 0.
+  // the one-byte SLOT of the code word's row inside a LUT stage (row = (m % G) * K + index < 128; LDS offset = slot * 64),
+  // with the channel axis in the order the gather waves consume it (QkSlots); padding entries point at slot 0.
   const int G = qcnn_stage_group(K);
   const size_t taps = (d.type == QCNN_CONV) ? (size_t)d.knlSiz * d.knlSiz : 1;
   const int groups = (d.type == QCNN_CONV) ? d.grpCnt : 1;
   const QkSlots sl = (d.type == QCNN_CONV) ? qk_conv_slots(Ct / groups, groups) : qk_fc_slots(Ct);
-  std::vector<uint16_t> asmt(s.asmtBytes / sizeof(uint16_t) + QCNN_ROWS_PAD / sizeof(uint16_t), 0);
+  std::vector<uint8_t> asmt(s.asmtBytes + QCNN_ROWS_PAD, 0);
   for (int ch = 0; ch < Ct; ++ch) {
     const int entry = qk_slot_entry(sl, ch / sl.C, ch % sl.C);
     for (size_t t = 0; t < taps; ++t)
       for (int m = 0; m < M; ++m) {
         const uint8_t v = asmt_file[((size_t)ch * taps + t) * M + m];
         if (v >= K) return fail(c, "layer %d: assignment %u >= K = %d", layer, (unsigned)v, K);
-        asmt[(t * M + m) * sl.rowStride + entry] = qcnn_row_offset((m % G) * K + v);
+        asmt[(t * M + m) * sl.rowStride + entry] = (uint8_t)qcnn_row_slot((m % G) * K + v);
       }
   }
   if (upload_bias_ctrd(c, layer, bias, ctrd_file)) return 1;
-  HIP_TRY(c, hipMemcpyAsync(c->arena + s.offAsmt, asmt.data(), asmt.size() * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->arena + s.offAsmt, asmt.data(), asmt.size(), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, build_program(c, layer, sl));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   s.loaded = true;
@@ -833,7 +833,7 @@ int qcnn_model_set_layer_params_cbn(QcnnCtx* c, int layer, const float* bias, co
   if (e == hipSuccess) e = hipMemsetAsync(bad, 0, sizeof(int), c->stream);
   if (e == hipSuccess) e = hipMemsetAsync(c->arena + s.offAsmt, 0, s.asmtBytes + QCNN_ROWS_PAD, c->stream);   // padding entries -> row 0
   if (e == hipSuccess)
-    e = qk_decode_cbn(dev, bits, n, Ct, (int)taps, s.M, s.K, sl, reinterpret_cast<uint16_t*>(c->arena + s.offAsmt), bad, c->stream);
+    e = qk_decode_cbn(dev, bits, n, Ct, (int)taps, s.M, s.K, sl, reinterpret_cast<uint8_t*>(c->arena + s.offAsmt), bad, c->stream);
   if (e == hipSuccess) e = build_program(c, layer, sl);
   int flag = 0;
   if (e == hipSuccess) e = hipMemcpyAsync(&flag, bad, sizeof(int), hipMemcpyDeviceToHost, c->stream);

@@ -11,8 +11,9 @@
 // of ds_read_b128 touches on distinct banks.  A gather lane carries FOUR images and one
 // ds_read_b128 serves TWO look-ups: lanes 0-31 read the row of one output channel, lanes 32-63 the row of
 // another.  Inside a tile the 16 rows of an MFMA result tile are stored in the order ds_write_addtid_b32
-// produces them (qcnn_row_slot).  Assignment tables live on the device as pre-scaled uint16 LDS offsets
-// (slot * 64 B) in the order the gather waves consume them (QkSlots).
+// produces them (qcnn_row_slot).  Assignment tables live on the device as one-byte row slots (LDS offset / 64) in
+// the order the gather waves consume them (QkSlots); the conv kernels with K = 128 read pre-scaled uint16 offsets
+// through a small per-layer program table built from them (QkProgram).
 #ifndef QCNN_KERNELS_H_
 #define QCNN_KERNELS_H_
 
@@ -39,26 +40,33 @@ __host__ __device__ static inline int qcnn_row_slot(int r) { return (r & 0x70) |
 __host__ __device__ static inline uint16_t qcnn_row_offset(int r) { return (uint16_t)(qcnn_row_slot(r) * 64); }
 
 // How the 12 gather waves of a workgroup split `C` output channels (conv: the channels of one group; FC: all
-// of them), and the device layout of the row-offset table that follows from it.  A wave owns `cpw`
+// of them), and the device layout of the assignment table that follows from it.  A wave owns `cpw`
 // consecutive channels: lanes 0-31 the first cpw/2, lanes 32-63 the second cpw/2.  Per (tap, sub-space) the
-// table holds, for every wave slot (group-major, then chunk, then wave) and each half, `hp` uint16 offsets
-// (cpw/2 used, padded to a whole number of dwords).
+// table holds, for every wave slot (group-major, then chunk, then wave) and each half, `hpB` BYTES: one row SLOT
+// (qcnn_row_slot of the code word's stage row, < 128) per channel of the half, padded to whole dwords.  Inside a dword
+// the four slots sit in the order (e0, e2, e1, e3): (w << 6) & 0x1fc01fc0 then is the pair of pre-scaled 16-bit row
+// offsets (e0, e1) the look-up blocks consume, (w >> 2) & 0x1fc01fc0 the pair (e2, e3) — two VALU instructions per
+// two look-up reads; the resident table is the size of the reference's uint8 assignment matrices (src/CaffeEva.cc:586,611).
 struct QkSlots {
   int cpw;        // channels per gather wave
-  int hp;         // uint16 entries per half-wave and (tap, sub-space)
+  int hp;         // slot entries per half-wave and (tap, sub-space): cpw/2 rounded up to even
+  int hpB;        // bytes per half-wave and (tap, sub-space): hp rounded up to a multiple of 4
   int chunks;     // workgroups along the channel axis (per group)
   int groups;
   int C;          // channels per group
-  int rowStride;  // uint16 entries per (tap, sub-space) = groups * chunks * 12 * 2 * hp
+  int rowStride;  // BYTES per (tap, sub-space) = groups * chunks * 12 * 2 * hpB
 };
 static inline QkSlots qk_make_slots(int C, int groups, int cpw) {
   QkSlots s;
   s.cpw = cpw; s.C = C; s.groups = groups;
   s.hp = ((cpw / 2 + 1) / 2) * 2;
+  s.hpB = (s.hp + 3) / 4 * 4;
   s.chunks = (C + QCNN_GATHER_WAVES * cpw - 1) / (QCNN_GATHER_WAVES * cpw);
-  s.rowStride = groups * s.chunks * QCNN_GATHER_WAVES * 2 * s.hp;
+  s.rowStride = groups * s.chunks * QCNN_GATHER_WAVES * 2 * s.hpB;
   return s;
 }
+// byte position of entry e of a half inside the half's hpB bytes (the (e0, e2, e1, e3) order of every dword)
+__host__ __device__ static inline int qk_entry_byte(int e) { return (e & ~3) | ((e & 1) << 1) | ((e >> 1) & 1); }
 // conv: channels per wave by the channel count of one group (then as many positions per wave as 64-72
 // accumulator registers allow: qk_conv_positions)
 static inline QkSlots qk_conv_slots(int Ctg, int groups) {
@@ -104,11 +112,11 @@ __host__ __device__ static inline QkProgram qk_conv_program(const QkSlots& sl, i
   return g;
 }
 static inline QkSlots qk_fc_slots(int Ct) { return qk_make_slots(Ct, 1, Ct >= 384 ? 32 : (Ct >= 96 ? 8 : 4)); }
-// table position (in uint16 entries, inside one (tap, sub-space) row) of channel c of group g, or -1
+// table position (byte index inside one (tap, sub-space) row) of channel c of group g, or -1
 __host__ __device__ static inline int qk_slot_entry(const QkSlots& s, int g, int c) {
   if (c < 0 || c >= s.C) return -1;
   const int wave = c / s.cpw, k = c % s.cpw, hc = s.cpw / 2;
-  return ((g * s.chunks * QCNN_GATHER_WAVES + wave) * 2 + k / hc) * s.hp + k % hc;
+  return ((g * s.chunks * QCNN_GATHER_WAVES + wave) * 2 + k / hc) * s.hpB + qk_entry_byte(k % hc);
 }
 struct ConvParams {
   int srcNchw;           // 1: src is the network input [nImages][Cin][H][W] read in place by the builders (first layer with
@@ -120,7 +128,7 @@ struct ConvParams {
   const float* ctrd;     // [M][Cs][K]      (PrepCtrdBuf layout, src/CaffeEva.cc:556-557)
   const void* ctrd2;     // [M][8 row tiles][4 k-slices][16 rows][8 bf16]: code book split in two bf16 parts (slices 0, 1:
                          // leading part, 2, 3: remainder) in v_mfma_f32_16x16x32_bf16 operand order; K = 128 layers only, else NULL
-  const uint16_t* rows;  // [kh][kw][M][rowStride] (PrepAsmtBuf order, src/CaffeEva.cc:585-586): row offsets, QkSlots order
+  const uint8_t* rows;   // [kh][kw][M][rowStride] (PrepAsmtBuf order, src/CaffeEva.cc:585-586): row slots, QkSlots order
   const uint16_t* prog;  // [rfH][rfW][M][rowU16]: the same offsets in consumption order (QkProgram); panel kernels only
   int H, W, Cin, Ho, Wo, Ct;
   int knl, stride, pad, grp;
@@ -152,7 +160,7 @@ struct FcParams {
   float* dst;            // [panels][Ct][128]
   const float* bias;
   const float* ctrd;     // [M][Cs][K]
-  const uint16_t* rows;  // [M][rowStride]  (src/CaffeEva.cc:610-611): row offsets, QkSlots order
+  const uint8_t* rows;   // [M][rowStride]  (src/CaffeEva.cc:610-611): row slots, QkSlots order
   int D, Ct, M, Cs, K;
   int relu;
   int panels;
@@ -176,10 +184,10 @@ hipError_t qk_fc_small(const FcParams& p, int n, hipStream_t st);
 // floor(32768 / bits) values packed MSB first, 0-based code-word indices in FILE order [Ct][taps][M]) straight
 // into the row-offset table [taps][M][rowStride] of the arena.  *bad is set when an index >= K is met.
 hipError_t qk_decode_cbn(const uint8_t* blocks, int bits, size_t n, int Ct, int taps, int M, int K, QkSlots sl,
-                         uint16_t* rows, int* bad, hipStream_t st);
+                         uint8_t* rows, int* bad, hipStream_t st);
 
 // rows (plain table of a conv layer) -> prog (QkProgram order); one thread per program entry
-hipError_t qk_build_program(const uint16_t* rows, uint16_t* prog, QkSlots sl, QkProgram pg, int knl, int stride, int M,
+hipError_t qk_build_program(const uint8_t* rows, uint16_t* prog, QkSlots sl, QkProgram pg, int knl, int stride, int M,
                             hipStream_t st);
 
 // dst row e = src row map[e], rows of 128 images ([panels][D][128]); the first FC layer consumes its input

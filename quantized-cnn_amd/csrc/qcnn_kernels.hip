@@ -134,16 +134,32 @@ __device__ __forceinline__ WaveRole assign_roles(char* lds, int wave, int lane) 
 // ------------------------------------------------------------------------------------------------
 template <int DW>
 struct Idx {
-  uint32_t w[DW];
+  uint32_t w[DW];                                    // pairs of pre-scaled 16-bit row offsets
 };
-
-template <int DW>
-__device__ __forceinline__ void vload_idx(Idx<DW>& o, const uint16_t* __restrict__ ap, uint32_t laneOff) {
-
+// The plain assignment table holds one-byte row slots, four per dword in the order (e0, e2, e1, e3) (QkSlots): a half-wave's
+// entries of one (tap, sub-space) are BW dwords ...
+__host__ __device__ constexpr int idx_bytes_dwords(int DW) { return (DW + 1) / 2; }
+template <int BW>
+struct IdxB {
+  uint32_t w[BW];
+};
+template <int BW>
+__device__ __forceinline__ void vload_idx(IdxB<BW>& o, const uint8_t* __restrict__ ap, uint32_t laneOff) {
   const uint32_t* __restrict__ ap4 =
       reinterpret_cast<const uint32_t*>(__builtin_assume_aligned(reinterpret_cast<const char*>(ap) + laneOff, 4));
 #pragma unroll
-  for (int j = 0; j < DW; ++j) o.w[j] = ap4[j];
+  for (int j = 0; j < BW; ++j) o.w[j] = ap4[j];
+}
+// ... and become the offset pairs of the look-up blocks with a shift and a mask each
+template <int DW>
+__device__ __forceinline__ Idx<DW> expand_idx(const IdxB<idx_bytes_dwords(DW)>& b) {
+  Idx<DW> o;
+#pragma unroll
+  for (int j = 0; j < idx_bytes_dwords(DW); ++j) {
+    if (2 * j < DW) o.w[2 * j] = (b.w[j] << 6) & 0x1fc01fc0u;
+    if (2 * j + 1 < DW) o.w[2 * j + 1] = (b.w[j] >> 2) & 0x1fc01fc0u;
+  }
+  return o;
 }
 
 #define Q_AD(a, w, sel) "v_xor_b32_sdwa " a ", %[" w "], %[b] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" sel " src1_sel:DWORD\n\t"
@@ -657,7 +673,7 @@ __device__ __forceinline__ void bf_store(BfSet& o, int bw) {
 struct ConvGeom {
   int W, Cin, knl, M, MG, G, wiL, wiU;
   uint32_t pixStride;   // bytes from one source pixel to the next: Cin * 512 (panels) or 4 (NCHW input read in place)
-  uint32_t rowStride;   // uint16 entries of one (tap, sub-space) row of the offset table
+  uint32_t rowStride;   // bytes of one (tap, sub-space) row of the assignment table
 };
 // Workgroups are dispatched in linear order, so the tiles are numbered heaviest first: interior tiles
 // (full receptive field = most stages), then the four edges, then the corners.  With a few workgroups per
@@ -696,8 +712,8 @@ __device__ __forceinline__ uint32_t pixel_off(const StagePos& c, const ConvGeom&
 // offsets of the first sub-space of stage c for every position of the tile (taps that do not exist are
 // clamped to an existing one: the load is harmless, the gather skips them)
 template <int TH, int TW, int CPW>
-__device__ __forceinline__ void conv_prefetch_idx(Idx<idx_dwords(CPW)> (&v)[TH * TW], const StagePos& c, const ConvGeom& g,
-                                                  const uint16_t* __restrict__ rowsW, const int (&rowStart)[TH],
+__device__ __forceinline__ void conv_prefetch_idx(IdxB<idx_bytes_dwords(idx_dwords(CPW))> (&v)[TH * TW], const StagePos& c,
+                                                  const ConvGeom& g, const uint8_t* __restrict__ rowsW, const int (&rowStart)[TH],
                                                   const int (&colStart)[TW], uint32_t laneOff) {
 #pragma unroll
   for (int dy = 0; dy < TH; ++dy) {
@@ -711,8 +727,9 @@ __device__ __forceinline__ void conv_prefetch_idx(Idx<idx_dwords(CPW)> (&v)[TH *
 }
 
 template <int TH, int TW, int CPW, bool ONE>
-__device__ __forceinline__ void conv_gather(f32x2 (&acc)[TH * TW][CPW], const Idx<idx_dwords(CPW)> (&first)[TH * TW],
-                                            const StagePos& c, const ConvGeom& g, const uint16_t* __restrict__ rowsW,
+__device__ __forceinline__ void conv_gather(f32x2 (&acc)[TH * TW][CPW],
+                                            const IdxB<idx_bytes_dwords(idx_dwords(CPW))> (&first)[TH * TW],
+                                            const StagePos& c, const ConvGeom& g, const uint8_t* __restrict__ rowsW,
                                             const int (&rowStart)[TH], const int (&colStart)[TW], uint32_t stage,
                                             uint32_t laneOff, bool live) {
 #pragma unroll
@@ -723,14 +740,14 @@ __device__ __forceinline__ void conv_gather(f32x2 (&acc)[TH * TW][CPW], const Id
     for (int dx = 0; dx < TW; ++dx) {
       const int kw = c.wi - colStart[dx];
       const int valid = uni((rowOk && (unsigned)kw < (unsigned)g.knl) ? 1 : 0);
-      gather_apply<CPW>(acc[dy * TW + dx], first[dy * TW + dx], stage, valid);
+      gather_apply<CPW>(acc[dy * TW + dx], expand_idx<idx_dwords(CPW)>(first[dy * TW + dx]), stage, valid);
       if (!ONE) {                              // further sub-spaces of the stage (K <= 64 only)
         const int m0 = c.mg * g.G;
         const int n = valid ? min(g.M, m0 + g.G) - m0 : 0;
         for (int i = 1; i < n; ++i) {
-          Idx<idx_dwords(CPW)> more;
+          IdxB<idx_bytes_dwords(idx_dwords(CPW))> more;
           vload_idx(more, rowsW + (size_t)((kh * g.knl + kw) * g.M + m0 + i) * g.rowStride, laneOff);
-          gather_apply<CPW>(acc[dy * TW + dx], more, stage, 1);
+          gather_apply<CPW>(acc[dy * TW + dx], expand_idx<idx_dwords(CPW)>(more), stage, 1);
         }
       }
     }
@@ -987,8 +1004,9 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
   const bool active = cw0 < Ctg;                     // waves without channels only keep the barriers
   const int cl0 = cw0 + half * HC;                   // first channel of this lane's half inside the group
   // this wave's entries inside one (tap, sub-space) row of the offset table; the two halves read different ones
-  const uint16_t* __restrict__ rowsW = p.rows + (size_t)((grp * chunksPerGrp + chunk) * NGW + gw) * 2 * (2 * DW);
-  const uint32_t laneOff = (uint32_t)half * (2 * DW) * 2;   // bytes
+  constexpr int BW = idx_bytes_dwords(DW);
+  const uint8_t* __restrict__ rowsW = p.rows + (size_t)((grp * chunksPerGrp + chunk) * NGW + gw) * 2 * (4 * BW);
+  const uint32_t laneOff = (uint32_t)half * (4 * BW);       // bytes
   // XOR-ed with a pre-scaled row offset it gives the lane's read address: tile, slot swizzle (tile >> 1), 16-byte quarter
   const uint32_t laneLds = (uint32_t)(quad >> 2) * TILEB | (uint32_t)(quad >> 3) * 64 | (uint32_t)(quad & 3) * 16;
 
@@ -1055,7 +1073,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
   } else {
     // Offsets from the plain table.  Per stage: [prefetch the offsets of stage s+1][gather stage s][barrier]; two
     // offset sets alternate.
-    Idx<DW> ia[NP], ib[NP];
+    IdxB<BW> ia[NP], ib[NP];
     StagePos c0p = first;
     StagePos c1p = next_pos(c0p, g);
     conv_prefetch_idx<TH, TW, CPW>(ia, c0p, g, rowsW, rowStart, colStart, laneOff);
@@ -1175,8 +1193,9 @@ __global__ __launch_bounds__(NW * 64) void k_fc_aprx(FcParams p, int G, int stag
   const int cw0 = (blockIdx.x * NGW + gw) * CPW;
   const bool active = cw0 < p.Ct;
   const int cl0 = cw0 + half * HC;
-  const uint16_t* __restrict__ rowsW = p.rows + (size_t)(blockIdx.x * NGW + gw) * 2 * (2 * DW);
-  const uint32_t laneOff = (uint32_t)half * (2 * DW) * 2;
+  constexpr int BW = idx_bytes_dwords(DW);
+  const uint8_t* __restrict__ rowsW = p.rows + (size_t)(blockIdx.x * NGW + gw) * 2 * (4 * BW);
+  const uint32_t laneOff = (uint32_t)half * (4 * BW);
   // XOR-ed with a pre-scaled row offset it gives the lane's read address: tile, slot swizzle (tile >> 1), 16-byte quarter
   const uint32_t laneLds = (uint32_t)(quad >> 2) * TILEB | (uint32_t)(quad >> 3) * 64 | (uint32_t)(quad & 3) * 16;
 
@@ -1196,7 +1215,7 @@ __global__ __launch_bounds__(NW * 64) void k_fc_aprx(FcParams p, int G, int stag
   // barrier closes a stage every G sub-spaces (a pair may straddle it).  Sub-spaces past mEnd (ragged last
   // stage) are skipped inside the look-up blocks; the stream is padded to Sp stages so that every wave meets
   // the same barriers.
-  Idx<DW> ia, ib;
+  IdxB<BW> ia, ib;
   const int activeI = in_range(cw0, p.Ct);             // `active` as an integer (see in_range)
   const int mClamp = max(mEnd - 1, mBeg);
   vload_idx(ia, rowsW + (size_t)mBeg * rowStride, laneOff);
@@ -1209,10 +1228,10 @@ __global__ __launch_bounds__(NW * 64) void k_fc_aprx(FcParams p, int G, int stag
     const int T = Sp * G;           // sub-space slots incl. padding (even)
     for (int k = 0; k < T; k += 2) {
       const int m = mBeg + k;
-      gather_apply<CPW>(acc, ia, stage, activeI & in_range(m, mEnd));
+      gather_apply<CPW>(acc, expand_idx<DW>(ia), stage, activeI & in_range(m, mEnd));
       vload_idx(ia, rowsW + (size_t)min(m + 2, mClamp) * rowStride, laneOff);
       if (++r == G) { r = 0; stage ^= STAGE_BYTES; barrier_plain(); }
-      gather_apply<CPW>(acc, ib, stage, activeI & in_range(m + 1, mEnd));
+      gather_apply<CPW>(acc, expand_idx<DW>(ib), stage, activeI & in_range(m + 1, mEnd));
       vload_idx(ib, rowsW + (size_t)min(m + 3, mClamp) * rowStride, laneOff);
       if (++r == G) { r = 0; stage ^= STAGE_BYTES; barrier_plain(); }
     }
@@ -1240,7 +1259,7 @@ __global__ __launch_bounds__(NW * 64) void k_fc_aprx(FcParams p, int G, int stag
 // straddle a block); it lands at [tap][m][slot entry of its channel] as the pre-scaled LDS offset of its stage row
 // (the same value qcnn_model_set_layer_params computes on the host).
 __global__ void k_decode_cbn(const uint8_t* __restrict__ blocks, int bits, size_t n, int Ct, int taps, int M, int K,
-                             int G, QkSlots sl, uint16_t* __restrict__ rows, int* __restrict__ bad) {
+                             int G, QkSlots sl, uint8_t* __restrict__ rows, int* __restrict__ bad) {
   const int per = 4096 * 8 / bits;
   for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
     const size_t blk = e / per;
@@ -1253,7 +1272,7 @@ __global__ void k_decode_cbn(const uint8_t* __restrict__ blocks, int bits, size_
     const int t = (int)(ct % taps), ch = (int)(ct / taps);
     if ((int)v >= K) { atomicOr(bad, 1); continue; }
     const int entry = qk_slot_entry(sl, ch / sl.C, ch % sl.C);
-    rows[((size_t)t * M + m) * sl.rowStride + entry] = qcnn_row_offset((m % G) * K + (int)v);
+    rows[((size_t)t * M + m) * sl.rowStride + entry] = (uint8_t)qcnn_row_slot((m % G) * K + (int)v);
   }
 }
 
@@ -1290,8 +1309,8 @@ hipError_t allow_big_lds(const void* kern, int bytes) {
   return hipSuccess;
 }
 
-// rows (plain table, [kh][kw][M][rowStride]) -> program table ([ry][rx][M][rowU16], QkProgram): one thread per entry
-__global__ __launch_bounds__(256) void k_build_program(const uint16_t* __restrict__ rows, uint16_t* __restrict__ prog,
+// rows (plain table of row slots, [kh][kw][M][rowStride]) -> program table of pre-scaled offsets ([ry][rx][M][rowU16], QkProgram): one thread per entry
+__global__ __launch_bounds__(256) void k_build_program(const uint8_t* __restrict__ rows, uint16_t* __restrict__ prog,
                                                        QkSlots sl, QkProgram pg, int knl, int stride, int M, size_t n) {
   for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
     const int r = (int)(e % (size_t)pg.rowU16);
@@ -1304,7 +1323,7 @@ __global__ __launch_bounds__(256) void k_build_program(const uint16_t* __restric
     if (pos < pg.np) {
       const int kh = ry - (pos / pg.tw) * stride, kw = rx - (pos % pg.tw) * stride;
       if ((unsigned)kh < (unsigned)knl && (unsigned)kw < (unsigned)knl)
-        v = rows[(size_t)((kh * knl + kw) * M + m) * sl.rowStride + wh * sl.hp + j];
+        v = (uint16_t)(rows[(size_t)((kh * knl + kw) * M + m) * sl.rowStride + wh * sl.hpB + qk_entry_byte(j)] * 64);
     }
     prog[e] = v;
   }
@@ -1511,7 +1530,7 @@ hipError_t qk_fc_aprx(const FcParams& pIn, int lutMode, hipStream_t st) {
 }
 
 hipError_t qk_decode_cbn(const uint8_t* blocks, int bits, size_t n, int Ct, int taps, int M, int K, QkSlots sl,
-                         uint16_t* rows, int* bad, hipStream_t st) {
+                         uint8_t* rows, int* bad, hipStream_t st) {
   if (bits < 1 || bits > 8) return hipErrorInvalidValue;
   const int grid = (int)std::min<size_t>((n + 255) / 256, 8192);
   hipLaunchKernelGGL(k_decode_cbn, dim3(grid ? grid : 1), dim3(256), 0, st, blocks, bits, n, Ct, taps, M, K,
@@ -1519,7 +1538,7 @@ hipError_t qk_decode_cbn(const uint8_t* blocks, int bits, size_t n, int Ct, int 
   return hipGetLastError();
 }
 
-hipError_t qk_build_program(const uint16_t* rows, uint16_t* prog, QkSlots sl, QkProgram pg, int knl, int stride, int M,
+hipError_t qk_build_program(const uint8_t* rows, uint16_t* prog, QkSlots sl, QkProgram pg, int knl, int stride, int M,
                             hipStream_t st) {
   const size_t n = (size_t)pg.rfH * pg.rfW * M * pg.rowU16;
   const int grid = (int)std::min<size_t>((n + 255) / 256, 8192);

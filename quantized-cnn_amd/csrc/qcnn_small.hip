@@ -9,8 +9,8 @@
 //                             then every thread walks the taps of its outputs and gathers
 //                             acc += LUT[pixel(tap)][m][assignment]   (CalcFeatMap_ConvAprx :840-863 / _FCntAprx :998-1023).
 // Activations stay in the panel layout ([E][128], image = lane index) so that the glue kernels and the large-batch
-// path interoperate; the assignment tables are the same pre-scaled uint16 row offsets the panel kernels use (the
-// code-word index is recovered from the row slot).  Summation runs over sub-space chunks first, so results agree
+// path interoperate; the assignment tables are the same one-byte row slots the panel kernels use (the code-word index
+// is recovered from the slot): one byte per look-up is streamed, as in the reference.  Summation runs over sub-space chunks first, so results agree
 // with the panel kernels / the reference to rounding (~1e-6), not bit for bit; the exact builder (QCNN_OPT_LUT_MODE = 0)
 // therefore always takes the panel kernels.
 #include "qcnn_kernels.h"
@@ -32,7 +32,7 @@ struct SmallConv {
   float* dst;              // panels [Ho*Wo*Ct][128]
   const float* bias;
   const float* ctrd;       // [M][Cs][K]
-  const uint16_t* rows;    // [taps][M][rowStride]
+  const uint8_t* rows;     // [taps][M][rowStride]: row slots
   int srcNchw, img0;       // img0: index of image 0 of this launch inside the batch (NCHW addressing)
   int H, W, Cin, Ho, Wo, Ct, knl, stride, pad, grp;
   int M, Cs, K, G, relu, rowStride;
@@ -46,9 +46,9 @@ __device__ __forceinline__ float load_x(const SmallConv& p, int img, int hi, int
   return p.src[((size_t)panel * p.H * p.W * p.Cin + (size_t)(hi * p.W + wi) * p.Cin + ch) * PANEL + lane];
 }
 
-// one look-up: pre-scaled row offset -> stage row -> code word of sub-space m -> table entry
-__device__ __forceinline__ float lut_at(const float* __restrict__ tab, uint16_t off, int mInStage, int K) {
-  return tab[slot_row(off >> 6) - mInStage * K];
+// one look-up: row slot -> stage row -> code word of sub-space m -> table entry
+__device__ __forceinline__ float lut_at(const float* __restrict__ tab, uint8_t slot, int mInStage, int K) {
+  return tab[slot_row(slot) - mInStage * K];
 }
 
 __global__ __launch_bounds__(NT) void k_conv_small(SmallConv p) {
@@ -129,13 +129,13 @@ __global__ __launch_bounds__(NT) void k_conv_small(SmallConv p) {
         float a = acc[j];
         for (int kh = khL; kh <= khU; ++kh) {
           const float* rowTab = lut + (ptrdiff_t)((hs + kh - hiL) * rfW + (ws - wiL)) * (p.MC * K);
-          const uint16_t* rowIdx = p.rows + ((size_t)(kh * p.knl) * p.M + m0) * p.rowStride + entry;
+          const uint8_t* rowIdx = p.rows + ((size_t)(kh * p.knl) * p.M + m0) * p.rowStride + entry;
           // batches of eight INDEPENDENT look-ups (offset loads in flight together, then the table reads, then the adds in
           // order); the tail of a batch re-reads the last valid element and is not added
           if (mc == 1) {                                 // one sub-space per pixel (first layer): run over the taps
             const int mi = m0 % p.G;
             for (int kw = kwL; kw <= kwU; kw += 8) {
-              uint16_t o[8];
+              uint8_t o[8];
               float v[8];
 #pragma unroll
               for (int u = 0; u < 8; ++u) o[u] = rowIdx[(size_t)min(kw + u, kwU) * p.M * p.rowStride];
@@ -148,9 +148,9 @@ __global__ __launch_bounds__(NT) void k_conv_small(SmallConv p) {
           } else {
             for (int kw = kwL; kw <= kwU; ++kw) {
               const float* tab = rowTab + (ptrdiff_t)kw * (p.MC * K);
-              const uint16_t* rr = rowIdx + (size_t)kw * p.M * p.rowStride;
+              const uint8_t* rr = rowIdx + (size_t)kw * p.M * p.rowStride;
               for (int ml = 0; ml < mc; ml += 8) {
-                uint16_t o[8];
+                uint8_t o[8];
                 float v[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) o[u] = rr[(size_t)min(ml + u, mc - 1) * p.rowStride];
@@ -193,7 +193,7 @@ struct SmallFc {
   float* lut;              // scratch [n][M][K]: the look-up table of every image, built once by k_fc_lut
   const float* bias;
   const float* ctrd;
-  const uint16_t* rows;    // [M][rowStride]
+  const uint8_t* rows;     // [M][rowStride]: row slots
   int D, Ct, M, Cs, K, G, relu, rowStride, MC;
   QkSlots sl;
 };
@@ -241,9 +241,9 @@ __global__ __launch_bounds__(NT) void k_fc_small(SmallFc p) {
     if (chOk) {
       const int per = (mc + FC_SLICES - 1) / FC_SLICES;
       const int a0 = slice * per, a1 = min(mc, a0 + per);
-      const uint16_t* rr = p.rows + (size_t)m0 * p.rowStride + entry;
+      const uint8_t* rr = p.rows + (size_t)m0 * p.rowStride + entry;
       for (int ml = a0; ml < a1; ml += 8) {                         // eight independent look-ups at a time
-        uint16_t o[8];
+        uint8_t o[8];
         float v[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) o[u] = rr[(size_t)min(ml + u, a1 - 1) * p.rowStride];
