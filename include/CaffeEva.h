@@ -6,9 +6,9 @@
 // approximate forward pass runs there.
 //
 // Behavioural notes
-//  * Only the approximate path exists (Init(true)).  Init(false) makes LoadCaffePara() fail with an
-//    [ERROR] line: the exact im2col+sgemm path needs convKnl/fcntWei files the reference never shipped
-//     and is out of this repository's scope.
+//  * Init(true) = the approximate path (the product); Init(false) = the reference's precise path (dense conv kernels /
+//    FC weights from convKnl.NN.bin / fcntWei.NN.bin, which the reference never shipped) as an exact baseline on the
+//    device (qcnn_model_set_layer_dense / _weights).
 //  * The reference hard-codes 1 image per batch and 100 batches (src/CaffeEva.cc:23-24).  Here they are
 //    the DEFAULTS of two environment variables read at LoadCaffePara():
 //        QCNN_BATCH    images per forward pass       (default 1)

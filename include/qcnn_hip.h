@@ -26,6 +26,8 @@
  *                               other), uploads overlapped with compute
  *   qcnn_host_register          pins CaffeEva::dataLst (LoadDataset)       src/CaffeEva.cc:95-107
  *   qcnn_forward_u8             BmpImgIO::RmMeanImg + CropImg in front     src/BmpImgIO.cc:180-224
+ *   qcnn_model_set_layer_dense  CaffePara::LoadLayerPara(false, ..) result src/CaffePara.cc:290-302
+ *   / _set_layer_weights        -> CalcFeatMap_ConvPrec / _FCntPrec        src/CaffeEva.cc:681-758, 932-966
  *   qcnn_run_layer              CaffeEva::CalcFeatMap on one layer         src/CaffeEva.cc:625-670
  *   qcnn_get_layer_output       featMapLst[l] read-back (parity dumps)     include/CaffeEva.h:109
  *   qcnn_get_layer_ms           swIndvLayerLst / DispElpsTime              src/CaffeEva.cc:297-326
@@ -113,6 +115,12 @@ int qcnn_model_begin(QcnnCtx* ctx, int layer_cnt, const QcnnLayerDesc* layers, i
 /* Declare the quantisation shape of conv/FC layer `layer` (M sub-spaces, K codewords, Cs dims each).
  * Must precede qcnn_model_commit for every conv/FC layer. */
 int qcnn_model_set_layer_shape(QcnnCtx* ctx, int layer, int M, int K, int Cs);
+/* The reference's PRECISE path (CaffeEva::Init(false): CalcFeatMap_ConvPrec src/CaffeEva.cc:681-758, _FCntPrec :932-966) as
+ * an on-device exact baseline: declare conv/FC layer `layer` dense (instead of qcnn_model_set_layer_shape, before commit)
+ * and upload bias [Ct] + weights in the reference's FILE layout after commit — conv kernels [Ct][Cin/grp][kh][kw]
+ * (convKnl.NN.bin), FC weights [Ct][D] (fcntWei.NN.bin).  Dense and quantised layers may be mixed in one model. */
+int qcnn_model_set_layer_dense(QcnnCtx* ctx, int layer);
+int qcnn_model_set_layer_weights(QcnnCtx* ctx, int layer, const float* bias, const float* weights_file);
 /* Size of the packed parameter arena (biases, permuted codebooks, permuted assignments). */
 int qcnn_model_arena_bytes(QcnnCtx* ctx, size_t* bytes);
 /* Plan buffers for up to max_batch images.  dev_arena: caller-owned device memory of
@@ -206,6 +214,8 @@ int qcnn_group_shard_bounds(const QcnnGroup* grp, int n, int rank, int* first, i
 int qcnn_group_set_option(QcnnGroup* grp, int option, int value);
 int qcnn_group_model_begin(QcnnGroup* grp, int layer_cnt, const QcnnLayerDesc* layers, int in_c, int in_h, int in_w);
 int qcnn_group_model_set_layer_shape(QcnnGroup* grp, int layer, int M, int K, int Cs);
+int qcnn_group_model_set_layer_dense(QcnnGroup* grp, int layer);
+int qcnn_group_model_set_layer_weights(QcnnGroup* grp, int layer, const float* bias, const float* weights_file);   /* rank 0 */
 /* max_batch: images of one GLOBAL batch; every rank plans the largest block it can be handed */
 int qcnn_group_model_commit(QcnnGroup* grp, int max_batch);
 /* uploads to rank 0 only; qcnn_group_model_broadcast then ships the packed arena to the other ranks */

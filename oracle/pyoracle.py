@@ -55,6 +55,7 @@ class COracle:
         lib.qo_net_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(QoLayer)]
         lib.qo_net_destroy.argtypes = [C.c_void_p]
         lib.qo_net_set_params.argtypes = [C.c_void_p, C.c_int, _f32p, _f32p, C.c_int, C.c_int, C.c_int, _u8p]
+        lib.qo_net_set_dense.argtypes = [C.c_void_p, C.c_int, _f32p, _f32p]
         lib.qo_net_fm_dims.argtypes = [C.c_void_p, C.c_int, _i32p]
         lib.qo_net_forward.argtypes = [C.c_void_p, _f32p, C.c_int]
         lib.qo_net_fm.restype = C.POINTER(C.c_float)
@@ -88,6 +89,15 @@ class COracle:
                                             np.ascontiguousarray(p["asmt"], np.uint8))
             if rc:
                 raise RuntimeError("qo_net_set_params(%d) -> %d" % (i, rc))
+
+    def set_dense(self, params):
+        """Precise path (the reference's Init(false)): {layer: dict(bias, weights)} with conv kernels [Ct][Cg][kh][kw] /
+        FC weights [Ct][D] in the convKnl / fcntWei file layout."""
+        for i, p in params.items():
+            rc = self.lib.qo_net_set_dense(self.h, i, np.ascontiguousarray(p["bias"], np.float32),
+                                           np.ascontiguousarray(p["weights"], np.float32).reshape(-1))
+            if rc:
+                raise RuntimeError("qo_net_set_dense(%d) -> %d" % (i, rc))
 
     def fm_dims(self, l):
         d = np.zeros(3, np.int32)
@@ -160,6 +170,8 @@ class RefLib:
         lib.qref_load_named.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p]
         lib.qref_load_custom.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int,
                                          C.c_int, _i32p, _i32p, _f32p]
+        if hasattr(lib, "qref_load_custom_prec"):
+            lib.qref_load_custom_prec.argtypes = lib.qref_load_custom.argtypes
         lib.qref_layer_cnt.argtypes = [C.c_void_p]
         lib.qref_fm_dims.argtypes = [C.c_void_p, C.c_int, _i32p]
         lib.qref_forward.argtypes = [C.c_void_p, _f32p, _f32p]
@@ -189,7 +201,8 @@ class RefLib:
             raise RuntimeError("reference LoadCaffePara failed for %s" % dir_path)
         self.L = self.lib.qref_layer_cnt(self.h)
 
-    def load_custom(self, dir_path, prefix, in_chw, layers):
+    def load_custom(self, dir_path, prefix, in_chw, layers, prec=False):
+        """prec: the reference's precise path (Init(false): convKnl / fcntWei files, im2col + sgemm)."""
         n = len(layers)
         types = np.array([l["type"] for l in layers], np.int32)
         ip = np.zeros((n, 7), np.int32)
@@ -199,8 +212,8 @@ class RefLib:
                      l.get("stride", 0), l.get("nod", 0), l.get("siz", 0)]
             fp[i] = [l.get("alp", 0.0), l.get("bet", 0.0), l.get("ini", 0.0), l.get("rat", 0.0)]
         with _Quiet():
-            rc = self.lib.qref_load_custom(self.h, dir_path.encode(), prefix.encode(), in_chw[0], in_chw[1],
-                                           in_chw[2], n, types, ip, fp)
+            fn = self.lib.qref_load_custom_prec if prec else self.lib.qref_load_custom
+            rc = fn(self.h, dir_path.encode(), prefix.encode(), in_chw[0], in_chw[1], in_chw[2], n, types, ip, fp)
         if rc:
             raise RuntimeError("reference LoadLayerPara failed for %s" % dir_path)
         self.L = n

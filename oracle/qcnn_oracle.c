@@ -265,6 +265,54 @@ void qo_cbn_decode(const uint8_t* blocks, int n, int bits, uint8_t* out) {
   }
 }
 
+/* ------------------------------------------------------------------ precise path ------------ */
+
+/* CaffeEva::CalcFeatMap_ConvPrec, src/CaffeEva.cc:681-758: per image and group, im2col (CvtFeatMapToFeatBuf
+ * :1195-1243, zero fill outside the map and — a quirk of its index arithmetic — at output row / column 0 for some taps of
+ * strided layers, see below; buffer row = (channel, kh, kw)) then the native cblas_sgemm_nn
+ * (src/BlasWrapper.cc:55-74: C = 0, then for every k in ascending order C += (A[k] * alpha) * B[k]), then the bias
+ * (:737-745).  src [B][H][W][Cin] NHWC, knl [Ct][Cin/grp][kh][kw] (file layout of convKnl.NN.bin), dst [B][Ho][Wo][Ct]. */
+void qo_conv_prec(const float* src, int B, int H, int W, int Cin, int knl, int stride, int pad, int grp, int Ct,
+                  const float* bias, const float* kn, float* dst) {
+  const int Ho = qo_conv_out(H, knl, stride, pad), Wo = qo_conv_out(W, knl, stride, pad);
+  const int Cg = Cin / grp, Ctg = Ct / grp, Kd = Cg * knl * knl;
+  for (int b = 0; b < B; ++b)
+    for (int g = 0; g < grp; ++g)
+      for (int c = 0; c < Ctg; ++c) {
+        const float* wr = kn + (size_t)(g * Ctg + c) * Kd;
+        for (int ho = 0; ho < Ho; ++ho)
+          for (int wo = 0; wo < Wo; ++wo) {
+            float acc = 0.0f;                                   /* pc[in] *= beta with beta = 0 */
+            for (int k = 0; k < Kd; ++k) {                      /* ik ascending: (channel, kh, kw) */
+              const int kw = k % knl, kh = k / knl % knl, ci = k / knl / knl;
+              const int hi = ho * stride - pad + kh, wi = wo * stride - pad + kw;
+              /* Rows / columns of the im2col buffer a tap fills (:1219-1226).  The lower bounds use C's truncating
+               * division on a NEGATIVE numerator: for 0 <= kh - pad <= stride - 2 they come out as 1 instead of 0, so
+               * with a stride >= 2 those taps never reach output row / column 0 (the buffer keeps its zero there).
+               * Reproduced as is: the reference's behaviour is the specification of this path. */
+              const int hoL = imax(0, (pad - kh - 1) / stride + 1), hoU = imin(Ho - 1, (pad - kh + H - 1) / stride);
+              const int woL = imax(0, (pad - kw - 1) / stride + 1), woU = imin(Wo - 1, (pad - kw + W - 1) / stride);
+              const float x = (ho >= hoL && ho <= hoU && wo >= woL && wo <= woU)
+                                  ? src[(((size_t)b * H + hi) * W + wi) * Cin + g * Cg + ci] : 0.0f;
+              const float va = wr[k] * 1.0f;                    /* pa[ik] * alpha */
+              acc = acc + va * x;
+            }
+            dst[(((size_t)b * Ho + ho) * Wo + wo) * Ct + g * Ctg + c] = acc + bias[g * Ctg + c];
+          }
+      }
+}
+
+/* CaffeEva::CalcFeatMap_FCntPrec, src/CaffeEva.cc:932-966: cblas_sgemm_nt (src/BlasWrapper.cc:77-97: val = sum over k
+ * ascending of A[k] * B[k], C = C * 0 + val * alpha), then the bias.  src [B][D], wei [Ct][D] (fcntWei.NN.bin), dst [B][Ct] */
+void qo_fc_prec(const float* src, int B, int D, int Ct, const float* bias, const float* wei, float* dst) {
+  for (int b = 0; b < B; ++b)
+    for (int c = 0; c < Ct; ++c) {
+      float val = 0.0f;
+      for (int k = 0; k < D; ++k) val = val + src[(size_t)b * D + k] * wei[(size_t)c * D + k];
+      dst[(size_t)b * Ct + c] = (0.0f + val * 1.0f) + bias[c];
+    }
+}
+
 /* ------------------------------------------------------------------ network runner ---------- */
 
 typedef struct {
@@ -272,6 +320,7 @@ typedef struct {
   float* ctrd;     /* [M][Cs][K] */
   uint8_t* asmt;   /* permuted */
   int M, K, Cs;
+  float* dense;    /* precise path: conv kernels [Ct][Cg][kh][kw] / FC weights [Ct][D] in file layout, or NULL */
 } QoParam;
 
 typedef struct {
@@ -316,7 +365,7 @@ void* qo_net_create(int inC, int inH, int inW, int L, const QoLayer* layers) {
 void qo_net_destroy(void* nv) {
   QoNet* n = (QoNet*)nv;
   for (int l = 0; l < n->L; ++l) {
-    free(n->pa[l].bias); free(n->pa[l].ctrd); free(n->pa[l].asmt);
+    free(n->pa[l].bias); free(n->pa[l].ctrd); free(n->pa[l].asmt); free(n->pa[l].dense);
   }
   for (int l = 0; l <= n->L; ++l) free(n->fm[l]);
   free(n->fm); free(n->dims); free(n->pa); free(n->ly); free(n);
@@ -343,6 +392,24 @@ int qo_net_set_params(void* nv, int l, const float* bias, const float* ctrdFile,
     p->asmt = (uint8_t*)malloc((size_t)Ct * M);
     qo_prep_asmt_fc(asmtFile, Ct, M, p->asmt);
   }
+  return 0;
+}
+
+/* precise path (CaffePara::LoadLayerPara(false, ..), src/CaffePara.cc:290-302): bias [Ct] + conv kernels
+ * [Ct][Cin/grp][kh][kw] or FC weights [Ct][D]; the layer then runs qo_conv_prec / qo_fc_prec */
+int qo_net_set_dense(void* nv, int l, const float* bias, const float* weights) {
+  QoNet* n = (QoNet*)nv;
+  const QoLayer* y = &n->ly[l];
+  QoParam* p = &n->pa[l];
+  const int Ct = n->dims[l + 1][2];
+  if (y->type != QO_CONV && y->type != QO_FCNT) return 1;
+  const size_t cnt = (y->type == QO_CONV) ? (size_t)Ct * (n->dims[l][2] / y->grpCnt) * y->knlSiz * y->knlSiz
+                                          : (size_t)Ct * n->dims[l][0] * n->dims[l][1] * n->dims[l][2];
+  free(p->bias); free(p->dense);
+  p->bias = (float*)malloc(sizeof(float) * Ct);
+  memcpy(p->bias, bias, sizeof(float) * Ct);
+  p->dense = (float*)malloc(sizeof(float) * cnt);
+  memcpy(p->dense, weights, sizeof(float) * cnt);
   return 0;
 }
 
@@ -373,6 +440,10 @@ static int run_layer(QoNet* n, int l, const float* in, int B, float* out) {
   const int Ct = n->dims[l + 1][2];
   switch (y->type) {
     case QO_CONV: {
+      if (p->dense) {
+        qo_conv_prec(in, B, H, W, C, y->knlSiz, y->stride, y->padSiz, y->grpCnt, Ct, p->bias, p->dense, out);
+        return 0;
+      }
       if (!p->ctrd) return 2;
       float* lut = (float*)malloc(sizeof(float) * (size_t)B * H * W * p->M * p->K);
       qo_conv_aprx(in, B, H, W, C, y->knlSiz, y->stride, y->padSiz, y->grpCnt, Ct, p->bias, p->ctrd,
@@ -381,6 +452,7 @@ static int run_layer(QoNet* n, int l, const float* in, int B, float* out) {
       return 0;
     }
     case QO_FCNT: {
+      if (p->dense) { qo_fc_prec(in, B, H * W * C, Ct, p->bias, p->dense, out); return 0; }
       if (!p->ctrd) return 2;
       float* lut = (float*)malloc(sizeof(float) * (size_t)B * p->M * p->K);
       qo_fc_aprx(in, B, H * W * C, Ct, p->bias, p->ctrd, p->M, p->Cs, p->K, p->asmt, out, lut);

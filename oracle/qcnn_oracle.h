@@ -46,6 +46,13 @@ void qo_conv_aprx(const float* src, int B, int H, int W, int Cin, int knl, int s
 void qo_fc_aprx(const float* src, int B, int D, int Ct, const float* bias, const float* ctrd,
                 int M, int Cs, int K, const uint8_t* asmt, float* dst, float* lutScratch);
 
+/* precise path (the reference's exact baseline, Init(false)): CalcFeatMap_ConvPrec src/CaffeEva.cc:681-758 = im2col
+ * (:1195-1243) + cblas_sgemm_nn (src/BlasWrapper.cc:55-74) + bias; kn [Ct][Cin/grp][kh][kw] */
+void qo_conv_prec(const float* src, int B, int H, int W, int Cin, int knl, int stride, int pad, int grp, int Ct,
+                  const float* bias, const float* kn, float* dst);
+/* CalcFeatMap_FCntPrec src/CaffeEva.cc:932-966 = cblas_sgemm_nt (src/BlasWrapper.cc:77-97) + bias; wei [Ct][D] */
+void qo_fc_prec(const float* src, int B, int D, int Ct, const float* bias, const float* wei, float* dst);
+
 void qo_relu(const float* src, int n, float* dst);                       /* :1027-1036 */
 void qo_lrn(const float* src, int B, int H, int W, int C, int lrnSiz, float alp, float bet, float ini,
             float* dst);                                                 /* :1038-1089 + BlasWrapper.h:101-162 */
@@ -69,6 +76,8 @@ void qo_net_destroy(void* net);
 /* parameters in FILE layout: bias [Ct], ctrd [M][K][Cs], asmt [Ct][kh][kw][M] or [Ct][M], 0-based */
 int qo_net_set_params(void* net, int layer, const float* bias, const float* ctrdFile, int M, int K, int Cs,
                       const uint8_t* asmtFile);
+/* precise path: bias [Ct] + conv kernels [Ct][Cin/grp][kh][kw] / FC weights [Ct][D] (convKnl / fcntWei file layout) */
+int qo_net_set_dense(void* net, int layer, const float* bias, const float* weights);
 int qo_net_fm_dims(void* net, int l, int* hwc3);
 /* in: [B][C][H][W]; keeps fm[0..L] (NHWC, first-FC input kept NHWC) until the next call */
 int qo_net_forward(void* net, const float* inNchw, int B);

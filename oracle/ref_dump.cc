@@ -95,11 +95,25 @@ int qref_load_named(void* hv, const char* model, const char* dir, const char* pf
 
 // Arbitrary topology through the reference's own loaders / buffer planners.
 // iparams[l] = {pad, knl, cnt, grp, stride, nod, lrnSiz}; fparams[l] = {lrnAlp, lrnBet, lrnIni, drpRat}
+static int load_custom(void* hv, const char* dir, const char* pfx, int inC, int inH, int inW,
+                       int layerCnt, const int* types, const int* iparams, const float* fparams, bool aprx);
+
 int qref_load_custom(void* hv, const char* dir, const char* pfx, int inC, int inH, int inW,
                      int layerCnt, const int* types, const int* iparams, const float* fparams) {
+  return load_custom(hv, dir, pfx, inC, inH, inW, layerCnt, types, iparams, fparams, true);
+}
+
+// The same with the reference's PRECISE path (Init(false): convKnl / fcntWei files, im2col + sgemm).
+int qref_load_custom_prec(void* hv, const char* dir, const char* pfx, int inC, int inH, int inW,
+                          int layerCnt, const int* types, const int* iparams, const float* fparams) {
+  return load_custom(hv, dir, pfx, inC, inH, inW, layerCnt, types, iparams, fparams, false);
+}
+
+static int load_custom(void* hv, const char* dir, const char* pfx, int inC, int inH, int inW,
+                       int layerCnt, const int* types, const int* iparams, const float* fparams, bool aprx) {
   RefHandle* h = static_cast<RefHandle*>(hv);
   CaffeEva& e = *h->eva;
-  e.Init(true);
+  e.Init(aprx);
   e.SetModelName("custom");
   e.SetModelPath(dir, pfx);
   CaffePara& p = e.caffeParaObj;
@@ -119,11 +133,13 @@ int qref_load_custom(void* hv, const char* dir, const char* pfx, int inC, int in
     li.stride = ip[4]; li.nodCnt = ip[5]; li.lrnSiz = ip[6];
     li.lrnAlp = fp[0]; li.lrnBet = fp[1]; li.lrnIni = fp[2]; li.drpRat = fp[3];
   }
-  if (!p.LoadLayerPara(true, ENUM_AsmtEnc::Compact)) return 1;
+  if (!p.LoadLayerPara(aprx, ENUM_AsmtEnc::Compact)) return 1;
   e.PrepFeatMap();
   e.PrepFeatBuf();
-  e.PrepCtrdBuf();
-  e.PrepAsmtBuf();
+  if (aprx) {                      // as CaffeEva::LoadCaffePara, src/CaffeEva.cc:141-146
+    e.PrepCtrdBuf();
+    e.PrepAsmtBuf();
+  }
   h->loaded = true;
   h->firstFc = find_first_fc(p);
   return 0;

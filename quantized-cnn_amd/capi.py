@@ -59,6 +59,10 @@ def load():
     lib.qcnn_sync.argtypes = [vp]
     lib.qcnn_model_begin.argtypes = [vp, i, C.POINTER(QcnnLayerDesc), i, i, i]
     lib.qcnn_model_set_layer_shape.argtypes = [vp, i, i, i, i]
+    lib.qcnn_model_set_layer_dense.argtypes = [vp, i]
+    lib.qcnn_model_set_layer_weights.argtypes = [vp, i, f32p, f32p]
+    lib.qcnn_group_model_set_layer_dense.argtypes = [vp, i]
+    lib.qcnn_group_model_set_layer_weights.argtypes = [vp, i, f32p, f32p]
     lib.qcnn_model_arena_bytes.argtypes = [vp, C.POINTER(C.c_size_t)]
     lib.qcnn_model_commit.argtypes = [vp, i, vp]
     lib.qcnn_model_set_layer_params.argtypes = [vp, i, f32p, f32p, u8p]

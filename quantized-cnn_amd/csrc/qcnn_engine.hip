@@ -24,6 +24,8 @@ std::string g_createError = "";
 
 struct LayerShape {
   int M = 0, K = 0, Cs = 0;
+  bool dense = false;                                          // precise path: bias + dense weights instead of a quantisation
+  size_t offDense = 0, denseFloats = 0;
   size_t offBias = 0, offCtrd = 0, offAsmt = 0, offDmap = 0;   // byte offsets into the arena
   size_t offCtrd2 = 0;                                         // bf16-pair split of the code book (0 bytes when not applicable)
   bool hasCtrd2 = false;
@@ -138,8 +140,18 @@ int plan_arena(QcnnCtx* c) {
     const QcnnLayerDesc& d = c->layers[l];
     if (d.type != QCNN_CONV && d.type != QCNN_FCNT) continue;
     LayerShape& s = c->shapes[l];
-    if (s.K <= 0) return fail(c, "layer %d: quantisation shape not declared (qcnn_model_set_layer_shape)", l);
     const int Ct = c->dims[l + 1].c;
+    if (s.dense) {                     // precise path: bias + weights [grp][taps][Cin/grp][Ct/grp]
+      s.offBias = off; off = align_up(off + sizeof(float) * Ct, 256);
+      const size_t taps = (d.type == QCNN_CONV) ? (size_t)d.knlSiz * d.knlSiz : 1;
+      const size_t cin = (d.type == QCNN_CONV) ? (size_t)c->dims[l].c / d.grpCnt : fm_elems(c, l);
+      s.denseFloats = taps * cin * Ct;
+      s.offDense = off; off = align_up(off + sizeof(float) * s.denseFloats, 256);
+      s.hasDmap = (d.type == QCNN_FCNT && l == c->firstFc && c->dims[l].h * c->dims[l].w > 1);
+      if (s.hasDmap) { s.offDmap = off; off = align_up(off + sizeof(int) * fm_elems(c, l), 256); }
+      continue;
+    }
+    if (s.K <= 0) return fail(c, "layer %d: neither a quantisation shape (qcnn_model_set_layer_shape) nor dense weights (qcnn_model_set_layer_dense) declared", l);
     s.offBias = off; off = align_up(off + sizeof(float) * Ct, 256);
     s.offCtrd = off; off = align_up(off + sizeof(float) * (size_t)s.M * s.Cs * s.K, 256);
     // conv layers with K = 128 and more than 4 dims per sub-space can run the bf16-pair builder (QCNN_OPT_LUT_MODE = 3)
@@ -238,6 +250,17 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
   switch (d.type) {
     case QCNN_CONV: {
       if (!s.loaded) return fail(c, "layer %d: parameters not uploaded", l);
+      if (s.dense) {                       // precise path (CalcFeatMap_ConvPrec, src/CaffeEva.cc:681-758)
+        DenseParams q;
+        q.src = src; q.dst = dst;
+        q.bias = reinterpret_cast<const float*>(c->arena + s.offBias);
+        q.wt = reinterpret_cast<const float*>(c->arena + s.offDense);
+        q.H = a.h; q.W = a.w; q.Cin = a.c; q.Ho = b.h; q.Wo = b.w; q.Ct = b.c;
+        q.knl = d.knlSiz; q.stride = d.stride; q.pad = d.padSiz; q.grp = d.grpCnt;
+        q.relu = fuseRelu ? 1 : 0; q.panels = panels;
+        e = qk_dense(q, st);
+        break;
+      }
       ConvParams p;
       p.src = src; p.dst = dst;
       p.srcNchw = 0; p.nImages = 0; p.panel0 = 0;
@@ -273,6 +296,23 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
     }
     case QCNN_FCNT: {
       if (!s.loaded) return fail(c, "layer %d: parameters not uploaded", l);
+      if (s.dense) {                       // precise path (CalcFeatMap_FCntPrec, src/CaffeEva.cc:932-966): a 1x1 conv on a 1x1 map
+        DenseParams q;
+        q.src = src; q.dst = dst;
+        if (s.hasDmap && !flatFcInput) {
+          float* flat = c->fcFlat + (size_t)p0 * fm_elems(c, l) * QCNN_PANEL;
+          e = qk_permute_rows(src, flat, reinterpret_cast<const int*>(c->arena + s.offDmap), a.h * a.w * a.c, panels, live, st);
+          if (e != hipSuccess) break;
+          q.src = flat;
+        }
+        q.bias = reinterpret_cast<const float*>(c->arena + s.offBias);
+        q.wt = reinterpret_cast<const float*>(c->arena + s.offDense);
+        q.H = 1; q.W = 1; q.Cin = a.h * a.w * a.c; q.Ho = 1; q.Wo = 1; q.Ct = b.c;
+        q.knl = 1; q.stride = 1; q.pad = 0; q.grp = 1;
+        q.relu = fuseRelu ? 1 : 0; q.panels = panels;
+        e = qk_dense(q, st);
+        break;
+      }
       FcParams p;
       p.src = src; p.dst = dst;
       p.bias = reinterpret_cast<const float*>(c->arena + s.offBias);
@@ -400,7 +440,7 @@ bool direct_input(const QcnnCtx* c) {
   const QcnnLayerDesc& d = c->layers[0];
   // ONE sub-space (a second one would be fetched from channel planes past the group's own, for the last image past the
   // caller's buffer), and the whole batch inside 4 GiB: the builders keep per-lane image offsets in 32 bits
-  if (c->shapes[0].M != 1) return false;
+  if (c->shapes[0].dense || c->shapes[0].M != 1) return false;
   if ((unsigned long long)c->maxBatch * c->inC * c->inH * c->inW * sizeof(float) >= (1ull << 32)) return false;
   return c->inC / d.grpCnt <= 4 && (c->lutMode == 0 || c->shapes[0].K == 128);
 }
@@ -652,6 +692,42 @@ int qcnn_model_set_layer_shape(QcnnCtx* c, int layer, int M, int K, int Cs) {
   return 0;
 }
 
+int qcnn_model_set_layer_dense(QcnnCtx* c, int layer) {
+  if (layer < 0 || layer >= c->L) return fail(c, "layer %d out of range", layer);
+  const QcnnLayerDesc& d = c->layers[layer];
+  if (d.type != QCNN_CONV && d.type != QCNN_FCNT) return fail(c, "layer %d carries no parameters", layer);
+  if (c->committed) return fail(c, "qcnn_model_set_layer_dense must precede qcnn_model_commit");
+  c->shapes[layer] = LayerShape();
+  c->shapes[layer].dense = true;
+  return 0;
+}
+
+int qcnn_model_set_layer_weights(QcnnCtx* c, int layer, const float* bias, const float* weights_file) {
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (!c->committed) return fail(c, "qcnn_model_commit must precede qcnn_model_set_layer_weights");
+  if (layer < 0 || layer >= c->L) return fail(c, "layer %d out of range", layer);
+  const QcnnLayerDesc& d = c->layers[layer];
+  LayerShape& s = c->shapes[layer];
+  if (!s.dense) return fail(c, "layer %d was not declared dense (qcnn_model_set_layer_dense)", layer);
+  const int Ct = c->dims[layer + 1].c;
+  const int grp = (d.type == QCNN_CONV) ? d.grpCnt : 1;
+  const int taps = (d.type == QCNN_CONV) ? d.knlSiz * d.knlSiz : 1;
+  const int Cg = (d.type == QCNN_CONV) ? c->dims[layer].c / grp : (int)fm_elems(c, layer);
+  const int Ctg = Ct / grp;
+  // file layout [Ct][Cg][kh][kw] (convKnl) / [Ct][D] (fcntWei)  ->  [grp][tap][Cg][Ctg], output channel innermost
+  std::vector<float> wt(s.denseFloats);
+  for (int g = 0; g < grp; ++g)
+    for (int ch = 0; ch < Ctg; ++ch)
+      for (int ci = 0; ci < Cg; ++ci)
+        for (int t = 0; t < taps; ++t)
+          wt[(((size_t)g * taps + t) * Cg + ci) * Ctg + ch] = weights_file[(((size_t)(g * Ctg + ch)) * Cg + ci) * taps + t];
+  HIP_TRY(c, hipMemcpyAsync(c->arena + s.offBias, bias, sizeof(float) * Ct, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->arena + s.offDense, wt.data(), sizeof(float) * wt.size(), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  s.loaded = true;
+  return 0;
+}
+
 int qcnn_model_arena_bytes(QcnnCtx* c, size_t* bytes) {
   if (plan_arena(c)) return 1;
   *bytes = c->arenaBytes;
@@ -779,7 +855,7 @@ int qcnn_model_set_layer_params(QcnnCtx* c, int layer, const float* bias, const 
   if (layer < 0 || layer >= c->L) return fail(c, "layer %d out of range", layer);
   const QcnnLayerDesc& d = c->layers[layer];
   LayerShape& s = c->shapes[layer];
-  if (s.K <= 0) return fail(c, "layer %d carries no parameters", layer);
+  if (s.K <= 0) return fail(c, "layer %d carries no quantised parameters", layer);
   const int Ct = c->dims[layer + 1].c;
   const int M = s.M, K = s.K;
   // PrepAsmtBuf: conv [Ct][kh][kw][M] -> [kh][kw][M][Ct] (:585-586); FC [Ct][M] -> [M][Ct] (:610-611).  Stored as
@@ -849,7 +925,7 @@ int qcnn_model_set_layer_params_cbn(QcnnCtx* c, int layer, const float* bias, co
 int qcnn_model_mark_loaded(QcnnCtx* c) {
   if (!c->committed) return fail(c, "model not committed");
   for (int l = 0; l < c->L; ++l)
-    if (c->shapes[l].K > 0) c->shapes[l].loaded = true;
+    if (c->shapes[l].K > 0 || c->shapes[l].dense) c->shapes[l].loaded = true;
   return 0;
 }
 

@@ -155,6 +155,18 @@ int qcnn_group_model_set_layer_shape(QcnnGroup* g, int layer, int M, int K, int 
   return 0;
 }
 
+int qcnn_group_model_set_layer_dense(QcnnGroup* g, int layer) {
+  FOR_ALL(g, qcnn_model_set_layer_dense(c, layer));
+  return 0;
+}
+
+int qcnn_group_model_set_layer_weights(QcnnGroup* g, int layer, const float* bias, const float* weights_file) {
+  if (qcnn_model_set_layer_weights(g->ctx[0], layer, bias, weights_file))
+    return gfail(g, "rank 0 (device %d): %s", g->devs[0], qcnn_last_error(g->ctx[0]));
+  g->broadcastDone = false;
+  return 0;
+}
+
 int qcnn_group_model_commit(QcnnGroup* g, int max_batch) {
   if (max_batch <= 0) return gfail(g, "max_batch must be positive");
   const int G = (int)g->ctx.size();

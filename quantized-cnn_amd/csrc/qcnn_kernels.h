@@ -167,6 +167,19 @@ struct FcParams {
   int lutF16;            // as ConvParams::lutF16
 };
 
+// Precise path (qcnn_dense.hip): conv and FC layers with dense weights (FC = 1x1 conv on a 1x1 map, Cin = D).
+struct DenseParams {
+  const float* src;      // [panels][H*W*Cin][128]
+  float* dst;            // [panels][Ho*Wo*Ct][128]
+  const float* bias;     // [Ct]
+  const float* wt;       // [grp][kh][kw][Cin/grp][Ct/grp]: the reference's [Ct][Cin/grp][kh][kw] kernels, output channel innermost
+  int H, W, Cin, Ho, Wo, Ct;
+  int knl, stride, pad, grp;
+  int relu;
+  int panels;
+};
+hipError_t qk_dense(const DenseParams& p, hipStream_t st);
+
 // lutMode: 0 exact VALU, 1 f32 MFMA (2 = f32 MFMA with fp16-rounded table entries, see lutF16), 3 = bf16-pair MFMA for
 // the conv layers with K = 128 and more than 4 dims per sub-space (every other layer as mode 1).  Return hipError_t of the launch.
 // bytes of ConvParams::ctrd2 for M sub-spaces

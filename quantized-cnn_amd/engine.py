@@ -102,6 +102,20 @@ class QcnnEngine:
         if upload:
             self.upload(params)
 
+    def load_dense_model(self, in_chw, layers, dense, max_batch):
+        """The reference's precise path (Init(false)): dense = {layer: dict(bias, weights)} in the convKnl / fcntWei file
+        layout (synth.make_dense_params)."""
+        arr = (capi.QcnnLayerDesc * len(layers))(*[capi.layer_desc(l) for l in layers])
+        self._chk(self.lib.qcnn_model_begin(self.h, len(layers), arr, in_chw[0], in_chw[1], in_chw[2]))
+        for i in dense:
+            self._chk(self.lib.qcnn_model_set_layer_dense(self.h, i))
+        self.layers, self.L, self.in_chw = layers, len(layers), tuple(in_chw)
+        self.commit(max_batch)
+        for i, p in dense.items():
+            bias = np.ascontiguousarray(p["bias"], np.float32)
+            w = np.ascontiguousarray(p["weights"], np.float32)
+            self._chk(self.lib.qcnn_model_set_layer_weights(self.h, i, bias.ctypes.data, w.ctypes.data))
+
     def fm_dims(self, l):
         d = (C.c_int * 3)()
         self._chk(self.lib.qcnn_fm_dims(self.h, l, d))

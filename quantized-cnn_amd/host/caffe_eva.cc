@@ -107,8 +107,6 @@ bool CaffeEva::LoadDataset(const std::string& dirPathData) {
 bool CaffeEva::LoadCaffePara(void) {
   printf("[CHECK-POINT] entering CaffeEva::LoadCaffePara()\n");
   modelReady_ = false;
-  if (!enblAprx)
-    return fail("the precise (im2col + sgemm) path is not part of this library; call Init(true)");
 
   caffeParaObj.Init(dirPathMain, fileNamePfx);
   if (modelName == "AlexNet") caffeParaObj.ConfigLayer_AlexNet();
@@ -176,6 +174,10 @@ bool CaffeEva::buildDeviceModel(void) {
   for (int l = 0; l < L; ++l) {
     const ENUM_LyrType t = caffeParaObj.layerInfoLst[l].type;
     if (t != ENUM_LyrType::Conv && t != ENUM_LyrType::FCnt) continue;
+    if (!enblAprx) {                     // precise path (Init(false)): dense kernels / weights, src/CaffeEva.cc:681-758, 932-966
+      if (qcnn_group_model_set_layer_dense(grp_, l)) return fail("qcnn_group_model_set_layer_dense");
+      continue;
+    }
     const Matrix<float>& ctrd = caffeParaObj.layerParaLst[l].ctrdLst;   // [M][K][Cs]
     if (ctrd.GetDimCnt() != 3) return fail("layer without a 3-D ctrdLst");
     if (qcnn_group_model_set_layer_shape(grp_, l, ctrd.GetDimLen(0), ctrd.GetDimLen(1), ctrd.GetDimLen(2)))
@@ -190,10 +192,22 @@ bool CaffeEva::buildDeviceModel(void) {
     int hwc[3];
     qcnn_fm_dims(ctx_, l + 1, hwc);
     const size_t Ct = static_cast<size_t>(hwc[2]);
-    const size_t M = static_cast<size_t>(lp.ctrdLst.GetDimLen(0));
     const size_t taps = (li.type == ENUM_LyrType::Conv) ? static_cast<size_t>(li.knlSiz) * li.knlSiz : 1;
     if (static_cast<size_t>(lp.biasVec.GetEleCnt()) != Ct)
       return fail("layer parameter files: biasVec does not have one entry per output channel");
+    if (!enblAprx) {
+      int in[3];
+      qcnn_fm_dims(ctx_, l, in);
+      const Matrix<float>& w = (li.type == ENUM_LyrType::Conv) ? lp.convKnlLst : lp.fcntWeiMat;
+      const size_t want = (li.type == ENUM_LyrType::Conv) ? Ct * (static_cast<size_t>(in[2]) / li.grpCnt) * taps
+                                                          : Ct * static_cast<size_t>(in[0]) * in[1] * in[2];
+      if (static_cast<size_t>(w.GetEleCnt()) != want)
+        return fail("layer parameter files: convKnl / fcntWei does not hold Ct x inputs x taps weights");
+      if (qcnn_group_model_set_layer_weights(grp_, l, lp.biasVec.GetDataPtr(), w.GetDataPtr()))
+        return fail("qcnn_group_model_set_layer_weights");
+      continue;
+    }
+    const size_t M = static_cast<size_t>(lp.ctrdLst.GetDimLen(0));
     if (static_cast<size_t>(lp.asmtLst.GetEleCnt()) != Ct * taps * M)
       return fail("layer parameter files: asmtLst does not hold Ct x taps x M assignments");
     if (qcnn_group_model_set_layer_params(grp_, l, lp.biasVec.GetDataPtr(), lp.ctrdLst.GetDataPtr(), lp.asmtLst.GetDataPtr()))

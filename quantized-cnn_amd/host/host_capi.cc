@@ -109,6 +109,23 @@ int qh_eva_featmaps(const char* mainDir, const char* bmpPath, const int* layers,
   return 0;
 }
 
+// CaffeEva with Init(aprx) on a data root laid out like the reference's, one image [3][227][227] in, probabilities out
+int qh_eva_prob(const char* mainDir, const char* model, const char* sub, const char* pfx, int aprx, const float* img,
+                int c, int h, int w, float* prob, int cap) {
+  CaffeEva eva;
+  eva.Init(aprx != 0);
+  eva.SetModelName(model);
+  eva.SetModelPath(std::string(mainDir) + "/" + sub, pfx);
+  if (!eva.LoadCaffePara()) return 3;
+  Matrix<float> in(1, c, h, w), out;
+  memcpy(in.GetDataPtr(), img, sizeof(float) * in.GetEleCnt());
+  eva.ExecForwardPass(in, &out);
+  if (!eva.GetErrorMsg().empty()) return 4;
+  if (out.GetEleCnt() > cap) return 6;
+  memcpy(prob, out.GetDataPtr(), sizeof(float) * out.GetEleCnt());
+  return out.GetEleCnt() > 0 ? 0 : 7;
+}
+
 #endif  // QH_NO_DEVICE
 
 // Matrix semantics the reference relies on; returns the number of failed checks

@@ -69,6 +69,42 @@ def make_params(in_chw, layers, seed=0, spec: Optional[Dict[int, dict]] = None):
     return out
 
 
+def make_dense_params(in_chw, layers, seed=0):
+    """Random parameters of the reference's PRECISE path (Init(false), src/CaffePara.cc:290-302): per conv/FC layer
+    dict(bias [Ct], weights) with conv kernels [Ct][Cin/grp][kh][kw] (convKnl.NN.bin) or FC weights [Ct][D]
+    (fcntWei.NN.bin).  Same scaling rule as make_params."""
+    sizes = fmap_sizes(in_chw, layers)
+    rng = np.random.default_rng(seed)
+    out = {}
+    first = True
+    for i, ly in enumerate(layers):
+        h, w, c = sizes[i]
+        if ly["type"] == CONV:
+            cg = c // ly["grp"]
+            fan_in = ly["knl"] * ly["knl"] * cg
+            shape = (ly["cnt"], cg, ly["knl"], ly["knl"])
+            ct = ly["cnt"]
+        elif ly["type"] == FCNT:
+            fan_in = h * w * c
+            shape = (ly["nod"], fan_in)
+            ct = ly["nod"]
+        else:
+            continue
+        scale = np.float32(np.sqrt(2.0 / fan_in) * (1.0 / 64.0 if first else 1.0))
+        first = False
+        out[i] = dict(bias=(rng.standard_normal(ct) * 0.1).astype(np.float32),
+                      weights=(rng.standard_normal(shape) * scale).astype(np.float32))
+    return out
+
+
+def write_dense_param_dir(dir_path: str, prefix: str, params) -> None:
+    os.makedirs(dir_path, exist_ok=True)
+    for i, p in params.items():
+        fileio.write_bin(fileio.param_path(dir_path, prefix, "biasVec", i + 1, "bin"), p["bias"])
+        kind = "convKnl" if p["weights"].ndim == 4 else "fcntWei"
+        fileio.write_bin(fileio.param_path(dir_path, prefix, kind, i + 1, "bin"), p["weights"])
+
+
 def write_param_dir(dir_path: str, prefix: str, params) -> None:
     os.makedirs(dir_path, exist_ok=True)
     for i, p in params.items():

@@ -165,3 +165,83 @@ def test_first_layer_with_two_subspaces_is_not_read_in_place():
     e_inf, e_l2 = rel_err(prob, orc.fm(len(layers)).reshape(5, -1))
     assert e_inf <= TOL and e_l2 <= TOL
     eng.close()
+
+
+# ---------------------------------------------------------------- the reference's precise path on the device ----
+def _dense_vs_oracle(in_chw, layers, n, seed):
+    dense = synth.make_dense_params(in_chw, layers, seed=seed)
+    imgs = synth.make_images(n, in_chw, seed=seed + 1)
+    orc = po.COracle(in_chw, layers)
+    orc.set_dense(dense)
+    orc.forward(imgs)
+    for keep_all in (1, 0):
+        eng = engine.QcnnEngine(0)
+        eng.set_option(capi.OPT_KEEP_ALL, keep_all)
+        eng.load_dense_model(in_chw, layers, dense, n)
+        prob, top5 = eng.forward_host(imgs)
+        if keep_all:
+            for l in range(len(layers) + 1):
+                e_inf, e_l2 = rel_err(eng.layer_output(l, n), orc.fm(l))
+                assert e_inf <= TOL and e_l2 <= TOL, "fm[%d]: %g %g" % (l, e_inf, e_l2)
+        e_inf, e_l2 = rel_err(prob, orc.fm(len(layers)).reshape(n, -1))
+        assert e_inf <= TOL and e_l2 <= TOL
+        assert np.array_equal(top5, np.stack([orc.top5(orc.fm(len(layers))[i]) for i in range(n)]))
+        eng.close()
+
+
+def test_precise_path_tiny_network():
+    """Init(false) of the reference (im2col + sgemm, src/CaffeEva.cc:681-758, 932-966) as dense layers on the device:
+    every feature map of the tiny network (strided first layer — the reference's im2col drops some taps at output row /
+    column 0 there, reproduced —, grouped padded conv, two FC layers) against the oracle, which is pinned bit for bit
+    to the compiled reference (tests/test_oracle_vs_reference.py); 131 images = two panels, the second ragged."""
+    in_chw, layers = topo.tiny_model()
+    _dense_vs_oracle(in_chw, layers, 131, seed=41)
+
+
+def test_precise_path_conv_geometries():
+    layers = [topo.conv(3, 7, 24, 1, 3), topo.relu(), topo.conv(0, 5, 96, 2, 2), topo.relu(),
+              topo.conv(0, 1, 16, 1, 2), topo.relu(), topo.conv(2, 3, 200, 1, 1), topo.relu(),
+              topo.fcnt(48), topo.smax()]
+    _dense_vs_oracle((3, 61, 85), layers, 3, seed=43)
+
+
+def test_precise_path_alexnet_first_layers():
+    """AlexNet's conv1 (11x11 stride 4: three of every eleven taps miss output row / column 0 in the reference), LRN, pool
+    and the grouped conv2 at full size, one image, against the oracle; the approximate and the precise layer types can be
+    mixed in one model (conv1 dense, conv2 quantised)."""
+    in_chw, layers, _, _ = topo.MODELS["AlexNet"]
+    layers = layers[:6]                                    # conv1 relu lrn pool conv2 relu
+    dense = synth.make_dense_params(in_chw, layers, seed=45)
+    imgs = synth.make_images(1, in_chw, seed=46)
+    orc = po.COracle(in_chw, layers)
+    orc.set_dense(dense)
+    orc.forward(imgs)
+    eng = engine.QcnnEngine(0)
+    eng.load_dense_model(in_chw, layers, dense, 1)
+    eng.forward_host(imgs, want_top5=False)
+    for l in (1, 4, 5):
+        e_inf, e_l2 = rel_err(eng.layer_output(l, 1), orc.fm(l))
+        assert e_inf <= TOL and e_l2 <= TOL, "fm[%d]: %g %g" % (l, e_inf, e_l2)
+    eng.close()
+    quant = synth.make_params(in_chw, layers, seed=47)
+    mixed = po.COracle(in_chw, layers)
+    mixed.set_dense({0: dense[0]})
+    mixed.set_params({4: quant[4]})
+    mixed.forward(imgs)
+    eng = engine.QcnnEngine(0)
+    lib = eng.lib
+    arr = (capi.QcnnLayerDesc * len(layers))(*[capi.layer_desc(l) for l in layers])
+    eng._chk(lib.qcnn_model_begin(eng.h, len(layers), arr, *in_chw))
+    eng._chk(lib.qcnn_model_set_layer_dense(eng.h, 0))
+    m, k, cs = quant[4]["ctrd"].shape
+    eng._chk(lib.qcnn_model_set_layer_shape(eng.h, 4, m, k, cs))
+    eng.layers, eng.L, eng.in_chw = layers, len(layers), in_chw
+    eng.commit(1)
+    w = np.ascontiguousarray(dense[0]["weights"], np.float32)
+    b = np.ascontiguousarray(dense[0]["bias"], np.float32)
+    eng._chk(lib.qcnn_model_set_layer_weights(eng.h, 0, b.ctypes.data, w.ctypes.data))
+    eng.upload({4: quant[4]})
+    eng.forward_host(imgs, want_top5=False)
+    e_inf, e_l2 = rel_err(eng.layer_output(5, 1), mixed.fm(5))
+    assert e_inf <= TOL and e_l2 <= TOL
+    eng.close()

@@ -260,3 +260,29 @@ def test_single_image_mode_matches_golden_top5(golden_alex_real):
                          env=dict(os.environ, QCNN_LUT="exact")).stdout
     got = [int(m) for m in re.findall(r"No\. \d: .* \((\d+) / [0-9.]+\)", out)]
     assert got == [int(x) for x in golden_alex_real["top5"][0]], out[-1500:]
+
+
+@pytest.mark.gpu
+def test_host_mirror_precise_path_alexnet(tmp_path):
+    """CaffeEva::Init(false) — the reference's precise path — through the C++ host mirror: AlexNet with synthetic dense
+    parameters written in the reference's convKnl / fcntWei file layout, one image, probabilities against the oracle's
+    restatement of CalcFeatMap_ConvPrec / _FCntPrec (pinned to the compiled reference on the CPU tier)."""
+    in_chw, layers, sub, pfx = topo.MODELS["AlexNet"]
+    dense = synth.make_dense_params(in_chw, layers, seed=61)
+    root = str(tmp_path)
+    synth.write_dense_param_dir(os.path.join(root, sub), pfx, dense)
+    img = synth.make_images(1, in_chw, seed=62)
+    orc = po.COracle(in_chw, layers)
+    orc.set_dense(dense)
+    orc.forward(img)
+    want = orc.fm(len(layers)).reshape(-1)
+    lib = host()
+    f32 = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+    lib.qh_eva_prob.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, f32, C.c_int, C.c_int, C.c_int, f32, C.c_int]
+    prob = np.zeros(1000, np.float32)
+    with po._Quiet():
+        rc = lib.qh_eva_prob(root.encode(), b"AlexNet", sub.encode(), pfx.encode(), 0, np.ascontiguousarray(img), 3, 227, 227,
+                             prob, prob.size)
+    assert rc == 0
+    assert np.abs(prob - want).max() <= 1e-4 * np.abs(want).max()
+    assert np.array_equal(np.argsort(-prob, kind="stable")[:5], np.argsort(-want, kind="stable")[:5])

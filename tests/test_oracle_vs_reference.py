@@ -93,3 +93,29 @@ def test_alexnet_real_bmp_all_feature_maps():
     for l in range(len(layers) + 1):
         assert np.array_equal(ref.fm(l), orc.fm(l)), "fm[%d]" % l
     assert np.array_equal(ref.top5(), orc.top5(orc.fm(len(layers))[0]))
+
+
+def test_precise_path_matches_reference(tmp_path):
+    """The reference's exact baseline (Init(false): im2col + sgemm, src/CaffeEva.cc:681-758, 932-966, native sgemm
+    src/BlasWrapper.cc:55-97): qo_conv_prec / qo_fc_prec against the compiled reference, every feature map of the tiny
+    network (grouped conv, padding, stride) bit for bit, and single layers on random activations."""
+    in_chw, layers = topo.tiny_model()
+    dense = synth.make_dense_params(in_chw, layers, seed=31)
+    synth.write_dense_param_dir(str(tmp_path), "t", dense)
+    ref = po.RefLib()
+    ref.load_custom(str(tmp_path), "t", in_chw, layers, prec=True)
+    orc = po.COracle(in_chw, layers)
+    orc.set_dense(dense)
+    imgs = synth.make_images(2, in_chw, seed=32)
+    orc.forward(imgs)
+    for i in range(2):
+        prob = ref.forward(imgs[i:i + 1])
+        for l in range(len(layers) + 1):
+            assert np.array_equal(ref.fm(l)[0], orc.fm(l)[i]), "image %d fm[%d]" % (i, l)
+        assert np.array_equal(prob, orc.fm(len(layers))[i].reshape(-1))
+    rng = np.random.default_rng(33)
+    for l, ly in enumerate(layers):
+        if ly["type"] in (topo.CONV, topo.FCNT):
+            h, w, c = orc.fm_dims(l)
+            x = (rng.standard_normal((1, h, w, c)) * 3.0).astype(np.float32)
+            assert np.array_equal(ref.run_layer(l, x), orc.run_layer(l, x, 1)), "layer %d" % l
