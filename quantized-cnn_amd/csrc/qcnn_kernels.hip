@@ -1495,10 +1495,17 @@ QkSplitPlan qk_conv_plan(const ConvParams& p, size_t scratchFloats) {
   double bestCost = makespan(tiles, 1);
   const long long wgs = (long long)tiles * p.panels * ny;
   const int rem = (int)(wgs % 256);                 // workgroups beyond whole rounds
-  int cand[2] = {0, tiles};
-  if (rem > 0 && wgs > 256) cand[1] = std::max(0, tiles - (rem + p.panels * ny - 1) / (p.panels * ny));
-  for (int ci = 0; ci < 2; ++ci) {
-    const int from = cand[ci];
+  // candidate tails: every tile; the tiles beyond whole rounds of 256 workgroups; that tail widened by a quarter, a half
+  // and a whole round (finer slices at the end of the launch balance the last round better)
+  std::vector<int> cand = {0};
+  if (rem > 0 && wgs > 256) {
+    const int perTile = p.panels * ny;
+    for (int extra : {0, 64, 128, 256}) {
+      const int from = tiles - (rem + extra + perTile - 1) / perTile;
+      if (from > 0 && std::find(cand.begin(), cand.end(), from) == cand.end()) cand.push_back(from);
+    }
+  }
+  for (const int from : cand) {
     if (from >= tiles) continue;
     int minS = S[from];
     for (int r = from; r < tiles; ++r) minS = std::min(minS, S[r]);
