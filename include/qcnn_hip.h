@@ -87,6 +87,13 @@ enum {
                               fixed order; FC layers pick their sub-space split for the panel count of the launch.  Results
                               then depend on the batch size to rounding (~1e-6).  Never applied with the exact builder
                               (QCNN_OPT_LUT_MODE = 0).  0 = one workgroup per tile, batch-size-invariant bits. */
+  QCNN_OPT_SLIDE = 7,      /* 1 (default): conv layers with K = 128 whose windows overlap in at most three output rows
+                              (knl <= 3 * stride) and whose channel count leaves room for three accumulator slots may run
+                              the SLIDING kernel — a workgroup sweeps the source rows under a segment of one output column
+                              and builds every source pixel of the strip once — when the launch planner predicts it to be
+                              faster than the tile kernel.  Same summation order as the tile kernels ((kh, kw, m)), MFMA
+                              builders only.  0 = tile kernels only; 2 = whenever
+                              a layer is eligible, whatever the planner predicts (tests). */
   QCNN_OPT_HOST_CHUNK = 6, /* panels per chunk (default 2) of a qcnn_forward_host batch of at least two chunks: every chunk is
                               uploaded on a copy stream and its layers start when it has arrived, so the upload of chunk
                               k + 1 runs under the layers of chunk k; all chunks fill the same whole-batch feature maps.
@@ -184,7 +191,8 @@ int qcnn_get_layer_output_range(QcnnCtx* ctx, int l, int first, int n, float* ho
 int qcnn_run_layer(QcnnCtx* ctx, int layer, const float* in_host, int n, float* out_host);
 
 /* How the last launch of conv layer `layer` was cut (QCNN_OPT_SPLIT): *slices = workgroups per split tile (1 = no tile
- * was split), *tiles_unsplit = tiles of the heaviest-first order that ran whole (-1 when nothing was split). */
+ * was split), *tiles_unsplit = tiles of the heaviest-first order that ran whole (-1 when nothing was split); sliding
+ * kernel (QCNN_OPT_SLIDE): *tiles_unsplit = -2, *slices = segments per output column. */
 int qcnn_get_layer_split(QcnnCtx* ctx, int layer, int* tiles_unsplit, int* slices);
 
 /* ---- timing (QCNN_OPT_PROFILE = 1) ---- */

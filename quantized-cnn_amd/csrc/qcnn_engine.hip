@@ -31,6 +31,8 @@ struct LayerShape {
   bool hasCtrd2 = false;
   size_t asmtBytes = 0;
   size_t offProg = 0, progBytes = 0;                           // conv with K = 128: offsets in consumption order (QkProgram)
+  size_t offProgS = 0, progSBytes = 0;                         // ... and in the order of the sliding variant, where it applies
+  int segN = 0, segBeg[9] = {0};                               // sliding plan of the last planned launch geometry
   bool hasDmap = false;
   bool loaded = false;
   int planKey = -1;                                            // conv: split plan of the last planned launch geometry (qk_conv_plan)
@@ -60,6 +62,7 @@ struct QcnnCtx {
   int nStreams = 2;                  // QCNN_OPT_STREAMS: sub-batches of whole panels run concurrently
   int smallBatch = 1;                // QCNN_OPT_SMALL_BATCH: few-image kernels for batches <= kSmallBatchMax
   int hostChunk = 2;                 // QCNN_OPT_HOST_CHUNK: panels per chunk of a large qcnn_forward_host batch (0: one launch)
+  int slide = 1;                     // QCNN_OPT_SLIDE: sliding-window conv kernels where they pay (MFMA builders only)
   int split = 1;                     // QCNN_OPT_SPLIT: launches that do not fill the chip split their tail (MFMA builders only)
   hipStream_t aux[3] = {nullptr, nullptr, nullptr};
   hipEvent_t evFork = nullptr, evJoin[3] = {nullptr, nullptr, nullptr};
@@ -167,6 +170,12 @@ int plan_arena(QcnnCtx* c) {
       const QkProgram pg = qk_conv_program(sl, d.knlSiz, d.stride);
       s.progBytes = (size_t)pg.rfH * pg.rfW * s.M * pg.rowU16 * sizeof(uint16_t);
       s.offProg = off; off = align_up(off + s.progBytes + QCNN_ROWS_PAD, 256);
+      s.progSBytes = 0;
+      if (qk_slide_slots(sl, d.knlSiz, d.stride) > 0) {
+        const QkProgram ps = qk_conv_program_slide(sl, d.knlSiz, d.stride);
+        s.progSBytes = (size_t)ps.rfH * ps.rfW * s.M * ps.rowU16 * sizeof(uint16_t);
+        s.offProgS = off; off = align_up(off + s.progSBytes + QCNN_ROWS_PAD, 256);
+      }
     }
     s.hasDmap = (d.type == QCNN_FCNT && l == c->firstFc && c->dims[l].h * c->dims[l].w > 1);
     if (s.hasDmap) { s.offDmap = off; off = align_up(off + sizeof(int) * fm_elems(c, l), 256); }
@@ -276,6 +285,7 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
       // few-image kernel unless the layer's shape is outside what it covers (a tap window x K that does not fit its LDS
       // table): the panel kernel handles every shape set_layer_shape accepts
       p.splitFrom = 0; p.splitZ = 1; p.partial = nullptr;
+      p.nSeg = 0; p.progS = s.progSBytes ? reinterpret_cast<const uint16_t*>(c->arena + s.offProgS) : nullptr;
       s.lastFrom = -1; s.lastZ = 1;
       e = small ? qk_conv_small(p, live, st) : hipErrorInvalidValue;
       if (e == hipErrorInvalidValue) {
@@ -284,8 +294,22 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
         if (c->split && c->lutMode >= 1 && c->convPartial) {
           const size_t share = kConvPartialFloats / (size_t)nsub;
           const int key = panels * 8 + nsub;
-          if (s.planKey != key) { s.plan = qk_conv_plan(p, share); s.planKey = key; }
-          if (s.plan.Z > 1) {
+          if (s.planKey != key) {
+            s.plan = qk_conv_plan(p, share);
+            s.planKey = key;
+            s.segN = 0;
+            if (c->slide && p.progS) {                // sliding variant where it is predicted to beat the (split) tile kernel
+              ConvParams t = p;
+              qk_conv_plan_slide(t, c->slide >= 2 ? 1e30 : s.plan.cost);   // 2: whenever the layer is eligible (tests)
+              s.segN = t.nSeg;
+              for (int i = 0; i <= t.nSeg && i < 9; ++i) s.segBeg[i] = t.segBeg[i];
+            }
+          }
+          if (s.segN > 0) {
+            p.nSeg = s.segN;
+            for (int i = 0; i <= s.segN; ++i) p.segBeg[i] = s.segBeg[i];
+            s.lastFrom = -2; s.lastZ = s.segN;       // reported by qcnn_get_layer_split as (-2, segments per row)
+          } else if (s.plan.Z > 1) {
             p.splitFrom = s.plan.splitFrom; p.splitZ = s.plan.Z; p.partial = c->convPartial + share * sub;
             s.lastFrom = s.plan.splitFrom; s.lastZ = s.plan.Z;
           }
@@ -620,7 +644,8 @@ int qcnn_set_option(QcnnCtx* c, int option, int value) {
     case QCNN_OPT_KEEP_ALL: c->keepAll = value ? 1 : 0; return 0;
     case QCNN_OPT_PROFILE: c->profile = value ? 1 : 0; return 0;
     case QCNN_OPT_SMALL_BATCH: c->smallBatch = value ? 1 : 0; return 0;
-    case QCNN_OPT_SPLIT: c->split = value ? 1 : 0; return 0;
+    case QCNN_OPT_SPLIT: c->split = value ? 1 : 0; for (LayerShape& ls : c->shapes) ls.planKey = -1; return 0;
+    case QCNN_OPT_SLIDE: c->slide = value < 0 ? 0 : (value > 2 ? 2 : value); for (LayerShape& ls : c->shapes) ls.planKey = -1; return 0;
     case QCNN_OPT_HOST_CHUNK:
       if (value < 0) return fail(c, "host chunk must be >= 0 panels");
       c->hostChunk = value; return 0;
@@ -842,9 +867,14 @@ hipError_t build_program(QcnnCtx* c, int layer, const QkSlots& sl) {
   const QcnnLayerDesc& d = c->layers[layer];
   const LayerShape& s = c->shapes[layer];
   if (!s.progBytes) return hipSuccess;
-  return qk_build_program(reinterpret_cast<const uint8_t*>(c->arena + s.offAsmt),
-                          reinterpret_cast<uint16_t*>(c->arena + s.offProg), sl, qk_conv_program(sl, d.knlSiz, d.stride),
-                          d.knlSiz, d.stride, s.M, c->stream);
+  hipError_t e = qk_build_program(reinterpret_cast<const uint8_t*>(c->arena + s.offAsmt),
+                                  reinterpret_cast<uint16_t*>(c->arena + s.offProg), sl,
+                                  qk_conv_program(sl, d.knlSiz, d.stride), d.knlSiz, d.stride, s.M, c->stream);
+  if (e == hipSuccess && s.progSBytes)
+    e = qk_build_program(reinterpret_cast<const uint8_t*>(c->arena + s.offAsmt),
+                         reinterpret_cast<uint16_t*>(c->arena + s.offProgS), sl,
+                         qk_conv_program_slide(sl, d.knlSiz, d.stride), d.knlSiz, d.stride, s.M, c->stream, 1);
+  return e;
 }
 }  // namespace
 

@@ -111,6 +111,25 @@ __host__ __device__ static inline QkProgram qk_conv_program(const QkSlots& sl, i
   g.rowU16 = sl.groups * sl.chunks * g.wgRowU16;
   return g;
 }
+// Sliding variant: slots per workgroup = output rows that look at one source row; 0 when the layer cannot slide
+// (the slots' accumulators must fit: slots * channels per wave <= 36 pairs)
+__host__ __device__ static inline int qk_slide_slots(const QkSlots& sl, int knl, int stride) {
+  const int ns = (knl + stride - 1) / stride;
+  return (ns >= 2 && ns <= 3 && ns * sl.cpw <= 36) ? ns : 0;
+}
+// program of the sliding variant: entry (source row modulo P = slots * stride, tap column kw, m) holds per slot q the
+// offsets of tap ((ry - q * stride) mod P, kw) — 0 where that is not a tap row (>= knl)
+__host__ __device__ static inline QkProgram qk_conv_program_slide(const QkSlots& sl, int knl, int stride) {
+  QkProgram g;
+  g.th = 1; g.tw = qk_slide_slots(sl, knl, stride);
+  g.np = g.tw;
+  g.rfH = g.tw * stride;
+  g.rfW = knl;
+  g.blkU16 = (g.np * sl.hp + 7) / 8 * 8;
+  g.wgRowU16 = QCNN_GATHER_WAVES * 2 * g.blkU16;
+  g.rowU16 = sl.groups * sl.chunks * g.wgRowU16;
+  return g;
+}
 static inline QkSlots qk_fc_slots(int Ct) { return qk_make_slots(Ct, 1, Ct >= 384 ? 32 : (Ct >= 96 ? 8 : 4)); }
 // table position (byte index inside one (tap, sub-space) row) of channel c of group g, or -1
 __host__ __device__ static inline int qk_slot_entry(const QkSlots& s, int g, int c) {
@@ -143,15 +162,26 @@ struct ConvParams {
   // qk_conv_plan; the summation order of a split tile differs from the reference's, so the exact builder never splits.
   int splitFrom, splitZ;
   float* partial;
+  // Sliding variant (k_conv_aprx<.., SLIDE>, qk_conv_plan_slide): every output column is cut into nSeg segments of
+  // output rows [segBeg[i], segBeg[i + 1]) (longest first); a workgroup sweeps one segment.  progS: the program table
+  // of that variant ([slots * stride][knl][M][rowU16]).  nSeg = 0: the tile kernel.
+  int nSeg;
+  int segBeg[9];
+  const uint16_t* progS;
 };
+constexpr int QK_MAX_SEGS = 8;
 struct QkSplitPlan {
   int splitFrom;         // first split tile rank (= number of tiles: nothing is split)
   int Z;                 // slices per split tile
   size_t partialFloats;  // scratch the launch needs
+  double cost;           // predicted duration of the launch in stage-times (list schedule on 256 CUs + reduction)
 };
 // decide the split of a conv launch over p.panels panels (p.partial / splitFrom / splitZ are ignored); scratchFloats =
 // what the caller can offer for partial sums
 QkSplitPlan qk_conv_plan(const ConvParams& p, size_t scratchFloats);
+// Segments of the sliding variant for a launch over p.panels panels: fills p.nSeg / p.segBeg when sliding is predicted to
+// beat `tileCost` (the list-scheduled stage-times of the tile kernel, QkSplitPlan::cost), else leaves nSeg = 0
+void qk_conv_plan_slide(ConvParams& p, double tileCost);
 
 struct FcParams {
   float* partial;        // [msplit][panels][Ct][128] scratch for split-M partial sums (msplit > 1)
@@ -201,7 +231,7 @@ hipError_t qk_decode_cbn(const uint8_t* blocks, int bits, size_t n, int Ct, int 
 
 // rows (plain table of a conv layer) -> prog (QkProgram order); one thread per program entry
 hipError_t qk_build_program(const uint8_t* rows, uint16_t* prog, QkSlots sl, QkProgram pg, int knl, int stride, int M,
-                            hipStream_t st);
+                            hipStream_t st, int slide = 0);
 
 // dst row e = src row map[e], rows of 128 images ([panels][D][128]); the first FC layer consumes its input
 // NCHW-flattened (src/CaffeEva.cc:187-189)

@@ -26,10 +26,13 @@
 #include "qcnn_kernels.h"
 
 #include <float.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 #include <algorithm>
 #include <atomic>
 #include <functional>
+#include <utility>
 #include <vector>
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -672,6 +675,8 @@ __device__ __forceinline__ void bf_store(BfSet& o, int bw) {
 // ------------------------------------------------------------------------------------------------
 struct ConvGeom {
   int W, Cin, knl, M, MG, G, wiL, wiU;
+  int slide, hiL, hiU;  // slide: the workgroup sweeps a strip of source rows under a segment of one output column (k_conv_aprx<.., SLIDE>)
+  int period;           // slide: slots * stride (the slot -> tap-column map repeats with it)
   uint32_t pixStride;   // bytes from one source pixel to the next: Cin * 512 (panels) or 4 (NCHW input read in place)
   uint32_t rowStride;   // bytes of one (tap, sub-space) row of the assignment table
 };
@@ -696,12 +701,16 @@ __host__ __device__ __forceinline__ void tile_of_rank(int r, int tilesY, int til
 }
 struct StagePos {
   int hi, wi, mg;
+  int ph;               // sliding variant: source row modulo the slot period (ConvGeom::period); else unused
 };
 __device__ __forceinline__ StagePos next_pos(const StagePos& c, const ConvGeom& g) {
   StagePos n = c;
   if (++n.mg == g.MG) {
     n.mg = 0;
-    if (++n.wi > g.wiU) { n.wi = g.wiL; ++n.hi; }
+    if (++n.wi > g.wiU) {
+      n.wi = g.wiL; ++n.hi;
+      if (g.slide && ++n.ph == g.period) n.ph = 0;
+    }
   }
   return n;
 }
@@ -818,10 +827,34 @@ __device__ __forceinline__ void conv_gather_prog(f32x2 (&acc)[TH * TW][CPW], con
   }
 }
 
-template <int TH, int TW, int CPW, int KT, int KS>
+// sliding variant: slot q currently holds an output row whose window starts at source row xq[q] (okq[q] = 0 when that
+// row lies outside the segment); it looks at source row c.hi through tap row d = c.hi - xq[q], 0 <= d < knl
+template <int TW, int CPW, int NB>
+__device__ __forceinline__ void conv_gather_slide(f32x2 (&acc)[TW][CPW], const IdxBlk<NB>& blk, const StagePos& c, int knl,
+                                                  const int (&xq)[TW], const int (&okq)[TW], uint32_t stage, int live) {
+  constexpr int DW = idx_dwords(CPW);
+#pragma unroll
+  for (int q = 0; q < TW; ++q) {
+    Idx<DW> o;
+#pragma unroll
+    for (int j = 0; j < DW; ++j) o.w[j] = blk.w[q * DW + j];
+    gather_apply<CPW>(acc[q], o, stage, live & okq[q] & in_range(c.hi - xq[q], knl));
+  }
+}
+
+// SLIDE (K = 128, MFMA builders): instead of a fixed TH x TW tile the workgroup owns a SEGMENT [segBeg, segEnd) of one
+// output COLUMN and sweeps the source rows under it from top to bottom (stages in the usual row-major order: the pixels
+// of a source row are neighbours in memory, so a first layer that reads the NCHW input in place keeps its cache lines).
+// A source row is looked at by ceil(knl / stride) output rows only, so TW = that many accumulator SLOTS suffice: slot q
+// holds output row segBeg + q, then + TW, ... — when the last row of a position's window has been consumed its sums are
+// stored and the slot starts over with the bias for the position TW rows further down.  Every source pixel of the strip
+// is built ONCE per segment (the tile kernel rebuilds it for every tile whose receptive field holds it): conv1 of AlexNet
+// 56 -> 44 stages per output position, a 3x3 / 1 layer with 128 channels 5 -> 3.5.  (The template's TH = 1, TW = slots.)
+template <int TH, int TW, int CPW, int KT, int KS, bool SLIDE = false>
 __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX, int tilesY, int chunksPerGrp, int G,
                                                         int rowStride) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
+  static_assert(!SLIDE || (KT == 8 && TH == 1), "the sliding variant exists for the program-table kernels, one output row");
   constexpr int NP = TH * TW;
   constexpr int HC = CPW / 2;
   constexpr int DW = idx_dwords(CPW);
@@ -832,8 +865,16 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
   // blockIdx.x = tile rank (heaviest first) * panels + panel for the tiles a single workgroup runs from end to end; the
   // ranks from p.splitFrom on (the tail of a launch that does not fill the chip: ConvParams::splitZ) follow, each cut into
   // splitZ workgroups that take consecutive slices of the tile's stage sequence and write partial sums
-  int ty, tx, panel, slice = 0, slices = 1, tailTile = 0;
-  {
+  int ty = 0, tx = 0, panel, slice = 0, slices = 1, tailTile = 0;
+  int segBeg = 0, segEnd = 0;                       // SLIDE: this workgroup's output rows of column tx
+  if constexpr (SLIDE) {
+    // blockIdx.x = (segment-major unit, longest segments first) * panels + panel
+    const unsigned unit = blockIdx.x / (unsigned)p.panels;
+    panel = (int)(blockIdx.x % (unsigned)p.panels);
+    const int seg = (int)(unit / (unsigned)p.Wo);
+    tx = (int)(unit % (unsigned)p.Wo);                 // the output column
+    segBeg = p.segBeg[seg]; segEnd = p.segBeg[seg + 1];   // its output rows
+  } else {
     const unsigned bx = blockIdx.x, nBody = (unsigned)p.splitFrom * (unsigned)p.panels;
     int rank;
     if (bx < nBody) {
@@ -853,8 +894,8 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
   const int Cg = p.Cin / p.grp, Ctg = p.Ct / p.grp;
   const int M = p.M;
 
-  const int ho0 = ty * TH, wo0 = tx * TW;
-  const int hoL = min(ho0 + TH, p.Ho) - 1, woL = min(wo0 + TW, p.Wo) - 1;   // last real position of the tile
+  const int ho0 = SLIDE ? segBeg : ty * TH, wo0 = SLIDE ? tx : tx * TW;
+  const int hoL = SLIDE ? segEnd - 1 : min(ho0 + TH, p.Ho) - 1, woL = SLIDE ? tx : min(wo0 + TW, p.Wo) - 1;   // last real position
   const int hiL = max(0, ho0 * p.stride - p.pad), hiU = min(p.H - 1, hoL * p.stride - p.pad + p.knl - 1);
   ConvGeom g;
   g.W = p.W; g.Cin = p.Cin; g.knl = p.knl; g.M = M; g.G = G; g.rowStride = (uint32_t)rowStride;
@@ -862,12 +903,14 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
   g.MG = (M + G - 1) / G;                           // stages per source pixel
   g.wiL = max(0, wo0 * p.stride - p.pad);
   g.wiU = min(p.W - 1, woL * p.stride - p.pad + p.knl - 1);
+  g.slide = SLIDE ? 1 : 0; g.hiL = hiL; g.hiU = hiU; g.period = TW * p.stride;
   const int cols = g.wiU - g.wiL + 1;
   const int Stot = (hiU - hiL + 1) * cols * g.MG;   // stages of the whole tile; this workgroup runs [sBeg, sBeg + S)
   const int sBeg = (int)((long long)Stot * slice / slices);
   const int S = (int)((long long)Stot * (slice + 1) / slices) - sBeg;
   const int Sp = (S + 1) & ~1;                      // every wave runs Sp stage periods (barriers)
-  const StagePos first = {hiL + (sBeg / g.MG) / cols, g.wiL + (sBeg / g.MG) % cols, sBeg % g.MG};
+  const StagePos first = {hiL + (sBeg / g.MG) / cols, g.wiL + (sBeg / g.MG) % cols, sBeg % g.MG,
+                          SLIDE ? (int)((unsigned)(hiL - (ho0 * p.stride - p.pad)) % (unsigned)(TW * p.stride)) : 0};
   if ((uint32_t)(uintptr_t)lds != 0u) __builtin_trap();   // the stage addressing assumes the dynamic segment starts at LDS byte 0
 
   const WaveRole role = assign_roles(lds, wave, lane);
@@ -1033,13 +1076,63 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
     // stage s+2 into the other row buffer][gather stage s][barrier].
     constexpr int NB = (NP * DW + 3) / 4 * 4;          // dwords of one wave half's block
     constexpr int WGROW = NGW * 2 * NB * 4;            // bytes of the workgroup's row of one program entry
-    const int rfW = (TW - 1) * p.stride + p.knl;
+    // program entry of a stage: (row, column) of its pixel relative to the unclipped receptive field of the tile — or,
+    // sliding, (source row modulo TW * stride: the slot -> tap-row map repeats with that period, tap column)
+    const int rfW = SLIDE ? p.knl : (TW - 1) * p.stride + p.knl;
     const int ry0 = ho0 * p.stride - p.pad, rx0 = wo0 * p.stride - p.pad;   // origin of the unclipped receptive field
     const uint32_t entryB = (uint32_t)(p.grp * chunksPerGrp) * WGROW;
-    const char* __restrict__ progWg = reinterpret_cast<const char*>(p.prog) + (size_t)(grp * chunksPerGrp + chunk) * WGROW;
+    const char* __restrict__ progWg =
+        reinterpret_cast<const char*>(SLIDE ? p.progS : p.prog) + (size_t)(grp * chunksPerGrp + chunk) * WGROW;
     auto rowOf = [&](const StagePos& q, int idx) {     // stages past the end: any existing row
       const StagePos c = (idx < S) ? q : first;
-      return progWg + (size_t)(uint32_t)(((c.hi - ry0) * rfW + (c.wi - rx0)) * M + c.mg) * entryB;
+      const int row = SLIDE ? c.ph : c.hi - ry0;
+      return progWg + (size_t)(uint32_t)((row * rfW + (c.wi - rx0)) * M + c.mg) * entryB;
+    };
+    // sliding: output column of every slot, the bias pointer for a slot's restart, the store of a finished position
+    int woq[TW], xq[TW], okq[TW];                       // slot state: output row, first source row of its window, in-segment
+#pragma unroll
+    for (int q = 0; q < TW; ++q) {
+      woq[q] = segBeg + q;
+      xq[q] = woq[q] * p.stride - p.pad;
+      okq[q] = in_range(q, segEnd - segBeg);
+    }
+    // a slot restarts from the bias every few stages: waves with few channels keep their bias values in registers, the
+    // others (12 channels and more: no register to spare, but also many stages per source column) re-read them
+    constexpr bool BIAS_REGS = SLIDE && CPW <= 8;
+    const float* __restrict__ biasP = p.bias + grp * Ctg + (active ? cl0 : 0);
+    float biasR[BIAS_REGS ? HC : 1];
+    if constexpr (BIAS_REGS) {
+#pragma unroll
+      for (int j = 0; j < HC; ++j) biasR[j] = biasP[j];
+    }
+    float* __restrict__ dstCol = p.dst + ((size_t)panel * p.Ho * p.Wo + (size_t)wo0) * p.Ct * PANEL +
+                                 (size_t)(grp * Ctg + (active ? cl0 : 0)) * PANEL + 4 * quad;
+    // after the last stage of a source row: positions whose window ends with this row (or with the strip) are stored and
+    // their slot restarts from the bias for the position TW rows further down
+    auto column_end = [&](const StagePos& c, int live) {
+      if (!(live && c.wi == g.wiU && c.mg == g.MG - 1)) return;
+#pragma unroll
+      for (int q = 0; q < TW; ++q) {
+        if ((c.hi - xq[q] == p.knl - 1 || c.hi == hiU) && okq[q]) {
+          float* o = dstCol + (size_t)woq[q] * p.Wo * p.Ct * PANEL;
+#pragma unroll
+          for (int j = 0; j < HC; ++j) {
+            if (cl0 + j < Ctg) {
+              f32x4 v = {acc[q][2 * j].x, acc[q][2 * j].y, acc[q][2 * j + 1].x, acc[q][2 * j + 1].y};
+              if (p.relu) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (0.0f < v[e]) ? v[e] : 0.0f;
+              }
+              *reinterpret_cast<f32x4*>(o + j * PANEL) = v;
+            }
+            const float b = BIAS_REGS ? biasR[BIAS_REGS ? j : 0] : biasP[j];
+            acc[q][2 * j] = f32x2{b, b}; acc[q][2 * j + 1] = f32x2{b, b};
+          }
+          woq[q] += TW;
+          xq[q] += TW * p.stride;
+          okq[q] = in_range(woq[q] - segBeg, segEnd - segBeg);
+        }
+      }
     };
     const uint32_t myBlk = (uint32_t)(gw * 2 + half) * NB * 4;
     const bool loader = gw == 0;
@@ -1048,6 +1141,8 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
     StagePos c0p = first;
     StagePos c1p = next_pos(c0p, g);
     StagePos c2p = next_pos(c1p, g);
+    StagePos cEnd = first;                             // sliding: the stage gathered last (its column may have ended)
+    int liveEnd = 0;
     blk_load(ba, rowOf(c0p, 0) + myBlk);
     if (loader) idx_row_to_lds<WGROW>(rowOf(c1p, 1), IDX_LDS + IDX_BUF, lane);
     barrier_after_lds_dma();
@@ -1055,7 +1150,15 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
       blk_load(bb, lds + IDX_LDS + IDX_BUF + myBlk);                      // stage s+1
       if (loader) idx_row_to_lds<WGROW>(rowOf(c2p, s + 2), IDX_LDS, lane);       // stage s+2
       TR_MID(s);
-      conv_gather_prog<TH, TW, CPW, NB>(acc, ba, c0p, g, rowStart, colStart, laneLds, activeI);   // S >= 1: stage s exists
+      if constexpr (SLIDE) {
+        // the positions the PREVIOUS stage finished are stored first: their stores then have this whole stage period
+        // before the barrier's vmcnt(0) (which the row DMA needs) would wait for them
+        column_end(cEnd, liveEnd);
+        conv_gather_slide<TW, CPW, NB>(acc, ba, c0p, p.knl, xq, okq, laneLds, activeI);
+        cEnd = c0p; liveEnd = activeI;
+      } else {
+        conv_gather_prog<TH, TW, CPW, NB>(acc, ba, c0p, g, rowStart, colStart, laneLds, activeI);   // S >= 1: stage s exists
+      }
       c0p = c1p; c1p = c2p; c2p = next_pos(c2p, g);
       TR_ARRIVE(s);
       barrier_after_lds_dma();
@@ -1063,13 +1166,20 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
       blk_load(ba, lds + IDX_LDS + myBlk);                                // stage s+2
       if (loader) idx_row_to_lds<WGROW>(rowOf(c2p, s + 3), IDX_LDS + IDX_BUF, lane);   // stage s+3
       TR_MID(s + 1);
-      conv_gather_prog<TH, TW, CPW, NB>(acc, bb, c0p, g, rowStart, colStart, laneLds | STAGE_BYTES,
-                                        activeI & in_range(s + 1, S));
+      if constexpr (SLIDE) {
+        column_end(cEnd, liveEnd);
+        conv_gather_slide<TW, CPW, NB>(acc, bb, c0p, p.knl, xq, okq, laneLds | STAGE_BYTES, activeI & in_range(s + 1, S));
+        cEnd = c0p; liveEnd = activeI & in_range(s + 1, S);
+      } else {
+        conv_gather_prog<TH, TW, CPW, NB>(acc, bb, c0p, g, rowStart, colStart, laneLds | STAGE_BYTES,
+                                          activeI & in_range(s + 1, S));
+      }
       c0p = c1p; c1p = c2p; c2p = next_pos(c2p, g);
       TR_ARRIVE(s + 1);
       barrier_after_lds_dma();
       TR_LEAVE(s + 1);
     }
+    if constexpr (SLIDE) column_end(cEnd, liveEnd);    // the strip's last column
   } else {
     // Offsets from the plain table.  Per stage: [prefetch the offsets of stage s+1][gather stage s][barrier]; two
     // offset sets alternate.
@@ -1097,7 +1207,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
     }
   }
 
-  if (active) {
+  if (active && !SLIDE) {          // (sliding: every position was stored when its window closed)
     // final map, or — a slice of a split tile — this slice's slab of partial sums [tail tile][slice][panel][position]
     // [Ct][128], which k_conv_sum adds up in slice order (ReLU there)
     const bool part = slices > 1;
@@ -1311,7 +1421,8 @@ hipError_t allow_big_lds(const void* kern, int bytes) {
 
 // rows (plain table of row slots, [kh][kw][M][rowStride]) -> program table of pre-scaled offsets ([ry][rx][M][rowU16], QkProgram): one thread per entry
 __global__ __launch_bounds__(256) void k_build_program(const uint8_t* __restrict__ rows, uint16_t* __restrict__ prog,
-                                                       QkSlots sl, QkProgram pg, int knl, int stride, int M, size_t n) {
+                                                       QkSlots sl, QkProgram pg, int knl, int stride, int M, size_t n,
+                                                       int slide) {
   for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
     const int r = (int)(e % (size_t)pg.rowU16);
     const int row = (int)(e / (size_t)pg.rowU16);
@@ -1321,7 +1432,10 @@ __global__ __launch_bounds__(256) void k_build_program(const uint8_t* __restrict
     const int pos = r3 / sl.hp, j = r3 % sl.hp;
     uint16_t v = 0;
     if (pos < pg.np) {
-      const int kh = ry - (pos / pg.tw) * stride, kw = rx - (pos % pg.tw) * stride;
+      // tile kernel: position (dy, dx) looks at tap (ry - dy * stride, rx - dx * stride); sliding: slot `pos` at tap row
+      // (ry - pos * stride) modulo the period rfH = slots * stride, tap column rx
+      const int kh = slide ? ((ry - pos * stride) % pg.rfH + pg.rfH) % pg.rfH : ry - (pos / pg.tw) * stride;
+      const int kw = slide ? rx : rx - (pos % pg.tw) * stride;
       if ((unsigned)kh < (unsigned)knl && (unsigned)kw < (unsigned)knl)
         v = (uint16_t)(rows[(size_t)((kh * knl + kw) * M + m) * sl.rowStride + wh * sl.hpB + qk_entry_byte(j)] * 64);
     }
@@ -1395,6 +1509,21 @@ hipError_t launch_conv(const ConvParams& p, const QkSlots& sl, int lutMode, hipS
   return hipGetLastError();
 }
 
+// sliding variant: grid.x = (segments x output columns, longest segments first) x panels
+template <int NS, int CPW>
+hipError_t launch_conv_slide(const ConvParams& p, const QkSlots& sl, int lutMode, hipStream_t st) {
+  const bool bf16Pairs = lutMode == 3;
+  const dim3 grid((unsigned)(p.nSeg * p.Wo * p.panels), sl.chunks * p.grp, 1);
+  const size_t shm = (size_t)2 * STAGE_BYTES + 2 * IDX_BUF;
+  const bool two = min(p.Cin / p.grp, p.Cs) > 4;
+  auto kern = two ? k_conv_aprx<1, NS, CPW, 8, 2, true> : k_conv_aprx<1, NS, CPW, 8, 1, true>;
+  if (bf16Pairs && two && p.ctrd2 != nullptr) kern = k_conv_aprx<1, NS, CPW, 8, 3, true>;
+  hipError_t e = allow_big_lds(reinterpret_cast<const void*>(kern), (int)shm);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, grid, dim3(NW * 64), shm, st, p, 0, 0, sl.chunks, 1, sl.rowStride);
+  return hipGetLastError();
+}
+
 template <int CPW>
 hipError_t launch_fc(const FcParams& p, const QkSlots& sl, int lutMode, hipStream_t st) {
   const int G = qcnn_stage_group(p.K);
@@ -1428,6 +1557,16 @@ hipError_t qk_conv_aprx(const ConvParams& pIn, int lutMode, hipStream_t st) {
   const int Ctg = p.Ct / p.grp;
   if (Ctg % 2 || p.Cs > QCNN_MAX_CS || p.K > QCNN_MAX_K) return hipErrorInvalidValue;
   const QkSlots sl = qk_conv_slots(Ctg, p.grp);
+  if (p.nSeg > 0 && p.progS != nullptr && p.K == 128 && lutMode != 0) {      // sliding variant (qk_conv_plan_slide)
+    const int ns = qk_slide_slots(sl, p.knl, p.stride);
+    if (ns == 3 && sl.cpw == 8) return launch_conv_slide<3, 8>(p, sl, lutMode, st);
+    if (ns == 3 && sl.cpw == 12) return launch_conv_slide<3, 12>(p, sl, lutMode, st);
+    if (ns == 3 && sl.cpw == 6) return launch_conv_slide<3, 6>(p, sl, lutMode, st);
+    if (ns == 3 && sl.cpw == 4) return launch_conv_slide<3, 4>(p, sl, lutMode, st);
+    if (ns == 2 && sl.cpw == 16) return launch_conv_slide<2, 16>(p, sl, lutMode, st);
+    if (ns == 2 && sl.cpw == 12) return launch_conv_slide<2, 12>(p, sl, lutMode, st);
+    if (ns == 2 && sl.cpw == 8) return launch_conv_slide<2, 8>(p, sl, lutMode, st);
+  }
   switch (sl.cpw) {
     case 32: return launch_conv<1, 1, 32>(p, sl, lutMode, st);   // 1 position  x 12 x 32 channels
     case 24: return launch_conv<1, 1, 24>(p, sl, lutMode, st);   // 1 position  x 12 x 24
@@ -1452,8 +1591,22 @@ QkSplitPlan qk_conv_plan(const ConvParams& p, size_t scratchFloats) {
   const int tilesX = (p.Wo + TW - 1) / TW, tilesY = (p.Ho + TH - 1) / TH, tiles = tilesX * tilesY;
   const int ny = sl.chunks * p.grp;
   const int G = qcnn_stage_group(p.K), MG = (p.M + G - 1) / G;
-  QkSplitPlan none = {tiles, 1, 0};
-  if ((long long)tiles * p.panels * ny >= 8 * 256) return none;          // enough workgroups for the tail not to matter
+  QkSplitPlan none = {tiles, 1, 0, 0.0};
+  if ((long long)tiles * p.panels * ny >= 8 * 256) {                     // enough workgroups for the tail not to matter
+    double stages = 0.0;
+    const int G0 = qcnn_stage_group(p.K), MG0 = (p.M + G0 - 1) / G0;
+    for (int r = 0; r < tiles; ++r) {
+      int ty, tx;
+      tile_of_rank(r, tilesY, tilesX, ty, tx);
+      const int ho0 = ty * TH, wo0 = tx * TW;
+      const int hoL = std::min(ho0 + TH, p.Ho) - 1, woL = std::min(wo0 + TW, p.Wo) - 1;
+      const int rows = std::min(p.H - 1, hoL * p.stride - p.pad + p.knl - 1) - std::max(0, ho0 * p.stride - p.pad) + 1;
+      const int cols = std::min(p.W - 1, woL * p.stride - p.pad + p.knl - 1) - std::max(0, wo0 * p.stride - p.pad) + 1;
+      stages += (double)std::max(rows, 0) * std::max(cols, 0) * MG0 + 10.0;
+    }
+    none.cost = stages * p.panels * ny / 256.0;
+    return none;
+  }
   std::vector<int> S(tiles);
   for (int r = 0; r < tiles; ++r) {
     int ty, tx;
@@ -1493,6 +1646,7 @@ QkSplitPlan qk_conv_plan(const ConvParams& p, size_t scratchFloats) {
   };
   QkSplitPlan best = none;
   double bestCost = makespan(tiles, 1);
+  best.cost = bestCost;
   const long long wgs = (long long)tiles * p.panels * ny;
   const int rem = (int)(wgs % 256);                 // workgroups beyond whole rounds
   // candidate tails: every tile; the tiles beyond whole rounds of 256 workgroups; that tail widened by a quarter, a half
@@ -1514,10 +1668,93 @@ QkSplitPlan qk_conv_plan(const ConvParams& p, size_t scratchFloats) {
       const size_t need = (size_t)(tiles - from) * Z * p.panels * TH * TW * p.Ct * PANEL;
       if (need > scratchFloats) break;
       const double c = makespan(from, Z) + reduceCost(from, Z);
-      if (c < bestCost * 0.97) { bestCost = c; best.splitFrom = from; best.Z = Z; best.partialFloats = need; }
+      if (c < bestCost * 0.97) { bestCost = c; best.splitFrom = from; best.Z = Z; best.partialFloats = need; best.cost = c; }
     }
   }
   return best;
+}
+
+// Segments of the sliding variant.  A segment of L output rows sweeps (L - 1) * stride + knl source rows (clipped), i.e.
+// it re-builds knl - stride rows of its upper neighbour's strip: few, long segments build the least, but a launch of
+// columns x segments x groups x panels workgroups must also fill 256 CUs evenly.  Candidates: 1 .. 4 equal segments and
+// "one long + one short" cuts; list-scheduled (longest first) like qk_conv_plan; taken when it beats the tile kernel.
+void qk_conv_plan_slide(ConvParams& p, double tileCost) {
+  p.nSeg = 0;
+  const int Ctg = p.Ct / p.grp;
+  const QkSlots sl = qk_conv_slots(Ctg, p.grp);
+  const int ns = qk_slide_slots(sl, p.knl, p.stride);
+  if (ns == 0 || p.K != 128 || p.progS == nullptr || p.Ho < 2 * ns) return;
+  const int ny = sl.chunks * p.grp;
+  const int G = qcnn_stage_group(p.K), MG = (p.M + G - 1) / G;
+  const double kFixed = 12.0;
+  auto segStages = [&](int wo, int a, int b) {         // output column wo, output rows [a, b)
+    const int cols = std::min(p.W - 1, wo * p.stride - p.pad + p.knl - 1) - std::max(0, wo * p.stride - p.pad) + 1;
+    const int rows = std::min(p.H - 1, (b - 1) * p.stride - p.pad + p.knl - 1) - std::max(0, a * p.stride - p.pad) + 1;
+    return (double)std::max(rows, 0) * std::max(cols, 0) * MG;
+  };
+  // a sliding stage costs a little more than a tile stage (three slots are tested per stage), and every source row
+  // ends with the store + restart of a slot.  Measured: AlexNet conv1 (11 stages per column) -10 %, conv5 (72) -15 %,
+  // VGG-16 conv1_2 (24) -12 %, its 128-channel layers (24 / 48) -25 %, but conv1_1 (3 stages per column: one sub-space,
+  // three rows) +47 % — a column must hold enough stages to carry its restart.
+  if (std::min(p.knl, p.W) * MG < 6) return;
+  auto segCost = [&](int wo, int a, int b) {
+    const int rows = std::min(p.H - 1, (b - 1) * p.stride - p.pad + p.knl - 1) - std::max(0, a * p.stride - p.pad) + 1;
+    return segStages(wo, a, b) * 1.03 + 0.5 * std::max(rows, 0);
+  };
+  std::vector<double> cu(256);
+  auto makespan = [&](const std::vector<int>& beg) {        // beg: nSeg + 1 boundaries, segments sorted longest first
+    std::fill(cu.begin(), cu.end(), 0.0);
+    std::make_heap(cu.begin(), cu.end(), std::greater<double>());
+    const int nSeg = (int)beg.size() - 1;
+    for (int y = 0; y < ny; ++y)
+      for (int sgi = 0; sgi < nSeg; ++sgi)
+        for (int wo = 0; wo < p.Wo; ++wo)
+          for (int pn = 0; pn < p.panels; ++pn) {
+            std::pop_heap(cu.begin(), cu.end(), std::greater<double>());
+            cu.back() += segCost(wo, beg[sgi], beg[sgi + 1]) + kFixed;
+            std::push_heap(cu.begin(), cu.end(), std::greater<double>());
+          }
+    return *std::max_element(cu.begin(), cu.end());
+  };
+  std::vector<std::vector<int> > cands;
+  for (int n = 1; n <= 4 && n * ns <= p.Ho; ++n) {            // n (nearly) equal segments
+    std::vector<int> b(n + 1);
+    for (int i = 0; i <= n; ++i) b[i] = (int)(((long long)p.Ho * i + n - 1) / n);   // the longer ones first
+    cands.push_back(b);
+  }
+  for (int shortLen = ns; shortLen * 2 < p.Ho; shortLen += std::max(1, p.Ho / 16))   // one long + one short segment
+    cands.push_back({0, p.Ho - shortLen, p.Ho});
+  if (const char* e = getenv("QCNN_SLIDE_SEGS")) {           // experiments: exactly that many equal segments
+    const int n = std::max(1, std::min(atoi(e), std::min(QK_MAX_SEGS, p.Ho / ns)));
+    std::vector<int> b(n + 1);
+    for (int i = 0; i <= n; ++i) b[i] = (int)(((long long)p.Ho * i + n - 1) / n);
+    cands.assign(1, b);
+    tileCost = 1e30;
+  }
+  double best = tileCost * 0.97;                             // sliding must be clearly better than the tile kernel
+  for (const std::vector<int>& b : cands) {
+    // order the segments longest first (dispatch order = LPT); boundaries stay contiguous per segment
+    std::vector<std::pair<int, int> > segs;
+    for (size_t i = 0; i + 1 < b.size(); ++i) segs.push_back({b[i], b[i + 1]});
+    std::stable_sort(segs.begin(), segs.end(), [](const std::pair<int, int>& x, const std::pair<int, int>& y) {
+      return x.second - x.first > y.second - y.first; });
+    // the kernel reads segment i as [segBeg[i], segBeg[i + 1]): only orders that keep the boundaries monotone fit that
+    // encoding — equal cuts and "long, short" do (longest first = left to right)
+    bool monotone = true;
+    for (size_t i = 0; i + 1 < segs.size(); ++i) monotone = monotone && segs[i].second == segs[i + 1].first;
+    if (!monotone || (int)segs.size() > QK_MAX_SEGS) continue;
+    const double c = makespan(b);
+    if (getenv("QCNN_DEBUG_PLAN")) {
+      fprintf(stderr, "[qcnn plan] slide Ho=%d Wo=%d panels=%d ny=%d: segs", p.Ho, p.Wo, p.panels, ny);
+      for (int v : b) fprintf(stderr, " %d", v);
+      fprintf(stderr, " -> %.0f stage-times (tile kernel %.0f)\n", c, tileCost);
+    }
+    if (c < best) {
+      best = c;
+      p.nSeg = (int)segs.size();
+      for (size_t i = 0; i < b.size(); ++i) p.segBeg[i] = b[i];
+    }
+  }
 }
 
 int qk_fc_channels_per_block(int Ct) { return NGW * qk_fc_slots(Ct).cpw; }
@@ -1546,9 +1783,9 @@ hipError_t qk_decode_cbn(const uint8_t* blocks, int bits, size_t n, int Ct, int 
 }
 
 hipError_t qk_build_program(const uint8_t* rows, uint16_t* prog, QkSlots sl, QkProgram pg, int knl, int stride, int M,
-                            hipStream_t st) {
+                            hipStream_t st, int slide) {
   const size_t n = (size_t)pg.rfH * pg.rfW * M * pg.rowU16;
   const int grid = (int)std::min<size_t>((n + 255) / 256, 8192);
-  hipLaunchKernelGGL(k_build_program, dim3(grid ? grid : 1), dim3(256), 0, st, rows, prog, sl, pg, knl, stride, M, n);
+  hipLaunchKernelGGL(k_build_program, dim3(grid ? grid : 1), dim3(256), 0, st, rows, prog, sl, pg, knl, stride, M, n, slide);
   return hipGetLastError();
 }

@@ -21,21 +21,27 @@ def main():
     eng.set_option(capi.OPT_STREAMS, streams)
     split = int(os.environ.get("QCNN_SPLIT", "1"))
     eng.set_option(capi.OPT_SPLIT, split)
+    eng.set_option(capi.OPT_SLIDE, int(os.environ.get("QCNN_SLIDE", "1")))
     eng.load_model(in_chw, layers, params, batch)
     imgs = synth.make_images(batch, in_chw, seed=2)
     import time
-    for _ in range(3):
-        eng.forward_host(imgs)
-    eng.set_option(capi.OPT_PROFILE, 1)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        eng.forward_host(imgs, want_prob=False)
-    wall = (time.perf_counter() - t0) / steps * 1e3
-    tot, _, fw = eng.layer_total_ms()
-    ms = tot / max(fw, 1)
-    names = [topo.TYPE_NAMES[l["type"]] for l in layers]
     x = torch.from_numpy(imgs).cuda()
     top5 = torch.empty((batch, 5), dtype=torch.int16, device="cuda")
+    import time
+    for _ in range(3):
+        eng.forward_dev(x.data_ptr(), batch, None, top5.data_ptr())
+    eng.sync()
+    eng.set_option(capi.OPT_PROFILE, 1)
+    for _ in range(steps):
+        eng.forward_dev(x.data_ptr(), batch, None, top5.data_ptr())
+    eng.sync()
+    tot, _, fw = eng.layer_total_ms()
+    ms = tot / max(fw, 1)
+    cuts = " ".join("%d:%dx%d" % ((l,) + eng.layer_split(l)) for l in (0, 4, 8, 10, 12))
+    t0 = time.perf_counter()
+    eng.forward_host(imgs, want_prob=False)
+    wall = (time.perf_counter() - t0) * 1e3
+    names = [topo.TYPE_NAMES[l["type"]] for l in layers]
     eng.set_option(capi.OPT_PROFILE, 0)
     for _ in range(3):
         eng.forward_dev(x.data_ptr(), batch, None, top5.data_ptr())
@@ -45,7 +51,6 @@ def main():
         eng.forward_dev(x.data_ptr(), batch, None, top5.data_ptr())
     eng.sync()
     dev = (time.perf_counter() - t0) / steps * 1e3
-    cuts = " ".join("%d:%dx%d" % ((l,) + eng.layer_split(l)) for l in (0, 4, 8, 10, 12))
     print("batch %d streams %d split %d: resident %.3f ms (%.0f img/s), forward_host %.3f ms, layers sum %.3f ms, cuts %s"
           % (batch, streams, split, dev, batch / dev * 1e3, wall, ms.sum(), cuts))
     print("  " + "  ".join("%02d_%s %.3f" % (i, names[i], ms[i]) for i in range(len(layers)) if ms[i] > 0.0005))
