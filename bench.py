@@ -341,6 +341,7 @@ def main():
 
     dt = measure(step, args.steps, args.warmup)
     layer_ms, recorded = eng.layer_ms()
+    segments = {i: eng.layer_segments(i) for i, l in enumerate(layers) if l["type"] == topo.CONV}   # sliding kernel, per layer
     ok = bool(torch.isfinite(prob[lo:hi]).all().item())
     images_per_step = B if (strong or world == 1) else B * world
 
@@ -395,9 +396,9 @@ def main():
                 speedup={str(B // nb): round(t1 / shard[nb][0], 2) for nb in sorted(shard, reverse=True)},
                 shard_ms={str(nb): round(1e3 * shard[nb][0], 4) for nb in sorted(shard)},
                 shard_streams={str(nb): shard[nb][1] for nb in sorted(shard)})
-        # PCIe-inclusive rates (never `value`).  fp32: qcnn_forward_host_batches — 8 batches from pinned host memory, the
+        # PCIe-inclusive rates (never `value`).  fp32: qcnn_forward_host_batches — 16 batches from pinned host memory, the
         # upload of batch b + 1 on a copy stream under the layers of batch b, results back through pinned buffers.
-        reps = 8
+        reps = 16        # as the u8 pipeline below: the one upload nothing overlaps is amortised as in a long stream
         pinned = torch.empty(imgs.shape, dtype=torch.float32, pin_memory=True)
         pinned.copy_(imgs)
         host_in = pinned.numpy()
@@ -449,7 +450,7 @@ def main():
         pipeline(k)
         torch.cuda.synchronize(dev)
         extras["value_incl_pinned_h2d_u8"] = round(B * k / (time.perf_counter() - t0), 2)
-        extras["h2d_note"] = ("f32: qcnn_forward_host_batches, 8 batches from pinned memory, upload of batch b+1 under the "
+        extras["h2d_note"] = ("f32: qcnn_forward_host_batches, 16 batches from pinned memory, upload of batch b+1 under the "
                               "layers of batch b, probabilities + top-5 returned to the host; _one_batch: a single "
                               "qcnn_forward_host call (two-panel chunks pipelined inside the call); u8: 8-bit sources "
                               "uploaded on a copy stream while the previous batch computes (double buffered)")
@@ -505,7 +506,7 @@ def main():
         vdt = timed(torch, dev, vf, 2)
         vms, _ = ve.layer_ms()
         vdom = int(np.argmax(vms))
-        rep = perf.layer_report(v_sizes, v_layers, v_params, vdom, vb, float(vms[vdom]))
+        rep = perf.layer_report(v_sizes, v_layers, v_params, vdom, vb, float(vms[vdom]), ve.layer_segments(vdom))
         conv_total = sum(float(vms[i]) for i, l in enumerate(v_layers) if l["type"] == topo.CONV)
         vgg = dict(value=round(vb * 2 / vdt, 2), unit="images/s", batch=vb, steps=2,
                    outputs_finite=bool(torch.isfinite(vp).all().item()), conv_ms_per_batch=round(conv_total, 3),
@@ -532,7 +533,7 @@ def main():
         total_lk = 0
         for i, l in enumerate(layers):
             if l["type"] in (topo.CONV, topo.FCNT) and layer_ms[i] > 0:
-                r = perf.layer_report(sizes, layers, params, i, launch_images, float(layer_ms[i]))
+                r = perf.layer_report(sizes, layers, params, i, launch_images, float(layer_ms[i]), segments.get(i))
                 r["ms"] = round(float(layer_ms[i]), 4)
                 per_layer["%02d_%s" % (i, topo.TYPE_NAMES[l["type"]])] = r
         for i, l in enumerate(layers):

@@ -194,6 +194,9 @@ int qcnn_run_layer(QcnnCtx* ctx, int layer, const float* in_host, int n, float* 
  * was split), *tiles_unsplit = tiles of the heaviest-first order that ran whole (-1 when nothing was split); sliding
  * kernel (QCNN_OPT_SLIDE): *tiles_unsplit = -2, *slices = segments per output column. */
 int qcnn_get_layer_split(QcnnCtx* ctx, int layer, int* tiles_unsplit, int* slices);
+/* Sliding kernel: the row segments [seg_beg9[i], seg_beg9[i + 1]) every output column of the last launch of `layer` was
+ * cut into (*n_seg of them; 0 when the layer ran the tile kernel). */
+int qcnn_get_layer_segments(QcnnCtx* ctx, int layer, int* seg_beg9, int* n_seg);
 
 /* ---- timing (QCNN_OPT_PROFILE = 1) ---- */
 /* Mean milliseconds of one LAUNCH per layer (a forward issues QCNN_OPT_STREAMS launches per layer, each over

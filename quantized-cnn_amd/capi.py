@@ -81,6 +81,7 @@ def load():
     lib.qcnn_get_layer_output_range.argtypes = [vp, i, i, i, f32p]
     lib.qcnn_run_layer.argtypes = [vp, i, f32p, i, f32p]
     lib.qcnn_get_layer_split.argtypes = [vp, i, C.POINTER(i), C.POINTER(i)]
+    lib.qcnn_get_layer_segments.argtypes = [vp, i, C.POINTER(i), C.POINTER(i)]
     lib.qcnn_get_layer_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(i)]
     lib.qcnn_reset_layer_ms.argtypes = [vp]
     lib.qcnn_get_layer_total_ms.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(i)]

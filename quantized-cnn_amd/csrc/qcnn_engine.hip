@@ -171,8 +171,9 @@ int plan_arena(QcnnCtx* c) {
       s.progBytes = (size_t)pg.rfH * pg.rfW * s.M * pg.rowU16 * sizeof(uint16_t);
       s.offProg = off; off = align_up(off + s.progBytes + QCNN_ROWS_PAD, 256);
       s.progSBytes = 0;
-      if (qk_slide_slots(sl, d.knlSiz, d.stride) > 0) {
-        const QkProgram ps = qk_conv_program_slide(sl, d.knlSiz, d.stride);
+      const QkSlide sc = qk_slide_config(Ct / d.grpCnt, d.grpCnt, d.knlSiz, d.stride);
+      if (sc.ns > 0) {
+        const QkProgram ps = qk_conv_program_slide(sc.sl, sc.ns, d.knlSiz, d.stride);
         s.progSBytes = (size_t)ps.rfH * ps.rfW * s.M * ps.rowU16 * sizeof(uint16_t);
         s.offProgS = off; off = align_up(off + s.progSBytes + QCNN_ROWS_PAD, 256);
       }
@@ -291,11 +292,14 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
       if (e == hipErrorInvalidValue) {
         // A launch of a few hundred workgroups (one GPU's share of a sharded batch) splits the tail of its tiles over
         // several workgroups (qk_conv_plan).  MFMA builders only: the exact builder keeps the reference's summation order.
-        if (c->split && c->lutMode >= 1 && c->convPartial) {
+        if (c->lutMode >= 1 && c->convPartial && (c->split || c->slide)) {
+          // Plan of this launch geometry (cached): tile kernel whole / with a split tail (QCNN_OPT_SPLIT; changes a cut
+          // tile's summation order) / sliding kernel (QCNN_OPT_SLIDE; same order and bits as the tile kernel).
           const size_t share = kConvPartialFloats / (size_t)nsub;
-          const int key = panels * 8 + nsub;
+          const int key = ((panels * 8 + nsub) * 2 + (c->split ? 1 : 0)) * 4 + c->slide;
           if (s.planKey != key) {
-            s.plan = qk_conv_plan(p, share);
+            const size_t scratch = c->split ? share : 0;            // no scratch: qk_conv_plan only prices the whole-tile launch
+            s.plan = qk_conv_plan(p, scratch);
             s.planKey = key;
             s.segN = 0;
             if (c->slide && p.progS) {                // sliding variant where it is predicted to beat the (split) tile kernel
@@ -308,7 +312,7 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
           if (s.segN > 0) {
             p.nSeg = s.segN;
             for (int i = 0; i <= s.segN; ++i) p.segBeg[i] = s.segBeg[i];
-            s.lastFrom = -2; s.lastZ = s.segN;       // reported by qcnn_get_layer_split as (-2, segments per row)
+            s.lastFrom = -2; s.lastZ = s.segN;       // reported by qcnn_get_layer_split as (-2, segments per column)
           } else if (s.plan.Z > 1) {
             p.splitFrom = s.plan.splitFrom; p.splitZ = s.plan.Z; p.partial = c->convPartial + share * sub;
             s.lastFrom = s.plan.splitFrom; s.lastZ = s.plan.Z;
@@ -868,12 +872,14 @@ hipError_t build_program(QcnnCtx* c, int layer, const QkSlots& sl) {
   const LayerShape& s = c->shapes[layer];
   if (!s.progBytes) return hipSuccess;
   hipError_t e = qk_build_program(reinterpret_cast<const uint8_t*>(c->arena + s.offAsmt),
-                                  reinterpret_cast<uint16_t*>(c->arena + s.offProg), sl,
+                                  reinterpret_cast<uint16_t*>(c->arena + s.offProg), sl, sl,
                                   qk_conv_program(sl, d.knlSiz, d.stride), d.knlSiz, d.stride, s.M, c->stream);
-  if (e == hipSuccess && s.progSBytes)
+  if (e == hipSuccess && s.progSBytes) {
+    const QkSlide sc = qk_slide_config(sl.C, sl.groups, d.knlSiz, d.stride);
     e = qk_build_program(reinterpret_cast<const uint8_t*>(c->arena + s.offAsmt),
-                         reinterpret_cast<uint16_t*>(c->arena + s.offProgS), sl,
-                         qk_conv_program_slide(sl, d.knlSiz, d.stride), d.knlSiz, d.stride, s.M, c->stream, 1);
+                         reinterpret_cast<uint16_t*>(c->arena + s.offProgS), sl, sc.sl,
+                         qk_conv_program_slide(sc.sl, sc.ns, d.knlSiz, d.stride), d.knlSiz, d.stride, s.M, c->stream, 1);
+  }
   return e;
 }
 }  // namespace
@@ -1248,6 +1254,16 @@ int qcnn_get_layer_split(QcnnCtx* c, int layer, int* tiles_unsplit, int* slices)
   const LayerShape& s = c->shapes[layer];
   if (tiles_unsplit) *tiles_unsplit = s.lastFrom;
   if (slices) *slices = s.lastZ;
+  return 0;
+}
+
+int qcnn_get_layer_segments(QcnnCtx* c, int layer, int* seg_beg9, int* n_seg) {
+  if (layer < 0 || layer >= c->L) return fail(c, "layer %d out of range", layer);
+  const LayerShape& s = c->shapes[layer];
+  const int n = (s.lastFrom == -2) ? s.segN : 0;
+  if (n_seg) *n_seg = n;
+  if (seg_beg9)
+    for (int i = 0; i < 9; ++i) seg_beg9[i] = (i <= n) ? s.segBeg[i] : 0;
   return 0;
 }
 

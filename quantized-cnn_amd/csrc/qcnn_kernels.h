@@ -111,23 +111,41 @@ __host__ __device__ static inline QkProgram qk_conv_program(const QkSlots& sl, i
   g.rowU16 = sl.groups * sl.chunks * g.wgRowU16;
   return g;
 }
-// Sliding variant: slots per workgroup = output rows that look at one source row; 0 when the layer cannot slide
-// (the slots' accumulators must fit: slots * channels per wave <= 36 pairs)
-__host__ __device__ static inline int qk_slide_slots(const QkSlots& sl, int knl, int stride) {
+// Sliding variant: slots per workgroup = output rows that look at one source row = ceil(knl / stride) (2 .. 5), and how
+// the 12 gather waves split the channels THERE: the slots' accumulators must fit (slots * channels per wave <= 36
+// pairs), so a layer may slide with fewer channels per wave — and more workgroups along the channel axis, each building
+// the same stages — than its tile kernel uses (AlexNet conv2: 5 slots x 6 channels per wave, two channel chunks).
+// ns = 0: the layer cannot slide.
+struct QkSlide {
+  int ns;
+  QkSlots sl;
+};
+static inline QkSlide qk_slide_config(int Ctg, int groups, int knl, int stride) {
+  QkSlide r;
+  r.ns = 0;
+  r.sl = qk_make_slots(Ctg, groups, 4);
   const int ns = (knl + stride - 1) / stride;
-  return (ns >= 2 && ns <= 3 && ns * sl.cpw <= 36) ? ns : 0;
+  if (ns < 2 || ns > 5) return r;
+  const int tileCpw = qk_conv_slots(Ctg, groups).cpw;
+  const int cands[5] = {16, 12, 8, 6, 4};
+  for (int i = 0; i < 5; ++i) {
+    const int c = cands[i];
+    const bool built = (ns == 2 && c >= 8) || (ns == 3 && c <= 12) || (ns == 4 && c == 8) || (ns == 5 && c <= 6);   // instantiated kernels
+    if (c <= tileCpw && ns * c <= 36 && built) { r.ns = ns; r.sl = qk_make_slots(Ctg, groups, c); return r; }
+  }
+  return r;
 }
 // program of the sliding variant: entry (source row modulo P = slots * stride, tap column kw, m) holds per slot q the
 // offsets of tap ((ry - q * stride) mod P, kw) — 0 where that is not a tap row (>= knl)
-__host__ __device__ static inline QkProgram qk_conv_program_slide(const QkSlots& sl, int knl, int stride) {
+__host__ __device__ static inline QkProgram qk_conv_program_slide(const QkSlots& slS, int ns, int knl, int stride) {
   QkProgram g;
-  g.th = 1; g.tw = qk_slide_slots(sl, knl, stride);
-  g.np = g.tw;
-  g.rfH = g.tw * stride;
+  g.th = 1; g.tw = ns;
+  g.np = ns;
+  g.rfH = ns * stride;
   g.rfW = knl;
-  g.blkU16 = (g.np * sl.hp + 7) / 8 * 8;
+  g.blkU16 = (g.np * slS.hp + 7) / 8 * 8;
   g.wgRowU16 = QCNN_GATHER_WAVES * 2 * g.blkU16;
-  g.rowU16 = sl.groups * sl.chunks * g.wgRowU16;
+  g.rowU16 = slS.groups * slS.chunks * g.wgRowU16;
   return g;
 }
 static inline QkSlots qk_fc_slots(int Ct) { return qk_make_slots(Ct, 1, Ct >= 384 ? 32 : (Ct >= 96 ? 8 : 4)); }
@@ -230,8 +248,10 @@ hipError_t qk_decode_cbn(const uint8_t* blocks, int bits, size_t n, int Ct, int 
                          uint8_t* rows, int* bad, hipStream_t st);
 
 // rows (plain table of a conv layer) -> prog (QkProgram order); one thread per program entry
-hipError_t qk_build_program(const uint8_t* rows, uint16_t* prog, QkSlots sl, QkProgram pg, int knl, int stride, int M,
-                            hipStream_t st, int slide = 0);
+// rows: the plain table in the order of `src` slots; prog: program in the order of `dst` slots (the same, or the sliding
+// variant's own channel split)
+hipError_t qk_build_program(const uint8_t* rows, uint16_t* prog, QkSlots src, QkSlots dst, QkProgram pg, int knl, int stride,
+                            int M, hipStream_t st, int slide = 0);
 
 // dst row e = src row map[e], rows of 128 images ([panels][D][128]); the first FC layer consumes its input
 // NCHW-flattened (src/CaffeEva.cc:187-189)

@@ -1421,7 +1421,7 @@ hipError_t allow_big_lds(const void* kern, int bytes) {
 
 // rows (plain table of row slots, [kh][kw][M][rowStride]) -> program table of pre-scaled offsets ([ry][rx][M][rowU16], QkProgram): one thread per entry
 __global__ __launch_bounds__(256) void k_build_program(const uint8_t* __restrict__ rows, uint16_t* __restrict__ prog,
-                                                       QkSlots sl, QkProgram pg, int knl, int stride, int M, size_t n,
+                                                       QkSlots src, QkSlots sl, QkProgram pg, int knl, int stride, int M, size_t n,
                                                        int slide) {
   for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
     const int r = (int)(e % (size_t)pg.rowU16);
@@ -1431,13 +1431,17 @@ __global__ __launch_bounds__(256) void k_build_program(const uint8_t* __restrict
     const int wh = r / pg.blkU16, r3 = r % pg.blkU16;       // (workgroup slice, wave, half) and the place inside its block
     const int pos = r3 / sl.hp, j = r3 % sl.hp;
     uint16_t v = 0;
-    if (pos < pg.np) {
+    if (pos < pg.np && j < sl.cpw / 2) {
       // tile kernel: position (dy, dx) looks at tap (ry - dy * stride, rx - dx * stride); sliding: slot `pos` at tap row
       // (ry - pos * stride) modulo the period rfH = slots * stride, tap column rx
       const int kh = slide ? ((ry - pos * stride) % pg.rfH + pg.rfH) % pg.rfH : ry - (pos / pg.tw) * stride;
       const int kw = slide ? rx : rx - (pos % pg.tw) * stride;
-      if ((unsigned)kh < (unsigned)knl && (unsigned)kw < (unsigned)knl)
-        v = (uint16_t)(rows[(size_t)((kh * knl + kw) * M + m) * sl.rowStride + wh * sl.hpB + qk_entry_byte(j)] * 64);
+      // the channel this entry belongs to in the destination's wave split, and where the source table keeps it
+      const int half = wh & 1, wave = (wh >> 1) % (sl.chunks * QCNN_GATHER_WAVES), g = (wh >> 1) / (sl.chunks * QCNN_GATHER_WAVES);
+      const int ch = wave * sl.cpw + half * (sl.cpw / 2) + j;
+      const int at = qk_slot_entry(src, g, ch);
+      if ((unsigned)kh < (unsigned)knl && (unsigned)kw < (unsigned)knl && at >= 0)
+        v = (uint16_t)(rows[(size_t)((kh * knl + kw) * M + m) * src.rowStride + at] * 64);
     }
     prog[e] = v;
   }
@@ -1558,14 +1562,20 @@ hipError_t qk_conv_aprx(const ConvParams& pIn, int lutMode, hipStream_t st) {
   if (Ctg % 2 || p.Cs > QCNN_MAX_CS || p.K > QCNN_MAX_K) return hipErrorInvalidValue;
   const QkSlots sl = qk_conv_slots(Ctg, p.grp);
   if (p.nSeg > 0 && p.progS != nullptr && p.K == 128 && lutMode != 0) {      // sliding variant (qk_conv_plan_slide)
-    const int ns = qk_slide_slots(sl, p.knl, p.stride);
-    if (ns == 3 && sl.cpw == 8) return launch_conv_slide<3, 8>(p, sl, lutMode, st);
-    if (ns == 3 && sl.cpw == 12) return launch_conv_slide<3, 12>(p, sl, lutMode, st);
-    if (ns == 3 && sl.cpw == 6) return launch_conv_slide<3, 6>(p, sl, lutMode, st);
-    if (ns == 3 && sl.cpw == 4) return launch_conv_slide<3, 4>(p, sl, lutMode, st);
-    if (ns == 2 && sl.cpw == 16) return launch_conv_slide<2, 16>(p, sl, lutMode, st);
-    if (ns == 2 && sl.cpw == 12) return launch_conv_slide<2, 12>(p, sl, lutMode, st);
-    if (ns == 2 && sl.cpw == 8) return launch_conv_slide<2, 8>(p, sl, lutMode, st);
+    const QkSlide sc = qk_slide_config(Ctg, p.grp, p.knl, p.stride);
+    switch (sc.ns * 100 + sc.sl.cpw) {
+      case 216: return launch_conv_slide<2, 16>(p, sc.sl, lutMode, st);
+      case 212: return launch_conv_slide<2, 12>(p, sc.sl, lutMode, st);
+      case 208: return launch_conv_slide<2, 8>(p, sc.sl, lutMode, st);
+      case 312: return launch_conv_slide<3, 12>(p, sc.sl, lutMode, st);
+      case 308: return launch_conv_slide<3, 8>(p, sc.sl, lutMode, st);
+      case 306: return launch_conv_slide<3, 6>(p, sc.sl, lutMode, st);
+      case 304: return launch_conv_slide<3, 4>(p, sc.sl, lutMode, st);
+      case 408: return launch_conv_slide<4, 8>(p, sc.sl, lutMode, st);
+      case 506: return launch_conv_slide<5, 6>(p, sc.sl, lutMode, st);
+      case 504: return launch_conv_slide<5, 4>(p, sc.sl, lutMode, st);
+      default: break;
+    }
   }
   switch (sl.cpw) {
     case 32: return launch_conv<1, 1, 32>(p, sl, lutMode, st);   // 1 position  x 12 x 32 channels
@@ -1681,10 +1691,10 @@ QkSplitPlan qk_conv_plan(const ConvParams& p, size_t scratchFloats) {
 void qk_conv_plan_slide(ConvParams& p, double tileCost) {
   p.nSeg = 0;
   const int Ctg = p.Ct / p.grp;
-  const QkSlots sl = qk_conv_slots(Ctg, p.grp);
-  const int ns = qk_slide_slots(sl, p.knl, p.stride);
+  const QkSlide sc = qk_slide_config(Ctg, p.grp, p.knl, p.stride);
+  const int ns = sc.ns;
   if (ns == 0 || p.K != 128 || p.progS == nullptr || p.Ho < 2 * ns) return;
-  const int ny = sl.chunks * p.grp;
+  const int ny = sc.sl.chunks * p.grp;               // every channel chunk builds the strip's stages again
   const int G = qcnn_stage_group(p.K), MG = (p.M + G - 1) / G;
   const double kFixed = 12.0;
   auto segStages = [&](int wo, int a, int b) {         // output column wo, output rows [a, b)
@@ -1696,7 +1706,7 @@ void qk_conv_plan_slide(ConvParams& p, double tileCost) {
   // ends with the store + restart of a slot.  Measured: AlexNet conv1 (11 stages per column) -10 %, conv5 (72) -15 %,
   // VGG-16 conv1_2 (24) -12 %, its 128-channel layers (24 / 48) -25 %, but conv1_1 (3 stages per column: one sub-space,
   // three rows) +47 % — a column must hold enough stages to carry its restart.
-  if (std::min(p.knl, p.W) * MG < 6) return;
+  if (std::min(p.knl, p.W) * MG < 6 && tileCost < 1e29) return;      // (forced mode, tests: slides anyway)
   auto segCost = [&](int wo, int a, int b) {
     const int rows = std::min(p.H - 1, (b - 1) * p.stride - p.pad + p.knl - 1) - std::max(0, a * p.stride - p.pad) + 1;
     return segStages(wo, a, b) * 1.03 + 0.5 * std::max(rows, 0);
@@ -1744,7 +1754,7 @@ void qk_conv_plan_slide(ConvParams& p, double tileCost) {
     for (size_t i = 0; i + 1 < segs.size(); ++i) monotone = monotone && segs[i].second == segs[i + 1].first;
     if (!monotone || (int)segs.size() > QK_MAX_SEGS) continue;
     const double c = makespan(b);
-    if (getenv("QCNN_DEBUG_PLAN")) {
+    if (const char* dbg = getenv("QCNN_DEBUG_PLAN"); dbg && atoi(dbg)) {
       fprintf(stderr, "[qcnn plan] slide Ho=%d Wo=%d panels=%d ny=%d: segs", p.Ho, p.Wo, p.panels, ny);
       for (int v : b) fprintf(stderr, " %d", v);
       fprintf(stderr, " -> %.0f stage-times (tile kernel %.0f)\n", c, tileCost);
@@ -1782,10 +1792,10 @@ hipError_t qk_decode_cbn(const uint8_t* blocks, int bits, size_t n, int Ct, int 
   return hipGetLastError();
 }
 
-hipError_t qk_build_program(const uint8_t* rows, uint16_t* prog, QkSlots sl, QkProgram pg, int knl, int stride, int M,
-                            hipStream_t st, int slide) {
+hipError_t qk_build_program(const uint8_t* rows, uint16_t* prog, QkSlots src, QkSlots dst, QkProgram pg, int knl, int stride,
+                            int M, hipStream_t st, int slide) {
   const size_t n = (size_t)pg.rfH * pg.rfW * M * pg.rowU16;
   const int grid = (int)std::min<size_t>((n + 255) / 256, 8192);
-  hipLaunchKernelGGL(k_build_program, dim3(grid ? grid : 1), dim3(256), 0, st, rows, prog, sl, pg, knl, stride, M, n, slide);
+  hipLaunchKernelGGL(k_build_program, dim3(grid ? grid : 1), dim3(256), 0, st, rows, prog, src, dst, pg, knl, stride, M, n, slide);
   return hipGetLastError();
 }

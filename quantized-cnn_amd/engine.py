@@ -178,6 +178,13 @@ class QcnnEngine:
         self._chk(self.lib.qcnn_get_layer_split(self.h, l, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def layer_segments(self, l: int):
+        """Row-segment boundaries of the sliding kernel's last launch of conv layer l ([] = the tile kernel ran)."""
+        seg = (C.c_int * 9)()
+        n = C.c_int(0)
+        self._chk(self.lib.qcnn_get_layer_segments(self.h, l, seg, C.byref(n)))
+        return [int(seg[i]) for i in range(n.value + 1)] if n.value > 0 else []
+
     # -- timing ---------------------------------------------------------------------------------
     def layer_ms(self):
         ms = (C.c_float * self.L)()

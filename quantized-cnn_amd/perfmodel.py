@@ -56,6 +56,28 @@ def conv_work(in_hwc, out_hwc, ly, m: int, k: int, cs: int):
                 tile="%dx%dx%d" % (th, tw, GATHER_WAVES * cpw), ks=ks)
 
 
+def conv_work_slide(in_hwc, out_hwc, ly, m: int, k: int, cs: int, seg_beg):
+    """The same counts for the sliding kernel (k_conv_aprx<.., SLIDE>): every output column is cut into the row segments
+    [seg_beg[i], seg_beg[i + 1]); a workgroup builds the source rows under its segment x the knl columns of its window."""
+    h, w, cin = in_hwc
+    ho, wo, ct = out_hwc
+    knl, s, p, grp = ly["knl"], ly["stride"], ly["pad"], ly["grp"]
+    base = conv_work(in_hwc, out_hwc, ly, m, k, cs)
+    _, _, cpw, chunks = conv_tile(ct // grp)
+    g = stage_group(k)
+    mg = (m + g - 1) // g
+    stages = 0
+    for x in range(wo):
+        cols = min(w - 1, x * s - p + knl - 1) - max(0, x * s - p) + 1
+        for a, b in zip(seg_beg[:-1], seg_beg[1:]):
+            rows = min(h - 1, (b - 1) * s - p + knl - 1) - max(0, a * s - p) + 1
+            stages += max(rows, 0) * max(cols, 0) * mg
+    stages *= chunks * grp
+    slots = (knl + s - 1) // s
+    return dict(base, stages=stages, mfma_flop=stages * 128 * 128 * 4 * base["ks"] * 2,
+                tile="slide %d slots x %d, %d segment(s) per column" % (slots, GATHER_WAVES * cpw, len(seg_beg) - 1))
+
+
 def fc_work(d: int, ct: int, m: int, k: int, cs: int, msplit_chunks: int):
     g = stage_group(k)
     stages = (m + g - 1) // g * msplit_chunks
@@ -64,11 +86,14 @@ def fc_work(d: int, ct: int, m: int, k: int, cs: int, msplit_chunks: int):
                 tile="fc", ks=ks)
 
 
-def layer_report(sizes, layers, params, l: int, images: float, ms: float):
-    """Roofline-style figures of conv/FC layer l for a launch over `images` images that took `ms` milliseconds."""
+def layer_report(sizes, layers, params, l: int, images: float, ms: float, seg_beg=None):
+    """Roofline-style figures of conv/FC layer l for a launch over `images` images that took `ms` milliseconds; seg_beg:
+    the sliding kernel's row segments when the layer ran it (QcnnEngine.layer_segments)."""
     ly = layers[l]
     mm, kk, cc = (int(x) for x in params[l]["ctrd"].shape)
-    if ly["type"] == CONV:
+    if ly["type"] == CONV and seg_beg:
+        wk = conv_work_slide(sizes[l], sizes[l + 1], ly, mm, kk, cc, seg_beg)
+    elif ly["type"] == CONV:
         wk = conv_work(sizes[l], sizes[l + 1], ly, mm, kk, cc)
     elif ly["type"] == FCNT:
         e = sizes[l][0] * sizes[l][1] * sizes[l][2]
