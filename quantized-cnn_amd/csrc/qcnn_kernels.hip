@@ -1734,6 +1734,9 @@ void qk_conv_plan_slide(ConvParams& p, double tileCost) {
   }
   for (int shortLen = ns; shortLen * 2 < p.Ho; shortLen += std::max(1, p.Ho / 16))   // one long + one short segment
     cands.push_back({0, p.Ho - shortLen, p.Ho});
+  for (int s2 = ns; s2 * 4 < p.Ho; s2 += std::max(1, p.Ho / 12))                      // long + medium + short
+    for (int s1 = s2 + std::max(1, p.Ho / 12); s1 + s2 < p.Ho - s1; s1 += std::max(1, p.Ho / 12))
+      cands.push_back({0, p.Ho - s1 - s2, p.Ho - s2, p.Ho});
   if (const char* e = getenv("QCNN_SLIDE_SEGS")) {           // experiments: exactly that many equal segments
     const int n = std::max(1, std::min(atoi(e), std::min(QK_MAX_SEGS, p.Ho / ns)));
     std::vector<int> b(n + 1);
