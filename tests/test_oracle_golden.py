@@ -100,3 +100,41 @@ def test_alexnet_real_fingerprints(golden_alex_real):
     assert abs(fingerprint(orc.fm(5))[0] + 1.106604e+07) < 10.0
     assert abs(fingerprint(orc.fm(15))[0] - 3.416127e+04) < 0.1
     assert abs(fingerprint(orc.fm(16))[0] - 1.858081e+04) < 0.1
+
+
+def test_precise_path_against_reference_golden():
+    """qo_conv_prec / qo_fc_prec (the reference's Init(false) path) against feature maps the COMPILED reference produced for
+    the tiny network (tests/golden/tiny_prec_ref.npz, oracle/make_golden.py): bit for bit, strided first layer (the
+    im2col quirk at output row / column 0), grouped padded conv and both FC layers included."""
+    from conftest import GOLDEN
+    z = np.load(os.path.join(GOLDEN, "tiny_prec_ref.npz"))
+    in_chw, layers = topo.tiny_model()
+    orc = po.COracle(in_chw, layers)
+    orc.set_dense(synth.make_dense_params(in_chw, layers, seed=13))
+    orc.forward(z["imgs"])
+    for l in range(len(layers) + 1):
+        assert np.array_equal(orc.fm(l), z["fm_%02d" % l]), "fm[%d] differs from the reference" % l
+
+
+def test_perfmodel_sliding_stage_counts():
+    """perfmodel.conv_work_slide (what bench.py reports for a layer that ran the sliding kernel) against a brute-force count
+    of the (source pixel, sub-space) stages of every (output column, row segment) workgroup; AlexNet conv1 / conv5."""
+    perf = pkg("perfmodel")
+    in_chw, layers, _, _ = topo.MODELS["AlexNet"]
+    sizes = topo.fmap_sizes(in_chw, layers)
+    for l, (m, k, cs), segs in ((0, (1, 128, 8), [0, 43, 55]), (12, (24, 128, 8), [0, 13])):
+        ly = layers[l]
+        wk = perf.conv_work_slide(sizes[l], sizes[l + 1], ly, m, k, cs, segs)
+        h, w, _ = sizes[l]
+        ho, wo, _ = sizes[l + 1]
+        brute = 0
+        for x in range(wo):
+            cols = [c for c in range(x * ly["stride"] - ly["pad"], x * ly["stride"] - ly["pad"] + ly["knl"]) if 0 <= c < w]
+            for a, b in zip(segs[:-1], segs[1:]):
+                rows = set()
+                for y in range(a, b):
+                    rows.update(r for r in range(y * ly["stride"] - ly["pad"], y * ly["stride"] - ly["pad"] + ly["knl"]) if 0 <= r < h)
+                brute += len(rows) * len(cols) * m
+        assert wk["stages"] == brute * ly["grp"], (l, wk["stages"], brute)
+        tile = perf.conv_work(sizes[l], sizes[l + 1], ly, m, k, cs)
+        assert wk["stages"] < tile["stages"] and wk["lookups"] == tile["lookups"]
