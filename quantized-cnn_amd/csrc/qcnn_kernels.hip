@@ -1702,14 +1702,14 @@ void qk_conv_plan_slide(ConvParams& p, double tileCost) {
     const int rows = std::min(p.H - 1, (b - 1) * p.stride - p.pad + p.knl - 1) - std::max(0, a * p.stride - p.pad) + 1;
     return (double)std::max(rows, 0) * std::max(cols, 0) * MG;
   };
-  // a sliding stage costs a little more than a tile stage (three slots are tested per stage), and every source row
-  // ends with the store + restart of a slot.  Measured: AlexNet conv1 (11 stages per column) -10 %, conv5 (72) -15 %,
+  // a sliding stage costs about what a tile stage costs (measured 0.68 vs 0.74 us per stage-time of this model on
+  // AlexNet conv1), and every source row ends with the store + restart of a slot.  Measured: AlexNet conv1 (11 stages per column) -10 %, conv5 (72) -15 %,
   // VGG-16 conv1_2 (24) -12 %, its 128-channel layers (24 / 48) -25 %, but conv1_1 (3 stages per column: one sub-space,
   // three rows) +47 % — a column must hold enough stages to carry its restart.
   if (std::min(p.knl, p.W) * MG < 6 && tileCost < 1e29) return;      // (forced mode, tests: slides anyway)
   auto segCost = [&](int wo, int a, int b) {
     const int rows = std::min(p.H - 1, (b - 1) * p.stride - p.pad + p.knl - 1) - std::max(0, a * p.stride - p.pad) + 1;
-    return segStages(wo, a, b) * 1.03 + 0.5 * std::max(rows, 0);
+    return segStages(wo, a, b) + 0.3 * std::max(rows, 0);
   };
   std::vector<double> cu(256);
   auto makespan = [&](const std::vector<int>& beg) {        // beg: nSeg + 1 boundaries, segments sorted longest first
@@ -1744,7 +1744,7 @@ void qk_conv_plan_slide(ConvParams& p, double tileCost) {
     cands.assign(1, b);
     tileCost = 1e30;
   }
-  double best = tileCost * 0.97;                             // sliding must be clearly better than the tile kernel
+  double best = tileCost;                                    // sliding must beat the (split) tile launch
   for (const std::vector<int>& b : cands) {
     // order the segments longest first (dispatch order = LPT); boundaries stay contiguous per segment
     std::vector<std::pair<int, int> > segs;
