@@ -173,7 +173,7 @@ int plan_arena(QcnnCtx* c) {
       s.progSBytes = 0;
       const QkSlide sc = qk_slide_config(Ct / d.grpCnt, d.grpCnt, d.knlSiz, d.stride);
       if (sc.ns > 0) {
-        const QkProgram ps = qk_conv_program_slide(sc.sl, sc.ns, d.knlSiz, d.stride);
+        const QkProgram ps = qk_conv_program_slide(sc.sl, sc.ns, sc.nc, d.knlSiz, d.stride);
         s.progSBytes = (size_t)ps.rfH * ps.rfW * s.M * ps.rowU16 * sizeof(uint16_t);
         s.offProgS = off; off = align_up(off + s.progSBytes + QCNN_ROWS_PAD, 256);
       }
@@ -878,7 +878,7 @@ hipError_t build_program(QcnnCtx* c, int layer, const QkSlots& sl) {
     const QkSlide sc = qk_slide_config(sl.C, sl.groups, d.knlSiz, d.stride);
     e = qk_build_program(reinterpret_cast<const uint8_t*>(c->arena + s.offAsmt),
                          reinterpret_cast<uint16_t*>(c->arena + s.offProgS), sl, sc.sl,
-                         qk_conv_program_slide(sc.sl, sc.ns, d.knlSiz, d.stride), d.knlSiz, d.stride, s.M, c->stream, 1);
+                         qk_conv_program_slide(sc.sl, sc.ns, sc.nc, d.knlSiz, d.stride), d.knlSiz, d.stride, s.M, c->stream, 1);
   }
   return e;
 }

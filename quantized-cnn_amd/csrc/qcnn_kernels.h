@@ -117,12 +117,14 @@ __host__ __device__ static inline QkProgram qk_conv_program(const QkSlots& sl, i
 // the same stages — than its tile kernel uses (AlexNet conv2: 5 slots x 6 channels per wave, two channel chunks).
 // ns = 0: the layer cannot slide.
 struct QkSlide {
-  int ns;
+  int ns;         // slots per output column
+  int nc;         // output columns per strip: 2 when six slots fit (<= 6 channels per wave: the 3 columns x 1 row a source
+                  // row serves become 3 x 2, i.e. 2 instead of 3 table builds per output position for a 3x3 / 1 layer)
   QkSlots sl;
 };
 static inline QkSlide qk_slide_config(int Ctg, int groups, int knl, int stride) {
   QkSlide r;
-  r.ns = 0;
+  r.ns = 0; r.nc = 1;
   r.sl = qk_make_slots(Ctg, groups, 4);
   const int ns = (knl + stride - 1) / stride;
   if (ns < 2 || ns > 5) return r;
@@ -131,18 +133,22 @@ static inline QkSlide qk_slide_config(int Ctg, int groups, int knl, int stride) 
   for (int i = 0; i < 5; ++i) {
     const int c = cands[i];
     const bool built = (ns == 2 && c >= 8) || (ns == 3 && c <= 12) || (ns == 4 && c == 8) || (ns == 5 && c <= 6);   // instantiated kernels
-    if (c <= tileCpw && ns * c <= 36 && built) { r.ns = ns; r.sl = qk_make_slots(Ctg, groups, c); return r; }
+    if (c <= tileCpw && ns * c <= 36 && built) {
+      r.ns = ns; r.sl = qk_make_slots(Ctg, groups, c);
+      r.nc = (ns == 3 && c <= 6) ? 2 : 1;
+      return r;
+    }
   }
   return r;
 }
-// program of the sliding variant: entry (source row modulo P = slots * stride, tap column kw, m) holds per slot q the
-// offsets of tap ((ry - q * stride) mod P, kw) — 0 where that is not a tap row (>= knl)
-__host__ __device__ static inline QkProgram qk_conv_program_slide(const QkSlots& slS, int ns, int knl, int stride) {
+// program of the sliding variant: entry (source row modulo P = slots * stride, column rx of the strip, m) holds per strip
+// column dx and slot q the offsets of tap ((ry - q * stride) mod P, rx - dx * stride) — 0 where that is not a tap
+__host__ __device__ static inline QkProgram qk_conv_program_slide(const QkSlots& slS, int ns, int nc, int knl, int stride) {
   QkProgram g;
-  g.th = 1; g.tw = ns;
-  g.np = ns;
+  g.th = nc; g.tw = ns;                 // positions = [strip column][slot]
+  g.np = nc * ns;
   g.rfH = ns * stride;
-  g.rfW = knl;
+  g.rfW = (nc - 1) * stride + knl;
   g.blkU16 = (g.np * slS.hp + 7) / 8 * 8;
   g.wgRowU16 = QCNN_GATHER_WAVES * 2 * g.blkU16;
   g.rowU16 = slS.groups * slS.chunks * g.wgRowU16;

@@ -828,17 +828,24 @@ __device__ __forceinline__ void conv_gather_prog(f32x2 (&acc)[TH * TW][CPW], con
 }
 
 // sliding variant: slot q currently holds an output row whose window starts at source row xq[q] (okq[q] = 0 when that
-// row lies outside the segment); it looks at source row c.hi through tap row d = c.hi - xq[q], 0 <= d < knl
-template <int TW, int CPW, int NB>
-__device__ __forceinline__ void conv_gather_slide(f32x2 (&acc)[TW][CPW], const IdxBlk<NB>& blk, const StagePos& c, int knl,
-                                                  const int (&xq)[TW], const int (&okq)[TW], uint32_t stage, int live) {
+// row lies outside the segment); it looks at source row c.hi through tap row d = c.hi - xq[q], 0 <= d < knl.  A strip of
+// NC output columns keeps NS slots per column (accumulators [column][slot]); column dx looks at source column c.wi
+// through tap column c.wi - colStart[dx]
+template <int NC, int NS, int CPW, int NB>
+__device__ __forceinline__ void conv_gather_slide(f32x2 (&acc)[NC * NS][CPW], const IdxBlk<NB>& blk, const StagePos& c, int knl,
+                                                  const int (&xq)[NS], const int (&okq)[NS], const int (&colStart)[NC],
+                                                  uint32_t stage, int live) {
   constexpr int DW = idx_dwords(CPW);
 #pragma unroll
-  for (int q = 0; q < TW; ++q) {
-    Idx<DW> o;
+  for (int dx = 0; dx < NC; ++dx) {
+    const int colOk = NC == 1 ? live : live & in_range(c.wi - colStart[dx], knl);
 #pragma unroll
-    for (int j = 0; j < DW; ++j) o.w[j] = blk.w[q * DW + j];
-    gather_apply<CPW>(acc[q], o, stage, live & okq[q] & in_range(c.hi - xq[q], knl));
+    for (int q = 0; q < NS; ++q) {
+      Idx<DW> o;
+#pragma unroll
+      for (int j = 0; j < DW; ++j) o.w[j] = blk.w[(dx * NS + q) * DW + j];
+      gather_apply<CPW>(acc[dx * NS + q], o, stage, colOk & okq[q] & in_range(c.hi - xq[q], knl));
+    }
   }
 }
 
@@ -854,7 +861,7 @@ template <int TH, int TW, int CPW, int KT, int KS, bool SLIDE = false>
 __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX, int tilesY, int chunksPerGrp, int G,
                                                         int rowStride) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  static_assert(!SLIDE || (KT == 8 && TH == 1), "the sliding variant exists for the program-table kernels, one output row");
+  static_assert(!SLIDE || (KT == 8 && TH <= 2), "the sliding variant exists for the program-table kernels; TH = output columns of the strip");
   constexpr int NP = TH * TW;
   constexpr int HC = CPW / 2;
   constexpr int DW = idx_dwords(CPW);
@@ -871,8 +878,9 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
     // blockIdx.x = (segment-major unit, longest segments first) * panels + panel
     const unsigned unit = blockIdx.x / (unsigned)p.panels;
     panel = (int)(blockIdx.x % (unsigned)p.panels);
-    const int seg = (int)(unit / (unsigned)p.Wo);
-    tx = (int)(unit % (unsigned)p.Wo);                 // the output column
+    const unsigned colGroups = (unsigned)(p.Wo + TH - 1) / TH;    // SLIDE: TH = output columns of the strip (1 or 2)
+    const int seg = (int)(unit / colGroups);
+    tx = (int)(unit % colGroups) * TH;                 // the strip's first output column
     segBeg = p.segBeg[seg]; segEnd = p.segBeg[seg + 1];   // its output rows
   } else {
     const unsigned bx = blockIdx.x, nBody = (unsigned)p.splitFrom * (unsigned)p.panels;
@@ -895,7 +903,8 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
   const int M = p.M;
 
   const int ho0 = SLIDE ? segBeg : ty * TH, wo0 = SLIDE ? tx : tx * TW;
-  const int hoL = SLIDE ? segEnd - 1 : min(ho0 + TH, p.Ho) - 1, woL = SLIDE ? tx : min(wo0 + TW, p.Wo) - 1;   // last real position
+  const int hoL = SLIDE ? segEnd - 1 : min(ho0 + TH, p.Ho) - 1;                                   // last real position
+  const int woL = SLIDE ? min(tx + TH, p.Wo) - 1 : min(wo0 + TW, p.Wo) - 1;
   const int hiL = max(0, ho0 * p.stride - p.pad), hiU = min(p.H - 1, hoL * p.stride - p.pad + p.knl - 1);
   ConvGeom g;
   g.W = p.W; g.Cin = p.Cin; g.knl = p.knl; g.M = M; g.G = G; g.rowStride = (uint32_t)rowStride;
@@ -1078,7 +1087,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
     constexpr int WGROW = NGW * 2 * NB * 4;            // bytes of the workgroup's row of one program entry
     // program entry of a stage: (row, column) of its pixel relative to the unclipped receptive field of the tile — or,
     // sliding, (source row modulo TW * stride: the slot -> tap-row map repeats with that period, tap column)
-    const int rfW = SLIDE ? p.knl : (TW - 1) * p.stride + p.knl;
+    const int rfW = SLIDE ? (TH - 1) * p.stride + p.knl : (TW - 1) * p.stride + p.knl;
     const int ry0 = ho0 * p.stride - p.pad, rx0 = wo0 * p.stride - p.pad;   // origin of the unclipped receptive field
     const uint32_t entryB = (uint32_t)(p.grp * chunksPerGrp) * WGROW;
     const char* __restrict__ progWg =
@@ -1089,6 +1098,9 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
       return progWg + (size_t)(uint32_t)((row * rfW + (c.wi - rx0)) * M + c.mg) * entryB;
     };
     // sliding: output column of every slot, the bias pointer for a slot's restart, the store of a finished position
+    int colS[TH];                                       // sliding: first source column of every strip column's window
+#pragma unroll
+    for (int dx = 0; dx < TH; ++dx) colS[dx] = (wo0 + dx < p.Wo) ? (wo0 + dx) * p.stride - p.pad : -(1 << 28);
     int woq[TW], xq[TW], okq[TW];                       // slot state: output row, first source row of its window, in-segment
 #pragma unroll
     for (int q = 0; q < TW; ++q) {
@@ -1098,7 +1110,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
     }
     // a slot restarts from the bias every few stages: waves with few channels keep their bias values in registers, the
     // others (12 channels and more: no register to spare, but also many stages per source column) re-read them
-    constexpr bool BIAS_REGS = SLIDE && CPW <= 8;
+    constexpr bool BIAS_REGS = SLIDE && CPW <= 8 && NP * CPW <= 24;
     const float* __restrict__ biasP = p.bias + grp * Ctg + (active ? cl0 : 0);
     float biasR[BIAS_REGS ? HC : 1];
     if constexpr (BIAS_REGS) {
@@ -1114,19 +1126,24 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
 #pragma unroll
       for (int q = 0; q < TW; ++q) {
         if ((c.hi - xq[q] == p.knl - 1 || c.hi == hiU) && okq[q]) {
-          float* o = dstCol + (size_t)woq[q] * p.Wo * p.Ct * PANEL;
 #pragma unroll
-          for (int j = 0; j < HC; ++j) {
-            if (cl0 + j < Ctg) {
-              f32x4 v = {acc[q][2 * j].x, acc[q][2 * j].y, acc[q][2 * j + 1].x, acc[q][2 * j + 1].y};
-              if (p.relu) {
+          for (int dx = 0; dx < TH; ++dx) {
+            float* o = dstCol + ((size_t)woq[q] * p.Wo + dx) * p.Ct * PANEL;
+            const bool colReal = wo0 + dx < p.Wo;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = (0.0f < v[e]) ? v[e] : 0.0f;
+            for (int j = 0; j < HC; ++j) {
+              if (colReal && cl0 + j < Ctg) {
+                f32x4 v = {acc[dx * TW + q][2 * j].x, acc[dx * TW + q][2 * j].y, acc[dx * TW + q][2 * j + 1].x,
+                           acc[dx * TW + q][2 * j + 1].y};
+                if (p.relu) {
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) v[e] = (0.0f < v[e]) ? v[e] : 0.0f;
+                }
+                *reinterpret_cast<f32x4*>(o + j * PANEL) = v;
               }
-              *reinterpret_cast<f32x4*>(o + j * PANEL) = v;
+              const float b = BIAS_REGS ? biasR[BIAS_REGS ? j : 0] : biasP[j];
+              acc[dx * TW + q][2 * j] = f32x2{b, b}; acc[dx * TW + q][2 * j + 1] = f32x2{b, b};
             }
-            const float b = BIAS_REGS ? biasR[BIAS_REGS ? j : 0] : biasP[j];
-            acc[q][2 * j] = f32x2{b, b}; acc[q][2 * j + 1] = f32x2{b, b};
           }
           woq[q] += TW;
           xq[q] += TW * p.stride;
@@ -1154,7 +1171,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
         // the positions the PREVIOUS stage finished are stored first: their stores then have this whole stage period
         // before the barrier's vmcnt(0) (which the row DMA needs) would wait for them
         column_end(cEnd, liveEnd);
-        conv_gather_slide<TW, CPW, NB>(acc, ba, c0p, p.knl, xq, okq, laneLds, activeI);
+        conv_gather_slide<TH, TW, CPW, NB>(acc, ba, c0p, p.knl, xq, okq, colS, laneLds, activeI);
         cEnd = c0p; liveEnd = activeI;
       } else {
         conv_gather_prog<TH, TW, CPW, NB>(acc, ba, c0p, g, rowStart, colStart, laneLds, activeI);   // S >= 1: stage s exists
@@ -1168,7 +1185,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
       TR_MID(s + 1);
       if constexpr (SLIDE) {
         column_end(cEnd, liveEnd);
-        conv_gather_slide<TW, CPW, NB>(acc, bb, c0p, p.knl, xq, okq, laneLds | STAGE_BYTES, activeI & in_range(s + 1, S));
+        conv_gather_slide<TH, TW, CPW, NB>(acc, bb, c0p, p.knl, xq, okq, colS, laneLds | STAGE_BYTES, activeI & in_range(s + 1, S));
         cEnd = c0p; liveEnd = activeI & in_range(s + 1, S);
       } else {
         conv_gather_prog<TH, TW, CPW, NB>(acc, bb, c0p, g, rowStart, colStart, laneLds | STAGE_BYTES,
@@ -1434,8 +1451,9 @@ __global__ __launch_bounds__(256) void k_build_program(const uint8_t* __restrict
     if (pos < pg.np && j < sl.cpw / 2) {
       // tile kernel: position (dy, dx) looks at tap (ry - dy * stride, rx - dx * stride); sliding: slot `pos` at tap row
       // (ry - pos * stride) modulo the period rfH = slots * stride, tap column rx
-      const int kh = slide ? ((ry - pos * stride) % pg.rfH + pg.rfH) % pg.rfH : ry - (pos / pg.tw) * stride;
-      const int kw = slide ? rx : rx - (pos % pg.tw) * stride;
+      // (slide: pg.tw = slots per column, positions are [column][slot])
+      const int kh = slide ? ((ry - (pos % pg.tw) * stride) % pg.rfH + pg.rfH) % pg.rfH : ry - (pos / pg.tw) * stride;
+      const int kw = slide ? rx - (pos / pg.tw) * stride : rx - (pos % pg.tw) * stride;
       // the channel this entry belongs to in the destination's wave split, and where the source table keeps it
       const int half = wh & 1, wave = (wh >> 1) % (sl.chunks * QCNN_GATHER_WAVES), g = (wh >> 1) / (sl.chunks * QCNN_GATHER_WAVES);
       const int ch = wave * sl.cpw + half * (sl.cpw / 2) + j;
@@ -1514,14 +1532,14 @@ hipError_t launch_conv(const ConvParams& p, const QkSlots& sl, int lutMode, hipS
 }
 
 // sliding variant: grid.x = (segments x output columns, longest segments first) x panels
-template <int NS, int CPW>
+template <int NC, int NS, int CPW>
 hipError_t launch_conv_slide(const ConvParams& p, const QkSlots& sl, int lutMode, hipStream_t st) {
   const bool bf16Pairs = lutMode == 3;
-  const dim3 grid((unsigned)(p.nSeg * p.Wo * p.panels), sl.chunks * p.grp, 1);
+  const dim3 grid((unsigned)(p.nSeg * ((p.Wo + NC - 1) / NC) * p.panels), sl.chunks * p.grp, 1);
   const size_t shm = (size_t)2 * STAGE_BYTES + 2 * IDX_BUF;
   const bool two = min(p.Cin / p.grp, p.Cs) > 4;
-  auto kern = two ? k_conv_aprx<1, NS, CPW, 8, 2, true> : k_conv_aprx<1, NS, CPW, 8, 1, true>;
-  if (bf16Pairs && two && p.ctrd2 != nullptr) kern = k_conv_aprx<1, NS, CPW, 8, 3, true>;
+  auto kern = two ? k_conv_aprx<NC, NS, CPW, 8, 2, true> : k_conv_aprx<NC, NS, CPW, 8, 1, true>;
+  if (bf16Pairs && two && p.ctrd2 != nullptr) kern = k_conv_aprx<NC, NS, CPW, 8, 3, true>;
   hipError_t e = allow_big_lds(reinterpret_cast<const void*>(kern), (int)shm);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, grid, dim3(NW * 64), shm, st, p, 0, 0, sl.chunks, 1, sl.rowStride);
@@ -1563,17 +1581,19 @@ hipError_t qk_conv_aprx(const ConvParams& pIn, int lutMode, hipStream_t st) {
   const QkSlots sl = qk_conv_slots(Ctg, p.grp);
   if (p.nSeg > 0 && p.progS != nullptr && p.K == 128 && lutMode != 0) {      // sliding variant (qk_conv_plan_slide)
     const QkSlide sc = qk_slide_config(Ctg, p.grp, p.knl, p.stride);
-    switch (sc.ns * 100 + sc.sl.cpw) {
-      case 216: return launch_conv_slide<2, 16>(p, sc.sl, lutMode, st);
-      case 212: return launch_conv_slide<2, 12>(p, sc.sl, lutMode, st);
-      case 208: return launch_conv_slide<2, 8>(p, sc.sl, lutMode, st);
-      case 312: return launch_conv_slide<3, 12>(p, sc.sl, lutMode, st);
-      case 308: return launch_conv_slide<3, 8>(p, sc.sl, lutMode, st);
-      case 306: return launch_conv_slide<3, 6>(p, sc.sl, lutMode, st);
-      case 304: return launch_conv_slide<3, 4>(p, sc.sl, lutMode, st);
-      case 408: return launch_conv_slide<4, 8>(p, sc.sl, lutMode, st);
-      case 506: return launch_conv_slide<5, 6>(p, sc.sl, lutMode, st);
-      case 504: return launch_conv_slide<5, 4>(p, sc.sl, lutMode, st);
+    switch (sc.nc * 1000 + sc.ns * 100 + sc.sl.cpw) {
+      case 1216: return launch_conv_slide<1, 2, 16>(p, sc.sl, lutMode, st);
+      case 1212: return launch_conv_slide<1, 2, 12>(p, sc.sl, lutMode, st);
+      case 1208: return launch_conv_slide<1, 2, 8>(p, sc.sl, lutMode, st);
+      case 1312: return launch_conv_slide<1, 3, 12>(p, sc.sl, lutMode, st);
+      case 1308: return launch_conv_slide<1, 3, 8>(p, sc.sl, lutMode, st);
+      case 1306: return launch_conv_slide<1, 3, 6>(p, sc.sl, lutMode, st);
+      case 1304: return launch_conv_slide<1, 3, 4>(p, sc.sl, lutMode, st);
+      case 1408: return launch_conv_slide<1, 4, 8>(p, sc.sl, lutMode, st);
+      case 1506: return launch_conv_slide<1, 5, 6>(p, sc.sl, lutMode, st);
+      case 1504: return launch_conv_slide<1, 5, 4>(p, sc.sl, lutMode, st);
+      case 2306: return launch_conv_slide<2, 3, 6>(p, sc.sl, lutMode, st);      // two-column strips: six slots of <= 6 channels
+      case 2304: return launch_conv_slide<2, 3, 4>(p, sc.sl, lutMode, st);
       default: break;
     }
   }
@@ -1697,8 +1717,11 @@ void qk_conv_plan_slide(ConvParams& p, double tileCost) {
   const int ny = sc.sl.chunks * p.grp;               // every channel chunk builds the strip's stages again
   const int G = qcnn_stage_group(p.K), MG = (p.M + G - 1) / G;
   const double kFixed = 12.0;
-  auto segStages = [&](int wo, int a, int b) {         // output column wo, output rows [a, b)
-    const int cols = std::min(p.W - 1, wo * p.stride - p.pad + p.knl - 1) - std::max(0, wo * p.stride - p.pad) + 1;
+  const int nc = sc.nc;                                // output columns per strip
+  const int colGroups = (p.Wo + nc - 1) / nc;
+  auto segStages = [&](int cgi, int a, int b) {        // strip of output columns [cgi * nc, ..), output rows [a, b)
+    const int wA = cgi * nc, wB = std::min(p.Wo, wA + nc) - 1;
+    const int cols = std::min(p.W - 1, wB * p.stride - p.pad + p.knl - 1) - std::max(0, wA * p.stride - p.pad) + 1;
     const int rows = std::min(p.H - 1, (b - 1) * p.stride - p.pad + p.knl - 1) - std::max(0, a * p.stride - p.pad) + 1;
     return (double)std::max(rows, 0) * std::max(cols, 0) * MG;
   };
@@ -1706,7 +1729,7 @@ void qk_conv_plan_slide(ConvParams& p, double tileCost) {
   // AlexNet conv1), and every source row ends with the store + restart of a slot.  Measured: AlexNet conv1 (11 stages per column) -10 %, conv5 (72) -15 %,
   // VGG-16 conv1_2 (24) -12 %, its 128-channel layers (24 / 48) -25 %, but conv1_1 (3 stages per column: one sub-space,
   // three rows) +47 % — a column must hold enough stages to carry its restart.
-  if (std::min(p.knl, p.W) * MG < 6 && tileCost < 1e29) return;      // (forced mode, tests: slides anyway)
+  if (std::min(p.knl + (sc.nc - 1) * p.stride, p.W) * MG < 6 && tileCost < 1e29) return;      // (forced mode, tests: slides anyway)
   auto segCost = [&](int wo, int a, int b) {
     const int rows = std::min(p.H - 1, (b - 1) * p.stride - p.pad + p.knl - 1) - std::max(0, a * p.stride - p.pad) + 1;
     return segStages(wo, a, b) + 0.3 * std::max(rows, 0);
@@ -1718,7 +1741,7 @@ void qk_conv_plan_slide(ConvParams& p, double tileCost) {
     const int nSeg = (int)beg.size() - 1;
     for (int y = 0; y < ny; ++y)
       for (int sgi = 0; sgi < nSeg; ++sgi)
-        for (int wo = 0; wo < p.Wo; ++wo)
+        for (int wo = 0; wo < colGroups; ++wo)
           for (int pn = 0; pn < p.panels; ++pn) {
             std::pop_heap(cu.begin(), cu.end(), std::greater<double>());
             cu.back() += segCost(wo, beg[sgi], beg[sgi + 1]) + kFixed;
@@ -1744,7 +1767,9 @@ void qk_conv_plan_slide(ConvParams& p, double tileCost) {
     cands.assign(1, b);
     tileCost = 1e30;
   }
-  double best = tileCost;                                    // sliding must beat the (split) tile launch
+  // sliding must beat the (split) tile launch — clearly (8 %) when it needs more channel chunks than the tile kernel: the
+  // model does not see the uneven last chunk (VGG-16's 14 x 14 x 512 layers measured 5 % slower where it predicted a tie)
+  double best = tileCost * (sc.sl.chunks > qk_conv_slots(Ctg, p.grp).chunks ? 0.92 : 1.0);
   for (const std::vector<int>& b : cands) {
     // order the segments longest first (dispatch order = LPT); boundaries stay contiguous per segment
     std::vector<std::pair<int, int> > segs;

@@ -66,16 +66,18 @@ def conv_work_slide(in_hwc, out_hwc, ly, m: int, k: int, cs: int, seg_beg):
     _, _, cpw, chunks = conv_tile(ct // grp)
     g = stage_group(k)
     mg = (m + g - 1) // g
+    slots = (knl + s - 1) // s
+    nc = 2 if (slots == 3 and cpw <= 6) else 1          # output columns per strip (qk_slide_config)
     stages = 0
-    for x in range(wo):
-        cols = min(w - 1, x * s - p + knl - 1) - max(0, x * s - p) + 1
+    for x0 in range(0, wo, nc):
+        x1 = min(wo, x0 + nc) - 1
+        cols = min(w - 1, x1 * s - p + knl - 1) - max(0, x0 * s - p) + 1
         for a, b in zip(seg_beg[:-1], seg_beg[1:]):
             rows = min(h - 1, (b - 1) * s - p + knl - 1) - max(0, a * s - p) + 1
             stages += max(rows, 0) * max(cols, 0) * mg
     stages *= chunks * grp
-    slots = (knl + s - 1) // s
     return dict(base, stages=stages, mfma_flop=stages * 128 * 128 * 4 * base["ks"] * 2,
-                tile="slide %d slots x %d, %d segment(s) per column" % (slots, GATHER_WAVES * cpw, len(seg_beg) - 1))
+                tile="slide %d column(s) x %d slots x %d, %d segment(s) per column" % (nc, slots, GATHER_WAVES * cpw, len(seg_beg) - 1))
 
 
 def fc_work(d: int, ct: int, m: int, k: int, cs: int, msplit_chunks: int):
