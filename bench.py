@@ -19,8 +19,9 @@ Extra objects on the JSON line:
                 passes when they were taken from THIS kernel source (hash check), else null; per conv/FC layer the
                 figures the kernels are really bounded by (stages built, rebuild factor, cycles per stage, look-ups
                 against the LDS read peak, matrix-pipe utilisation).
-  parity        the first images of the timed batch run through the CPU reference (or the C port) and compared
-                with what the GPU produced for them: probabilities, pool5 feature map, top-5.  > 1e-4 aborts.
+  parity        images of the timed batch — half from the first panel, half from the end of the last, ragged one — run
+                through the CPU reference (or the C port) and compared with what the GPU produced for them:
+                probabilities, pool5 feature map, top-5.  > 1e-4 aborts.
   cpu_baseline  the reference itself (oracle/_ref/libqcnn_ref.so, kind "reference") — or the C port when that was
                 never built — timed single-threaded on this host on a bounded sample (N = 1 only).
 """
@@ -468,12 +469,20 @@ def main():
             step()
             torch.cuda.synchronize(dev)
             fm_idx = max(i + 1 for i, l in enumerate(layers) if l["type"] == topo.POOL)
-            parity = parity_check(kind, cpu, layers, mine[:pn].cpu().numpy(), prob[lo:lo + pn].cpu().numpy(),
-                                  top5[lo:lo + pn].cpu().numpy().view(np.uint16), eng.layer_output(fm_idx, pn), fm_idx)
+            # half of the checked images from the first panel, half from the END of this rank's block (the last, ragged panel)
+            head = (pn + 1) // 2
+            tail = pn - head if n_local >= pn else 0
+            idx = list(range(head)) + list(range(n_local - tail, n_local))
+            sel = torch.tensor(idx, device=dev)
+            fm = np.concatenate([eng.layer_output_range(fm_idx, 0, head)] +
+                                ([eng.layer_output_range(fm_idx, n_local - tail, tail)] if tail else []))
+            parity = parity_check(kind, cpu, layers, mine[sel].cpu().numpy(), prob[lo:hi][sel].cpu().numpy(),
+                                  top5[lo:hi][sel].cpu().numpy().view(np.uint16), fm, fm_idx)
+            parity["image_indices"] = [lo + i for i in idx]
             if bf_prob is not None:                      # the opt-in builder's probabilities against the same reference
-                ref = prob[lo:lo + pn].cpu().numpy()
+                ref = prob[lo:lo + bf_prob.shape[0]].cpu().numpy()
                 extras["bf16_pairs_max_rel_diff_vs_f32_builder"] = float(
-                    max(np.abs(bf_prob[i] - ref[i]).max() / np.abs(ref[i]).max() for i in range(pn)))
+                    max(np.abs(bf_prob[i] - ref[i]).max() / np.abs(ref[i]).max() for i in range(bf_prob.shape[0])))
         if args.cpu_sample > 0 and world == 1:
             cb = cpu_baseline(kind, cpu, imgs[: args.cpu_sample].cpu().numpy())
 
