@@ -243,18 +243,23 @@ __global__ __launch_bounds__(256) void k_pool4(const float4* __restrict__ src, f
 // Every normalised value is evaluated once per block (the one-pixel halo between tiles: 81/64 = 1.27x) instead of
 // once per window that contains it (2.25x: that version lost to the two separate kernels), and the
 // map takes one HBM read instead of write + read.
-constexpr int LP_PT = 4;                        // pool outputs per tile side
+#ifndef QCNN_LP_PT
+#define QCNN_LP_PT 4
+#define QCNN_LP_Q 8
+#define QCNN_LP_THREADS 704
+#endif
+constexpr int LP_PT = QCNN_LP_PT;               // pool outputs per tile side
 constexpr int LP_IT = (LP_PT - 1) * 2 + 3;      // source pixels per tile side
 constexpr int LP_PIX = LP_IT * LP_IT;
-constexpr int LP_Q = 8;                         // float4 lanes (4 images each) per block
-constexpr int LP_THREADS = 704;                 // >= LP_PIX * LP_Q, >= 16 * 5 * LP_Q
+constexpr int LP_Q = QCNN_LP_Q;                 // float4 lanes (4 images each) per block (a power of two)
+constexpr int LP_THREADS = QCNN_LP_THREADS;     // >= LP_PIX * LP_Q, >= LP_PT^2 * 5 * LP_Q
 template <int N, bool B34>
 __global__ __launch_bounds__(LP_THREADS) void k_lrn_pool(const float4* __restrict__ src, float4* __restrict__ dst, int H,
                                                          int W, int C, int Ho, int Wo, int tilesX, float coeff, float nbet,
                                                          float ini, int liveQuads) {
   constexpr int RAD = (N - 1) / 2;
   __shared__ float4 slab[N * LP_PIX * LP_Q];
-  const int q = threadIdx.x & (LP_Q - 1), rest = threadIdx.x >> 3;
+  const int q = threadIdx.x & (LP_Q - 1), rest = threadIdx.x / LP_Q;
   const int slices = 32 / LP_Q;
   const int slice = blockIdx.x % slices, tile = blockIdx.x / slices;
   const int panel = blockIdx.y;
