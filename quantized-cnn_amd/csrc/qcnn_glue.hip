@@ -340,65 +340,91 @@ __global__ __launch_bounds__(LP_THREADS) void k_lrn_pool(const float4* __restric
   }
 }
 
-// Softmax through LDS: a block = 32 images x 8 class lanes.  expf of every logit in parallel into an
-// LDS tile [C][32], the reference's SEQUENTIAL float sum over the classes (src/CaffeEva.cc:1107-1114) by
-// one thread per image out of LDS, then the division in parallel.  Same values as k_softmax.
-__global__ __launch_bounds__(256) void k_softmax_lds(const float* __restrict__ src, float* __restrict__ dst, int C) {
+// Softmax through LDS: a block = 32 images x 32 class lanes.  expf of every logit in parallel into an LDS tile
+// [C][33] (odd row stride: both the image-major and the class-major access below are conflict-free), the reference's
+// SEQUENTIAL float sum over the classes (src/CaffeEva.cc:1107-1114) by one thread per image out of LDS — reads
+// issued sixteen ahead of the dependent adds —, then the division in parallel.  Same values as k_softmax.
+constexpr int SM_LD = 33;
+__global__ __launch_bounds__(1024) void k_softmax_lds(const float* __restrict__ src, float* __restrict__ dst, int C) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  float* tile = reinterpret_cast<float*>(lds);            // [C][32]
-  float* sums = tile + (size_t)C * 32;                    // [32]
+  float* tile = reinterpret_cast<float*>(lds);            // [C][33]
+  float* sums = tile + (size_t)C * SM_LD;                 // [32]
   const int img = threadIdx.x & 31, cl = threadIdx.x >> 5;
   const size_t off = (size_t)blockIdx.y * C * PANEL + blockIdx.x * 32 + img;
   const float* x = src + off;
   float* y = dst + off;
-  for (int c = cl; c < C; c += 8) tile[c * 32 + img] = expf(x[(size_t)c * PANEL]);
+  int c = cl;
+  for (; c + 96 < C; c += 128) {                          // four independent loads in flight per thread
+    const float v0 = x[(size_t)c * PANEL], v1 = x[(size_t)(c + 32) * PANEL], v2 = x[(size_t)(c + 64) * PANEL],
+                v3 = x[(size_t)(c + 96) * PANEL];
+    tile[c * SM_LD + img] = expf(v0);
+    tile[(c + 32) * SM_LD + img] = expf(v1);
+    tile[(c + 64) * SM_LD + img] = expf(v2);
+    tile[(c + 96) * SM_LD + img] = expf(v3);
+  }
+  for (; c < C; c += 32) tile[c * SM_LD + img] = expf(x[(size_t)c * PANEL]);
   __syncthreads();
   if (cl == 0) {
     float sum = 0.0f;
-    for (int c = 0; c < C; ++c) sum = __fadd_rn(sum, tile[c * 32 + img]);
+    int k = 0;
+    for (; k + 16 <= C; k += 16) {
+      float v[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) v[j] = tile[(k + j) * SM_LD + img];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) sum = __fadd_rn(sum, v[j]);
+    }
+    for (; k < C; ++k) sum = __fadd_rn(sum, tile[k * SM_LD + img]);
     sums[img] = sum;
   }
   __syncthreads();
   const float sum = sums[img];
-  for (int c = cl; c < C; c += 8) y[(size_t)c * PANEL] = __fdiv_rn(tile[c * 32 + img], sum);
+  for (c = cl; c < C; c += 32) y[(size_t)c * PANEL] = __fdiv_rn(tile[c * SM_LD + img], sum);
 }
 
-// Top-5 through LDS: a block = 32 images x 8 class lanes; per sweep every class lane finds the first
-// maximum (strict '<' from FLT_MIN) of its classes, the eight candidates are merged (larger value, then
-// lower index = the sequential sweep's first occurrence), the winner is zeroed (src/CaffeEva.cc:1173-1188).
-__global__ __launch_bounds__(256) void k_top5_lds(const float* __restrict__ prob, uint16_t* __restrict__ out, int n,
-                                                  int C) {
+// Top-5 through LDS: a block stages 32 images x C classes as [C][33]; then every half-wave owns ONE image, its 32
+// lanes sweep the classes c = lane, lane + 32, ... for their first maximum (strict '<' from FLT_MIN), a butterfly
+// over the 32 lanes merges the candidates (larger value, then lower index = the sequential sweep's first
+// occurrence), the winner is zeroed (src/CaffeEva.cc:1173-1188).  An image's column is touched by its own
+// half-wave only: no workgroup barrier inside the five sweeps.
+__global__ __launch_bounds__(1024) void k_top5_lds(const float* __restrict__ prob, uint16_t* __restrict__ out, int n,
+                                                   int C) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  float* tile = reinterpret_cast<float*>(lds);            // [C][32]
-  float* candV = tile + (size_t)C * 32;                   // [8][32]
-  int* candI = reinterpret_cast<int*>(candV + 8 * 32);    // [8][32]
-  const int img = threadIdx.x & 31, cl = threadIdx.x >> 5;
-  const int gi = blockIdx.y * PANEL + blockIdx.x * 32 + img;
-  const float* x = prob + (size_t)blockIdx.y * C * PANEL + blockIdx.x * 32 + img;
-  for (int c = cl; c < C; c += 8) tile[c * 32 + img] = x[(size_t)c * PANEL];
+  float* tile = reinterpret_cast<float*>(lds);            // [C][33]
+  {
+    const int img = threadIdx.x & 31, cl = threadIdx.x >> 5;
+    const float* x = prob + (size_t)blockIdx.y * C * PANEL + blockIdx.x * 32 + img;
+    int c = cl;
+    for (; c + 96 < C; c += 128) {
+      const float v0 = x[(size_t)c * PANEL], v1 = x[(size_t)(c + 32) * PANEL], v2 = x[(size_t)(c + 64) * PANEL],
+                  v3 = x[(size_t)(c + 96) * PANEL];
+      tile[c * SM_LD + img] = v0;
+      tile[(c + 32) * SM_LD + img] = v1;
+      tile[(c + 64) * SM_LD + img] = v2;
+      tile[(c + 96) * SM_LD + img] = v3;
+    }
+    for (; c < C; c += 32) tile[c * SM_LD + img] = x[(size_t)c * PANEL];
+  }
   __syncthreads();
+  const int img = threadIdx.x >> 5, cl = threadIdx.x & 31;
+  const int gi = blockIdx.y * PANEL + blockIdx.x * 32 + img;
   for (int r = 0; r < 5; ++r) {
     float best = FLT_MIN;
     int bi = 0;
-    for (int c = cl; c < C; c += 8) {
-      const float v = tile[c * 32 + img];
+    for (int c = cl; c < C; c += 32) {
+      const float v = tile[c * SM_LD + img];
       if (best < v) { best = v; bi = c; }
     }
-    candV[cl * 32 + img] = best;
-    candI[cl * 32 + img] = bi;
-    __syncthreads();
-    if (cl == 0) {
-      float b = candV[img];
-      int i = candI[img];
-      for (int k = 1; k < 8; ++k) {
-        const float v = candV[k * 32 + img];
-        const int vi = candI[k * 32 + img];
-        if (b < v || (b == v && vi < i)) { b = v; i = vi; }
-      }
-      if (gi < n) out[(size_t)gi * 5 + r] = (uint16_t)i;
-      tile[i * 32 + img] = 0.0f;
+#pragma unroll
+    for (int d = 16; d >= 1; d >>= 1) {
+      const float v = __shfl_xor(best, d, 32);
+      const int vi = __shfl_xor(bi, d, 32);
+      if (best < v || (best == v && vi < bi)) { best = v; bi = vi; }
     }
-    __syncthreads();
+    if ((bi & 31) == cl) {                                // the lane that sweeps class bi: it reads the zero next round
+      tile[bi * SM_LD + img] = 0.0f;
+      if (gi < n) out[(size_t)gi * 5 + r] = (uint16_t)bi;
+    }
   }
 }
 
@@ -610,12 +636,12 @@ hipError_t qk_pool(const float* src, float* dst, int panels, int H, int W, int C
 }
 
 hipError_t qk_softmax(const float* src, float* dst, int panels, int C, int live, hipStream_t st) {
-  const size_t shm = ((size_t)C * 32 + 32) * sizeof(float);
+  const size_t shm = ((size_t)C * SM_LD + 32) * sizeof(float);
   if (shm <= 160 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_softmax_lds),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_softmax_lds, dim3((live + 31) / 32, panels), dim3(256), shm, st, src, dst, C);
+    hipLaunchKernelGGL(k_softmax_lds, dim3((live + 31) / 32, panels), dim3(1024), shm, st, src, dst, C);
     return hipGetLastError();
   }
   hipLaunchKernelGGL(k_softmax, dim3((panels * PANEL + 63) / 64), dim3(64), 0, st, src, dst, panels, C);
@@ -623,12 +649,12 @@ hipError_t qk_softmax(const float* src, float* dst, int panels, int C, int live,
 }
 
 hipError_t qk_top5(const float* prob, uint16_t* out, int n, int C, hipStream_t st) {
-  const size_t shm = ((size_t)C * 32 + 2 * 8 * 32) * sizeof(float);
+  const size_t shm = (size_t)C * SM_LD * sizeof(float);
   if (shm <= 160 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_top5_lds),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_top5_lds, dim3(n <= PANEL ? (n + 31) / 32 : PANEL / 32, panels_of(n)), dim3(256), shm, st, prob, out, n, C);
+    hipLaunchKernelGGL(k_top5_lds, dim3(n <= PANEL ? (n + 31) / 32 : PANEL / 32, panels_of(n)), dim3(1024), shm, st, prob, out, n, C);
     return hipGetLastError();
   }
   hipLaunchKernelGGL(k_top5, dim3((n + 63) / 64), dim3(64), 0, st, prob, out, n, C);

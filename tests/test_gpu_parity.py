@@ -306,6 +306,35 @@ def test_fallback_glue_kernels():
     eng.close()
 
 
+def test_top5_ties_and_softmax_tile():
+    """Soft-max / top-5 through the LDS tile (200 classes over 32 class lanes): classes c and c + 100 share their
+    bias and assignment rows, so every probability ties with its twin and the first occurrence must win, exactly as
+    the reference's sequential sweeps pick it (src/CaffeEva.cc:1173-1188); the soft-max sum is the sequential one."""
+    layers = [topo.conv(1, 3, 32, 1, 1), topo.relu(), topo.pool(0, 2, 2), topo.fcnt(200), topo.smax()]
+    in_chw = (3, 8, 8)
+    params = synth.make_params(in_chw, layers, seed=81)
+    fc = params[3]
+    fc["bias"][100:] = fc["bias"][:100]
+    fc["asmt"][100:] = fc["asmt"][:100]
+    imgs = synth.make_images(70, in_chw, seed=82)                      # three blocks of 32 images, the last ragged
+    orc = po.COracle(in_chw, layers)
+    orc.set_params(params)
+    orc.forward(imgs)
+    L = len(layers)
+    want = np.stack([orc.top5(orc.fm(L)[i]) for i in range(70)])
+    assert np.array_equal(want[:, 1], want[:, 0] + 100) and np.array_equal(want[:, 3], want[:, 2] + 100)   # first, then twin
+    for n in (70, 1):
+        eng = make_engine(in_chw, layers, params, n, lut=capi.LUT_EXACT)
+        prob, top5 = eng.forward_host(imgs[:n])
+        assert np.array_equal(prob[:, :100], prob[:, 100:])
+        assert np.array_equal(top5, np.stack([orc.top5(prob[i]) for i in range(n)]))   # the sweeps on the device's own bits
+        if n > 2:                                                      # panel kernels: bit-identical with the reference
+            assert np.array_equal(top5, want[:n])
+        e_inf, e_l2 = rel_err(prob, orc.fm(L)[:n])
+        assert e_inf <= TOL_LIBM and e_l2 <= TOL_LIBM
+        eng.close()
+
+
 def test_vgg16_two_panel_batch():
     """BASELINE.json configs[3] beyond one panel: 130 images (one full panel + 2).  The oracle needs ~10 s per VGG-16
     image, so: image 129 of the batch must equal the same image run alone bit for bit (batch invariance), and that
