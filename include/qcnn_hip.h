@@ -94,6 +94,13 @@ enum {
                               faster than the tile kernel.  Same summation order as the tile kernels ((kh, kw, m)), MFMA
                               builders only.  0 = tile kernels only; 2 = whenever
                               a layer is eligible, whatever the planner predicts (tests). */
+  QCNN_OPT_DECODE = 8,     /* 1 (default): a conv layer with ONE sub-space of <= 4 dims (the RGB input layer: AlexNet conv1,
+                              VGG-16 conv1_1) is evaluated through the code words its assignments name — the look-up
+                              tables of src/CaffeEva.cc:1261-1296 are not materialised, the same sum goes to the matrix
+                              pipe (a look-up there stands for <= 4 multiply-adds and the table of a pixel costs more than
+                              the look-ups it serves).  Same parameters, same function, results within the MFMA modes'
+                              tolerance; the network input is then packed into panels first.  MFMA modes only
+                              (QCNN_OPT_LUT_MODE 1, 3), batches above QCNN_SMALL_BATCH_MAX.  0 = table kernels for every layer */
   QCNN_OPT_HOST_CHUNK = 6, /* panels per chunk (default 2) of a qcnn_forward_host batch of at least two chunks: every chunk is
                               uploaded on a copy stream and its layers start when it has arrived, so the upload of chunk
                               k + 1 runs under the layers of chunk k; all chunks fill the same whole-batch feature maps.

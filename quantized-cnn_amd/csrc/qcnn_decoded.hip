@@ -1,0 +1,272 @@
+// qcnn_decoded.hip — quantised conv layers with ONE sub-space of <= 4 dims (AlexNet conv1, VGG-16 conv1_1: the RGB input).
+//
+// For such a layer a table look-up replaces Cin <= 4 multiply-adds and the table of a source pixel (K code words x 128
+// images, 64 KB of LDS stores) serves only knl^2 / stride^2 x Ct look-ups: in k_conv_aprx two thirds of a conv1 stage are
+// the table build.  The same sum
+//
+//     dst[pos][c] = bias[c] + sum_taps  LUT[pixel(pos, tap)][asmt[tap][c]],     LUT[p][k] = sum_d x[p][d] * ctrd[d][k]
+//                                                                   (src/CaffeEva.cc:816-865 over :1261-1296)
+//
+// is evaluated here WITHOUT materialising the tables: every assignment is replaced by the code word it names
+// (k_decode_weights: w[tap][d][c] = ctrd[d][asmt[tap][c]], once per parameter upload) and the products go to the matrix
+// pipe — v_mfma_f32_16x16x4_f32 with A = decoded code words [16 channels x 4 k], B = the panel rows themselves
+// [4 k x 16 images]; k runs over the (column, input channel) pairs of ONE kernel row, which are consecutive panel rows,
+// so there is no im2col buffer and no address table.  Same quantised parameters, same function; the sum is fused
+// multiply-adds in (tap, d) order instead of d-sums rounded into a table first — within the north-star tolerance like
+// every MFMA path (the exact builder, QCNN_LUT_EXACT, never takes this path).
+//
+// A workgroup = 2 * PW consecutive output positions (row-major, any row boundaries) x all channels x one 128-image
+// panel; wave = (image tile of 16, position group): CT x PW accumulator tiles.  The code words of one kernel row sit in
+// LDS ([k][channel], double buffered, 16 KB for conv1); B operands are plain global loads (four 64-byte segments each).
+#include "qcnn_kernels.h"
+#include <algorithm>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#ifndef QCNN_DEC_VAR
+#define QCNN_DEC_VAR 0      // timing experiments only (scripts/build_variant.sh): 1 no B loads, 2 no A reads, 4 no row barrier
+#endif
+
+namespace {
+
+constexpr int PANEL = QCNN_PANEL;
+
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// rows: [kh][kw][M = 1][rowStride] slot bytes (QkSlots order); ctrd: [Cs][K]; out: [knl][Kp][S]
+__global__ void k_decode_weights(const uint8_t* __restrict__ rows, const float* __restrict__ ctrd, float* __restrict__ out,
+                                 QkSlots sl, int knl, int Cin, int K, int Ct, int Kp, int S) {
+  const int total = knl * Kp * S;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int ch = i % S, k = (i / S) % Kp, kh = i / (S * Kp);
+    float w = 0.0f;
+    if (ch < Ct && k < knl * Cin) {
+      const int kw = k / Cin, d = k % Cin;
+      const int slot = rows[(size_t)(kh * knl + kw) * sl.rowStride + qk_slot_entry(sl, 0, ch)];
+      w = ctrd[(size_t)d * K + qcnn_row_slot(slot)];            // qcnn_row_slot is its own inverse; M = 1: stage row = code word
+    }
+    out[i] = w;
+  }
+}
+
+// Persistent waves: a workgroup loads ALL decoded code words into LDS once ([knl * Kp][S], <= 152 KB), then every wave
+// walks its own list of work items without any workgroup synchronisation: the waves of a SIMD drift apart, so one wave's
+// operand loads and result stores sit under the other waves' matrix instructions.
+//
+// A work item = (panel, PW consecutive output positions, 64 of the panel's images, 16 * CT channels).  Every memory
+// instruction between two matrix instructions costs matrix-pipe time (measured: ~20 cycles per load, ~55 per store), so
+// the operands come in wide: ONE buffer_load_dwordx4 brings the B operands of FOUR image tiles — a lane (k row kq, li)
+// holds images 4 li .. 4 li + 3 of its 64, image tile t = the images with index t modulo 4, any partition of the images
+// into sixteens serves —, one ds_read2_b32 the A operands of two channel tiles; the results leave as dwordx4 rows of four
+// consecutive images.  B operands run three steps ahead of the products (a ring of three register sets over the flat
+// (kernel row, step) sequence), A operands one step ahead.
+template <int CT, int PW, bool PADDED, int R>
+__global__ __launch_bounds__(1024) void k_conv_dec(DecParams p) {
+  extern __shared__ __attribute__((aligned(16))) float ldsW[];          // [knl * Kp][S]
+  const int lane = threadIdx.x & 63, wave = uni(threadIdx.x >> 6);
+  const int li = lane & 15, kq = lane >> 4;
+  const int P = p.Ho * p.Wo;
+  {
+    const int wq = (p.knl * p.Kp * p.S) >> 2;
+    const f32x4* __restrict__ wsrc = reinterpret_cast<const f32x4*>(p.wdec);
+    f32x4* ldsW4 = reinterpret_cast<f32x4*>(ldsW);
+    for (int i = threadIdx.x; i < wq; i += 1024) ldsW4[i] = wsrc[i];
+  }
+  __syncthreads();
+  const int NS = p.Kp >> 2;                                             // steps (of four k) per kernel row
+  const int T = p.knl * NS;                                             // steps per work item
+  const int groups = (P + PW - 1) / PW;                                 // position groups per panel
+  const int halves = (p.live + 63) >> 6;                                // 64-image blocks a panel has (a small batch: one)
+  const int chunks = p.Ct / (16 * CT);                                  // channel chunks
+  const int nItems = p.panels * groups * halves * chunks;
+  const int kClamp = p.Kr - 1;
+  // Workgroups go to the eight XCDs round-robin (workgroup i -> XCD i % 8) and every XCD has its own L2: an XCD takes a
+  // CONTIGUOUS eighth of the item list (whole panels for a 1000-image batch), so that the windows its waves read overlap
+  // in ITS L2 instead of every L2 fetching the whole input.
+  const int xcd = blockIdx.x & 7, nX = gridDim.x < 8 ? gridDim.x : 8;
+  const int wgX = (gridDim.x - xcd + 7) >> 3;                           // workgroups of this XCD
+  const int itemBeg = (int)((long long)nItems * xcd / nX), itemEnd = (int)((long long)nItems * (xcd + 1) / nX);
+  for (int item = itemBeg + (blockIdx.x >> 3) * 16 + wave; item < itemEnd; item += wgX * 16) {
+    // channel chunk fastest, then image block: the waves of a workgroup share their B rows through the L1
+    const int cc = item % chunks, ib = (item / chunks) % halves, pgi = item / (chunks * halves);
+    const int panel = pgi / groups, pos0 = (pgi % groups) * PW;
+    int r0[PW], c0[PW];
+#pragma unroll
+    for (int j = 0; j < PW; ++j) {
+      const int q = pos0 + j < P ? pos0 + j : P - 1;                    // positions past the map (last group): computed, not stored
+      r0[j] = (q / p.Wo) * p.stride - p.pad;
+      c0[j] = (q % p.Wo) * p.stride - p.pad;
+    }
+    // Vector ALU work takes matrix-pipe time on a SIMD, so a B load costs no vector instruction besides
+    // itself: a buffer load with the lane's part of the address (k row kq, images 4 li ..) in ONE constant VGPR and
+    // everything else — position, kernel row, step — in the scalar offset.  Reads past the end of the batch's map (the k
+    // padding of the very last window) return 0 by the buffer's range check; those before it are the next pixel's rows.
+    const float* __restrict__ srcU = p.src + (size_t)panel * p.H * p.W * p.Cin * PANEL + ib * 64;
+    const size_t left = (size_t)(p.panels - panel) * p.H * p.W * p.Cin * PANEL * sizeof(float) - ib * 256;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(srcU), 0, left < 0xffffffffull ? (unsigned)left : 0xffffffffu, 0x00020000);
+    const int laneOff = (kq * PANEL + 4 * li) * (int)sizeof(float);
+    int posOff[PW];                                                     // byte offset of the window's first row, per position
+#pragma unroll
+    for (int j = 0; j < PW; ++j) posOff[j] = (r0[j] * p.W + c0[j]) * p.Cin * PANEL * (int)sizeof(float);
+    const int rowPitch = p.W * p.Cin * PANEL * (int)sizeof(float);
+    constexpr int kStep = 4 * PANEL * (int)sizeof(float);                // bytes between two steps' first rows
+    // B operands of step `step` of kernel row `kh`: four consecutive panel rows (k) x 64 images, per position
+    auto load_b = [&](int kh, int step, int soff, f32x4 (&b)[PW]) {
+#if QCNN_DEC_VAR & 1
+      for (int j = 0; j < PW; ++j) b[j] = f32x4{(float)kh, (float)step, (float)j, 1.0f};
+      return;
+#endif
+#pragma unroll
+      for (int j = 0; j < PW; ++j) {
+        if (PADDED) {
+          const int row = r0[j] + kh;
+          const int k = 4 * step + kq;
+          const int kc = k < kClamp ? k : kClamp;                       // k >= Kr: any finite operand, its code word is zero
+          const int col = c0[j] + kc / p.Cin;
+          const bool ok = row >= 0 && row < p.H && col >= 0 && col < p.W;
+          const f32x4 v = *reinterpret_cast<const f32x4*>(srcU + (ok ? ((row * p.W + c0[j]) * p.Cin + kc) * PANEL + 4 * li : 0));
+          b[j] = ok ? v : f32x4{0.0f, 0.0f, 0.0f, 0.0f};               // a panel map is < 2^31 floats (qk_conv_dec)
+        } else {
+          b[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, laneOff, posOff[j] + soff, 0));
+        }
+      }
+    };
+    f32x4 acc[PW][CT][4];                                               // [position][channel tile][image tile]
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + (cc * CT + ct) * 16 + 4 * kq);   // D row 4 * kq + r = channel
+#pragma unroll
+      for (int j = 0; j < PW; ++j)
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti) acc[j][ct][ti] = b4;
+    }
+    // (kernel row, step) of the next B load and its byte offset from the window's first row.  Past the last step the
+    // sequence simply runs on (rows below the window, or the buffer's zero): those operands are never multiplied, and
+    // loads that are unconditional let the compiler count the ones in flight.
+    int khL = 0, stL = 0, soffL = 0;
+    f32x4 b[R][PW];                                                     // R = operand sets in flight (2 or 3)
+    float a[R][CT];
+    auto next_b = [&](f32x4 (&bb)[PW]) {
+      load_b(khL, stL, soffL, bb);
+      const int wrap = stL + 1 == NS ? 1 : 0;
+      stL = wrap ? 0 : stL + 1;
+      khL += wrap;
+      soffL += wrap ? rowPitch - (NS - 1) * kStep : kStep;
+    };
+    // A operands of flat step t: k rows 4 t .. 4 t + 3 (= kh * Kp + 4 * step) of this wave's channels; past the end: LDS zeros
+    const float* __restrict__ wl = ldsW + kq * p.S + cc * 16 * CT + li;
+    const int aStep = 4 * p.S;
+    auto load_a = [&](const float* __restrict__ w, float (&aa)[CT]) {
+#if QCNN_DEC_VAR & 2
+      for (int ct = 0; ct < CT; ++ct) aa[ct] = (float)ct;
+      return;
+#endif
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) aa[ct] = w[ct * 16];
+    };
+    auto products = [&](const float (&aa)[CT], const f32x4 (&bb)[PW]) {
+#pragma unroll
+      for (int j = 0; j < PW; ++j)
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct)
+            acc[j][ct][ti] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[ct], bb[j][ti], acc[j][ct][ti], 0, 0, 0);
+    };
+#pragma unroll
+    for (int u = 0; u < R; ++u) next_b(b[u]);
+    load_a(wl, a[0]);
+    int t = 0;
+    for (; t + R <= T; t += R) {
+#pragma unroll
+      for (int u = 0; u < R; ++u) {
+        wl += aStep;
+        load_a(wl, a[(u + 1) % R]);
+        __builtin_amdgcn_sched_barrier(0);
+        products(a[u], b[u]);
+        __builtin_amdgcn_sched_barrier(0);
+        next_b(b[u]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < R - 1; ++u)                                     // the steps left when T is not a multiple of R
+      if (t + u < T) {
+        wl += aStep;
+        load_a(wl, a[(u + 1) % R]);
+        products(a[u], b[u]);
+      }
+    // D tile ti, element r of lane (li, kq): channel 4 * kq + r of the tile, image 4 * li + ti of the 64
+#pragma unroll
+    for (int j = 0; j < PW; ++j) {
+      if (pos0 + j >= P) continue;
+      float* __restrict__ dst = p.dst + ((size_t)panel * P + pos0 + j) * p.Ct * PANEL + ib * 64 + 4 * li;
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          f32x4 v = {acc[j][ct][0][r], acc[j][ct][1][r], acc[j][ct][2][r], acc[j][ct][3][r]};
+          if (p.relu) {
+            v[0] = (0.0f < v[0]) ? v[0] : 0.0f; v[1] = (0.0f < v[1]) ? v[1] : 0.0f;
+            v[2] = (0.0f < v[2]) ? v[2] : 0.0f; v[3] = (0.0f < v[3]) ? v[3] : 0.0f;
+          }
+#if QCNN_DEC_VAR & 8
+          if (v[0] == 1.2345f)
+#endif
+          *reinterpret_cast<f32x4*>(dst + (size_t)((cc * CT + ct) * 16 + 4 * kq + r) * PANEL) = v;
+        }
+    }
+  }
+}
+
+template <int CT, int PW, bool PADDED, int R>
+hipError_t launch_dec(const DecParams& p, hipStream_t st) {
+  const int P = p.Ho * p.Wo;
+  const long long items = (long long)p.panels * ((P + PW - 1) / PW) * ((p.live + 63) / 64) * (p.Ct / (16 * CT));
+  const int blocks = (int)std::min<long long>(256, (items + 15) / 16);    // one persistent workgroup per CU
+  const size_t shm = (size_t)p.knl * p.Kp * p.S * sizeof(float);
+  auto kern = k_conv_dec<CT, PW, PADDED, R>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(1024), shm, st, p);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+bool qk_conv_dec_shape(int Cin, int grp, int M, int Ct, int knl, int* Kp, int* S) {
+  if (grp != 1 || M != 1 || Cin < 1 || Cin > 4) return false;
+  if (Ct < 32 || Ct % 32) return false;                   // a wave owns 32, 64 or 96 channels
+  const int kp = (knl * Cin + 3) / 4 * 4;
+  // channel stride: four consecutive k rows of 16 channels on distinct banks (stride = 16 or 48 mod 64) when all code
+  // words still fit the LDS that way, else dense rows (AlexNet conv1: 11 x 36 x 96 floats = 152 KB; its A reads then are
+  // two-way bank conflicts, 8 instead of 4 LDS cycles per ds_read2_b32 — a sixth of the LDS pipe)
+  const size_t lim = 160 * 1024;
+  int s = Ct;
+  while ((s & 63) != 16 && (s & 63) != 48) s += 16;
+  if ((size_t)knl * kp * s * sizeof(float) > lim) s = Ct;
+  if ((size_t)knl * kp * s * sizeof(float) > lim) return false;
+  *Kp = kp; *S = s;
+  return true;
+}
+
+hipError_t qk_decode_weights(const uint8_t* rows, const float* ctrd, float* out, const QkSlots& sl, int knl, int Cin, int K,
+                             int Ct, int Kp, int S, hipStream_t st) {
+  const int total = knl * Kp * S;
+  hipLaunchKernelGGL(k_decode_weights, dim3((total + 255) / 256), dim3(256), 0, st, rows, ctrd, out, sl, knl, Cin, K, Ct, Kp, S);
+  return hipGetLastError();
+}
+
+hipError_t qk_conv_dec(const DecParams& p, hipStream_t st) {
+  if ((long long)p.H * p.W * p.Cin * QCNN_PANEL >= (1ll << 31)) return hipErrorInvalidValue;   // 32-bit row indices inside a panel
+  if (p.Ct % 32) return hipErrorInvalidValue;
+  // channels per wave x positions per wave x operand sets in flight: as many accumulator tiles as 128 registers hold,
+  // all channels in one wave where they fit (a chunk of the channels = the B rows loaded once more)
+  if (p.pad) {
+    if (p.Ct % 64 == 0) return launch_dec<4, 1, true, 2>(p, st);
+    return launch_dec<2, 1, true, 3>(p, st);
+  }
+  if (p.Ct % 96 == 0) return launch_dec<6, 1, false, 2>(p, st);
+  if (p.Ct % 64 == 0) return launch_dec<4, 1, false, 3>(p, st);
+  return launch_dec<2, 2, false, 3>(p, st);
+}

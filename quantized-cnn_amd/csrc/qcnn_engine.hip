@@ -32,6 +32,7 @@ struct LayerShape {
   size_t asmtBytes = 0;
   size_t offProg = 0, progBytes = 0;                           // conv with K = 128: offsets in consumption order (QkProgram)
   size_t offProgS = 0, progSBytes = 0;                         // ... and in the order of the sliding variant, where it applies
+  size_t offDec = 0; int decKp = 0, decS = 0;                  // decoded code words of a one-sub-space layer (qcnn_decoded.hip); decKp = 0: not eligible
   int segN = 0, segBeg[9] = {0};                               // sliding plan of the last planned launch geometry
   bool hasDmap = false;
   bool loaded = false;
@@ -62,6 +63,7 @@ struct QcnnCtx {
   int nStreams = 2;                  // QCNN_OPT_STREAMS: sub-batches of whole panels run concurrently
   int smallBatch = 1;                // QCNN_OPT_SMALL_BATCH: few-image kernels for batches <= kSmallBatchMax
   int hostChunk = 2;                 // QCNN_OPT_HOST_CHUNK: panels per chunk of a large qcnn_forward_host batch (0: one launch)
+  int decode = 1;                    // QCNN_OPT_DECODE: one-sub-space conv layers through their decoded code words (MFMA builders only)
   int slide = 1;                     // QCNN_OPT_SLIDE: sliding-window conv kernels where they pay (MFMA builders only)
   int split = 1;                     // QCNN_OPT_SPLIT: launches that do not fill the chip split their tail (MFMA builders only)
   hipStream_t aux[3] = {nullptr, nullptr, nullptr};
@@ -178,6 +180,12 @@ int plan_arena(QcnnCtx* c) {
         s.offProgS = off; off = align_up(off + s.progSBytes + QCNN_ROWS_PAD, 256);
       }
     }
+    s.decKp = 0;
+    if (d.type == QCNN_CONV && qk_conv_dec_shape(c->dims[l].c, d.grpCnt, s.M, Ct, d.knlSiz, &s.decKp, &s.decS)) {
+      s.offDec = off; off = align_up(off + sizeof(float) * (size_t)d.knlSiz * s.decKp * s.decS, 256);
+    } else {
+      s.decKp = 0;
+    }
     s.hasDmap = (d.type == QCNN_FCNT && l == c->firstFc && c->dims[l].h * c->dims[l].w > 1);
     if (s.hasDmap) { s.offDmap = off; off = align_up(off + sizeof(int) * fm_elems(c, l), 256); }
   }
@@ -249,6 +257,13 @@ int ensure_pipeline(QcnnCtx* c) {
 // live: images every panel of this launch holds (128, or the batch size of a single-panel forward); small: the
 // few-image kernels (qcnn_small.hip) run the conv/FC layers
 // sub / nsub: index and number of the sub-batches (streams) of this forward: each has its own share of the scratch
+// Does conv layer l run through its decoded code words (qcnn_decoded.hip)?  The f32 / bf16-pair MFMA modes only: the exact
+// builder keeps the reference's summation order and the fp16 study is about the tables themselves.
+bool decoded_layer(const QcnnCtx* c, int l) {
+  const LayerShape& s = c->shapes[l];
+  return c->decode && s.decKp > 0 && !s.dense && (c->lutMode == 1 || c->lutMode == 3) && c->layers[l].type == QCNN_CONV;
+}
+
 int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bool fuseRelu, bool flatFcInput,
                  int p0, hipStream_t st, const float* inNchw = nullptr, int nImages = 0, int live = QCNN_PANEL,
                  bool small = false, int sub = 0, int nsub = 1) {
@@ -269,6 +284,19 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
         q.knl = d.knlSiz; q.stride = d.stride; q.pad = d.padSiz; q.grp = d.grpCnt;
         q.relu = fuseRelu ? 1 : 0; q.panels = panels;
         e = qk_dense(q, st);
+        break;
+      }
+      if (decoded_layer(c, l) && !small && !inNchw) {     // one sub-space of <= 4 dims: decoded code words on the matrix pipe
+        DecParams q;
+        q.src = src; q.dst = dst;
+        q.bias = reinterpret_cast<const float*>(c->arena + s.offBias);
+        q.wdec = reinterpret_cast<const float*>(c->arena + s.offDec);
+        q.H = a.h; q.W = a.w; q.Cin = a.c; q.Ho = b.h; q.Wo = b.w; q.Ct = b.c;
+        q.knl = d.knlSiz; q.stride = d.stride; q.pad = d.padSiz;
+        q.Kr = d.knlSiz * a.c; q.Kp = s.decKp; q.S = s.decS;
+        q.relu = fuseRelu ? 1 : 0; q.panels = panels; q.live = live;
+        s.lastFrom = -3; s.lastZ = 1;                     // reported by qcnn_get_layer_split as (-3, 1)
+        e = qk_conv_dec(q, st);
         break;
       }
       ConvParams p;
@@ -463,8 +491,10 @@ int lrn_pool_min_blocks() {
   return v;
 }
 
-bool direct_input(const QcnnCtx* c) {
+bool direct_input(const QcnnCtx* c, int n) {
   if (c->keepAll || c->L == 0 || c->layers[0].type != QCNN_CONV) return false;
+  // a first layer that runs through its decoded code words reads packed panels (the few-image kernels do not take that path)
+  if (decoded_layer(c, 0) && !(c->smallBatch && c->lutMode == 1 && n <= kSmallBatchMax)) return false;
   const QcnnLayerDesc& d = c->layers[0];
   // ONE sub-space (a second one would be fetched from channel planes past the group's own, for the last image past the
   // caller's buffer), and the whole batch inside 4 GiB: the builders keep per-lane image offsets in 32 bits
@@ -649,6 +679,7 @@ int qcnn_set_option(QcnnCtx* c, int option, int value) {
     case QCNN_OPT_PROFILE: c->profile = value ? 1 : 0; return 0;
     case QCNN_OPT_SMALL_BATCH: c->smallBatch = value ? 1 : 0; return 0;
     case QCNN_OPT_SPLIT: c->split = value ? 1 : 0; for (LayerShape& ls : c->shapes) ls.planKey = -1; return 0;
+    case QCNN_OPT_DECODE: c->decode = value ? 1 : 0; return 0;
     case QCNN_OPT_SLIDE: c->slide = value < 0 ? 0 : (value > 2 ? 2 : value); for (LayerShape& ls : c->shapes) ls.planKey = -1; return 0;
     case QCNN_OPT_HOST_CHUNK:
       if (value < 0) return fail(c, "host chunk must be >= 0 panels");
@@ -870,8 +901,13 @@ namespace {
 hipError_t build_program(QcnnCtx* c, int layer, const QkSlots& sl) {
   const QcnnLayerDesc& d = c->layers[layer];
   const LayerShape& s = c->shapes[layer];
-  if (!s.progBytes) return hipSuccess;
-  hipError_t e = qk_build_program(reinterpret_cast<const uint8_t*>(c->arena + s.offAsmt),
+  hipError_t e = hipSuccess;
+  if (s.decKp > 0)                  // one sub-space of <= 4 dims: the code word every assignment names (qcnn_decoded.hip)
+    e = qk_decode_weights(reinterpret_cast<const uint8_t*>(c->arena + s.offAsmt), reinterpret_cast<const float*>(c->arena + s.offCtrd),
+                          reinterpret_cast<float*>(c->arena + s.offDec), sl, d.knlSiz, c->dims[layer].c, s.K,
+                          c->dims[layer + 1].c, s.decKp, s.decS, c->stream);
+  if (e != hipSuccess || !s.progBytes) return e;
+  e = qk_build_program(reinterpret_cast<const uint8_t*>(c->arena + s.offAsmt),
                                   reinterpret_cast<uint16_t*>(c->arena + s.offProg), sl, sl,
                                   qk_conv_program(sl, d.knlSiz, d.stride), d.knlSiz, d.stride, s.M, c->stream);
   if (e == hipSuccess && s.progSBytes) {
@@ -997,7 +1033,7 @@ int qcnn_forward(QcnnCtx* c, const float* in_nchw_dev, int n, float* prob_dev, u
   HIP_TRY(c, hipSetDevice(c->device));
   if (!c->committed) return fail(c, "model not committed");
   if (n <= 0 || n > c->maxBatch) return fail(c, "batch %d outside (0, %d]", n, c->maxBatch);
-  if (direct_input(c)) return forward_tail(c, n, prob_dev, top5_dev, in_nchw_dev);   // conv1's builders read it in place
+  if (direct_input(c, n)) return forward_tail(c, n, prob_dev, top5_dev, in_nchw_dev);   // conv1's builders read it in place
   hipError_t e = qk_pack_nchw(in_nchw_dev, c->fmBuf[0], n, c->inC, c->inH, c->inW, c->stream);
   if (e != hipSuccess) return fail(c, "input pack launch failed: %s", hipGetErrorString(e));
   return forward_tail(c, n, prob_dev, top5_dev);
@@ -1144,7 +1180,7 @@ int qcnn_forward_host(QcnnCtx* c, const float* in_nchw_host, int n, float* prob_
       HIP_TRY(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
       c->evChunk.push_back(ev);
     }
-    const bool direct = direct_input(c);
+    const bool direct = direct_input(c, n);
     HIP_TRY(c, hipEventRecord(c->evFreed[0], c->stream));            // the buffer may still feed an earlier forward
     HIP_TRY(c, hipStreamWaitEvent(c->copyStream, c->evFreed[0], 0));
     for (int k = 0; k < nc; ++k) {

@@ -276,6 +276,22 @@ hipError_t qk_lrn_pool(const float* src, float* dst, int panels, int H, int W, i
                        float bet, float ini, int live, hipStream_t st);
 hipError_t qk_pool(const float* src, float* dst, int panels, int H, int W, int C, int Ho, int Wo, int knl,
                    int stride, int pad, int live, hipStream_t st);
+// Quantised conv layer with one sub-space of <= 4 dims evaluated through its decoded code words on the matrix pipe
+// (qcnn_decoded.hip).  wdec: [knl][Kp][S] — kernel row, k = column * Cin + d (padded to Kp, zeros), channel (row stride S)
+struct DecParams {
+  const float* src;      // [panels][H*W*Cin][128]
+  float* dst;            // [panels][Ho*Wo*Ct][128]
+  const float* bias;     // [Ct]
+  const float* wdec;
+  int H, W, Cin, Ho, Wo, Ct;
+  int knl, stride, pad;
+  int Kr, Kp, S;         // knl * Cin, the same rounded up to a multiple of 4, channel stride of wdec
+  int relu, panels, live;
+};
+bool qk_conv_dec_shape(int Cin, int grp, int M, int Ct, int knl, int* Kp, int* S);   // is the layer eligible (and its wdec shape)
+hipError_t qk_decode_weights(const uint8_t* rows, const float* ctrd, float* out, const QkSlots& sl, int knl, int Cin, int K,
+                             int Ct, int Kp, int S, hipStream_t st);
+hipError_t qk_conv_dec(const DecParams& p, hipStream_t st);
 hipError_t qk_softmax(const float* src, float* dst, int panels, int C, int live, hipStream_t st);
 hipError_t qk_top5(const float* prob, uint16_t* out, int n, int C, hipStream_t st);   // prob panel layout -> [n][5]
 

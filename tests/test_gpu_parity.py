@@ -26,13 +26,16 @@ SAMPLE_STRIDE = 97
 BITWISE_TYPES = (topo.CONV, topo.FCNT, topo.RELU, topo.POOL, topo.DRPT)
 
 
-def make_engine(in_chw, layers, params, max_batch, lut=capi.LUT_EXACT, keep_all=1, split=0):
+def make_engine(in_chw, layers, params, max_batch, lut=capi.LUT_EXACT, keep_all=1, split=0, decode=0):
     """split = 0: one workgroup per tile whatever the batch size (QCNN_OPT_SPLIT off) — the setting under which an image's
-    bits do not depend on its batch, which many tests below rely on; the split itself has its own tests."""
+    bits do not depend on its batch, which many tests below rely on; the split itself has its own tests.  decode = 0: the
+    table kernels for the first layer too (QCNN_OPT_DECODE off) — what these tests are about; the decoded first layer
+    has its own tests below and is the default everywhere else (host pipeline, group, bench)."""
     eng = pkg("engine").QcnnEngine(0)
     eng.set_option(capi.OPT_LUT_MODE, lut)
     eng.set_option(capi.OPT_KEEP_ALL, keep_all)
     eng.set_option(capi.OPT_SPLIT, split)
+    eng.set_option(capi.OPT_DECODE, decode)
     eng.load_model(in_chw, layers, params, max_batch)
     return eng
 
@@ -723,6 +726,74 @@ def test_split_tiles_small_geometries():
             eng.close()
         assert np.array_equal(outs[0][1], outs[1][1])
         assert np.abs(outs[0][0] - outs[1][0]).max() <= 1e-5 * np.abs(outs[0][0]).max()
+
+
+# ---------------------------------------------------------------- decoded first layer ----
+def test_decoded_first_layer_alexnet():
+    """QCNN_OPT_DECODE (default on): AlexNet conv1 — one sub-space of 3 dims — runs through the code words its assignments
+    name on the matrix pipe instead of through look-up tables.  Same parameters, same function: against the table kernels
+    within 2e-6 of the map's largest value (both are fp32 sums of the same products, associated differently), against the
+    oracle within 1e-4, top-5 equal; the exact builder and the few-image kernels never take the path."""
+    in_chw, layers, _, _ = topo.MODELS["AlexNet"]
+    params = synth.make_params(in_chw, layers, seed=0)
+    imgs = synth.make_images(131, in_chw, seed=83)                     # a full panel + 3 images (one live image tile)
+    base = make_engine(in_chw, layers, params, 131, lut=capi.LUT_MFMA, keep_all=1)
+    p0, t0 = base.forward_host(imgs)
+    assert base.layer_split(0)[0] != -3
+    fm0 = {l: base.layer_output(l, 131) for l in (1, 2)}
+    base.close()
+    for keep in (1, 0):
+        eng = make_engine(in_chw, layers, params, 131, lut=capi.LUT_MFMA, keep_all=keep, decode=1)
+        p1, t1 = eng.forward_host(imgs)
+        assert eng.layer_split(0) == (-3, 1)
+        if keep:
+            for l, want in fm0.items():
+                got = eng.layer_output(l, 131)
+                assert np.abs(got - want).max() <= 2e-6 * np.abs(want).max(), "fm[%d]" % l
+        assert np.abs(p1 - p0).max() <= 1e-5 * p0.max() and np.array_equal(t0, t1)
+        if keep:
+            orc = po.COracle(in_chw, layers)
+            orc.set_params(params)
+            orc.forward(imgs[129:])
+            for l in (1, 2, 5):
+                e_inf, e_l2 = rel_err(eng.layer_output_range(l, 129, 2), orc.fm(l))
+                assert e_inf <= TOL and e_l2 <= TOL, "fm[%d] vs oracle: %g %g" % (l, e_inf, e_l2)
+            p2, t2 = eng.forward_host(imgs[:2])                        # few-image kernels: tables
+            assert eng.layer_split(0)[0] != -3
+            eng.set_option(capi.OPT_LUT_MODE, capi.LUT_EXACT)          # the exact builder: tables, the reference's bits
+            eng.forward_host(imgs[:5])
+            assert eng.layer_split(0)[0] != -3
+        eng.close()
+
+
+@pytest.mark.parametrize("cin,knl,stride,pad,ct", [(3, 3, 1, 1, 64), (3, 5, 2, 0, 32), (1, 3, 1, 1, 32), (4, 7, 3, 2, 96),
+                                                   (2, 4, 2, 1, 64), (3, 1, 1, 0, 96)])
+def test_decoded_first_layer_geometries(cin, knl, stride, pad, ct):
+    """Decoded first layers on shapes AlexNet does not have: VGG-16's padded 3x3 / 1 with 64 channels, 32 and 96 channels,
+    1, 2 and 4 input channels (kernel rows of 3 ... 28 products, padded to fours), even kernels, 1x1, strides 1-3, padding
+    on every side; 200 images (a ragged second panel), all positions of maps whose size is not a multiple of the
+    workgroup's positions.  Against the oracle within 1e-4 and against the table kernels within 2e-6."""
+    layers = [topo.conv(pad, knl, ct, 1, stride), topo.relu(), topo.pool(0, 2, 2), topo.fcnt(40), topo.smax()]
+    in_chw = (cin, 19, 23)
+    params = synth.make_params(in_chw, layers, seed=90 + cin)
+    rng = np.random.default_rng(91)
+    imgs = (rng.integers(0, 256, size=(200,) + in_chw).astype(np.float32) - 120.0)
+    orc = po.COracle(in_chw, layers)
+    orc.set_params(params)
+    orc.forward(imgs[126:131])
+    base = make_engine(in_chw, layers, params, 200, lut=capi.LUT_MFMA, keep_all=1)
+    base.forward_host(imgs)
+    want = base.layer_output(1, 200)
+    base.close()
+    eng = make_engine(in_chw, layers, params, 200, lut=capi.LUT_MFMA, keep_all=1, decode=1)
+    prob, top5 = eng.forward_host(imgs)
+    assert eng.layer_split(0) == (-3, 1)
+    got = eng.layer_output(1, 200)
+    assert np.abs(got - want).max() <= 2e-6 * np.abs(want).max()
+    for l in range(1, len(layers) + 1):
+        e_inf, e_l2 = rel_err(eng.layer_output_range(l, 126, 5), orc.fm(l))
+        assert e_inf <= TOL and e_l2 <= TOL, "fm[%d] vs oracle: %g %g" % (l, e_inf, e_l2)
+    eng.close()
 
 
 # ---------------------------------------------------------------- sliding-window conv kernels ----
