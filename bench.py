@@ -343,6 +343,7 @@ def main():
     dt = measure(step, args.steps, args.warmup)
     layer_ms, recorded = eng.layer_ms()
     segments = {i: eng.layer_segments(i) for i, l in enumerate(layers) if l["type"] == topo.CONV}   # sliding kernel, per layer
+    decoded = {i for i, l in enumerate(layers) if l["type"] == topo.CONV and eng.layer_split(i)[0] == -3}   # decoded first layer
     ok = bool(torch.isfinite(prob[lo:hi]).all().item())
     images_per_step = B if (strong or world == 1) else B * world
 
@@ -542,7 +543,8 @@ def main():
         total_lk = 0
         for i, l in enumerate(layers):
             if l["type"] in (topo.CONV, topo.FCNT) and layer_ms[i] > 0:
-                r = perf.layer_report(sizes, layers, params, i, launch_images, float(layer_ms[i]), segments.get(i))
+                r = (perf.decoded_report(sizes, layers, i, launch_images, float(layer_ms[i])) if i in decoded else
+                     perf.layer_report(sizes, layers, params, i, launch_images, float(layer_ms[i]), segments.get(i)))
                 r["ms"] = round(float(layer_ms[i]), 4)
                 per_layer["%02d_%s" % (i, topo.TYPE_NAMES[l["type"]])] = r
         for i, l in enumerate(layers):
@@ -552,7 +554,8 @@ def main():
                 total_lk += shapes[i][0] * l["nod"]
         step_bytes = sum(algorithmic_bytes(sizes, layers, params, l, n_local) for l in range(len(layers))
                          if layer_ms[l] > 0)
-        roof = dict(bound="hbm", kernel="k_%s_aprx (layer %d, %s)" % ("conv" if dom in conv_idx else "fc", dom, name),
+        roof = dict(bound="hbm", kernel=("k_conv_dec (layer %d, %s)" % (dom, name)) if dom in decoded else
+                    "k_%s_aprx (layer %d, %s)" % ("conv" if dom in conv_idx else "fc", dom, name),
                     achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic, traffic_source=tsrc,
                     ms_per_launch=round(dom_ms, 4), launches_timed=recorded * ns, launches_per_step=ns,
@@ -581,6 +584,8 @@ def main():
             "outputs_finite": ok,
             "lookups_per_image": int(total_lk),
             "lookups_per_s": round(total_lk * value, 0),
+            "lookups_note": "the reference's look-up count; layers %s evaluate theirs as products of the code words the "
+                            "assignments name (QCNN_OPT_DECODE)" % sorted(decoded) if decoded else "all evaluated as table look-ups",
             "roofline": roof,
         }
         out.update(extras)

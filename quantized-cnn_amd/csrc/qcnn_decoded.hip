@@ -232,6 +232,120 @@ hipError_t launch_dec(const DecParams& p, hipStream_t st) {
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// FC layers whose sub-spaces have ONE dim (a 1000-way classifier behind 4096 features: AlexNet / VGG-16 fc8, 16 code
+// words of one float each): a look-up there stands for one multiply-add, so the table build — 4096 sub-spaces x 16 code
+// words x 128 images per panel — is pure overhead.  out[c] = bias[c] + sum_k x[k] * w[k][c], w[k][c] = ctrd[k][asmt[k][c]].
+//
+// A workgroup = 64 channels x 64 images of one panel x one slice of the k axis; its 16 waves take 16 sub-slices, each
+// with a 4 x 4 block of accumulator tiles fed by ONE dwordx4 of code words (channel tile t = the channels 4 i + t) and
+// ONE dwordx4 of activations (image tile t = the images 4 i + t) per four k; the 16 partial blocks are added through LDS
+// in a fixed tree (w + (w + 8), then + 4, + 2, + 1).  gridDim.z > 1: k slices over workgroups too, partial sums to
+// scratch for k_sum_partials (few panels: one GPU's share of a sharded batch).
+__global__ __launch_bounds__(1024) void k_fc_dec(FcDecParams p) {
+  extern __shared__ __attribute__((aligned(16))) float ldsR[];          // 8 waves x 16 tiles x 256 floats
+  const int lane = threadIdx.x & 63, wave = uni(threadIdx.x >> 6);
+  const int li = lane & 15, kq = lane >> 4;
+  const int cb = blockIdx.x, half = blockIdx.y % p.halves, panel = blockIdx.y / p.halves, z = blockIdx.z;
+  const int steps = p.D / (4 * 16 * (int)gridDim.z);                    // steps of four k per wave
+  const int k0 = (z * 16 + wave) * steps * 4;
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.wdec), 0, (unsigned)((size_t)p.D * p.S * sizeof(float)), 0x00020000);
+  const float* __restrict__ xb = p.src + (size_t)panel * p.D * PANEL;
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(xb), 0, (unsigned)((size_t)p.D * PANEL * sizeof(float)), 0x00020000);
+  const int aLane = (kq * p.S + cb * 64 + 4 * li) * (int)sizeof(float);
+  const int bLane = (kq * PANEL + half * 64 + 4 * li) * (int)sizeof(float);
+  const int aStep = 4 * p.S * (int)sizeof(float), bStep = 4 * PANEL * (int)sizeof(float);
+  f32x4 acc[4][4];                                                      // [channel tile][image tile]
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti) acc[ct][ti] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  constexpr int R = 3;
+  f32x4 a[R], b[R];
+  int aoff = k0 * p.S * (int)sizeof(float), boff = k0 * PANEL * (int)sizeof(float);
+  auto next = [&](f32x4& aa, f32x4& bb) {                               // past the slice: rows of the next slice, never multiplied
+    aa = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, aLane, aoff, 0));
+    bb = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, bLane, boff, 0));
+    aoff += aStep; boff += bStep;
+  };
+  auto products = [&](const f32x4& aa, const f32x4& bb) {
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int ti = 0; ti < 4; ++ti) acc[ct][ti] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[ct], bb[ti], acc[ct][ti], 0, 0, 0);
+  };
+#pragma unroll
+  for (int u = 0; u < R; ++u) next(a[u], b[u]);
+  int t = 0;
+  for (; t + R <= steps; t += R) {
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+      products(a[u], b[u]);
+      __builtin_amdgcn_sched_barrier(0);
+      next(a[u], b[u]);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < R - 1; ++u)
+    if (t + u < steps) products(a[u], b[u]);
+  // fixed-order tree over the 16 waves
+  f32x4* lds4 = reinterpret_cast<f32x4*>(ldsR);
+#pragma unroll
+  for (int stride = 8; stride >= 1; stride >>= 1) {
+    if (wave >= stride && wave < 2 * stride) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) lds4[((wave - stride) * 16 + i) * 64 + lane] = acc[i >> 2][i & 3];
+    }
+    __syncthreads();
+    if (wave < stride) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const f32x4 v = lds4[(wave * 16 + i) * 64 + lane];
+        acc[i >> 2][i & 3] += v;
+      }
+    }
+    __syncthreads();
+  }
+  if (wave != 0) return;
+  // tile ct, row 4 kq + r: channel 64 cb + 4 (4 kq + r) + ct; tile ti, column li: image 64 half + 4 li + ti
+  float* __restrict__ out = (gridDim.z > 1 ? p.partial + (size_t)z * p.panels * p.Ct * PANEL : p.dst) +
+                            (size_t)panel * p.Ct * PANEL + half * 64 + 4 * li;
+  const bool first = z == 0;
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ch = cb * 64 + 4 * (4 * kq + r) + ct;
+      if (ch < p.Ct) {
+        const float bv = first ? p.bias[ch] : 0.0f;
+        f32x4 v = {acc[ct][0][r] + bv, acc[ct][1][r] + bv, acc[ct][2][r] + bv, acc[ct][3][r] + bv};
+        if (p.relu && gridDim.z == 1) {
+          v[0] = (0.0f < v[0]) ? v[0] : 0.0f; v[1] = (0.0f < v[1]) ? v[1] : 0.0f;
+          v[2] = (0.0f < v[2]) ? v[2] : 0.0f; v[3] = (0.0f < v[3]) ? v[3] : 0.0f;
+        }
+        *reinterpret_cast<f32x4*>(out + (size_t)ch * PANEL) = v;
+      }
+    }
+}
+
+// rows: [M = D][rowStride] slot bytes (QkSlots order); ctrd: [M][1][K]; out: [D][S]
+__global__ void k_decode_fc_weights(const uint8_t* __restrict__ rows, const float* __restrict__ ctrd, float* __restrict__ out,
+                                    QkSlots sl, int D, int K, int Ct, int S) {
+  const int G = qcnn_stage_group(K);
+  const size_t total = (size_t)D * S;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % S), k = (int)(i / S);
+    float w = 0.0f;
+    if (ch < Ct) {
+      const int slot = rows[(size_t)k * sl.rowStride + qk_slot_entry(sl, 0, ch)];
+      w = ctrd[(size_t)k * K + (qcnn_row_slot(slot) - (k % G) * K)];    // stage row = (m % G) * K + code word
+    }
+    out[i] = w;
+  }
+}
+
 }  // namespace
 
 bool qk_conv_dec_shape(int Cin, int grp, int M, int Ct, int knl, int* Kp, int* S) {
@@ -269,4 +383,37 @@ hipError_t qk_conv_dec(const DecParams& p, hipStream_t st) {
   if (p.Ct % 96 == 0) return launch_dec<6, 1, false, 2>(p, st);
   if (p.Ct % 64 == 0) return launch_dec<4, 1, false, 3>(p, st);
   return launch_dec<2, 2, false, 3>(p, st);
+}
+
+bool qk_fc_dec_shape(int D, int M, int Cs, int Ct, int* S) {
+  if (Cs != 1 || M != D || D % 64 || Ct < 1) return false;
+  if ((size_t)D * PANEL * sizeof(float) >= (1ull << 32)) return false;
+  *S = (Ct + 63) / 64 * 64;
+  return (size_t)D * *S * sizeof(float) < (1ull << 32);
+}
+
+hipError_t qk_decode_fc_weights(const uint8_t* rows, const float* ctrd, float* out, const QkSlots& sl, int D, int K, int Ct,
+                                int S, hipStream_t st) {
+  hipLaunchKernelGGL(k_decode_fc_weights, dim3(2048), dim3(256), 0, st, rows, ctrd, out, sl, D, K, Ct, S);
+  return hipGetLastError();
+}
+
+int qk_fc_dec_slices(int D, int Ct, int panels, int live) {
+  // k slices over workgroups: until the launch has about a workgroup per CU, every wave keeping >= 4 steps
+  const int wgs = ((Ct + 63) / 64) * panels * ((live + 63) / 64);
+  int z = 1;
+  while (wgs * z < 192 && D % (64 * 2 * z) == 0 && D / (64 * 2 * z) >= 4) z *= 2;
+  return z;
+}
+
+hipError_t qk_fc_dec(const FcDecParams& p, int slices, int live, hipStream_t st) {
+  if (p.D % (64 * slices)) return hipErrorInvalidValue;
+  FcDecParams q = p;
+  q.halves = (live + 63) / 64;
+  const dim3 grid((unsigned)((p.Ct + 63) / 64), (unsigned)(p.panels * q.halves), (unsigned)slices);
+  const size_t shm = 8 * 16 * 256 * sizeof(float);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fc_dec), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_fc_dec, grid, dim3(1024), shm, st, q);
+  return hipGetLastError();
 }

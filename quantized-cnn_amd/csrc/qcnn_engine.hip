@@ -32,7 +32,8 @@ struct LayerShape {
   size_t asmtBytes = 0;
   size_t offProg = 0, progBytes = 0;                           // conv with K = 128: offsets in consumption order (QkProgram)
   size_t offProgS = 0, progSBytes = 0;                         // ... and in the order of the sliding variant, where it applies
-  size_t offDec = 0; int decKp = 0, decS = 0;                  // decoded code words of a one-sub-space layer (qcnn_decoded.hip); decKp = 0: not eligible
+  size_t offDec = 0; int decKp = 0, decS = 0;                  // decoded code words (qcnn_decoded.hip): conv layer with one sub-space of
+                                                               // <= 4 dims (decKp > 0), FC layer with one-dim sub-spaces (decKp = -1); 0: not eligible
   int segN = 0, segBeg[9] = {0};                               // sliding plan of the last planned launch geometry
   bool hasDmap = false;
   bool loaded = false;
@@ -181,12 +182,15 @@ int plan_arena(QcnnCtx* c) {
       }
     }
     s.decKp = 0;
+    s.hasDmap = (d.type == QCNN_FCNT && l == c->firstFc && c->dims[l].h * c->dims[l].w > 1);
     if (d.type == QCNN_CONV && qk_conv_dec_shape(c->dims[l].c, d.grpCnt, s.M, Ct, d.knlSiz, &s.decKp, &s.decS)) {
       s.offDec = off; off = align_up(off + sizeof(float) * (size_t)d.knlSiz * s.decKp * s.decS, 256);
+    } else if (d.type == QCNN_FCNT && !s.hasDmap && qk_fc_dec_shape((int)fm_elems(c, l), s.M, s.Cs, Ct, &s.decS)) {
+      s.decKp = -1;                   // FC layer with one-dim sub-spaces: [D][decS] decoded code words
+      s.offDec = off; off = align_up(off + sizeof(float) * fm_elems(c, l) * s.decS, 256);
     } else {
       s.decKp = 0;
     }
-    s.hasDmap = (d.type == QCNN_FCNT && l == c->firstFc && c->dims[l].h * c->dims[l].w > 1);
     if (s.hasDmap) { s.offDmap = off; off = align_up(off + sizeof(int) * fm_elems(c, l), 256); }
   }
   c->arenaBytes = off + kSlack;
@@ -262,6 +266,10 @@ int ensure_pipeline(QcnnCtx* c) {
 bool decoded_layer(const QcnnCtx* c, int l) {
   const LayerShape& s = c->shapes[l];
   return c->decode && s.decKp > 0 && !s.dense && (c->lutMode == 1 || c->lutMode == 3) && c->layers[l].type == QCNN_CONV;
+}
+bool decoded_fc(const QcnnCtx* c, int l) {
+  const LayerShape& s = c->shapes[l];
+  return c->decode && s.decKp < 0 && !s.dense && (c->lutMode == 1 || c->lutMode == 3) && c->layers[l].type == QCNN_FCNT;
 }
 
 int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bool fuseRelu, bool flatFcInput,
@@ -367,6 +375,22 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
         q.knl = 1; q.stride = 1; q.pad = 0; q.grp = 1;
         q.relu = fuseRelu ? 1 : 0; q.panels = panels;
         e = qk_dense(q, st);
+        break;
+      }
+      if (decoded_fc(c, l)) {              // one-dim sub-spaces: decoded code words on the matrix pipe (qcnn_decoded.hip)
+        FcDecParams q;
+        q.src = src; q.dst = dst; q.partial = nullptr;
+        q.bias = reinterpret_cast<const float*>(c->arena + s.offBias);
+        q.wdec = reinterpret_cast<const float*>(c->arena + s.offDec);
+        q.D = a.h * a.w * a.c; q.Ct = b.c; q.S = s.decS;
+        q.relu = fuseRelu ? 1 : 0; q.panels = panels; q.halves = 2;
+        int z = qk_fc_dec_slices(q.D, q.Ct, panels, live);
+        const size_t need = (size_t)z * panels * q.Ct * QCNN_PANEL;
+        const size_t poff = (size_t)kMaxFcSplit * p0 * c->fcMaxCt * QCNN_PANEL;    // every sub-batch has its own slab
+        if (z > 1 && poff + need <= c->fcPartialElems) q.partial = c->fcPartial + poff; else z = 1;
+        e = qk_fc_dec(q, z, live, st);
+        if (e == hipSuccess && z > 1)
+          e = qk_sum_partials(q.partial, dst, z, (size_t)panels * q.Ct * QCNN_PANEL, q.relu, st);
         break;
       }
       FcParams p;
@@ -902,6 +926,10 @@ hipError_t build_program(QcnnCtx* c, int layer, const QkSlots& sl) {
   const QcnnLayerDesc& d = c->layers[layer];
   const LayerShape& s = c->shapes[layer];
   hipError_t e = hipSuccess;
+  if (s.decKp < 0)                  // FC layer with one-dim sub-spaces
+    e = qk_decode_fc_weights(reinterpret_cast<const uint8_t*>(c->arena + s.offAsmt), reinterpret_cast<const float*>(c->arena + s.offCtrd),
+                             reinterpret_cast<float*>(c->arena + s.offDec), sl, (int)fm_elems(c, layer), s.K,
+                             c->dims[layer + 1].c, s.decS, c->stream);
   if (s.decKp > 0)                  // one sub-space of <= 4 dims: the code word every assignment names (qcnn_decoded.hip)
     e = qk_decode_weights(reinterpret_cast<const uint8_t*>(c->arena + s.offAsmt), reinterpret_cast<const float*>(c->arena + s.offCtrd),
                           reinterpret_cast<float*>(c->arena + s.offDec), sl, d.knlSiz, c->dims[layer].c, s.K,

@@ -475,10 +475,17 @@ __global__ __launch_bounds__(256) void k_pack(const float* __restrict__ in, floa
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int e0 = blockIdx.x * 64;
   const int panel = blockIdx.y;
-  for (int i = wave; i < PANEL; i += 4) {
-    const int img = panel * PANEL + i;
-    const int e = e0 + lane;
-    tile[i][lane] = (img < n && e < E) ? in[(size_t)img * E + e] : 0.0f;
+  const int e = e0 + lane;
+#pragma unroll
+  for (int b = 0; b < PANEL / 4; b += 8) {          // eight independent loads in flight per thread
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int img = panel * PANEL + wave + 4 * (b + u);
+      v[u] = (img < n && e < E) ? in[(size_t)img * E + e] : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) tile[wave + 4 * (b + u)][lane] = v[u];
   }
   __syncthreads();
   for (int j = wave; j < 64; j += 4) {
@@ -517,9 +524,19 @@ __global__ __launch_bounds__(256) void k_pack_u8(const uint8_t* __restrict__ in,
     if (mean) m = mean[soff];
   }
   const size_t srcImg = (size_t)C * Hs * Ws;
-  for (int i = wave; i < PANEL; i += 4) {
-    const int img = panel * PANEL + i;
-    tile[i][lane] = (img < n && e < E) ? ((float)in[(size_t)img * srcImg + soff] - m) : 0.0f;
+#pragma unroll
+  for (int b = 0; b < PANEL / 4; b += 8) {          // eight independent loads in flight per thread
+    uint8_t v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int img = panel * PANEL + wave + 4 * (b + u);
+      v[u] = (img < n && e < E) ? in[(size_t)img * srcImg + soff] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int img = panel * PANEL + wave + 4 * (b + u);
+      tile[wave + 4 * (b + u)][lane] = (img < n && e < E) ? ((float)v[u] - m) : 0.0f;
+    }
   }
   __syncthreads();
   for (int j = wave; j < 64; j += 4) {

@@ -292,6 +292,21 @@ bool qk_conv_dec_shape(int Cin, int grp, int M, int Ct, int knl, int* Kp, int* S
 hipError_t qk_decode_weights(const uint8_t* rows, const float* ctrd, float* out, const QkSlots& sl, int knl, int Cin, int K,
                              int Ct, int Kp, int S, hipStream_t st);
 hipError_t qk_conv_dec(const DecParams& p, hipStream_t st);
+// FC layer with one-dim sub-spaces through its decoded code words (qcnn_decoded.hip).  wdec: [D][S], S = Ct rounded up to 64
+struct FcDecParams {
+  const float* src;      // [panels][D][128]
+  float* dst;            // [panels][Ct][128]
+  float* partial;        // [slices][panels][Ct][128] when the k axis is cut over workgroups (qk_fc_dec_slices > 1)
+  const float* bias;
+  const float* wdec;
+  int D, Ct, S;
+  int relu, panels, halves;
+};
+bool qk_fc_dec_shape(int D, int M, int Cs, int Ct, int* S);
+hipError_t qk_decode_fc_weights(const uint8_t* rows, const float* ctrd, float* out, const QkSlots& sl, int D, int K, int Ct,
+                                int S, hipStream_t st);
+int qk_fc_dec_slices(int D, int Ct, int panels, int live);
+hipError_t qk_fc_dec(const FcDecParams& p, int slices, int live, hipStream_t st);   // slices > 1: add with qk_sum_partials
 hipError_t qk_softmax(const float* src, float* dst, int panels, int C, int live, hipStream_t st);
 hipError_t qk_top5(const float* prob, uint16_t* out, int n, int C, hipStream_t st);   // prob panel layout -> [n][5]
 

@@ -88,6 +88,23 @@ def fc_work(d: int, ct: int, m: int, k: int, cs: int, msplit_chunks: int):
                 tile="fc", ks=ks)
 
 
+def decoded_report(sizes, layers, l: int, images: float, ms: float):
+    """A conv layer that ran through its decoded code words (qcnn_decoded.hip): products issued on the matrix pipe — kernel
+    rows of knl * Cin products padded to fours, positions x channels x images — against the dense f32 peak and against
+    what `scripts/ubench/mfma_clock.hip` sustains on all CUs (145 TFLOP/s at the 2.29 GHz the chip holds under that load)."""
+    ly = layers[l]
+    h, w, c = sizes[l]
+    ho, wo, ct = sizes[l + 1]
+    kp = (ly["knl"] * c + 3) // 4 * 4
+    flop = 2.0 * ho * wo * ct * ly["knl"] * kp * images
+    t = ms * 1e-3
+    return dict(tile="decoded code words: %d x %d products per output, 64 images x %d channels per wave" %
+                     (ly["knl"], kp, 96 if ct % 96 == 0 else (64 if ct % 64 == 0 else 32)),
+                issued_mfma_flop_per_image=int(flop / images), mfma_util=round(flop / t / F32_MFMA_FLOPS, 4) if t > 0 else 0.0,
+                mfma_util_of_sustained=round(flop / t / 145.0e12, 4) if t > 0 else 0.0,
+                lookups_replaced_per_image=int(conv_work(sizes[l], sizes[l + 1], ly, 1, 128, c)["lookups"]))
+
+
 def layer_report(sizes, layers, params, l: int, images: float, ms: float, seg_beg=None):
     """Roofline-style figures of conv/FC layer l for a launch over `images` images that took `ms` milliseconds; seg_beg:
     the sliding kernel's row segments when the layer ran it (QcnnEngine.layer_segments)."""

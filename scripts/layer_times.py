@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Per-layer device time (QCNN_OPT_PROFILE events) of an AlexNet forward at a given batch size.
-usage: layer_times.py [batch=128] [steps=20] [streams=1]"""
+"""Per-layer device time (QCNN_OPT_PROFILE events) of a forward at a given batch size.
+usage: [QCNN_MODEL=AlexNet|VGG16] layer_times.py [batch=128] [steps=20] [streams=1]"""
 import importlib, os, sys
 import numpy as np
 import torch   # before libqcnn_hip.so: both must bind to the HIP runtime torch ships
@@ -14,7 +14,7 @@ def main():
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
     streams = int(sys.argv[3]) if len(sys.argv) > 3 else 1
     capi, topo, synth = pkg("capi"), pkg("topology"), pkg("synth")
-    in_chw, layers, _, _ = topo.MODELS["AlexNet"]
+    in_chw, layers, _, _ = topo.MODELS[os.environ.get("QCNN_MODEL", "AlexNet")]
     params = synth.make_params(in_chw, layers, seed=0)
     eng = pkg("engine").QcnnEngine(0)
     eng.set_option(capi.OPT_KEEP_ALL, 0)
@@ -37,7 +37,7 @@ def main():
     eng.sync()
     tot, _, fw = eng.layer_total_ms()
     ms = tot / max(fw, 1)
-    cuts = " ".join("%d:%dx%d" % ((l,) + eng.layer_split(l)) for l in (0, 4, 8, 10, 12))
+    cuts = " ".join("%d:%dx%d" % ((l,) + eng.layer_split(l)) for l in [i for i, ly in enumerate(layers) if ly["type"] == topo.CONV])
     t0 = time.perf_counter()
     eng.forward_host(imgs, want_prob=False)
     wall = (time.perf_counter() - t0) * 1e3

@@ -534,6 +534,7 @@ def test_cbn_payload_decoded_on_the_device(golden_tiny):
     e1 = make_engine(in_chw, layers, params, 2, lut=capi.LUT_MFMA)
     e2 = pkg("engine").QcnnEngine(0)
     e2.set_option(capi.OPT_SPLIT, 0)
+    e2.set_option(capi.OPT_DECODE, 0)          # like make_engine: the tables themselves are what is compared
     e2.configure(in_chw, layers, shapes)
     e2.commit(2)
     e2.upload_cbn(params)
@@ -793,6 +794,35 @@ def test_decoded_first_layer_geometries(cin, knl, stride, pad, ct):
     for l in range(1, len(layers) + 1):
         e_inf, e_l2 = rel_err(eng.layer_output_range(l, 126, 5), orc.fm(l))
         assert e_inf <= TOL and e_l2 <= TOL, "fm[%d] vs oracle: %g %g" % (l, e_inf, e_l2)
+    eng.close()
+
+
+def test_decoded_classifier():
+    """An FC layer whose sub-spaces have one dim (the 1000-way classifier behind fc7: 16 code words of one float) runs
+    through its decoded code words: x @ w with w[k][c] = ctrd[k][asmt[k][c]].  1000 channels = 15 blocks of 64 + 40, 1024
+    inputs; 200 images (k slices inside the workgroups only), 3 and 1 images (k slices over workgroups too, partial sums
+    added in fixed order).  Against the table kernels within 2e-6, against the oracle within 1e-4."""
+    layers = [topo.conv(0, 3, 32, 1, 2), topo.relu(), topo.fcnt(1024), topo.relu(), topo.fcnt(1000), topo.smax()]
+    in_chw = (3, 9, 9)
+    params = synth.make_params(in_chw, layers, seed=95)
+    assert params[4]["ctrd"].shape == (1024, 16, 1)
+    imgs = synth.make_images(200, in_chw, seed=96)
+    orc = po.COracle(in_chw, layers)
+    orc.set_params(params)
+    orc.forward(imgs[:4])
+    base = make_engine(in_chw, layers, params, 200, lut=capi.LUT_MFMA, keep_all=1)
+    base.forward_host(imgs)
+    want = base.layer_output(5, 200)
+    base.close()
+    eng = make_engine(in_chw, layers, params, 200, lut=capi.LUT_MFMA, keep_all=1, decode=1)
+    for n in (200, 3, 1):
+        prob, top5 = eng.forward_host(imgs[:n])
+        got = eng.layer_output(5, n)
+        assert np.abs(got - want[:n]).max() <= 2e-6 * np.abs(want).max(), n
+        m = min(n, 4)
+        for l in (5, 6):
+            e_inf, e_l2 = rel_err(eng.layer_output(l, m), orc.fm(l)[:m])
+            assert e_inf <= TOL and e_l2 <= TOL, "n = %d fm[%d] vs oracle: %g %g" % (n, l, e_inf, e_l2)
     eng.close()
 
 
