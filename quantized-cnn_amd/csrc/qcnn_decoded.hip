@@ -60,7 +60,9 @@ __global__ void k_decode_weights(const uint8_t* __restrict__ rows, const float* 
 // into sixteens serves —, one ds_read2_b32 the A operands of two channel tiles; the results leave as dwordx4 rows of four
 // consecutive images.  B operands run three steps ahead of the products (a ring of three register sets over the flat
 // (kernel row, step) sequence), A operands one step ahead.
-template <int CT, int PW, bool PADDED, int R>
+// IT = image tiles per wave: 4 (64 images, dwordx4 operands and results) or 1 (16 images, dwords: batches of <= 16 images,
+// where three quarters of a 64-image item would multiply zeros).
+template <int CT, int PW, bool PADDED, int R, int IT>
 __global__ __launch_bounds__(1024) void k_conv_dec(DecParams p) {
   extern __shared__ __attribute__((aligned(16))) float ldsW[];          // [knl * Kp][S]
   const int lane = threadIdx.x & 63, wave = uni(threadIdx.x >> 6);
@@ -76,7 +78,8 @@ __global__ __launch_bounds__(1024) void k_conv_dec(DecParams p) {
   const int NS = p.Kp >> 2;                                             // steps (of four k) per kernel row
   const int T = p.knl * NS;                                             // steps per work item
   const int groups = (P + PW - 1) / PW;                                 // position groups per panel
-  const int halves = (p.live + 63) >> 6;                                // 64-image blocks a panel has (a small batch: one)
+  constexpr int IB = 16 * IT;                                           // images per work item
+  const int halves = (p.live + IB - 1) / IB;                            // image blocks a panel has (a small batch: fewer)
   const int chunks = p.Ct / (16 * CT);                                  // channel chunks
   const int nItems = p.panels * groups * halves * chunks;
   const int kClamp = p.Kr - 1;
@@ -101,20 +104,20 @@ __global__ __launch_bounds__(1024) void k_conv_dec(DecParams p) {
     // itself: a buffer load with the lane's part of the address (k row kq, images 4 li ..) in ONE constant VGPR and
     // everything else — position, kernel row, step — in the scalar offset.  Reads past the end of the batch's map (the k
     // padding of the very last window) return 0 by the buffer's range check; those before it are the next pixel's rows.
-    const float* __restrict__ srcU = p.src + (size_t)panel * p.H * p.W * p.Cin * PANEL + ib * 64;
-    const size_t left = (size_t)(p.panels - panel) * p.H * p.W * p.Cin * PANEL * sizeof(float) - ib * 256;
+    const float* __restrict__ srcU = p.src + (size_t)panel * p.H * p.W * p.Cin * PANEL + ib * IB;
+    const size_t left = (size_t)(p.panels - panel) * p.H * p.W * p.Cin * PANEL * sizeof(float) - ib * IB * sizeof(float);
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(srcU), 0, left < 0xffffffffull ? (unsigned)left : 0xffffffffu, 0x00020000);
-    const int laneOff = (kq * PANEL + 4 * li) * (int)sizeof(float);
+    const int laneOff = (kq * PANEL + IT * li) * (int)sizeof(float);
     int posOff[PW];                                                     // byte offset of the window's first row, per position
 #pragma unroll
     for (int j = 0; j < PW; ++j) posOff[j] = (r0[j] * p.W + c0[j]) * p.Cin * PANEL * (int)sizeof(float);
     const int rowPitch = p.W * p.Cin * PANEL * (int)sizeof(float);
     constexpr int kStep = 4 * PANEL * (int)sizeof(float);                // bytes between two steps' first rows
     // B operands of step `step` of kernel row `kh`: four consecutive panel rows (k) x 64 images, per position
-    auto load_b = [&](int kh, int step, int soff, f32x4 (&b)[PW]) {
+    auto load_b = [&](int kh, int step, int soff, float (&b)[PW][IT]) {
 #if QCNN_DEC_VAR & 1
-      for (int j = 0; j < PW; ++j) b[j] = f32x4{(float)kh, (float)step, (float)j, 1.0f};
+      for (int j = 0; j < PW; ++j) for (int ti = 0; ti < IT; ++ti) b[j][ti] = (float)(kh + step + j + ti);
       return;
 #endif
 #pragma unroll
@@ -125,29 +128,40 @@ __global__ __launch_bounds__(1024) void k_conv_dec(DecParams p) {
           const int kc = k < kClamp ? k : kClamp;                       // k >= Kr: any finite operand, its code word is zero
           const int col = c0[j] + kc / p.Cin;
           const bool ok = row >= 0 && row < p.H && col >= 0 && col < p.W;
-          const f32x4 v = *reinterpret_cast<const f32x4*>(srcU + (ok ? ((row * p.W + c0[j]) * p.Cin + kc) * PANEL + 4 * li : 0));
-          b[j] = ok ? v : f32x4{0.0f, 0.0f, 0.0f, 0.0f};               // a panel map is < 2^31 floats (qk_conv_dec)
+          const float* __restrict__ px = srcU + (ok ? ((row * p.W + c0[j]) * p.Cin + kc) * PANEL + IT * li : 0);   // a panel map is < 2^31 floats (qk_conv_dec)
+          if (IT == 4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(px);
+#pragma unroll
+            for (int ti = 0; ti < IT; ++ti) b[j][ti] = ok ? v[ti] : 0.0f;
+          } else {
+            const float v = *px;
+            b[j][0] = ok ? v : 0.0f;
+          }
+        } else if (IT == 4) {
+          const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, laneOff, posOff[j] + soff, 0));
+#pragma unroll
+          for (int ti = 0; ti < IT; ++ti) b[j][ti] = v[ti];
         } else {
-          b[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, laneOff, posOff[j] + soff, 0));
+          b[j][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, laneOff, posOff[j] + soff, 0));
         }
       }
     };
-    f32x4 acc[PW][CT][4];                                               // [position][channel tile][image tile]
+    f32x4 acc[PW][CT][IT];                                              // [position][channel tile][image tile]
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
       const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + (cc * CT + ct) * 16 + 4 * kq);   // D row 4 * kq + r = channel
 #pragma unroll
       for (int j = 0; j < PW; ++j)
 #pragma unroll
-        for (int ti = 0; ti < 4; ++ti) acc[j][ct][ti] = b4;
+        for (int ti = 0; ti < IT; ++ti) acc[j][ct][ti] = b4;
     }
     // (kernel row, step) of the next B load and its byte offset from the window's first row.  Past the last step the
     // sequence simply runs on (rows below the window, or the buffer's zero): those operands are never multiplied, and
     // loads that are unconditional let the compiler count the ones in flight.
     int khL = 0, stL = 0, soffL = 0;
-    f32x4 b[R][PW];                                                     // R = operand sets in flight (2 or 3)
+    float b[R][PW][IT];                                                 // R = operand sets in flight (2 or 3)
     float a[R][CT];
-    auto next_b = [&](f32x4 (&bb)[PW]) {
+    auto next_b = [&](float (&bb)[PW][IT]) {
       load_b(khL, stL, soffL, bb);
       const int wrap = stL + 1 == NS ? 1 : 0;
       stL = wrap ? 0 : stL + 1;
@@ -165,11 +179,11 @@ __global__ __launch_bounds__(1024) void k_conv_dec(DecParams p) {
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) aa[ct] = w[ct * 16];
     };
-    auto products = [&](const float (&aa)[CT], const f32x4 (&bb)[PW]) {
+    auto products = [&](const float (&aa)[CT], const float (&bb)[PW][IT]) {
 #pragma unroll
       for (int j = 0; j < PW; ++j)
 #pragma unroll
-        for (int ti = 0; ti < 4; ++ti)
+        for (int ti = 0; ti < IT; ++ti)
 #pragma unroll
           for (int ct = 0; ct < CT; ++ct)
             acc[j][ct][ti] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[ct], bb[j][ti], acc[j][ct][ti], 0, 0, 0);
@@ -196,36 +210,41 @@ __global__ __launch_bounds__(1024) void k_conv_dec(DecParams p) {
         load_a(wl, a[(u + 1) % R]);
         products(a[u], b[u]);
       }
-    // D tile ti, element r of lane (li, kq): channel 4 * kq + r of the tile, image 4 * li + ti of the 64
+    // D tile ti, element r of lane (li, kq): channel 4 * kq + r of the tile, image IT * li + ti of the block
 #pragma unroll
     for (int j = 0; j < PW; ++j) {
       if (pos0 + j >= P) continue;
-      float* __restrict__ dst = p.dst + ((size_t)panel * P + pos0 + j) * p.Ct * PANEL + ib * 64 + 4 * li;
+      float* __restrict__ dst = p.dst + ((size_t)panel * P + pos0 + j) * p.Ct * PANEL + ib * IB + IT * li;
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          f32x4 v = {acc[j][ct][0][r], acc[j][ct][1][r], acc[j][ct][2][r], acc[j][ct][3][r]};
-          if (p.relu) {
-            v[0] = (0.0f < v[0]) ? v[0] : 0.0f; v[1] = (0.0f < v[1]) ? v[1] : 0.0f;
-            v[2] = (0.0f < v[2]) ? v[2] : 0.0f; v[3] = (0.0f < v[3]) ? v[3] : 0.0f;
+          float v[IT];
+#pragma unroll
+          for (int ti = 0; ti < IT; ++ti) {
+            v[ti] = acc[j][ct][ti][r];
+            if (p.relu) v[ti] = (0.0f < v[ti]) ? v[ti] : 0.0f;
           }
+          float* __restrict__ o = dst + (size_t)((cc * CT + ct) * 16 + 4 * kq + r) * PANEL;
 #if QCNN_DEC_VAR & 8
           if (v[0] == 1.2345f)
 #endif
-          *reinterpret_cast<f32x4*>(dst + (size_t)((cc * CT + ct) * 16 + 4 * kq + r) * PANEL) = v;
+          {
+            if (IT == 4) *reinterpret_cast<f32x4*>(o) = f32x4{v[0], v[IT > 1 ? 1 : 0], v[IT > 2 ? 2 : 0], v[IT > 3 ? 3 : 0]};
+            else *o = v[0];
+          }
         }
     }
   }
 }
 
-template <int CT, int PW, bool PADDED, int R>
+template <int CT, int PW, bool PADDED, int R, int IT>
 hipError_t launch_dec(const DecParams& p, hipStream_t st) {
   const int P = p.Ho * p.Wo;
-  const long long items = (long long)p.panels * ((P + PW - 1) / PW) * ((p.live + 63) / 64) * (p.Ct / (16 * CT));
+  const long long items = (long long)p.panels * ((P + PW - 1) / PW) * ((p.live + 16 * IT - 1) / (16 * IT)) * (p.Ct / (16 * CT));
   const int blocks = (int)std::min<long long>(256, (items + 15) / 16);    // one persistent workgroup per CU
   const size_t shm = (size_t)p.knl * p.Kp * p.S * sizeof(float);
-  auto kern = k_conv_dec<CT, PW, PADDED, R>;
+  auto kern = k_conv_dec<CT, PW, PADDED, R, IT>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(1024), shm, st, p);
@@ -374,15 +393,21 @@ hipError_t qk_decode_weights(const uint8_t* rows, const float* ctrd, float* out,
 hipError_t qk_conv_dec(const DecParams& p, hipStream_t st) {
   if ((long long)p.H * p.W * p.Cin * QCNN_PANEL >= (1ll << 31)) return hipErrorInvalidValue;   // 32-bit row indices inside a panel
   if (p.Ct % 32) return hipErrorInvalidValue;
-  // channels per wave x positions per wave x operand sets in flight: as many accumulator tiles as 128 registers hold,
-  // all channels in one wave where they fit (a chunk of the channels = the B rows loaded once more)
-  if (p.pad) {
-    if (p.Ct % 64 == 0) return launch_dec<4, 1, true, 2>(p, st);
-    return launch_dec<2, 1, true, 3>(p, st);
+  // channels per wave x positions per wave x operand sets in flight x image tiles: as many accumulator tiles as 128
+  // registers hold, all channels in one wave where they fit (a chunk of the channels = the B rows loaded once more)
+  if (p.live <= 16) {               // at most one image tile: 16-image items (four positions of 32 channels for padded layers)
+    if (p.pad) return launch_dec<2, 4, true, 2, 1>(p, st);
+    if (p.Ct % 96 == 0) return launch_dec<6, 2, false, 3, 1>(p, st);
+    if (p.Ct % 64 == 0) return launch_dec<4, 4, false, 3, 1>(p, st);
+    return launch_dec<2, 6, false, 3, 1>(p, st);
   }
-  if (p.Ct % 96 == 0) return launch_dec<6, 1, false, 2>(p, st);
-  if (p.Ct % 64 == 0) return launch_dec<4, 1, false, 3>(p, st);
-  return launch_dec<2, 2, false, 3>(p, st);
+  if (p.pad) {
+    if (p.Ct % 64 == 0) return launch_dec<4, 1, true, 2, 4>(p, st);
+    return launch_dec<2, 1, true, 3, 4>(p, st);
+  }
+  if (p.Ct % 96 == 0) return launch_dec<6, 1, false, 2, 4>(p, st);
+  if (p.Ct % 64 == 0) return launch_dec<4, 1, false, 3, 4>(p, st);
+  return launch_dec<2, 2, false, 3, 4>(p, st);
 }
 
 bool qk_fc_dec_shape(int D, int M, int Cs, int Ct, int* S) {

@@ -517,7 +517,8 @@ int lrn_pool_min_blocks() {
 
 bool direct_input(const QcnnCtx* c, int n) {
   if (c->keepAll || c->L == 0 || c->layers[0].type != QCNN_CONV) return false;
-  // a first layer that runs through its decoded code words reads packed panels (the few-image kernels do not take that path)
+  // a first layer that runs through its decoded code words reads packed panels (the few-image kernels do not take that
+  // path: one or two images in a 128-image panel layout are 64-byte segments with one float each, they read NCHW densely)
   if (decoded_layer(c, 0) && !(c->smallBatch && c->lutMode == 1 && n <= kSmallBatchMax)) return false;
   const QcnnLayerDesc& d = c->layers[0];
   // ONE sub-space (a second one would be fetched from channel planes past the group's own, for the last image past the

@@ -761,6 +761,13 @@ def test_decoded_first_layer_alexnet():
                 assert e_inf <= TOL and e_l2 <= TOL, "fm[%d] vs oracle: %g %g" % (l, e_inf, e_l2)
             p2, t2 = eng.forward_host(imgs[:2])                        # few-image kernels: tables
             assert eng.layer_split(0)[0] != -3
+            for n in (3, 16, 17):                                      # <= 16 images: 16-image work items
+                p2, t2 = eng.forward_host(imgs[129 - n + 2:131])
+                assert eng.layer_split(0) == (-3, 1)
+                m = min(n, 2)
+                for l in (1, 2):
+                    e_inf, e_l2 = rel_err(eng.layer_output_range(l, n - m, m), orc.fm(l)[2 - m:])
+                    assert e_inf <= TOL and e_l2 <= TOL, "n = %d fm[%d] vs oracle: %g %g" % (n, l, e_inf, e_l2)
             eng.set_option(capi.OPT_LUT_MODE, capi.LUT_EXACT)          # the exact builder: tables, the reference's bits
             eng.forward_host(imgs[:5])
             assert eng.layer_split(0)[0] != -3
