@@ -343,7 +343,7 @@ def main():
     dt = measure(step, args.steps, args.warmup)
     layer_ms, recorded = eng.layer_ms()
     segments = {i: eng.layer_segments(i) for i, l in enumerate(layers) if l["type"] == topo.CONV}   # sliding kernel, per layer
-    decoded = {i for i, l in enumerate(layers) if l["type"] == topo.CONV and eng.layer_split(i)[0] == -3}   # decoded first layer
+    decoded = {i for i, l in enumerate(layers) if l["type"] in (topo.CONV, topo.FCNT) and eng.layer_split(i)[0] == -3}   # decoded layers
     ok = bool(torch.isfinite(prob[lo:hi]).all().item())
     images_per_step = B if (strong or world == 1) else B * world
 
@@ -364,6 +364,15 @@ def main():
             step()
             extras["value_two_streams"] = round(B * 3 / timed(torch, dev, step, 3), 2)
             eng.set_option(capi.OPT_STREAMS, 1)
+        if args.model == "AlexNet":
+            # every layer through look-up tables + indexed accumulation (QCNN_OPT_DECODE = 0): the north star's algorithm for
+            # the two degenerate layers too (conv1: one sub-space of 3 dims; fc8: one-dim sub-spaces), which `value` evaluates
+            # through the code words their assignments name
+            eng.set_option(capi.OPT_DECODE, 0)
+            step()
+            extras["value_tables_only"] = round(B * 3 / timed(torch, dev, step, 3), 2)
+            eng.set_option(capi.OPT_DECODE, 1)
+            step()
         # opt-in bf16-pair LUT builder for the 8-dim conv layers (QCNN_OPT_LUT_MODE = 3): rate and its own parity figures
         if args.lut == "mfma":
             eng.set_option(capi.OPT_LUT_MODE, capi.LUT_MFMA_BF16X2)
@@ -543,7 +552,10 @@ def main():
         total_lk = 0
         for i, l in enumerate(layers):
             if l["type"] in (topo.CONV, topo.FCNT) and layer_ms[i] > 0:
-                r = (perf.decoded_report(sizes, layers, i, launch_images, float(layer_ms[i])) if i in decoded else
+                r = (perf.decoded_report(sizes, layers, i, launch_images, float(layer_ms[i])) if (i in decoded and l["type"] == topo.CONV) else
+                     dict(tile="decoded code words: x @ w on the matrix pipe, 64 channels x 64 images per workgroup",
+                          issued_mfma_flop_per_image=2 * sizes[i][0] * sizes[i][1] * sizes[i][2] * ((l["nod"] + 63) // 64 * 64),
+                          lookups_replaced_per_image=sizes[i][0] * sizes[i][1] * sizes[i][2] * l["nod"]) if i in decoded else
                      perf.layer_report(sizes, layers, params, i, launch_images, float(layer_ms[i]), segments.get(i)))
                 r["ms"] = round(float(layer_ms[i]), 4)
                 per_layer["%02d_%s" % (i, topo.TYPE_NAMES[l["type"]])] = r

@@ -388,11 +388,13 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
         const size_t need = (size_t)z * panels * q.Ct * QCNN_PANEL;
         const size_t poff = (size_t)kMaxFcSplit * p0 * c->fcMaxCt * QCNN_PANEL;    // every sub-batch has its own slab
         if (z > 1 && poff + need <= c->fcPartialElems) q.partial = c->fcPartial + poff; else z = 1;
+        s.lastFrom = -3; s.lastZ = z;        // reported by qcnn_get_layer_split as (-3, k slices over workgroups)
         e = qk_fc_dec(q, z, live, st);
         if (e == hipSuccess && z > 1)
           e = qk_sum_partials(q.partial, dst, z, (size_t)panels * q.Ct * QCNN_PANEL, q.relu, st);
         break;
       }
+      s.lastFrom = -1; s.lastZ = 1;
       FcParams p;
       p.src = src; p.dst = dst;
       p.bias = reinterpret_cast<const float*>(c->arena + s.offBias);
