@@ -138,3 +138,16 @@ def test_perfmodel_sliding_stage_counts():
         assert wk["stages"] == brute * ly["grp"], (l, wk["stages"], brute)
         tile = perf.conv_work(sizes[l], sizes[l + 1], ly, m, k, cs)
         assert wk["stages"] < tile["stages"] and wk["lookups"] == tile["lookups"]
+
+
+def test_perfmodel_decoded_layer_counts():
+    """perfmodel.decoded_report (what bench.py reports for a conv layer that ran through its decoded code words): the matrix
+    FLOP issued = outputs x kernel rows x (knl * Cin rounded up to four) x 2, the look-ups it replaces = the reference's
+    border-clipped count (35 138 400 for AlexNet conv1)."""
+    perf = pkg("perfmodel")
+    in_chw, layers, _, _ = topo.MODELS["AlexNet"]
+    sizes = topo.fmap_sizes(in_chw, layers)
+    r = perf.decoded_report(sizes, layers, 0, 1000.0, 1.8)
+    assert r["issued_mfma_flop_per_image"] == 2 * 55 * 55 * 96 * 11 * 36
+    assert r["lookups_replaced_per_image"] == 35138400
+    assert 0.80 < r["mfma_util"] < 0.82 and r["mfma_util_of_sustained"] > r["mfma_util"]
