@@ -405,7 +405,13 @@ hipError_t qk_conv_dec(const DecParams& p, hipStream_t st) {
     if (p.Ct % 64 == 0) return launch_dec<4, 1, true, 2, 4>(p, st);
     return launch_dec<2, 1, true, 3, 4>(p, st);
   }
-  if (p.Ct % 96 == 0) return launch_dec<6, 1, false, 2, 4>(p, st);
+  if (p.Ct % 96 == 0) {
+    // a launch of a few thousand 96-channel items (one panel: 6050 on 4096 waves = two rounds for 1.5 rounds of work) runs
+    // half-items of 48 channels instead (three rounds of half the length; B rows loaded twice)
+    const long long items = (long long)p.panels * p.Ho * p.Wo * ((p.live + 63) / 64) * (p.Ct / 96);
+    if (items > 4096 && items < 2 * 4096) return launch_dec<3, 1, false, 3, 4>(p, st);
+    return launch_dec<6, 1, false, 2, 4>(p, st);
+  }
   if (p.Ct % 64 == 0) return launch_dec<4, 1, false, 3, 4>(p, st);
   return launch_dec<2, 2, false, 3, 4>(p, st);
 }
