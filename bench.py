@@ -159,7 +159,7 @@ def cpu_baseline(kind, cpu, imgs_host):
                 host_cores=os.cpu_count(), ms_per_image=1000.0 * dt / sample)
 
 
-def via_reference_main(params, imgs_host, batches=8):
+def via_reference_main(params, imgs_host, batches=16):
     """images/s of the reference's UNMODIFIED src/Main.cc + src/UnitTest.cc (build/bin/QuanCNN_hip, linked against the
     host mirror) on a staged data root holding this run's parameters and images: QCNN_BATCH = len(imgs) images per
     forward pass, `batches` passes over the same window (the reference's window rule for a one-batch dataset,
