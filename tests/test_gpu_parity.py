@@ -775,7 +775,8 @@ def test_decoded_first_layer_alexnet():
 
 
 @pytest.mark.parametrize("cin,knl,stride,pad,ct", [(3, 3, 1, 1, 64), (3, 5, 2, 0, 32), (1, 3, 1, 1, 32), (4, 7, 3, 2, 96),
-                                                   (2, 4, 2, 1, 64), (3, 1, 1, 0, 96)])
+                                                   (2, 4, 2, 1, 64), (3, 1, 1, 0, 96), (3, 3, 1, 1, 128), (3, 3, 2, 0, 160),
+                                                   (3, 6, 2, 0, 192), (3, 5, 1, 0, 64)])
 def test_decoded_first_layer_geometries(cin, knl, stride, pad, ct):
     """Decoded first layers on shapes AlexNet does not have: VGG-16's padded 3x3 / 1 with 64 channels, 32 and 96 channels,
     1, 2 and 4 input channels (kernel rows of 3 ... 28 products, padded to fours), even kernels, 1x1, strides 1-3, padding
