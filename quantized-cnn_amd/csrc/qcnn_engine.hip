@@ -513,7 +513,7 @@ int drain_profile(QcnnCtx* c) {
 // sub-space of <= 4 dims: exactly what the operand loads of one stage touch) and K = 128 or the exact builder.
 // workgroups a fused LRN + pool launch must have (QCNN_LRNPOOL_MIN overrides it for experiments)
 int lrn_pool_min_blocks() {
-  static const int v = [] { const char* e = getenv("QCNN_LRNPOOL_MIN"); return (e && atoi(e) > 0) ? atoi(e) : 192; }();
+  static const int v = [] { const char* e = getenv("QCNN_LRNPOOL_MIN"); return (e && atoi(e) > 0) ? atoi(e) : 256; }();
   return v;
 }
 

@@ -88,14 +88,16 @@ __device__ __forceinline__ float lrn_scale(float s, float nbet) {
 template <int N, bool B34>
 __global__ __launch_bounds__(256) void k_lrn_stream(const float4* __restrict__ src, float4* __restrict__ dst,
                                                     size_t pixels, int C, int segLen, float coeff, float nbet, float ini,
-                                                    int liveQuads) {
+                                                    int liveQuads, int qlShift) {
   constexpr int RAD = (N - 1) / 2;
-  const size_t px = blockIdx.x * (size_t)(blockDim.x >> 5) + (threadIdx.x >> 5);
-  if (px >= pixels || (int)(threadIdx.x & 31) >= liveQuads) return;   // lanes of images a small batch does not have
+  // 1 << qlShift lanes per pixel (32 = a whole 512-byte row; a batch of a few images: just the float4 lanes it has, so
+  // that a block covers 256 >> qlShift pixels instead of 8 with most lanes idle)
+  const size_t px = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> qlShift;
+  const int q = threadIdx.x & ((1 << qlShift) - 1);
+  if (px >= pixels || q >= liveQuads) return;   // lanes of images a small batch does not have
   // blockIdx.y = channel segment [cs, ce): few pixels (a single panel of a 13x13 map) would otherwise leave most of
   // the chip idle.  segLen is a multiple of N, so channel k always lives in ring slot k % N.
   const int cs = blockIdx.y * segLen, ce = min(C, cs + segLen);
-  const int q = threadIdx.x & 31;
   const float4* __restrict__ x = src + px * (size_t)C * 32 + q;
   float4* __restrict__ y = dst + px * (size_t)C * 32 + q;
   const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -203,11 +205,11 @@ __global__ void k_pool(const float* __restrict__ src, float* __restrict__ dst, i
 // max-pool, four images per thread (32 lanes = one row, a wave = two adjacent channels): same window rule
 __global__ __launch_bounds__(256) void k_pool4(const float4* __restrict__ src, float4* __restrict__ dst, int panels,
                                                int H, int W, int C, int Ho, int Wo, int knl, int stride, int pad,
-                                               int liveQuads) {
+                                               int liveQuads, int qlShift) {
   const size_t rows = (size_t)panels * Ho * Wo * C;
-  const size_t r = blockIdx.x * (size_t)(blockDim.x >> 5) + (threadIdx.x >> 5);
-  if (r >= rows || (int)(threadIdx.x & 31) >= liveQuads) return;
-  const int q = threadIdx.x & 31;
+  const size_t r = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> qlShift;   // 1 << qlShift lanes per row (k_lrn_stream)
+  const int q = threadIdx.x & ((1 << qlShift) - 1);
+  if (r >= rows || q >= liveQuads) return;
   const int c = (int)(r % C);
   size_t t = r / C;
   const int wo = (int)(t % Wo);
@@ -597,15 +599,28 @@ hipError_t qk_relu(const float* src, float* dst, size_t n, hipStream_t st) {
   return hipGetLastError();
 }
 
+namespace {
+// log2 of the float4 lanes a row gets in the streaming glue kernels: 32 (the whole 512-byte row) unless the batch is a single
+// panel with fewer live images
+int live_shift(int live) {
+  const int quads = (live + 3) / 4;
+  int s = 0;
+  while ((1 << s) < quads) ++s;
+  return s > 5 ? 5 : s;
+}
+}  // namespace
+
 hipError_t qk_lrn(const float* src, float* dst, int panels, int HW, int C, int lrnSiz, float alp, float bet, float ini,
                   int live, hipStream_t st) {
   const size_t rows = (size_t)panels * HW * C;
   const float coeff = alp / lrnSiz;   // float / int, as src/CaffeEva.cc:1055
-  if (lrnSiz == 5 || lrnSiz == 3) {   // streaming kernel: 8 pixels per block
+  if (lrnSiz == 5 || lrnSiz == 3) {   // streaming kernel: 8 pixels per block (more when a small batch has few float4 lanes)
     const size_t pixels = (size_t)panels * HW;
-    const size_t blocks = (pixels + 7) / 8;
-    // channel segments (blockIdx.y) until ~8 blocks per CU exist; a segment keeps >= 4 window lengths of channels
-    int segs = (int)std::min<size_t>((2048 + blocks - 1) / blocks, (size_t)std::max(1, C / (4 * lrnSiz)));
+    const int qlShift = live_shift(live);
+    const size_t blocks = ((pixels << qlShift) + 255) / 256;
+    // channel segments (blockIdx.y) until ~8 blocks per CU exist; a segment keeps >= 4 window lengths of channels (a few
+    // images: >= 2 — the walk along the channels is a chain of dependent loads, short segments cut it)
+    int segs = (int)std::min<size_t>((2048 + blocks - 1) / blocks, (size_t)std::max(1, C / ((qlShift < 5 ? 2 : 4) * lrnSiz)));
     int segLen = ((C + segs - 1) / segs + lrnSiz - 1) / lrnSiz * lrnSiz;
     segs = (C + segLen - 1) / segLen;
     const dim3 grid((unsigned)blocks, (unsigned)segs);
@@ -613,7 +628,7 @@ hipError_t qk_lrn(const float* src, float* dst, int panels, int HW, int C, int l
     if (lrnSiz == 5) kern = (bet == 0.75f) ? k_lrn_stream<5, true> : k_lrn_stream<5, false>;
     else kern = (bet == 0.75f) ? k_lrn_stream<3, true> : k_lrn_stream<3, false>;
     hipLaunchKernelGGL(kern, grid, dim3(256), 0, st, reinterpret_cast<const float4*>(src),
-                       reinterpret_cast<float4*>(dst), pixels, C, segLen, coeff, -bet, ini, (live + 3) / 4);
+                       reinterpret_cast<float4*>(dst), pixels, C, segLen, coeff, -bet, ini, (live + 3) / 4, qlShift);
     return hipGetLastError();
   }
   const int blocks = (int)((rows + 3) / 4 < 8192 ? (rows + 3) / 4 : 8192);
@@ -642,8 +657,10 @@ hipError_t qk_pool(const float* src, float* dst, int panels, int H, int W, int C
                    int pad, int live, hipStream_t st) {
   const size_t rows = (size_t)panels * Ho * Wo * C;
   if ((rows + 7) / 8 < (size_t)1 << 31) {
-    hipLaunchKernelGGL(k_pool4, dim3((unsigned)((rows + 7) / 8)), dim3(256), 0, st, reinterpret_cast<const float4*>(src),
-                       reinterpret_cast<float4*>(dst), panels, H, W, C, Ho, Wo, knl, stride, pad, (live + 3) / 4);
+    const int qlShift = live_shift(live);
+    hipLaunchKernelGGL(k_pool4, dim3((unsigned)(((rows << qlShift) + 255) / 256)), dim3(256), 0, st,
+                       reinterpret_cast<const float4*>(src), reinterpret_cast<float4*>(dst), panels, H, W, C, Ho, Wo, knl,
+                       stride, pad, (live + 3) / 4, qlShift);
     return hipGetLastError();
   }
   const int blocks = (int)((rows + 3) / 4 < 8192 ? (rows + 3) / 4 : 8192);
