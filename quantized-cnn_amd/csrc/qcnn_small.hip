@@ -21,8 +21,8 @@ namespace {
 
 constexpr int PANEL = QCNN_PANEL;
 constexpr int NT = 512;                     // threads per workgroup
-constexpr int LUT_BYTES = 112 * 1024;       // LDS given to the table (160 KB per CU) ...
-constexpr int XS_BYTES = 40 * 1024;         // ... and to the staged activations of the current sub-space chunk
+constexpr int LUT_BYTES = 112 * 1024;       // LDS given to the FC table chunk (k_fc_small)
+constexpr int CONV_LDS = 156 * 1024;        // conv: table chunk + staged activations + staged assignments of a sub-space chunk
 
 // inverse of qcnn_row_slot (the permutation swaps two 2-bit fields: it is its own inverse)
 __device__ __forceinline__ int slot_row(int s) { return (s & 0x70) | ((s & 3) << 2) | ((s >> 2) & 3); }
@@ -37,6 +37,7 @@ struct SmallConv {
   int H, W, Cin, Ho, Wo, Ct, knl, stride, pad, grp;
   int M, Cs, K, G, relu, rowStride;
   int TH, TW, tilesX, CH, chunks, MC;   // output tile, channels per workgroup, chunks per group, sub-spaces per LUT chunk
+  int lutFloats, xsFloats;              // LDS: table [npx][MC][K], activations [npx][MC * Cs], then assignments [taps][MC][CH] bytes
   QkSlots sl;
 };
 
@@ -54,7 +55,8 @@ __device__ __forceinline__ float lut_at(const float* __restrict__ tab, uint8_t s
 __global__ __launch_bounds__(NT) void k_conv_small(SmallConv p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* __restrict__ lut = lds;                                   // [npx][MC][K]
-  float* __restrict__ xs = lds + LUT_BYTES / 4;                    // [npx][MC * Cs] activations of the current chunk
+  float* __restrict__ xs = lds + p.lutFloats;                      // [npx][MC * Cs] activations of the current chunk
+  uint8_t* __restrict__ idx = reinterpret_cast<uint8_t*>(xs + p.xsFloats);   // [taps][mc][CH] row slots of the current chunk
   const int t = threadIdx.x;
   const int img = blockIdx.z;
   const int ty = blockIdx.x / p.tilesX, tx = blockIdx.x % p.tilesX;
@@ -73,7 +75,6 @@ __global__ __launch_bounds__(NT) void k_conv_small(SmallConv p) {
   const int cg = chunk * p.CH + cl;                     // channel inside the group
   const bool chOk = pslot < slots && cg < Ctg;
   const int c = grp * Ctg + cg;
-  const int entry = chOk ? qk_slot_entry(p.sl, grp, cg) : 0;
   const int NP = p.TH * p.TW;
   float acc[4];
   const float b = chOk ? p.bias[c] : 0.0f;
@@ -88,6 +89,30 @@ __global__ __launch_bounds__(NT) void k_conv_small(SmallConv p) {
       const int px = e / dims, d = e % dims;
       const int ch = m0 * Cs + d;
       xs[e] = (ch < Cg) ? load_x(p, img, hiL + px / rfW, wiL + px % rfW, grp * Cg + ch) : 0.0f;
+    }
+    // ---- stage the chunk's assignments of this workgroup's channels: the gather below then never waits for HBM / L2 (a
+    //      look-up used to be a one-byte global load followed by the table read that depends on it: the whole kernel ran
+    //      at the latency of that chain)
+    {
+      // NT is a multiple of CH: a thread always stages the bytes of ONE channel (its table position is computed once);
+      // sixteen independent loads in flight per thread, then the stores
+      const int c2 = t % p.CH, prStep = NT / p.CH, npair = p.knl * p.knl * mc;
+      const int cg2 = chunk * p.CH + c2;
+      const bool ok2 = cg2 < Ctg;
+      const uint8_t* __restrict__ rbase = p.rows + (size_t)m0 * p.rowStride + (ok2 ? qk_slot_entry(p.sl, grp, cg2) : 0);
+      for (int pair = t / p.CH; pair < npair; pair += prStep * 16) {
+        uint8_t v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const int pp = min(pair + u * prStep, npair - 1);
+          v[u] = rbase[((size_t)(pp / mc) * p.M + pp % mc) * p.rowStride];
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const int pp = pair + u * prStep;
+          if (pp < npair) idx[pp * p.CH + c2] = ok2 ? v[u] : (uint8_t)0;
+        }
+      }
     }
     __syncthreads();
     // ---- build: a thread owns a (sub-space, code word) pair, keeps the code word in registers and walks pixels; when
@@ -129,7 +154,7 @@ __global__ __launch_bounds__(NT) void k_conv_small(SmallConv p) {
         float a = acc[j];
         for (int kh = khL; kh <= khU; ++kh) {
           const float* rowTab = lut + (ptrdiff_t)((hs + kh - hiL) * rfW + (ws - wiL)) * (p.MC * K);
-          const uint8_t* rowIdx = p.rows + ((size_t)(kh * p.knl) * p.M + m0) * p.rowStride + entry;
+          const uint8_t* rowIdx = idx + (size_t)(kh * p.knl) * mc * p.CH + cl;      // [kw][ml][CH]
           // batches of eight INDEPENDENT look-ups (offset loads in flight together, then the table reads, then the adds in
           // order); the tail of a batch re-reads the last valid element and is not added
           if (mc == 1) {                                 // one sub-space per pixel (first layer): run over the taps
@@ -138,7 +163,7 @@ __global__ __launch_bounds__(NT) void k_conv_small(SmallConv p) {
               uint8_t o[8];
               float v[8];
 #pragma unroll
-              for (int u = 0; u < 8; ++u) o[u] = rowIdx[(size_t)min(kw + u, kwU) * p.M * p.rowStride];
+              for (int u = 0; u < 8; ++u) o[u] = rowIdx[min(kw + u, kwU) * mc * p.CH];
 #pragma unroll
               for (int u = 0; u < 8; ++u) v[u] = lut_at(rowTab + (ptrdiff_t)min(kw + u, kwU) * (p.MC * K), o[u], mi, K);
 #pragma unroll
@@ -148,12 +173,12 @@ __global__ __launch_bounds__(NT) void k_conv_small(SmallConv p) {
           } else {
             for (int kw = kwL; kw <= kwU; ++kw) {
               const float* tab = rowTab + (ptrdiff_t)kw * (p.MC * K);
-              const uint8_t* rr = rowIdx + (size_t)kw * p.M * p.rowStride;
+              const uint8_t* rr = rowIdx + kw * mc * p.CH;
               for (int ml = 0; ml < mc; ml += 8) {
                 uint8_t o[8];
                 float v[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) o[u] = rr[(size_t)min(ml + u, mc - 1) * p.rowStride];
+                for (int u = 0; u < 8; ++u) o[u] = rr[min(ml + u, mc - 1) * p.CH];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                   const int mm = min(ml + u, mc - 1);
@@ -295,9 +320,10 @@ hipError_t qk_conv_small(const ConvParams& cp, int n, hipStream_t st) {
   // output tile: 2 x 2 unless the map is tiny; shrink until the table chunk holds >= min(M, 4) sub-spaces
   int th = std::min(2, cp.Ho), tw = std::min(2, cp.Wo);
   auto rf = [&](int a) { return (a - 1) * cp.stride + cp.knl; };
-  // sub-spaces per chunk: the table [npx][mc][K] and the staged activations [npx][mc * Cs] both have to fit
+  // sub-spaces per chunk: the table [npx][mc][K], the staged activations [npx][mc * Cs] and the staged assignments
+  // [taps][mc][CH] have to fit
   auto mcFor = [&](int a, int b) {
-    return std::min(LUT_BYTES / (rf(a) * rf(b) * cp.K * 4), XS_BYTES / (rf(a) * rf(b) * cp.Cs * 4));
+    return CONV_LDS / (rf(a) * rf(b) * (cp.K + cp.Cs) * 4 + cp.knl * cp.knl * p.CH);
   };
   while ((mcFor(th, tw) < std::min(cp.M, 4) || th * tw > 4 * slots) && (th > 1 || tw > 1)) {
     if (tw >= th && tw > 1) --tw; else --th;
@@ -305,11 +331,14 @@ hipError_t qk_conv_small(const ConvParams& cp, int n, hipStream_t st) {
   if (mcFor(th, tw) < 1) return hipErrorInvalidValue;      // a single pixel's window does not fit: not a small-path layer
   p.TH = th; p.TW = tw;
   p.MC = std::min(cp.M, mcFor(th, tw));
+  p.lutFloats = rf(th) * rf(tw) * p.MC * cp.K;
+  p.xsFloats = rf(th) * rf(tw) * p.MC * cp.Cs;
+  const int ldsBytes = (p.lutFloats + p.xsFloats) * 4 + cp.knl * cp.knl * p.MC * p.CH;
   p.tilesX = (cp.Wo + tw - 1) / tw;
   const int tilesY = (cp.Ho + th - 1) / th;
-  hipError_t e = allow_lds(reinterpret_cast<const void*>(k_conv_small), LUT_BYTES + XS_BYTES);
+  hipError_t e = allow_lds(reinterpret_cast<const void*>(k_conv_small), ldsBytes);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_conv_small, dim3(p.tilesX * tilesY, p.chunks * cp.grp, n), dim3(NT), LUT_BYTES + XS_BYTES, st, p);
+  hipLaunchKernelGGL(k_conv_small, dim3(p.tilesX * tilesY, p.chunks * cp.grp, n), dim3(NT), ldsBytes, st, p);
   return hipGetLastError();
 }
 
