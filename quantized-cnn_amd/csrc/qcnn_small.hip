@@ -124,6 +124,7 @@ __global__ __launch_bounds__(NT) void k_conv_small(SmallConv p) {
       const int pg = npairs < NT ? t / npairs : 0;
       for (int pair = (npairs < NT ? t % npairs : t); pair < npairs && pg < groups; pair += NT) {
         const int k = pair % K, mloc = pair / K;
+        const int kst = (p.G == 1) ? qcnn_row_slot(k) : k;   // K = 128: entries in ROW-SLOT order, a look-up is tab[byte]
         const int m = m0 + mloc;
         const int dsel = min(Cg - m * Cs, Cs);
         float cw[QCNN_MAX_CS];
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(NT) void k_conv_small(SmallConv p) {
 #pragma unroll
           for (int d = 0; d < QCNN_MAX_CS; ++d)
             if (d < dsel) v = fmaf(xr[px * dims + d], cw[d], v);
-          lut[(px * p.MC + mloc) * K + k] = v;
+          lut[(px * p.MC + mloc) * K + kst] = v;
         }
       }
     }
@@ -165,7 +166,10 @@ __global__ __launch_bounds__(NT) void k_conv_small(SmallConv p) {
 #pragma unroll
               for (int u = 0; u < 8; ++u) o[u] = rowIdx[min(kw + u, kwU) * mc * p.CH];
 #pragma unroll
-              for (int u = 0; u < 8; ++u) v[u] = lut_at(rowTab + (ptrdiff_t)min(kw + u, kwU) * (p.MC * K), o[u], mi, K);
+              for (int u = 0; u < 8; ++u) {
+                const float* tb = rowTab + (ptrdiff_t)min(kw + u, kwU) * (p.MC * K);
+                v[u] = (p.G == 1) ? tb[o[u]] : lut_at(tb, o[u], mi, K);
+              }
 #pragma unroll
               for (int u = 0; u < 8; ++u)
                 if (kw + u <= kwU) a += v[u];
@@ -182,7 +186,7 @@ __global__ __launch_bounds__(NT) void k_conv_small(SmallConv p) {
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                   const int mm = min(ml + u, mc - 1);
-                  v[u] = lut_at(tab + mm * K, o[u], (m0 + mm) % p.G, K);
+                  v[u] = (p.G == 1) ? tab[mm * K + o[u]] : lut_at(tab + mm * K, o[u], (m0 + mm) & (p.G - 1), K);
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u)
