@@ -17,6 +17,8 @@
 
 #include <algorithm>
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 namespace {
 
 constexpr int PANEL = QCNN_PANEL;
@@ -118,7 +120,33 @@ __global__ __launch_bounds__(NT) void k_conv_small(SmallConv p) {
     // ---- build: a thread owns a (sub-space, code word) pair, keeps the code word in registers and walks pixels; when
     //      there are fewer pairs than threads (first layer: one sub-space) the pixels are dealt out to NT / pairs thread
     //      groups.  Activation reads are LDS broadcasts, table writes are consecutive in k.
-    {
+    if (K % 16 == 0) {
+      // Matrix build: the chunk's table is a small product [pixels x dims] x [dims x K] per sub-space — 16 x 16 tiles of
+      // v_mfma_f32_16x16x4_f32 dealt out to the eight waves (A = staged activations out of LDS, B = the code book rows,
+      // 64-byte segments from L2).  The scalar build below took a third of the kernel's time for one image.
+      const int wave = t >> 6, lane = t & 63, li = lane & 15, kq = lane >> 4;
+      const int rowTiles = (npx + 15) >> 4, colTiles = K >> 4;
+      for (int tile = wave; tile < mc * rowTiles * colTiles; tile += NT / 64) {
+        const int mloc = tile / (rowTiles * colTiles), rt = (tile / colTiles) % rowTiles, ctile = tile % colTiles;
+        const int m = m0 + mloc;
+        const int dsel = min(Cg - m * Cs, Cs);
+        const int pxA = rt * 16 + li;
+        f32x4 accT = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int d0 = 0; d0 < dsel; d0 += 4) {
+          const int d = d0 + kq;
+          const float av = (pxA < npx && d < dsel) ? xs[pxA * dims + mloc * Cs + d] : 0.0f;
+          const float bv = (d < dsel) ? p.ctrd[((size_t)m * Cs + d) * K + ctile * 16 + li] : 0.0f;
+          accT = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, accT, 0, 0, 0);
+        }
+        const int kc = ctile * 16 + li;
+        const int kst = (p.G == 1) ? qcnn_row_slot(kc) : kc;   // K = 128: entries in ROW-SLOT order, a look-up is tab[byte]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int px = rt * 16 + 4 * kq + r;                  // D[4 kq + r][li]
+          if (px < npx) lut[(px * p.MC + mloc) * K + kst] = accT[r];
+        }
+      }
+    } else {
       const int npairs = mc * K;
       const int groups = npairs < NT ? NT / npairs : 1;
       const int pg = npairs < NT ? t / npairs : 0;
