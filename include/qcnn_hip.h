@@ -46,7 +46,7 @@ extern "C" {
 
 #define QCNN_ABI_VERSION 3
 
-#define QCNN_SMALL_BATCH_MAX 2   /* batches up to this size can take the few-image kernels (QCNN_OPT_SMALL_BATCH) */
+#define QCNN_SMALL_BATCH_MAX 3   /* batches up to this size can take the few-image kernels (QCNN_OPT_SMALL_BATCH) */
 
 typedef struct QcnnCtx QcnnCtx;
 

@@ -47,7 +47,7 @@ struct FmDims { int h, w, c; };
 constexpr int kProfRing = 32;    // forwards whose per-layer events are kept
 constexpr int kMaxStreams = 4;   // sub-batches (streams) of one forward
 constexpr int kSmallBatchMax = QCNN_SMALL_BATCH_MAX;  // batches up to this size run the few-image kernels (QCNN_OPT_SMALL_BATCH): beyond, a
-                                   // 128-image panel is cheaper (measured: 2 images 1.6 ms, 4 images 3.3 ms, a panel 2.8 ms)
+                                   // 128-image panel is cheaper (measured: 1 / 2 / 3 / 4 images 0.58 / 0.85 / 1.15 / 1.47 ms, a panel 1.50 ms)
 constexpr int kMaxFcSplit = 32;  // workgroups along the sub-space axis of an FC layer (partial sums reduced in fixed order)
 constexpr size_t kConvPartialFloats = (size_t)64 << 20;   // 256 MB of partial sums for split conv tiles (all sub-batches)
 constexpr size_t kSlack = 64 * 1024;   // bytes of slack behind every device buffer: the MFMA operand loads are

@@ -109,12 +109,12 @@ def test_two_ranks_on_one_device(monkeypatch):
 
 
 def test_group_kernel_family_follows_the_global_batch(monkeypatch):
-    """A shard of one or two images of a LARGER batch must not take the few-image kernels (bits would then depend on
-    the number of GPUs): 3 images over 2 ranks = shards of 1 and 2 images, panel kernels on both."""
+    """A shard of a few images of a LARGER batch must not take the few-image kernels (bits would then depend on
+    the number of GPUs): 4 images (> QCNN_SMALL_BATCH_MAX) over 2 ranks = shards of 2 images, panel kernels on both."""
     monkeypatch.setenv("QCNN_GROUP_ALLOW_DUP", "1")
     in_chw, layers = topo.tiny_model()
     params = synth.make_params(in_chw, layers, seed=27)
-    imgs = synth.make_images(3, in_chw, seed=28)
+    imgs = synth.make_images(4, in_chw, seed=28)
     single = _engine(in_chw, layers, params, 8, small=0)
     want = single.forward_host(imgs)
     single.close()

@@ -761,7 +761,7 @@ def test_decoded_first_layer_alexnet():
                 assert e_inf <= TOL and e_l2 <= TOL, "fm[%d] vs oracle: %g %g" % (l, e_inf, e_l2)
             p2, t2 = eng.forward_host(imgs[:2])                        # few-image kernels: tables
             assert eng.layer_split(0)[0] != -3
-            for n in (3, 16, 17):                                      # <= 16 images: 16-image work items
+            for n in (5, 16, 17):                                      # <= 16 images: 16-image work items
                 p2, t2 = eng.forward_host(imgs[129 - n + 2:131])
                 assert eng.layer_split(0) == (-3, 1)
                 m = min(n, 2)
@@ -835,7 +835,7 @@ def test_decoded_classifier():
 
 
 # ---------------------------------------------------------------- sliding-window conv kernels ----
-@pytest.mark.parametrize("n_img", [3, 300])
+@pytest.mark.parametrize("n_img", [5, 300])
 def test_sliding_kernels_alexnet(n_img):
     """QCNN_OPT_SLIDE = 2 (forced): the conv layers of AlexNet run the sliding kernel — a workgroup sweeps the source rows
     under a segment of one output column and builds every source pixel of the strip once.  Against the tile kernels on
