@@ -15,16 +15,15 @@
 // multiply-adds in (tap, d) order instead of d-sums rounded into a table first — within the north-star tolerance like
 // every MFMA path (the exact builder, QCNN_LUT_EXACT, never takes this path).
 //
-// A workgroup = 2 * PW consecutive output positions (row-major, any row boundaries) x all channels x one 128-image
-// panel; wave = (image tile of 16, position group): CT x PW accumulator tiles.  The code words of one kernel row sit in
-// LDS ([k][channel], double buffered, 16 KB for conv1); B operands are plain global loads (four 64-byte segments each).
+// Kernels: k_conv_dec (below: persistent waves, all code words of the layer in LDS, wide buffer loads) and, for FC layers
+// whose sub-spaces have ONE dim, k_fc_dec (further down).  Both are opt-out (QCNN_OPT_DECODE = 0: table kernels).
 #include "qcnn_kernels.h"
 #include <algorithm>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #ifndef QCNN_DEC_VAR
-#define QCNN_DEC_VAR 0      // timing experiments only (scripts/build_variant.sh): 1 no B loads, 2 no A reads, 4 no row barrier
+#define QCNN_DEC_VAR 0      // timing experiments only (scripts/build_variant.sh, scripts/variants_dec.sh): 1 no B loads, 2 no A reads, 8 no stores
 #endif
 
 namespace {

@@ -85,6 +85,21 @@ __device__ __forceinline__ float lrn_scale(float s, float nbet) {
   return expf(__fmul_rn(nbet, logf(s)));
 }
 
+// Native four-wide values in the LRN kernels: a float4 struct behind a conditional was scalarised into four dword loads
+// and unpacked adds (36 global_load_dword per chunk of k_lrn_stream); an ext-vector loads as ONE dwordx4 and its +, * are
+// v_pk_add_f32 / v_pk_mul_f32 — the same IEEE operations in the same order, half the instructions.
+__device__ __forceinline__ f32x4 ld4(const float4* p, bool on) {
+  f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+  if (on) v = *reinterpret_cast<const f32x4*>(p);
+  return v;
+}
+__device__ __forceinline__ f32x4 lrn_sq(f32x4 v, float coeff) { return (v * v) * coeff; }   // (x * x) * (alpha / n), two roundings
+template <bool B34>
+__device__ __forceinline__ f32x4 lrn_out(f32x4 xc, f32x4 s, float nbet) {
+  const f32x4 sc = {lrn_scale<B34>(s[0], nbet), lrn_scale<B34>(s[1], nbet), lrn_scale<B34>(s[2], nbet), lrn_scale<B34>(s[3], nbet)};
+  return xc * sc;
+}
+
 template <int N, bool B34>
 __global__ __launch_bounds__(256) void k_lrn_stream(const float4* __restrict__ src, float4* __restrict__ dst,
                                                     size_t pixels, int C, int segLen, float coeff, float nbet, float ini,
@@ -100,43 +115,31 @@ __global__ __launch_bounds__(256) void k_lrn_stream(const float4* __restrict__ s
   const int cs = blockIdx.y * segLen, ce = min(C, cs + segLen);
   const float4* __restrict__ x = src + px * (size_t)C * 32 + q;
   float4* __restrict__ y = dst + px * (size_t)C * 32 + q;
-  const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-  float4 raw[N], sq[N];          // ring: slot (t mod N) holds channel t
+  const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+  f32x4 raw[N], sq[N];           // ring: slot (t mod N) holds channel t
 #pragma unroll
   for (int j = 0; j < N; ++j) { raw[j] = zero; sq[j] = zero; }
   // channels cs-RAD .. cs+RAD-1 enter the window before the first output of the segment
 #pragma unroll
   for (int d = -RAD; d < RAD; ++d) {
     const int t = cs + d;
-    const float4 v = (t >= 0 && t < C) ? x[(size_t)t * 32] : zero;
+    const f32x4 v = ld4(x + (size_t)(t >= 0 && t < C ? t : 0) * 32, t >= 0 && t < C);
     raw[(d + N) % N] = v;
-    sq[(d + N) % N] = make_float4(__fmul_rn(__fmul_rn(v.x, v.x), coeff), __fmul_rn(__fmul_rn(v.y, v.y), coeff),
-                                  __fmul_rn(__fmul_rn(v.z, v.z), coeff), __fmul_rn(__fmul_rn(v.w, v.w), coeff));
+    sq[(d + N) % N] = lrn_sq(v, coeff);
   }
   for (int c0 = cs; c0 < ce; c0 += N) {
 #pragma unroll
     for (int u = 0; u < N; ++u) {
       const int c = c0 + u;                 // output channel; slot of channel k is (u + k - c) mod N
       const int tin = c + RAD;              // channel entering the window
-      const float4 v = (tin < C) ? x[(size_t)tin * 32] : zero;
+      const f32x4 v = ld4(x + (size_t)(tin < C ? tin : 0) * 32, tin < C);
       raw[(u + RAD) % N] = v;
-      sq[(u + RAD) % N] = make_float4(__fmul_rn(__fmul_rn(v.x, v.x), coeff), __fmul_rn(__fmul_rn(v.y, v.y), coeff),
-                                      __fmul_rn(__fmul_rn(v.z, v.z), coeff), __fmul_rn(__fmul_rn(v.w, v.w), coeff));
+      sq[(u + RAD) % N] = lrn_sq(v, coeff);
       if (c < ce) {
-        float4 sacc = make_float4(ini, ini, ini, ini);
+        f32x4 sacc = {ini, ini, ini, ini};
 #pragma unroll
-        for (int j = 0; j < N; ++j) {       // window channel c - RAD + j lives in slot (u - RAD + j) mod N
-          const float4 w = sq[(u - RAD + j + N) % N];
-          sacc.x = __fadd_rn(sacc.x, w.x); sacc.y = __fadd_rn(sacc.y, w.y);
-          sacc.z = __fadd_rn(sacc.z, w.z); sacc.w = __fadd_rn(sacc.w, w.w);
-        }
-        const float4 xc = raw[u % N];
-        float4 o;
-        o.x = __fmul_rn(xc.x, lrn_scale<B34>(sacc.x, nbet));
-        o.y = __fmul_rn(xc.y, lrn_scale<B34>(sacc.y, nbet));
-        o.z = __fmul_rn(xc.z, lrn_scale<B34>(sacc.z, nbet));
-        o.w = __fmul_rn(xc.w, lrn_scale<B34>(sacc.w, nbet));
-        y[(size_t)c * 32] = o;
+        for (int j = 0; j < N; ++j) sacc = sacc + sq[(u - RAD + j + N) % N];   // window channel c - RAD + j, j ascending
+        *reinterpret_cast<f32x4*>(y + (size_t)c * 32) = lrn_out<B34>(raw[u % N], sacc, nbet);
       }
     }
   }
@@ -280,48 +283,38 @@ __global__ __launch_bounds__(LP_THREADS) void k_lrn_pool(const float4* __restric
   const int hL = (po / LP_PT) * 2, wL = (po % LP_PT) * 2;
   float4* __restrict__ y = dst + ((size_t)panel * Ho * Wo + (size_t)(poolOn ? ho * Wo + wo : 0)) * C * 32 + qg;
 
-  const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-  float4 raw[N], sq[N];          // ring: slot (t mod N) holds channel t (k_lrn_stream)
+  const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+  f32x4 raw[N], sq[N];           // ring: slot (t mod N) holds channel t (k_lrn_stream)
 #pragma unroll
   for (int j = 0; j < N; ++j) { raw[j] = zero; sq[j] = zero; }
 #pragma unroll
   for (int d = -RAD; d < RAD; ++d) {
-    const float4 v = (lrnOn && d >= 0 && d < C) ? x[(size_t)d * 32] : zero;
+    const bool on = lrnOn && d >= 0 && d < C;
+    const f32x4 v = ld4(x + (size_t)(on ? d : 0) * 32, on);
     raw[(d + N) % N] = v;
-    sq[(d + N) % N] = make_float4(__fmul_rn(__fmul_rn(v.x, v.x), coeff), __fmul_rn(__fmul_rn(v.y, v.y), coeff),
-                                  __fmul_rn(__fmul_rn(v.z, v.z), coeff), __fmul_rn(__fmul_rn(v.w, v.w), coeff));
+    sq[(d + N) % N] = lrn_sq(v, coeff);
   }
+  f32x4* __restrict__ slab4 = reinterpret_cast<f32x4*>(slab);
   for (int c0 = 0; c0 < C; c0 += N) {
     if (lrnOn) {
 #pragma unroll
       for (int u = 0; u < N; ++u) {
         const int c = c0 + u;
         const int tin = c + RAD;
-        const float4 v = (tin < C) ? x[(size_t)tin * 32] : zero;
+        const f32x4 v = ld4(x + (size_t)(tin < C ? tin : 0) * 32, tin < C);
         raw[(u + RAD) % N] = v;
-        sq[(u + RAD) % N] = make_float4(__fmul_rn(__fmul_rn(v.x, v.x), coeff), __fmul_rn(__fmul_rn(v.y, v.y), coeff),
-                                        __fmul_rn(__fmul_rn(v.z, v.z), coeff), __fmul_rn(__fmul_rn(v.w, v.w), coeff));
+        sq[(u + RAD) % N] = lrn_sq(v, coeff);
         if (c < C) {
-          float4 sacc = make_float4(ini, ini, ini, ini);
+          f32x4 sacc = {ini, ini, ini, ini};
 #pragma unroll
-          for (int j = 0; j < N; ++j) {
-            const float4 w = sq[(u - RAD + j + N) % N];
-            sacc.x = __fadd_rn(sacc.x, w.x); sacc.y = __fadd_rn(sacc.y, w.y);
-            sacc.z = __fadd_rn(sacc.z, w.z); sacc.w = __fadd_rn(sacc.w, w.w);
-          }
-          const float4 xc = raw[u % N];
-          float4 o;
-          o.x = __fmul_rn(xc.x, lrn_scale<B34>(sacc.x, nbet));
-          o.y = __fmul_rn(xc.y, lrn_scale<B34>(sacc.y, nbet));
-          o.z = __fmul_rn(xc.z, lrn_scale<B34>(sacc.z, nbet));
-          o.w = __fmul_rn(xc.w, lrn_scale<B34>(sacc.w, nbet));
-          slab[(u * LP_PIX + rest) * LP_Q + q] = o;
+          for (int j = 0; j < N; ++j) sacc = sacc + sq[(u - RAD + j + N) % N];
+          slab4[(u * LP_PIX + rest) * LP_Q + q] = lrn_out<B34>(raw[u % N], sacc, nbet);
         }
       }
     }
     __syncthreads();
     if (poolOn && c0 + pu < C) {
-      float4 v = zero;
+      float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
       bool first = true;
       for (int h = hL; h <= hU; ++h)
         for (int w = wL; w <= wU; ++w) {

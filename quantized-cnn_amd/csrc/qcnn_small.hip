@@ -4,7 +4,8 @@
 // The panel kernels (qcnn_kernels.hip) put 128 images on the lanes of a wave: a single image pays for a whole
 // panel (2.8 ms).  Here the lanes are OUTPUT CHANNELS and positions instead, one workgroup per (output tile,
 // channel chunk, image):
-//   per chunk of sub-spaces:  build the tile's look-up table  LUT[source pixel][sub-space][code word]  in LDS
+//   per chunk of sub-spaces:  stage the receptive field's activations and the chunk's assignment bytes in LDS, build
+//                             the tile's look-up table  LUT[source pixel][sub-space][code word]  in LDS on the matrix pipe
 //                             (GetInPdMat, src/CaffeEva.cc:1261-1296, for the pixels of the tile's receptive field),
 //                             then every thread walks the taps of its outputs and gathers
 //                             acc += LUT[pixel(tap)][m][assignment]   (CalcFeatMap_ConvAprx :840-863 / _FCntAprx :998-1023).
