@@ -248,6 +248,9 @@ __global__ __launch_bounds__(256) void k_pool4(const float4* __restrict__ src, f
 // Every normalised value is evaluated once per block (the one-pixel halo between tiles: 81/64 = 1.27x) instead of
 // once per window that contains it (2.25x: that version lost to the two separate kernels), and the
 // map takes one HBM read instead of write + read.
+#ifndef QCNN_LP_PREFETCH
+#define QCNN_LP_PREFETCH 0
+#endif
 #ifndef QCNN_LP_PT
 #define QCNN_LP_PT 4
 #define QCNN_LP_Q 8
@@ -259,7 +262,7 @@ constexpr int LP_PIX = LP_IT * LP_IT;
 constexpr int LP_Q = QCNN_LP_Q;                 // float4 lanes (4 images each) per block (a power of two)
 constexpr int LP_THREADS = QCNN_LP_THREADS;     // >= LP_PIX * LP_Q, >= LP_PT^2 * 5 * LP_Q
 template <int N, bool B34>
-__global__ __launch_bounds__(LP_THREADS) void k_lrn_pool(const float4* __restrict__ src, float4* __restrict__ dst, int H,
+__global__ __launch_bounds__(LP_THREADS, QCNN_LP_PREFETCH ? 2 : 1) void k_lrn_pool(const float4* __restrict__ src, float4* __restrict__ dst, int H,
                                                          int W, int C, int Ho, int Wo, int tilesX, float coeff, float nbet,
                                                          float ini, int liveQuads) {
   constexpr int RAD = (N - 1) / 2;
@@ -295,13 +298,26 @@ __global__ __launch_bounds__(LP_THREADS) void k_lrn_pool(const float4* __restric
     sq[(d + N) % N] = lrn_sq(v, coeff);
   }
   f32x4* __restrict__ slab4 = reinterpret_cast<f32x4*>(slab);
+#if QCNN_LP_PREFETCH
+  f32x4 nxt[N];                                    // the N channels entering the window in the NEXT chunk: in flight under
+#pragma unroll                                     // this chunk's arithmetic, its pool phase and both barriers
+  for (int u = 0; u < N; ++u) nxt[u] = ld4(x + (size_t)(u + RAD < C ? u + RAD : 0) * 32, lrnOn && u + RAD < C);
+#endif
   for (int c0 = 0; c0 < C; c0 += N) {
     if (lrnOn) {
 #pragma unroll
       for (int u = 0; u < N; ++u) {
         const int c = c0 + u;
         const int tin = c + RAD;
+#if QCNN_LP_PREFETCH
+        const f32x4 v = nxt[u];
+        {
+          const int tn = c0 + N + u + RAD;          // the same slot of the next chunk
+          nxt[u] = ld4(x + (size_t)(tn < C ? tn : 0) * 32, tn < C);
+        }
+#else
         const f32x4 v = ld4(x + (size_t)(tin < C ? tin : 0) * 32, tin < C);
+#endif
         raw[(u + RAD) % N] = v;
         sq[(u + RAD) % N] = lrn_sq(v, coeff);
         if (c < C) {
