@@ -805,6 +805,36 @@ def test_decoded_first_layer_geometries(cin, knl, stride, pad, ct):
     eng.close()
 
 
+def test_decoded_first_layer_vgg16_shape():
+    """VGG-16's conv1_1 at full size (224x224x3 -> 64 channels, 3x3 / 1, pad 1): the padded decoded kernel with its border
+    predicates on every side of a large map; 5 images (16-image work items) and 130 (64-image items, ragged second panel)
+    against the oracle (<= 1e-4) and the table kernels (<= 2e-6)."""
+    layers = [topo.conv(1, 3, 64, 1, 1), topo.relu(), topo.pool(0, 8, 8), topo.fcnt(40), topo.smax()]
+    in_chw = (3, 224, 224)
+    params = synth.make_params(in_chw, layers, seed=97)
+    rng = np.random.default_rng(98)
+    imgs = (rng.integers(0, 256, size=(130,) + in_chw).astype(np.float32) - 120.0)
+    orc = po.COracle(in_chw, layers)
+    orc.set_params(params)
+    orc.forward(imgs[127:130])
+    base = make_engine(in_chw, layers, params, 130, lut=capi.LUT_MFMA, keep_all=1)
+    base.forward_host(imgs)
+    want = base.layer_output_range(1, 127, 3)
+    base.close()
+    eng = make_engine(in_chw, layers, params, 130, lut=capi.LUT_MFMA, keep_all=1, decode=1)
+    eng.forward_host(imgs)
+    assert eng.layer_split(0) == (-3, 1)
+    got = eng.layer_output_range(1, 127, 3)
+    assert np.abs(got - want).max() <= 2e-6 * np.abs(want).max()
+    for l in range(1, len(layers) + 1):
+        e_inf, e_l2 = rel_err(eng.layer_output_range(l, 127, 3), orc.fm(l))
+        assert e_inf <= TOL and e_l2 <= TOL, "fm[%d] vs oracle: %g %g" % (l, e_inf, e_l2)
+    eng.forward_host(imgs[125:130])
+    e_inf, e_l2 = rel_err(eng.layer_output_range(1, 2, 3), orc.fm(1))
+    assert e_inf <= TOL and e_l2 <= TOL, "5 images: %g %g" % (e_inf, e_l2)
+    eng.close()
+
+
 def test_decoded_classifier():
     """An FC layer whose sub-spaces have one dim (the 1000-way classifier behind fc7: 16 code words of one float) runs
     through its decoded code words: x @ w with w[k][c] = ctrd[k][asmt[k][c]].  1000 channels = 15 blocks of 64 + 40, 1024
