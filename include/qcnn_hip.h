@@ -101,6 +101,11 @@ enum {
                               the look-ups it serves).  Same parameters, same function, results within the MFMA modes'
                               tolerance; the network input is then packed into panels first.  MFMA modes only
                               (QCNN_OPT_LUT_MODE 1, 3), batches above QCNN_SMALL_BATCH_MAX.  0 = table kernels for every layer */
+  QCNN_OPT_SYM = 9,        /* 1 (default): a conv layer with exactly 128 channels per group and K = 128 (AlexNet conv2) that neither
+                              slides nor splits may run SYMMETRIC workgroups — all 16 waves build and gather, 8 channels x a
+                              2x2 tile per wave: fewer table builds per output position and no idle gather lane — when the
+                              launch planner predicts them faster.  Bit-identical to the tile kernels; f32 MFMA mode only.
+                              0 = never; 2 = whenever eligible (tests) */
   QCNN_OPT_HOST_CHUNK = 6, /* panels per chunk (default 2) of a qcnn_forward_host batch of at least two chunks: every chunk is
                               uploaded on a copy stream and its layers start when it has arrived, so the upload of chunk
                               k + 1 runs under the layers of chunk k; all chunks fill the same whole-batch feature maps.
@@ -200,7 +205,8 @@ int qcnn_run_layer(QcnnCtx* ctx, int layer, const float* in_host, int n, float* 
 /* How the last launch of conv layer `layer` was cut (QCNN_OPT_SPLIT): *slices = workgroups per split tile (1 = no tile
  * was split), *tiles_unsplit = tiles of the heaviest-first order that ran whole (-1 when nothing was split); sliding
  * kernel (QCNN_OPT_SLIDE): *tiles_unsplit = -2, *slices = segments per output column; a conv or FC layer that ran through
- * its decoded code words (QCNN_OPT_DECODE): *tiles_unsplit = -3, *slices = 1 (FC: slices of the input axis over workgroups). */
+ * its decoded code words (QCNN_OPT_DECODE): *tiles_unsplit = -3, *slices = 1 (FC: slices of the input axis over workgroups);
+ * symmetric workgroups (QCNN_OPT_SYM): *tiles_unsplit = -4. */
 int qcnn_get_layer_split(QcnnCtx* ctx, int layer, int* tiles_unsplit, int* slices);
 /* Sliding kernel: the row segments [seg_beg9[i], seg_beg9[i + 1]) every output column of the last launch of `layer` was
  * cut into (*n_seg of them; 0 when the layer ran the tile kernel). */

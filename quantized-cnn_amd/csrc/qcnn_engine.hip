@@ -32,6 +32,8 @@ struct LayerShape {
   size_t asmtBytes = 0;
   size_t offProg = 0, progBytes = 0;                           // conv with K = 128: offsets in consumption order (QkProgram)
   size_t offProgS = 0, progSBytes = 0;                         // ... and in the order of the sliding variant, where it applies
+  size_t offProgY = 0, progYBytes = 0;                         // ... and of the symmetric kernel's (8 channels per wave, 2x2 tile) layout
+  double symCost = 0.0;                                        // its predicted duration for the last planned launch geometry
   size_t offDec = 0; int decKp = 0, decS = 0;                  // decoded code words (qcnn_decoded.hip): conv layer with one sub-space of
                                                                // <= 4 dims (decKp > 0), FC layer with one-dim sub-spaces (decKp = -1); 0: not eligible
   int segN = 0, segBeg[9] = {0};                               // sliding plan of the last planned launch geometry
@@ -64,6 +66,7 @@ struct QcnnCtx {
   int nStreams = 2;                  // QCNN_OPT_STREAMS: sub-batches of whole panels run concurrently
   int smallBatch = 1;                // QCNN_OPT_SMALL_BATCH: few-image kernels for batches <= kSmallBatchMax
   int hostChunk = 2;                 // QCNN_OPT_HOST_CHUNK: panels per chunk of a large qcnn_forward_host batch (0: one launch)
+  int sym = 1;                       // QCNN_OPT_SYM: symmetric workgroups for 128-channel layers where predicted faster (2: whenever eligible)
   int decode = 1;                    // QCNN_OPT_DECODE: one-sub-space conv layers through their decoded code words (MFMA builders only)
   int slide = 1;                     // QCNN_OPT_SLIDE: sliding-window conv kernels where they pay (MFMA builders only)
   int split = 1;                     // QCNN_OPT_SPLIT: launches that do not fill the chip split their tail (MFMA builders only)
@@ -180,6 +183,12 @@ int plan_arena(QcnnCtx* c) {
         s.progSBytes = (size_t)ps.rfH * ps.rfW * s.M * ps.rowU16 * sizeof(uint16_t);
         s.offProgS = off; off = align_up(off + s.progSBytes + QCNN_ROWS_PAD, 256);
       }
+    }
+    s.progYBytes = 0;
+    if (d.type == QCNN_CONV && qk_conv_sym_shape(c->dims[l].c, d.grpCnt, Ct, s.M, s.Cs, s.K)) {
+      const QkProgram py = qk_conv_program(qk_make_slots(Ct / d.grpCnt, d.grpCnt, 8), d.knlSiz, d.stride);
+      s.progYBytes = (size_t)py.rfH * py.rfW * s.M * py.rowU16 * sizeof(uint16_t);
+      s.offProgY = off; off = align_up(off + s.progYBytes + QCNN_ROWS_PAD, 256);
     }
     s.decKp = 0;
     s.hasDmap = (d.type == QCNN_FCNT && l == c->firstFc && c->dims[l].h * c->dims[l].w > 1);
@@ -328,22 +337,31 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
       if (e == hipErrorInvalidValue) {
         // A launch of a few hundred workgroups (one GPU's share of a sharded batch) splits the tail of its tiles over
         // several workgroups (qk_conv_plan).  MFMA builders only: the exact builder keeps the reference's summation order.
-        if (c->lutMode >= 1 && c->convPartial && (c->split || c->slide)) {
+        if (c->lutMode >= 1 && c->convPartial && (c->split || c->slide || c->sym)) {
           // Plan of this launch geometry (cached): tile kernel whole / with a split tail (QCNN_OPT_SPLIT; changes a cut
           // tile's summation order) / sliding kernel (QCNN_OPT_SLIDE; same order and bits as the tile kernel).
           const size_t share = kConvPartialFloats / (size_t)nsub;
-          const int key = ((panels * 8 + nsub) * 2 + (c->split ? 1 : 0)) * 4 + c->slide;
+          const int key = (((panels * 8 + nsub) * 2 + (c->split ? 1 : 0)) * 4 + c->slide) * 4 + c->sym;
           if (s.planKey != key) {
             const size_t scratch = c->split ? share : 0;            // no scratch: qk_conv_plan only prices the whole-tile launch
             s.plan = qk_conv_plan(p, scratch);
             s.planKey = key;
             s.segN = 0;
+            s.symCost = (c->sym && s.progYBytes && c->lutMode == 1 && !inNchw) ? qk_conv_sym_cost(p) : 0.0;
             if (c->slide && p.progS) {                // sliding variant where it is predicted to beat the (split) tile kernel
               ConvParams t = p;
               qk_conv_plan_slide(t, c->slide >= 2 ? 1e30 : s.plan.cost);   // 2: whenever the layer is eligible (tests)
               s.segN = t.nSeg;
               for (int i = 0; i <= t.nSeg && i < 9; ++i) s.segBeg[i] = t.segBeg[i];
             }
+          }
+          // symmetric workgroups: 128-channel layers that neither slide nor split, when predicted at least 3 % faster
+          if (s.symCost > 0.0 && s.segN == 0 && s.plan.Z <= 1 && c->lutMode == 1 && !inNchw &&
+              (c->sym >= 2 || s.symCost < 0.97 * s.plan.cost)) {
+            p.progS = reinterpret_cast<const uint16_t*>(c->arena + s.offProgY);
+            s.lastFrom = -4; s.lastZ = 1;             // reported by qcnn_get_layer_split as (-4, 1)
+            e = qk_conv_sym(p, st);
+            break;
           }
           if (s.segN > 0) {
             p.nSeg = s.segN;
@@ -707,6 +725,7 @@ int qcnn_set_option(QcnnCtx* c, int option, int value) {
     case QCNN_OPT_SMALL_BATCH: c->smallBatch = value ? 1 : 0; return 0;
     case QCNN_OPT_SPLIT: c->split = value ? 1 : 0; for (LayerShape& ls : c->shapes) ls.planKey = -1; return 0;
     case QCNN_OPT_DECODE: c->decode = value ? 1 : 0; return 0;
+    case QCNN_OPT_SYM: c->sym = value < 0 ? 0 : (value > 2 ? 2 : value); for (LayerShape& ls : c->shapes) ls.planKey = -1; return 0;
     case QCNN_OPT_SLIDE: c->slide = value < 0 ? 0 : (value > 2 ? 2 : value); for (LayerShape& ls : c->shapes) ls.planKey = -1; return 0;
     case QCNN_OPT_HOST_CHUNK:
       if (value < 0) return fail(c, "host chunk must be >= 0 panels");
@@ -937,6 +956,11 @@ hipError_t build_program(QcnnCtx* c, int layer, const QkSlots& sl) {
     e = qk_decode_weights(reinterpret_cast<const uint8_t*>(c->arena + s.offAsmt), reinterpret_cast<const float*>(c->arena + s.offCtrd),
                           reinterpret_cast<float*>(c->arena + s.offDec), sl, d.knlSiz, c->dims[layer].c, s.K,
                           c->dims[layer + 1].c, s.decKp, s.decS, c->stream);
+  if (e == hipSuccess && s.progYBytes) {       // symmetric kernel: the (8 channels per wave, 2x2 tile) layout of the same table
+    const QkSlots s8 = qk_make_slots(sl.C, sl.groups, 8);
+    e = qk_build_program(reinterpret_cast<const uint8_t*>(c->arena + s.offAsmt), reinterpret_cast<uint16_t*>(c->arena + s.offProgY),
+                         sl, s8, qk_conv_program(s8, d.knlSiz, d.stride), d.knlSiz, d.stride, s.M, c->stream);
+  }
   if (e != hipSuccess || !s.progBytes) return e;
   e = qk_build_program(reinterpret_cast<const uint8_t*>(c->arena + s.offAsmt),
                                   reinterpret_cast<uint16_t*>(c->arena + s.offProg), sl, sl,

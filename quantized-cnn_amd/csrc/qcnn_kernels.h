@@ -206,6 +206,12 @@ QkSplitPlan qk_conv_plan(const ConvParams& p, size_t scratchFloats);
 // Segments of the sliding variant for a launch over p.panels panels: fills p.nSeg / p.segBeg when sliding is predicted to
 // beat `tileCost` (the list-scheduled stage-times of the tile kernel, QkSplitPlan::cost), else leaves nSeg = 0
 void qk_conv_plan_slide(ConvParams& p, double tileCost);
+// Symmetric workgroups (k_conv_sym: all 16 waves build and gather, 8 channels x a 2x2 tile per wave) for layers with exactly
+// 128 channels per group: eligibility, predicted duration in stage-times, launch (p.progS = the program table of the
+// (8 channels per wave, 2x2 tile) layout: qk_make_slots(128, groups, 8) / qk_conv_program)
+bool qk_conv_sym_shape(int Cin, int grp, int Ct, int M, int Cs, int K);
+double qk_conv_sym_cost(const ConvParams& p);
+hipError_t qk_conv_sym(const ConvParams& p, hipStream_t st);
 
 struct FcParams {
   float* partial;        // [msplit][panels][Ct][128] scratch for split-M partial sums (msplit > 1)

@@ -22,6 +22,7 @@ def main():
     split = int(os.environ.get("QCNN_SPLIT", "1"))
     eng.set_option(capi.OPT_SPLIT, split)
     eng.set_option(capi.OPT_SLIDE, int(os.environ.get("QCNN_SLIDE", "1")))
+    eng.set_option(capi.OPT_SYM, int(os.environ.get("QCNN_SYM", "1")))
     eng.load_model(in_chw, layers, params, batch)
     imgs = synth.make_images(batch, in_chw, seed=2)
     import time

@@ -864,6 +864,68 @@ def test_decoded_classifier():
     eng.close()
 
 
+# ---------------------------------------------------------------- symmetric workgroups (128-channel layers) ----
+@pytest.mark.parametrize("n_img", [5, 300])
+def test_symmetric_workgroups_alexnet(n_img):
+    """QCNN_OPT_SYM = 2 (forced): AlexNet conv2 (2 groups x 128 channels, 5x5, 6 sub-spaces of 8 dims) runs k_conv_sym — all
+    16 waves build and gather, 8 channels x a 2x2 tile per wave.  Same table entries in the same (kh, kw, m) order per
+    output: BIT-IDENTICAL to the tile kernels; conv5 (also 128 channels per group) is eligible too."""
+    in_chw, layers, _, _ = topo.MODELS["AlexNet"]
+    params = synth.make_params(in_chw, layers, seed=0)
+    imgs = synth.make_images(n_img, in_chw, seed=99)
+    base = make_engine(in_chw, layers, params, n_img, lut=capi.LUT_MFMA, keep_all=1, split=0)
+    base.set_option(capi.OPT_SYM, 0)
+    base.set_option(capi.OPT_SLIDE, 0)
+    p0, t0 = base.forward_host(imgs)
+    fm0 = {l: base.layer_output_range(l, n_img - 2, 2) for l in (5, 13, 15)}
+    assert base.layer_split(4)[0] != -4
+    base.close()
+    eng = make_engine(in_chw, layers, params, n_img, lut=capi.LUT_MFMA, keep_all=1, split=0)
+    eng.set_option(capi.OPT_SLIDE, 0)
+    eng.set_option(capi.OPT_SYM, 2)
+    p1, t1 = eng.forward_host(imgs)
+    assert eng.layer_split(4) == (-4, 1) and eng.layer_split(12) == (-4, 1)
+    assert eng.layer_split(8)[0] != -4 and eng.layer_split(10)[0] != -4      # 384 / 192 channels per group: not eligible
+    for l, want in fm0.items():
+        assert np.array_equal(eng.layer_output_range(l, n_img - 2, 2), want), "fm[%d]" % l
+    assert np.array_equal(p0, p1) and np.array_equal(t0, t1)
+    eng.set_option(capi.OPT_LUT_MODE, capi.LUT_EXACT)                  # the exact builder: tile kernels
+    eng.forward_host(imgs[:5])
+    assert eng.layer_split(4)[0] != -4
+    eng.close()
+
+
+def test_symmetric_workgroups_geometries():
+    """k_conv_sym on shapes AlexNet does not have: padded 3x3 / 1 and 5x5 / 2 with 128 channels (one group, 8- and 16-
+    channel inputs: one and two sub-spaces of 8 dims), a 4-dim sub-space layer (one k-step), an even kernel, odd maps
+    (tiles hanging over the border), in two groups — forced on, against the tile kernels (bit-identical) and the oracle."""
+    layers = [topo.conv(1, 3, 16, 1, 1), topo.relu(), topo.conv(1, 3, 128, 1, 1), topo.relu(), topo.conv(2, 5, 256, 2, 2),
+              topo.relu(), topo.conv(0, 2, 128, 1, 1), topo.relu(), topo.fcnt(40), topo.smax()]
+    in_chw = (3, 21, 17)
+    params = synth.make_params(in_chw, layers, seed=101)
+    imgs = synth.make_images(131, in_chw, seed=102)
+    orc = po.COracle(in_chw, layers)
+    orc.set_params(params)
+    orc.forward(imgs[129:])
+    base = make_engine(in_chw, layers, params, 131, lut=capi.LUT_MFMA, keep_all=1, split=0)
+    base.set_option(capi.OPT_SYM, 0)
+    base.set_option(capi.OPT_SLIDE, 0)
+    base.forward_host(imgs)
+    want = {l: base.layer_output(l, 131) for l in (3, 5, 7)}
+    base.close()
+    eng = make_engine(in_chw, layers, params, 131, lut=capi.LUT_MFMA, keep_all=1, split=0)
+    eng.set_option(capi.OPT_SLIDE, 0)
+    eng.set_option(capi.OPT_SYM, 2)
+    eng.forward_host(imgs)
+    assert [eng.layer_split(l)[0] for l in (2, 4, 6)] == [-4, -4, -4]
+    for l, w in want.items():
+        assert np.array_equal(eng.layer_output(l, 131), w), "fm[%d]" % l
+    for l in (3, 5, 7, len(layers)):
+        e_inf, e_l2 = rel_err(eng.layer_output_range(l, 129, 2), orc.fm(l))
+        assert e_inf <= TOL and e_l2 <= TOL, "fm[%d] vs oracle: %g %g" % (l, e_inf, e_l2)
+    eng.close()
+
+
 # ---------------------------------------------------------------- sliding-window conv kernels ----
 @pytest.mark.parametrize("n_img", [5, 300])
 def test_sliding_kernels_alexnet(n_img):
