@@ -344,6 +344,7 @@ def main():
     layer_ms, recorded = eng.layer_ms()
     segments = {i: eng.layer_segments(i) for i, l in enumerate(layers) if l["type"] == topo.CONV}   # sliding kernel, per layer
     decoded = {i for i, l in enumerate(layers) if l["type"] in (topo.CONV, topo.FCNT) and eng.layer_split(i)[0] == -3}   # decoded layers
+    symmetric = {i for i, l in enumerate(layers) if l["type"] == topo.CONV and eng.layer_split(i)[0] == -4}            # k_conv_sym
     ok = bool(torch.isfinite(prob[lo:hi]).all().item())
     images_per_step = B if (strong or world == 1) else B * world
 
@@ -556,7 +557,7 @@ def main():
                      dict(tile="decoded code words: x @ w on the matrix pipe, 64 channels x 64 images per workgroup",
                           issued_mfma_flop_per_image=2 * sizes[i][0] * sizes[i][1] * sizes[i][2] * ((l["nod"] + 63) // 64 * 64),
                           lookups_replaced_per_image=sizes[i][0] * sizes[i][1] * sizes[i][2] * l["nod"]) if i in decoded else
-                     perf.layer_report(sizes, layers, params, i, launch_images, float(layer_ms[i]), segments.get(i)))
+                     perf.layer_report(sizes, layers, params, i, launch_images, float(layer_ms[i]), segments.get(i), i in symmetric))
                 r["ms"] = round(float(layer_ms[i]), 4)
                 per_layer["%02d_%s" % (i, topo.TYPE_NAMES[l["type"]])] = r
         for i, l in enumerate(layers):
@@ -567,6 +568,7 @@ def main():
         step_bytes = sum(algorithmic_bytes(sizes, layers, params, l, n_local) for l in range(len(layers))
                          if layer_ms[l] > 0)
         roof = dict(bound="hbm", kernel=("k_conv_dec (layer %d, %s)" % (dom, name)) if dom in decoded else
+                    ("k_conv_sym (layer %d, %s)" % (dom, name)) if dom in symmetric else
                     "k_%s_aprx (layer %d, %s)" % ("conv" if dom in conv_idx else "fc", dom, name),
                     achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic, traffic_source=tsrc,

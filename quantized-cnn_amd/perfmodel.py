@@ -29,13 +29,13 @@ def stage_group(k: int) -> int:
     return 128 // k if k <= 64 else 1
 
 
-def conv_work(in_hwc, out_hwc, ly, m: int, k: int, cs: int):
+def conv_work(in_hwc, out_hwc, ly, m: int, k: int, cs: int, sym: bool = False):
     """Per 128-image panel: stages built, look-ups (border clipped), ideal stages (every (pixel, sub-space group)
-    once per group), f32 MFMA FLOP issued."""
+    once per group), f32 MFMA FLOP issued.  sym: the symmetric kernel's 2x2 tile of all 128 channels (k_conv_sym)."""
     h, w, cin = in_hwc
     ho, wo, ct = out_hwc
     knl, s, p, grp = ly["knl"], ly["stride"], ly["pad"], ly["grp"]
-    th, tw, cpw, chunks = conv_tile(ct // grp)
+    th, tw, cpw, chunks = (2, 2, 8, 1) if sym else conv_tile(ct // grp)
     g = stage_group(k)
     mg = (m + g - 1) // g
     stages = 0
@@ -53,7 +53,7 @@ def conv_work(in_hwc, out_hwc, ly, m: int, k: int, cs: int):
     ideal = h * w * mg * grp
     ks = 2 if min(cin // grp, cs) > 4 else 1
     return dict(stages=stages, lookups=lookups, ideal_stages=ideal, mfma_flop=stages * 128 * 128 * 4 * ks * 2,
-                tile="%dx%dx%d" % (th, tw, GATHER_WAVES * cpw), ks=ks)
+                tile=("symmetric %dx%dx%d" % (th, tw, 16 * cpw)) if sym else "%dx%dx%d" % (th, tw, GATHER_WAVES * cpw), ks=ks)
 
 
 def conv_work_slide(in_hwc, out_hwc, ly, m: int, k: int, cs: int, seg_beg):
@@ -105,7 +105,7 @@ def decoded_report(sizes, layers, l: int, images: float, ms: float):
                 lookups_replaced_per_image=int(conv_work(sizes[l], sizes[l + 1], ly, 1, 128, c)["lookups"]))
 
 
-def layer_report(sizes, layers, params, l: int, images: float, ms: float, seg_beg=None):
+def layer_report(sizes, layers, params, l: int, images: float, ms: float, seg_beg=None, sym: bool = False):
     """Roofline-style figures of conv/FC layer l for a launch over `images` images that took `ms` milliseconds; seg_beg:
     the sliding kernel's row segments when the layer ran it (QcnnEngine.layer_segments)."""
     ly = layers[l]
@@ -113,7 +113,7 @@ def layer_report(sizes, layers, params, l: int, images: float, ms: float, seg_be
     if ly["type"] == CONV and seg_beg:
         wk = conv_work_slide(sizes[l], sizes[l + 1], ly, mm, kk, cc, seg_beg)
     elif ly["type"] == CONV:
-        wk = conv_work(sizes[l], sizes[l + 1], ly, mm, kk, cc)
+        wk = conv_work(sizes[l], sizes[l + 1], ly, mm, kk, cc, sym)
     elif ly["type"] == FCNT:
         e = sizes[l][0] * sizes[l][1] * sizes[l][2]
         cpw = 32 if ly["nod"] >= 384 else (8 if ly["nod"] >= 96 else 4)

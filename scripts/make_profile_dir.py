@@ -33,7 +33,8 @@ def main():
     table = list(csv.DictReader(io.StringIO(pmc)))
     bench = json.loads(open(os.path.join(src, "trace_bench.json")).readline())
     dom_layer = int(bench["roofline"]["kernel"].split("layer ")[1].split(",")[0])
-    dom = max((r for r in table if r["kernel"].startswith("k_conv_aprx") or r["kernel"].startswith("k_fc_aprx")),
+    # the table-kernel family (tile / sliding / symmetric conv, FC): the dominant one by wave cycles is the layer the bench names
+    dom = max((r for r in table if r["kernel"].startswith(("k_conv_aprx", "k_conv_sym", "k_fc_aprx"))),
               key=lambda r: float(r["SQ_WAVE_CYCLES"] or 0))
     fetch_kib, write_kib = float(dom["FETCH_SIZE"]), float(dom["WRITE_SIZE"])
     sys.path.insert(0, ROOT)
