@@ -1808,8 +1808,9 @@ double qk_conv_sym_cost(const ConvParams& p) {
     const int hoL = std::min(ho0 + 2, p.Ho) - 1, woL = std::min(wo0 + 2, p.Wo) - 1;
     const int rows = std::min(p.H - 1, hoL * p.stride - p.pad + p.knl - 1) - std::max(0, ho0 * p.stride - p.pad) + 1;
     const int cols = std::min(p.W - 1, woL * p.stride - p.pad + p.knl - 1) - std::max(0, wo0 * p.stride - p.pad) + 1;
-    // a symmetric stage serves a third more look-ups than the 1x3 tile's and takes 9 % longer (measured on AlexNet conv2:
-    // 2740 against 2508 cycles)
+    // a symmetric stage serves a quarter more look-ups than the 1x3 tile's and takes longer; the factor is calibrated on
+    // AlexNet conv2 so that the planner's choice matches the measurements (1000 / 500 / 250 images: symmetric -5.9 / -4.2 /
+    // -2.0 %, 125 images: +17 %)
     cost[r] = 1.09 * ((double)std::max(rows, 0) * std::max(cols, 0) * p.M) + 10.0;
   }
   const long long wgs = (long long)tiles * p.panels * p.grp;
