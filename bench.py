@@ -65,7 +65,8 @@ def kernel_hash():
 def pmc_traffic(layer, launches_per_forward):
     """HBM bytes per launch of the dominant kernel from the newest committed rocprofv3 --pmc summary
     (profiles/*/traffic.json: FETCH_SIZE doubled per the guide's gfx950 correction + WRITE_SIZE, separate passes,
-    mean per dispatch) — only if it was taken from the kernel source that is being benchmarked."""
+    mean per dispatch) — only if it was taken from the kernel source that is being benchmarked.  Returns (bytes or None,
+    source / reason, {layer: entry} of every kernel the summary covers)."""
     prof = os.path.join(ROOT, "profiles")
     best = None
     for d in sorted(os.listdir(prof)) if os.path.isdir(prof) else []:
@@ -73,18 +74,23 @@ def pmc_traffic(layer, launches_per_forward):
         if os.path.exists(p):
             best = p
     if best is None:
-        return None, "no profiles/*/traffic.json"
+        return None, "no profiles/*/traffic.json", {}
     try:
         with open(best) as f:
             t = json.load(f)
         rel = os.path.relpath(best, ROOT)
         if t.get("kernel_hash") != kernel_hash():
-            return None, "%s was taken from another build of quantized-cnn_amd/csrc (hash mismatch)" % rel
-        if int(t["layer"]) != int(layer) or int(t.get("launches_per_forward", 1)) != int(launches_per_forward):
-            return None, "%s covers layer %s" % (rel, t["layer"])
-        return int(t["bytes"]), rel
+            return None, "%s was taken from another build of quantized-cnn_amd/csrc (hash mismatch)" % rel, {}
+        if int(t.get("launches_per_forward", 1)) != int(launches_per_forward):
+            return None, "%s was taken with %s launches per forward" % (rel, t.get("launches_per_forward")), {}
+        table = {int(k): v for k, v in t.get("kernels", {}).items()}
+        if "layer" in t and int(t["layer"]) not in table:
+            table[int(t["layer"])] = dict(kernel=t.get("kernel"), bytes=int(t["bytes"]))
+        if int(layer) not in table:
+            return None, "%s covers layers %s" % (rel, sorted(table)), table
+        return int(table[int(layer)]["bytes"]), rel, table
     except (OSError, ValueError, KeyError) as e:
-        return None, "unreadable: %s" % e
+        return None, "unreadable: %s" % e, {}
 
 
 def algorithmic_bytes(sizes, layers, params, l, batch):
@@ -116,27 +122,32 @@ def cpu_side(in_chw, layers, params):
     return "port", orc, po
 
 
-def parity_check(kind, cpu, layers, imgs_host, gpu_prob, gpu_top5, gpu_fm, fm_idx):
-    """Compare the GPU's outputs for imgs_host with the CPU checker's.  Error = max |a-b| / max |b| per map."""
-    worst_prob = worst_fm = 0.0
+def parity_check(kind, cpu, layers, imgs_host, gpu_prob, gpu_top5, gpu_fms):
+    """Compare the GPU's outputs for imgs_host with the CPU checker's: soft-max outputs, top-5 and the feature maps
+    gpu_fms = {index: [n, ...]}.  Error = max |a-b| / max |b| per map and image."""
+    worst_prob = 0.0
+    worst_fm = {l: 0.0 for l in gpu_fms}
     agree = 0
+    distinct = set()
     n = imgs_host.shape[0]
     for i in range(n):
         if kind == "reference":
             prob = cpu.forward(imgs_host[i:i + 1])
-            fm = cpu.fm(fm_idx)[0]
             top5 = cpu.top5()
         else:
             cpu.forward(imgs_host[i:i + 1])
             prob = cpu.fm(len(layers)).reshape(-1)
-            fm = cpu.fm(fm_idx)[0]
             top5 = cpu.top5(prob)
+        for l in gpu_fms:
+            fm = cpu.fm(l)[0]
+            worst_fm[l] = max(worst_fm[l], float(np.abs(gpu_fms[l][i] - fm).max() / max(np.abs(fm).max(), 1e-30)))
         worst_prob = max(worst_prob, float(np.abs(gpu_prob[i] - prob).max() / max(np.abs(prob).max(), 1e-30)))
-        worst_fm = max(worst_fm, float(np.abs(gpu_fm[i] - fm).max() / max(np.abs(fm).max(), 1e-30)))
         agree += int(np.array_equal(np.asarray(gpu_top5[i], np.uint16), np.asarray(top5, np.uint16)))
-    return dict(images=n, checker=kind, top5_agree=agree, max_rel_err_prob=worst_prob,
-                max_rel_err_fm=worst_fm, fm_checked=fm_idx, tolerance=TOL,
-                ok=bool(agree == n and worst_prob <= TOL and worst_fm <= TOL))
+        distinct.add(tuple(int(x) for x in top5))
+    return dict(images=n, checker=kind, top5_agree=agree, distinct_top5=len(distinct), max_rel_err_prob=worst_prob,
+                max_rel_err_fm=max(worst_fm.values()) if worst_fm else 0.0,
+                fm_checked={str(l): v for l, v in worst_fm.items()}, tolerance=TOL,
+                ok=bool(agree == n and worst_prob <= TOL and all(v <= TOL for v in worst_fm.values())))
 
 
 def cpu_baseline(kind, cpu, imgs_host):
@@ -233,6 +244,11 @@ def main():
     ap.add_argument("--model", default="AlexNet")
     ap.add_argument("--lut", default="mfma", choices=["mfma", "exact", "bf16"],
                     help="LUT builder: f32 MFMA (default), exact VALU (bit-identical conv/FC), bf16 = opt-in bf16-pair MFMA for the 8-dim conv layers")
+    ap.add_argument("--params", default="auto", choices=["auto", "shipped", "synthetic"],
+                    help="AlexNet parameters: shipped = the reference's own files staged under oracle/_ref/data (+ the fc6 table the "
+                         "mount lacks, SURVEY.md §8c fixture 1) and inputs minus the shipped mean image (SURVEY.md §8d); synthetic = "
+                         "seeded, same shapes; auto = shipped where the staged files exist")
+    ap.add_argument("--vgg-batch", type=int, default=1000, help="images of the VGG-16 run (BASELINE configs[3]; SURVEY.md §8d: 1000)")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="N > 1: strong = one --batch sharded over the GPUs (BASELINE configs[2]); weak = --batch per GPU")
     ap.add_argument("--cpu-sample", type=int, default=100, help="images for the CPU baseline (0 = skip)")
@@ -268,7 +284,17 @@ def main():
     topo, synth, capi, dmod, perf = pkg("topology"), pkg("synth"), pkg("capi"), pkg("dist"), pkg("perfmodel")
     in_chw, layers, _, _ = topo.MODELS[args.model]
     sizes = topo.fmap_sizes(in_chw, layers)
-    params = synth.make_params(in_chw, layers, seed=0)      # every rank knows the SHAPES; rank 0 owns the VALUES
+    data_root = os.path.join(ROOT, "oracle", "_ref", "data")     # staged DATA files of the reference (not its code): parameters, mean image
+    have_shipped = args.model == "AlexNet" and os.path.exists(os.path.join(data_root, "AlexNet/Bin.Files/bvlc_alexnet_aCaF.ctrdLst.01.bin"))
+    if args.params == "shipped" and not have_shipped:
+        raise SystemExit("bench.py --params shipped: %s holds no staged AlexNet parameter files" % data_root)
+    shipped = have_shipped and args.params != "synthetic"
+    if shipped:
+        params = synth.load_alexnet_shipped(data_root, layers, fixture=1)
+        params2 = synth.load_alexnet_shipped(data_root, layers, fixture=2)   # non-degenerate tail: second parity pass only
+    else:
+        params = synth.make_params(in_chw, layers, seed=0)  # every rank knows the SHAPES; rank 0 owns the VALUES
+        params2 = None
     B = args.batch
     strong = world > 1 and args.scaling == "strong"
     lo, hi = dmod.shard_bounds(B, rank, world) if strong else (0, B)
@@ -303,12 +329,16 @@ def main():
 
     # synthetic device-resident input: 8-bit pixels minus the BGR channel means (range of BmpImgIO's output); image i of
     # the global batch is the same whatever the number of ranks
-    g = torch.Generator(device=dev)
-    g.manual_seed(1234)
-    full = torch.randint(0, 256, (B,) + tuple(in_chw), generator=g, device=dev, dtype=torch.int32)
-    imgs = full.to(torch.float32)
-    del full
-    imgs -= torch.tensor([104.0, 117.0, 123.0], device=dev)[: in_chw[0]].view(1, -1, 1, 1)
+    if shipped:
+        # pixel = U{0..255} (numpy default_rng(1234)) minus the centre crop of the shipped mean image
+        imgs = torch.from_numpy(synth.make_images(B, in_chw, seed=1234, mean=synth.shipped_mean_image(data_root))).to(dev)
+    else:
+        g = torch.Generator(device=dev)
+        g.manual_seed(1234)
+        full = torch.randint(0, 256, (B,) + tuple(in_chw), generator=g, device=dev, dtype=torch.int32)
+        imgs = full.to(torch.float32)
+        del full
+        imgs -= torch.tensor([104.0, 117.0, 123.0], device=dev)[: in_chw[0]].view(1, -1, 1, 1)
     classes = sizes[-1][0] * sizes[-1][1] * sizes[-1][2]
     prob = torch.empty((B, classes), dtype=torch.float32, device=dev)
     top5 = torch.empty((B, 5), dtype=torch.int16, device=dev)
@@ -479,17 +509,40 @@ def main():
             # the reference is compared with: probabilities, top-5 and the last pooling map
             step()
             torch.cuda.synchronize(dev)
-            fm_idx = max(i + 1 for i, l in enumerate(layers) if l["type"] == topo.POOL)
+            # maps of the fast path that exist on both sides: the last pooling map and the (ReLU-fused) outputs of the
+            # hidden FC layers behind it
+            fcs = [i for i, l in enumerate(layers) if l["type"] == topo.FCNT]
+            fm_ids = [max(i + 1 for i, l in enumerate(layers) if l["type"] == topo.POOL)] + [i + 2 for i in fcs[:-1]]
             # half of the checked images from the first panel, half from the END of this rank's block (the last, ragged panel)
             head = (pn + 1) // 2
             tail = pn - head if n_local >= pn else 0
             idx = list(range(head)) + list(range(n_local - tail, n_local))
             sel = torch.tensor(idx, device=dev)
-            fm = np.concatenate([eng.layer_output_range(fm_idx, 0, head)] +
-                                ([eng.layer_output_range(fm_idx, n_local - tail, tail)] if tail else []))
-            parity = parity_check(kind, cpu, layers, mine[sel].cpu().numpy(), prob[lo:hi][sel].cpu().numpy(),
-                                  top5[lo:hi][sel].cpu().numpy().view(np.uint16), fm, fm_idx)
+
+            def fetch(l):
+                return np.concatenate([eng.layer_output_range(l, 0, head)] +
+                                      ([eng.layer_output_range(l, n_local - tail, tail)] if tail else []))
+            sel_imgs = mine[sel].cpu().numpy()
+            parity = parity_check(kind, cpu, layers, sel_imgs, prob[lo:hi][sel].cpu().numpy(),
+                                  top5[lo:hi][sel].cpu().numpy().view(np.uint16), {l: fetch(l) for l in fm_ids})
             parity["image_indices"] = [lo + i for i in idx]
+            parity["parameters"] = "shipped + fc6 fixture 1" if shipped else "seeded synthetic"
+            if shipped:
+                # with fixture 1 the real network's fc7 is all-negative (fc8 = bias, one top-5 for every image: SURVEY.md §8c
+                # "Trap"): the tail is checked a second time with the fc6 table of fixture 2, same kernels, same images
+                fc6 = synth.ALEXNET_FC6
+                eng.upload({fc6: params2[fc6]})
+                step()
+                torch.cuda.synchronize(dev)
+                kind2, cpu2, _ = cpu_side(in_chw, layers, params2)
+                p2 = parity_check(kind2, cpu2, layers, sel_imgs, prob[lo:hi][sel].cpu().numpy(),
+                                  top5[lo:hi][sel].cpu().numpy().view(np.uint16), {l: fetch(l) for l in fm_ids[1:]})
+                p2["parameters"] = "shipped + fc6 fixture 2 (non-degenerate tail)"
+                parity["tail_fixture2"] = p2
+                parity["ok"] = bool(parity["ok"] and p2["ok"])
+                eng.upload({fc6: params[fc6]})
+                step()
+                torch.cuda.synchronize(dev)
             if bf_prob is not None:                      # the opt-in builder's probabilities against the same reference
                 ref = prob[lo:lo + bf_prob.shape[0]].cpu().numpy()
                 extras["bf16_pairs_max_rel_diff_vs_f32_builder"] = float(
@@ -510,13 +563,13 @@ def main():
         v_chw, v_layers, _, _ = topo.MODELS["VGG16"]
         v_params = synth.make_params(v_chw, v_layers, seed=0)
         v_sizes = topo.fmap_sizes(v_chw, v_layers)
-        vb = 256
+        vb = args.vgg_batch                              # N = 1000 (its feature maps are ~60 GB of the 288 GB)
         ve = pkg("engine").QcnnEngine(local, stream.cuda_stream)
         ve.set_option(capi.OPT_KEEP_ALL, 0)
         ve.set_option(capi.OPT_PROFILE, 1)
         ve.set_option(capi.OPT_STREAMS, 1)
         ve.load_model(v_chw, v_layers, v_params, vb)
-        vi = torch.randint(0, 256, (vb,) + tuple(v_chw), device=dev, dtype=torch.int32).to(torch.float32) - 110.0
+        vi = torch.randint(0, 256, (vb,) + tuple(v_chw), device=dev, dtype=torch.uint8).to(torch.float32) - 110.0
         vp = torch.empty((vb, 1000), dtype=torch.float32, device=dev)
         vt = torch.empty((vb, 5), dtype=torch.int16, device=dev)
         vf = lambda: ve.forward_dev(vi.data_ptr(), vb, vp.data_ptr(), vt.data_ptr())
@@ -528,9 +581,21 @@ def main():
         vdom = int(np.argmax(vms))
         rep = perf.layer_report(v_sizes, v_layers, v_params, vdom, vb, float(vms[vdom]), ve.layer_segments(vdom))
         conv_total = sum(float(vms[i]) for i, l in enumerate(v_layers) if l["type"] == topo.CONV)
+        slow = {}
+        for i in sorted((i for i, l in enumerate(v_layers) if l["type"] in (topo.CONV, topo.FCNT)), key=lambda i: -vms[i])[:5]:
+            split = ve.layer_split(i)[0]
+            r = (perf.decoded_report(v_sizes, v_layers, i, vb, float(vms[i])) if (split == -3 and v_layers[i]["type"] == topo.CONV) else
+                 perf.layer_report(v_sizes, v_layers, v_params, i, vb, float(vms[i]), ve.layer_segments(i), split == -4))
+            r["ms"] = round(float(vms[i]), 4)
+            r["in_hwc"], r["out_hwc"] = list(v_sizes[i]), list(v_sizes[i + 1])
+            slow["%02d_%s" % (i, topo.TYPE_NAMES[v_layers[i]["type"]])] = r
+        v_lut_flop = sum(perf.conv_work(v_sizes[i], v_sizes[i + 1], l, *[int(x) for x in v_params[i]["ctrd"].shape])["alg_flop"] / 128.0
+                         for i, l in enumerate(v_layers) if l["type"] == topo.CONV)
         vgg = dict(value=round(vb * 2 / vdt, 2), unit="images/s", batch=vb, steps=2,
                    outputs_finite=bool(torch.isfinite(vp).all().item()), conv_ms_per_batch=round(conv_total, 3),
-                   dominant_layer=vdom, dominant_ms=round(float(vms[vdom]), 4), dominant=rep,
+                   dominant_layer=vdom, dominant_ms=round(float(vms[vdom]), 4), dominant=rep, slowest_layers=slow,
+                   lut_build_algorithmic_tflops=round(v_lut_flop * vb * 2 / vdt / 1e12, 2),
+                   lut_build_algorithmic_frac_of_f32_mfma_peak=round(v_lut_flop * vb * 2 / vdt / perf.F32_MFMA_FLOPS, 4),
                    parameters="seeded synthetic, conv Cs=8 K=128, fc Cs=4 K=32, classifier Cs=1 K=16")
         ve.close()
 
@@ -548,7 +613,8 @@ def main():
         achieved = abytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         conv_idx = [i for i, l in enumerate(layers) if l["type"] == topo.CONV]
         name = "%s%d" % (topo.TYPE_NAMES[layers[dom]["type"]], (conv_idx.index(dom) + 1) if dom in conv_idx else dom)
-        traffic, tsrc = pmc_traffic(dom, ns) if (n_local == 1000 and args.model == "AlexNet") else (None, "batch/model differ from the profiled run")
+        traffic, tsrc, ttable = (pmc_traffic(dom, ns) if (n_local == 1000 and args.model == "AlexNet")
+                                 else (None, "batch/model differ from the profiled run", {}))
         per_layer = {}
         total_lk = 0
         for i, l in enumerate(layers):
@@ -560,22 +626,48 @@ def main():
                      perf.layer_report(sizes, layers, params, i, launch_images, float(layer_ms[i]), segments.get(i), i in symmetric))
                 r["ms"] = round(float(layer_ms[i]), 4)
                 per_layer["%02d_%s" % (i, topo.TYPE_NAMES[l["type"]])] = r
+        table_lk = 0                                    # look-ups of the layers that really ran as table look-ups
         for i, l in enumerate(layers):
+            lk = 0
             if l["type"] == topo.CONV:
-                total_lk += perf.conv_work(sizes[i], sizes[i + 1], l, *shapes[i])["lookups"]
+                lk = perf.conv_work(sizes[i], sizes[i + 1], l, *shapes[i])["lookups"]
             elif l["type"] == topo.FCNT:
-                total_lk += shapes[i][0] * l["nod"]
+                lk = shapes[i][0] * l["nod"]
+            total_lk += lk
+            if i not in decoded:
+                table_lk += lk
         step_bytes = sum(algorithmic_bytes(sizes, layers, params, l, n_local) for l in range(len(layers))
                          if layer_ms[l] > 0)
-        roof = dict(bound="hbm", kernel=("k_conv_dec (layer %d, %s)" % (dom, name)) if dom in decoded else
+        # The pipe that bounds the dominant kernel.  Table kernels (LUT build + indexed accumulation): neither HBM (a few
+        # per cent of 8 TB/s) nor the matrix pipe but the LDS read path of the look-ups — `achieved` = look-up bytes (4 B per
+        # look-up and image) per second against 256 CUs x 256 B/clk x 2.4 GHz; the HBM and matrix-pipe figures sit beside
+        # it.  A decoded layer (products on the matrix pipe): issued f32 MFMA FLOP against the dense f32 peak.
+        dom_rep = per_layer.get("%02d_%s" % (dom, topo.TYPE_NAMES[layers[dom]["type"]]), {})
+        lds_peak_gbs = perf.LDS_READ_BYTES_PER_CLK * perf.CUS * perf.CLOCK_HZ / 1e9
+        if dom in decoded:
+            bound = dict(bound="mfma", achieved=round(dom_rep.get("mfma_util", 0.0) * perf.F32_MFMA_FLOPS / 1e12, 2),
+                         peak=round(perf.F32_MFMA_FLOPS / 1e12, 1), unit="TFLOP/s", frac=dom_rep.get("mfma_util"))
+        else:
+            bound = dict(bound="lds", achieved=dom_rep.get("lookup_gbs"), peak=round(lds_peak_gbs, 1), unit="GB/s",
+                         frac=dom_rep.get("lds_frac"),
+                         mfma_issued_frac=dom_rep.get("mfma_util"), mfma_algorithmic_frac=dom_rep.get("mfma_algorithmic_frac"))
+        other = {}
+        for l2, ent in sorted(ttable.items()):          # HBM traffic of the other profiled kernels (e.g. the decoded first layer)
+            if l2 != dom and layer_ms[l2] > 0:
+                ab = algorithmic_bytes(sizes, layers, params, l2, launch_images)
+                other[str(l2)] = dict(kernel=ent.get("kernel"), traffic=int(ent["bytes"]), fetched=ent.get("fetch_bytes"),
+                                      written=ent.get("write_bytes"), algorithmic_bytes_per_launch=int(ab),
+                                      traffic_over_algorithmic=round(ent["bytes"] / ab, 2))
+        roof = dict(bound, kernel=("k_conv_dec (layer %d, %s)" % (dom, name)) if dom in decoded else
                     ("k_conv_sym (layer %d, %s)" % (dom, name)) if dom in symmetric else
                     "k_%s_aprx (layer %d, %s)" % ("conv" if dom in conv_idx else "fc", dom, name),
-                    achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic, traffic_source=tsrc,
+                    traffic=traffic, traffic_source=tsrc,
+                    traffic_over_algorithmic=round(traffic / abytes, 2) if traffic else None, other_kernels_traffic=other,
+                    hbm_achieved=round(achieved, 2), hbm_peak=HBM_PEAK_GBS, hbm_frac=round(achieved / HBM_PEAK_GBS, 5),
                     ms_per_launch=round(dom_ms, 4), launches_timed=recorded * ns, launches_per_step=ns,
                     images_per_launch=launch_images, algorithmic_bytes_per_launch=int(abytes),
                     whole_step_hbm_frac=round(step_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                    lds_frac=per_layer.get("%02d_%s" % (dom, topo.TYPE_NAMES[layers[dom]["type"]]), {}).get("lds_frac"),
+                    whole_step_lds_frac=round(table_lk * 4 * value / 1e9 / lds_peak_gbs, 4),
                     lds_read_peak="256 CUs x 256 B/clk x 2.4 GHz (ds_read_b64/b128)",
                     layers=per_layer,
                     layer_ms={"%02d_%s" % (i, topo.TYPE_NAMES[layers[i]["type"]]): round(float(m), 4)
@@ -592,14 +684,18 @@ def main():
             "config": {"workload": "%s Q-CNN approximate forward (fp32 LUT + uint8 indices), one batch of %d synthetic %dx%d "
                                    "images per step, device-resident" % (args.model, images_per_step, in_chw[1], in_chw[2]),
                        "global_batch": images_per_step, "images_on_rank0": n_local, "lut_builder": args.lut,
-                       "parameters": "seeded synthetic (seed 0), shipped AlexNet quantisation shapes",
+                       "parameters": ("the reference's shipped AlexNet files (oracle/_ref/data) + fc6 assignments of SURVEY.md §8c "
+                                      "fixture 1 (the mount lacks that file); inputs U{0..255} minus the shipped mean image") if shipped
+                       else "seeded synthetic (seed 0), shipped AlexNet quantisation shapes",
                        "streams_per_gpu": ns, "parallelism": par},
             "rccl_ranks": world, "param_broadcast_ms": round(bcast_ms, 3),
             "outputs_finite": ok,
             "lookups_per_image": int(total_lk),
-            "lookups_per_s": round(total_lk * value, 0),
-            "lookups_note": "the reference's look-up count; layers %s evaluate theirs as products of the code words the "
-                            "assignments name (QCNN_OPT_DECODE)" % sorted(decoded) if decoded else "all evaluated as table look-ups",
+            "lookups_per_s": round(table_lk * value, 0),
+            "lookups_performed_per_image": int(table_lk),
+            "lookups_note": ("lookups_per_s counts the %d look-ups per image that ran as table look-ups; layers %s evaluate "
+                             "theirs (%d) as products of the code words the assignments name (QCNN_OPT_DECODE)"
+                             % (table_lk, sorted(decoded), total_lk - table_lk)) if decoded else "all evaluated as table look-ups",
             "roofline": roof,
         }
         out.update(extras)

@@ -52,7 +52,9 @@ def conv_work(in_hwc, out_hwc, ly, m: int, k: int, cs: int, sym: bool = False):
     lookups = taps_h * taps_w * m * ct                      # per image
     ideal = h * w * mg * grp
     ks = 2 if min(cin // grp, cs) > 4 else 1
-    return dict(stages=stages, lookups=lookups, ideal_stages=ideal, mfma_flop=stages * 128 * 128 * 4 * ks * 2,
+    # algorithmic LUT build (SURVEY.md §8 table "LUT-MAC/img"): every (pixel, sub-space) table once, over the dims it has
+    alg_flop = 2 * h * w * grp * k * sum(min(cs, cin // grp - i * cs) for i in range(m)) * 128
+    return dict(stages=stages, lookups=lookups, ideal_stages=ideal, mfma_flop=stages * 128 * 128 * 4 * ks * 2, alg_flop=alg_flop,
                 tile=("symmetric %dx%dx%d" % (th, tw, 16 * cpw)) if sym else "%dx%dx%d" % (th, tw, GATHER_WAVES * cpw), ks=ks)
 
 
@@ -84,8 +86,9 @@ def fc_work(d: int, ct: int, m: int, k: int, cs: int, msplit_chunks: int):
     g = stage_group(k)
     stages = (m + g - 1) // g * msplit_chunks
     ks = 2 if min(d, cs) > 4 else 1
+    alg_flop = 2 * k * sum(min(cs, d - i * cs) for i in range(m)) * 128
     return dict(stages=stages, lookups=m * ct, ideal_stages=(m + g - 1) // g, mfma_flop=stages * 128 * 128 * 4 * ks * 2,
-                tile="fc", ks=ks)
+                alg_flop=alg_flop, tile="fc", ks=ks)
 
 
 def decoded_report(sizes, layers, l: int, images: float, ms: float):
@@ -130,4 +133,7 @@ def layer_report(sizes, layers, params, l: int, images: float, ms: float, seg_be
                 lookups_per_stage=round(wk["lookups"] / wk["stages"], 1),   # row look-ups (128 images each) per built stage
                 stage_cycles=round(cycles, 0),
                 mfma_util=round(wk["mfma_flop"] * panels / t / F32_MFMA_FLOPS, 4) if t > 0 else 0.0,
+                # the LUT build the algorithm asks for (every table once), on the images the launch really holds
+                mfma_algorithmic_frac=round(wk["alg_flop"] * images / PANEL / t / F32_MFMA_FLOPS, 4) if t > 0 else 0.0,
+                lookup_gbs=round(lookups * 4 / t / 1e9, 1) if t > 0 else 0.0,
                 lds_frac=round(lookups * 4 / t / (LDS_READ_BYTES_PER_CLK * CUS * CLOCK_HZ), 4) if t > 0 else 0.0)

@@ -140,3 +140,43 @@ def make_images(n: int, in_chw, seed=1234, mean: Optional[np.ndarray] = None) ->
         ch_mean = np.array([104.0, 117.0, 123.0], dtype=np.float32)[:c]
         px -= ch_mean[None, :, None, None]
     return px
+
+
+# ---- the shipped AlexNet parameter set + the one file the mount lacks (fc6 assignments) ----
+ALEXNET_FC6 = 15                     # layer index of fc6 (file number 16)
+FC6_FIXTURE2_NAME = "AlexNet/fixtures/bvlc_alexnet_aCaF.asmtLst.16.fx2.cbn"
+
+
+def fc6_fixture(ctrd: np.ndarray, fixture: int) -> np.ndarray:
+    """Synthetic fc6 assignment matrix [4096, M] (0-based, < K) for the shipped fc6 code book ``ctrd`` [M, K, Cs].
+
+    fixture 1  SURVEY.md §8c recipe: default_rng(0).integers(0, K).  With it the real network's tail degenerates (fc7
+               all-negative, fc8 = bias, every image the same top-5), so it cannot test fc7 / fc8 / top-5.
+    fixture 2  default_rng(2) picks, per (channel, sub-space), one of the EIGHT code words of smallest norm: fc6
+               activations stay in the range the trained fc7 expects (28 % positive, max ~12), fc7 keeps ~14 % of its
+               units alive, fc8 and the top-5 differ from image to image (7 distinct top-1 over the 10 shipped BMPs).
+    """
+    m, k, _ = ctrd.shape
+    if fixture == 1:
+        return np.random.default_rng(0).integers(0, k, size=(4096, m), dtype=np.uint8)
+    if fixture != 2:
+        raise ValueError("fc6 fixture %r" % (fixture,))
+    order = np.argsort(np.sqrt((ctrd.astype(np.float64) ** 2).sum(-1)), axis=1, kind="stable")   # [M, K], smallest norm first
+    pick = np.random.default_rng(2).integers(0, 8, size=(4096, m))
+    return order[np.arange(m)[None, :], pick].astype(np.uint8)
+
+
+def load_alexnet_shipped(data_root: str, layers, fixture: int = 1):
+    """The shipped AlexNet parameters from a staged data root (oracle/_ref/data: AlexNet/Bin.Files/*), fc6 assignments =
+    the staged fixture 1 file or (fixture 2) the staged / regenerated non-degenerate one."""
+    params = load_param_dir(os.path.join(data_root, "AlexNet/Bin.Files"), "bvlc_alexnet_aCaF", layers)
+    if fixture == 2:
+        path = os.path.join(data_root, FC6_FIXTURE2_NAME)
+        asmt = fileio.read_cbn(path)[0] if os.path.exists(path) else fc6_fixture(params[ALEXNET_FC6]["ctrd"], 2)
+        params[ALEXNET_FC6] = dict(params[ALEXNET_FC6], asmt=asmt)
+    return params
+
+
+def shipped_mean_image(data_root: str) -> np.ndarray:
+    """AlexNet/imagenet_mean.single.bin [3, 256, 256] (BGR) of a staged data root."""
+    return fileio.read_bin(os.path.join(data_root, "AlexNet/imagenet_mean.single.bin"), np.float32)

@@ -40,7 +40,15 @@ def main():
     sys.path.insert(0, ROOT)
     import bench as bench_mod
     h = bench_mod.kernel_hash()          # every device source under quantized-cnn_amd/csrc
-    json.dump({"kernel": dom["kernel"], "layer": dom_layer, "launches_per_forward": 1,
+    # per-layer table: the dominant table kernel and the decoded first layer (k_conv_dec runs layer 0 only)
+    kernels = {str(dom_layer): dict(kernel=dom["kernel"], bytes=int((2.0 * fetch_kib + write_kib) * 1024),
+                                    fetch_bytes=int(2.0 * fetch_kib * 1024), write_bytes=int(write_kib * 1024))}
+    for r in table:
+        if r["kernel"].startswith("k_conv_dec") and r.get("FETCH_SIZE") and r.get("WRITE_SIZE"):
+            f, w = float(r["FETCH_SIZE"]), float(r["WRITE_SIZE"])
+            kernels.setdefault("0", dict(kernel=r["kernel"], bytes=int((2.0 * f + w) * 1024), fetch_bytes=int(2.0 * f * 1024),
+                                         write_bytes=int(w * 1024)))
+    json.dump({"kernel": dom["kernel"], "layer": dom_layer, "launches_per_forward": 1, "kernels": kernels,
                "bytes": int((2.0 * fetch_kib + write_kib) * 1024),
                "fetch_size_kib_raw": fetch_kib, "write_size_kib_raw": write_kib, "kernel_hash": h,
                "note": "rocprofv3 FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports exactly half of the bytes "

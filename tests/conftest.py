@@ -80,3 +80,28 @@ def rel_err(a, b):
     den_inf = max(np.abs(b).max(), 1e-30)
     den_l2 = max(np.sqrt((b * b).sum()), 1e-30)
     return np.abs(a - b).max() / den_inf, np.sqrt(((a - b) ** 2).sum()) / den_l2
+
+
+@pytest.fixture(scope="session")
+def golden_alex_real10():
+    return np.load(os.path.join(GOLDEN, "alexnet_real10_ref.npz"))
+
+
+def real_bmp_images():
+    """The ten shipped Bmp.Files/*.BMP as the network input [10, 3, 227, 227] (mean-subtracted BGR crop): through the
+    compiled reference's own BmpImgIO where oracle/_ref/libqcnn_ref.so exists, else through the host mirror's (which
+    tests/test_host_mirror.py holds bit-identical to it).  Needs oracle/_ref/data."""
+    import ctypes as C
+    import pyoracle as po
+    mean = os.path.join(po.REF_DATA, "AlexNet/imagenet_mean.single.bin")
+    bmps = [os.path.join(po.REF_DATA, "Bmp.Files/ILSVRC2012_val_%08d.BMP" % i) for i in range(1, 11)]
+    if po.have_ref():
+        ref = po.RefLib()
+        return np.concatenate([ref.load_bmp(mean, b) for b in bmps])
+    lib = C.CDLL(os.path.join(ROOT, "quantized-cnn_amd", "libqcnn_host.so"))
+    lib.qh_bmp_load.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")]
+    out = np.empty((10, 3, 227, 227), np.float32)
+    for i, b in enumerate(bmps):
+        with po._Quiet():
+            assert lib.qh_bmp_load(mean.encode(), b.encode(), 256, 227, 0, out[i:i + 1]) == 0
+    return out

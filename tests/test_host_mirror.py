@@ -148,6 +148,64 @@ def test_reference_main_drives_the_hip_path(tmp_path):
         assert re.findall(r"ACCURACY@(\d): (\d+), ([0-9.]+)%", ref_out) == acc
 
 
+def _make_fixture2_root(tmp_path, golden):
+    """A data root whose ACCURACY@k lines depend on every single prediction: the shipped parameters with fc6 fixture 2
+    (non-degenerate tail), the ten shipped BMPs tiled to 100 images, and a label file crafted from the COMPILED
+    reference's own top-5 for those images (golden `top5_2`): image i is labelled with the reference's rank-(i mod 5)
+    prediction, every sixth image with a class outside its top-5 — so hits@k is known exactly and any image whose
+    top-5 (or its order) differs from the reference's moves a count."""
+    from conftest import real_bmp_images
+    root = str(tmp_path / "root2")
+    os.makedirs(os.path.join(root, "ILSVRC12.227x227.IMG"))
+    os.makedirs(os.path.join(root, "AlexNet", "Bin.Files"))
+    for rel in ("Cls.Names", "Bmp.Files"):
+        os.symlink(os.path.join(po.REF_DATA, rel), os.path.join(root, rel))
+    os.symlink(os.path.join(po.REF_DATA, "AlexNet/imagenet_mean.single.bin"), os.path.join(root, "AlexNet/imagenet_mean.single.bin"))
+    src = os.path.join(po.REF_DATA, "AlexNet/Bin.Files")
+    for name in sorted(os.listdir(src)):
+        os.symlink(os.path.join(src, name), os.path.join(root, "AlexNet/Bin.Files", name))
+    fc6 = os.path.join(root, "AlexNet/Bin.Files/bvlc_alexnet_aCaF.asmtLst.16.cbn")
+    os.remove(fc6)
+    os.symlink(os.path.join(po.REF_DATA, synth.FC6_FIXTURE2_NAME), fc6)
+    imgs = real_bmp_images()[np.arange(100) % 10]
+    fileio.write_bin(os.path.join(root, "ILSVRC12.227x227.IMG/dataMatTst.single.bin"), imgs)
+    top5 = golden["top5_2"]
+    labels = np.zeros((1, 1, 1, 1000), np.uint16)
+    want = [0] * 5
+    for i in range(100):
+        t = [int(x) for x in top5[i % 10]]
+        if i % 6 == 5:
+            labels[0, 0, 0, i] = next(c for c in range(1000) if c not in t)
+        else:
+            labels[0, 0, 0, i] = t[i % 5]
+            for k in range(i % 5, 5):
+                want[k] += 1
+    fileio.write_bin(os.path.join(root, "ILSVRC12.227x227.IMG/lablVecTst.uint16.bin"), labels)
+    return root, want
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.isdir(po.REF_DATA), reason="needs the staged shipped parameters")
+@pytest.mark.parametrize("env", [{}, {"QCNN_LUT": "exact"}, {"QCNN_BATCH": "25", "QCNN_BATCHES": "4"}])
+def test_reference_main_predictions_match_reference(tmp_path, golden_alex_real10, env):
+    """The reference's unmodified Main.cc / UnitTest.cc on the HIP path, shipped parameters + fc6 fixture 2 (fc7 / fc8 /
+    top-5 differ from image to image): the ACCURACY@k counts must be exactly the ones the compiled reference's
+    predictions imply — i.e. lablVecPred equals the reference's, image by image and rank by rank, not merely the
+    accuracy of identical predictions (with fixture 1 every image gets the same top-5)."""
+    exe = os.path.join(ROOT, "build", "bin", "QuanCNN_hip")
+    if not os.path.exists(exe):
+        pytest.skip("build/bin/QuanCNN_hip not built (needs /root/reference at build time)")
+    root, want = _make_fixture2_root(tmp_path, golden_alex_real10)
+    out = subprocess.run([exe], cwd=root, capture_output=True, text=True, timeout=600, env=dict(os.environ, **env)).stdout
+    acc = re.findall(r"ACCURACY@(\d): (\d+), ([0-9.]+)%", out)
+    assert [int(a[1]) for a in acc] == want, out[-2000:]
+    assert want == [16, 33, 50, 67, 84]
+    ref_exe = os.path.join(po.REF_DIR, "QuanCNN")
+    if os.path.exists(ref_exe) and not env:      # the reference binary itself on the same root prints the same lines
+        ref_out = subprocess.run([ref_exe], cwd=root, capture_output=True, text=True, timeout=900).stdout
+        assert re.findall(r"ACCURACY@(\d): (\d+), ([0-9.]+)%", ref_out) == acc
+
+
 @pytest.mark.gpu
 @pytest.mark.skipif(not os.path.isdir(po.REF_DATA), reason="needs the staged shipped parameters")
 @pytest.mark.parametrize("lut", ["exact", "mfma"])

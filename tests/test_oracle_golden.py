@@ -102,6 +102,32 @@ def test_alexnet_real_fingerprints(golden_alex_real):
     assert abs(fingerprint(orc.fm(16))[0] - 1.858081e+04) < 0.1
 
 
+@pytest.mark.skipif(not os.path.isdir(po.REF_DATA), reason="shipped parameters not staged (oracle/_ref/data)")
+def test_alexnet_real10_oracle_matches_reference_golden(golden_alex_real10):
+    """All ten shipped BMPs, shipped parameters, both fc6 fixtures: the C restatement reproduces bit for bit what the
+    COMPILED reference produced (tests/golden/alexnet_real10_ref.npz) — every feature map with fixture 1, the tail
+    fm[16..23] with fixture 2 (where fc7 / fc8 / top-5 are not degenerate), soft-max outputs in full, top-5."""
+    from conftest import real_bmp_images
+    z = golden_alex_real10
+    in_chw, layers, _, _ = topo.MODELS["AlexNet"]
+    imgs = real_bmp_images()
+    assert np.allclose(np.stack([fingerprint(imgs[i]) for i in range(10)]), z["img_fp"], rtol=1e-12, atol=0)
+    L = len(layers)
+    for fx in (1, 2):
+        orc = po.COracle(in_chw, layers)
+        orc.set_params(synth.load_alexnet_shipped(po.REF_DATA, layers, fixture=fx))
+        orc.forward(imgs)
+        for l in range(16 if fx == 2 else 0, L + 1):
+            fm = orc.fm(l).reshape(10, -1)
+            assert np.array_equal(fm[:, ::SAMPLE_STRIDE], z["smp%d_%02d" % (fx, l)]), "fixture %d fm[%d]" % (fx, l)
+            for i in range(10):
+                assert np.allclose(fingerprint(fm[i]), z["fp%d_%02d" % (fx, l)][i], rtol=1e-12, atol=0)
+        prob = orc.fm(L).reshape(10, -1)
+        assert np.array_equal(prob, z["prob%d" % fx])
+        assert np.array_equal(np.stack([orc.top5(prob[i]) for i in range(10)]), z["top5_%d" % fx])
+    assert len(set(z["top5_2"][:, 0])) >= 5 and len(set(z["top5_1"][:, 0])) == 1     # fixture 2 is the informative one
+
+
 def test_precise_path_against_reference_golden():
     """qo_conv_prec / qo_fc_prec (the reference's Init(false) path) against feature maps the COMPILED reference produced for
     the tiny network (tests/golden/tiny_prec_ref.npz, oracle/make_golden.py): bit for bit, strided first layer (the
