@@ -93,6 +93,7 @@ class CaffeEva {
   bool keepAll_;                    // QCNN_KEEP_ALL: layer-for-layer mode (every feature map materialised)
   float* pinned_;                   // dataLst storage registered with the HIP runtime (qcnn_host_register), or NULL
   float* pinnedCopy_;               // the images in a pinned buffer of the HIP runtime (qcnn_host_alloc), or NULL
+  int pinnedImages_;                // leading images of the dataset the pinned buffer / registration covers
   std::string lastError_;
   StopWatch swWall_;                // wall clock around the forward passes (host view)
 

@@ -32,14 +32,25 @@ constexpr int PANEL = QCNN_PANEL;
 
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// Product index of padded row k (< Kp) of a kernel row with Kr = knl * Cin real products: the steps (four k each) cover
+// [0, 4), [4, 8), ... and the LAST one [Kr - 4, Kr) (Kr >= 4: it overlaps the step before it; an overlapped row carries a
+// zero code word in the last step, reported as -1) — every operand row a step loads lies inside the window.  Kr < 4: the
+// single step is [0, 4), rows >= Kr are padding (-1; the kernel clamps their loads: PADDED path).
+__host__ __device__ __forceinline__ int qk_dec_krow(int k, int Kr, int Kp) {
+  const int last = Kp - 4;                                  // first padded row of the last step
+  if (k < last || Kr < 4) return k < Kr ? k : -1;
+  const int real = Kr - 4 + (k - last);
+  return real >= last ? real : -1;
+}
+
 // rows: [kh][kw][M = 1][rowStride] slot bytes (QkSlots order); ctrd: [Cs][K]; out: [knl][Kp][S]
 __global__ void k_decode_weights(const uint8_t* __restrict__ rows, const float* __restrict__ ctrd, float* __restrict__ out,
                                  QkSlots sl, int knl, int Cin, int K, int Ct, int Kp, int S) {
   const int total = knl * Kp * S;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    const int ch = i % S, k = (i / S) % Kp, kh = i / (S * Kp);
+    const int ch = i % S, k = qk_dec_krow((i / S) % Kp, knl * Cin, Kp), kh = i / (S * Kp);
     float w = 0.0f;
-    if (ch < Ct && k < knl * Cin) {
+    if (ch < Ct && k >= 0) {
       const int kw = k / Cin, d = k % Cin;
       const int slot = rows[(size_t)(kh * knl + kw) * sl.rowStride + qk_slot_entry(sl, 0, ch)];
       w = ctrd[(size_t)d * K + qcnn_row_slot(slot)];            // qcnn_row_slot is its own inverse; M = 1: stage row = code word
@@ -89,6 +100,12 @@ __global__ __launch_bounds__(1024) void k_conv_dec(DecParams p) {
   const int wgX = (gridDim.x - xcd + 7) >> 3;                           // workgroups of this XCD
   const int itemBeg = (int)((long long)nItems * xcd / nX), itemEnd = (int)((long long)nItems * (xcd + 1) / nX);
   for (int item = itemBeg + (blockIdx.x >> 3) * 16 + wave; item < itemEnd; item += wgX * 16) {
+    // The lane-derived address parts are RE-DERIVED per item from an opaque copy of the lane id: as loop invariants they
+    // would have to live through the whole item loop beside 96 accumulator registers, and the compiler spilled two of
+    // them to scratch (a handful of vector instructions per ~76 000-cycle item instead).
+    int laneI = lane;
+    asm volatile("" : "+v"(laneI));
+    const int li = laneI & 15, kq = laneI >> 4;
     // channel chunk fastest, then image block: the waves of a workgroup share their B rows through the L1
     const int cc = item % chunks, ib = (item / chunks) % halves, pgi = item / (chunks * halves);
     const int panel = pgi / groups, pos0 = (pgi % groups) * PW;
@@ -101,8 +118,11 @@ __global__ __launch_bounds__(1024) void k_conv_dec(DecParams p) {
     }
     // Vector ALU work takes matrix-pipe time on a SIMD, so a B load costs no vector instruction besides
     // itself: a buffer load with the lane's part of the address (k row kq, images 4 li ..) in ONE constant VGPR and
-    // everything else — position, kernel row, step — in the scalar offset.  Reads past the end of the batch's map (the k
-    // padding of the very last window) return 0 by the buffer's range check; those before it are the next pixel's rows.
+    // everything else — position, kernel row, step — in the scalar offset.  A kernel row of Kr = knl * Cin products is
+    // padded to Kp = a multiple of four by letting its LAST step start at k = Kr - 4 (qk_dec_krow): it re-reads rows the
+    // step before it already multiplied — their code words are zero in that step (k_decode_weights) — instead of rows of
+    // the pixel next to the window: 0 x Inf / NaN of a value outside the window must not reach an output the window does
+    // not cover (the table kernels have no such coupling either).  All in the scalar offset: no vector instruction.
     const float* __restrict__ srcU = p.src + (size_t)panel * p.H * p.W * p.Cin * PANEL + ib * IB;
     const size_t left = (size_t)(p.panels - panel) * p.H * p.W * p.Cin * PANEL * sizeof(float) - ib * IB * sizeof(float);
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -123,8 +143,8 @@ __global__ __launch_bounds__(1024) void k_conv_dec(DecParams p) {
       for (int j = 0; j < PW; ++j) {
         if (PADDED) {
           const int row = r0[j] + kh;
-          const int k = 4 * step + kq;
-          const int kc = k < kClamp ? k : kClamp;                       // k >= Kr: any finite operand, its code word is zero
+          const int k = (step == NS - 1 && p.Kr >= 4) ? p.Kr - 4 + kq : 4 * step + kq;   // the last step ends at the window's last row
+          const int kc = k < kClamp ? k : kClamp;                       // k >= Kr (Kr < 4): an operand of the window, its code word is zero
           const int col = c0[j] + kc / p.Cin;
           const bool ok = row >= 0 && row < p.H && col >= 0 && col < p.W;
           const float* __restrict__ px = srcU + (ok ? ((row * p.W + c0[j]) * p.Cin + kc) * PANEL + IT * li : 0);   // a panel map is < 2^31 floats (qk_conv_dec)
@@ -157,6 +177,9 @@ __global__ __launch_bounds__(1024) void k_conv_dec(DecParams p) {
     // (kernel row, step) of the next B load and its byte offset from the window's first row.  Past the last step the
     // sequence simply runs on (rows below the window, or the buffer's zero): those operands are never multiplied, and
     // loads that are unconditional let the compiler count the ones in flight.
+    const int lastOff = NS > 1 ? (p.Kr - 4) * PANEL * (int)sizeof(float) : 0;   // first row of a kernel row's last step
+    const int incLast = NS > 1 ? lastOff - (NS - 2) * kStep : 0;        // from the step before the last one to the last one
+    const int incWrap = rowPitch - lastOff;                             // from a row's last step to the next row's first
     int khL = 0, stL = 0, soffL = 0;
     float b[R][PW][IT];                                                 // R = operand sets in flight (2 or 3)
     float a[R][CT];
@@ -165,7 +188,7 @@ __global__ __launch_bounds__(1024) void k_conv_dec(DecParams p) {
       const int wrap = stL + 1 == NS ? 1 : 0;
       stL = wrap ? 0 : stL + 1;
       khL += wrap;
-      soffL += wrap ? rowPitch - (NS - 1) * kStep : kStep;
+      soffL += wrap ? incWrap : (stL == NS - 1 ? incLast : kStep);
     };
     // A operands of flat step t: k rows 4 t .. 4 t + 3 (= kh * Kp + 4 * step) of this wave's channels; past the end: LDS zeros
     const float* __restrict__ wl = ldsW + kq * p.S + cc * 16 * CT + li;
@@ -390,17 +413,18 @@ hipError_t qk_decode_weights(const uint8_t* rows, const float* ctrd, float* out,
 }
 
 hipError_t qk_conv_dec(const DecParams& p, hipStream_t st) {
-  if ((long long)p.H * p.W * p.Cin * QCNN_PANEL >= (1ll << 31)) return hipErrorInvalidValue;   // 32-bit row indices inside a panel
+  if ((long long)p.H * p.W * p.Cin * QCNN_PANEL * 4 >= (1ll << 31)) return hipErrorInvalidValue;   // 32-bit BYTE offsets inside a panel
   if (p.Ct % 32) return hipErrorInvalidValue;
   // channels per wave x positions per wave x operand sets in flight x image tiles: as many accumulator tiles as 128
   // registers hold, all channels in one wave where they fit (a chunk of the channels = the B rows loaded once more)
+  const bool clamped = p.pad || p.Kr < 4;     // per-lane window clamps: padded layers, and kernel rows of fewer than four products
   if (p.live <= 16) {               // at most one image tile: 16-image items (four positions of 32 channels for padded layers)
-    if (p.pad) return launch_dec<2, 4, true, 2, 1>(p, st);
+    if (clamped) return launch_dec<2, 4, true, 2, 1>(p, st);
     if (p.Ct % 96 == 0) return launch_dec<6, 2, false, 3, 1>(p, st);
     if (p.Ct % 64 == 0) return launch_dec<4, 4, false, 3, 1>(p, st);
     return launch_dec<2, 6, false, 3, 1>(p, st);
   }
-  if (p.pad) {
+  if (clamped) {
     if (p.Ct % 64 == 0) return launch_dec<4, 1, true, 2, 4>(p, st);
     return launch_dec<2, 1, true, 3, 4>(p, st);
   }
@@ -432,7 +456,7 @@ int qk_fc_dec_slices(int D, int Ct, int panels, int live) {
   // k slices over workgroups: until the launch has about a workgroup per CU, every wave keeping >= 4 steps
   const int wgs = ((Ct + 63) / 64) * panels * ((live + 63) / 64);
   int z = 1;
-  while (wgs * z < 192 && D % (64 * 2 * z) == 0 && D / (64 * 2 * z) >= 4) z *= 2;
+  while (wgs * z < 192 && D % (64 * 2 * z) == 0 && D / (64 * 2 * z) >= 4 && 2 * z <= 32) z *= 2;   // <= 32 slabs of scratch per sub-batch
   return z;
 }
 

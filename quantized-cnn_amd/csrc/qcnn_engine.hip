@@ -12,6 +12,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -33,14 +34,20 @@ struct LayerShape {
   size_t offProg = 0, progBytes = 0;                           // conv with K = 128: offsets in consumption order (QkProgram)
   size_t offProgS = 0, progSBytes = 0;                         // ... and in the order of the sliding variant, where it applies
   size_t offProgY = 0, progYBytes = 0;                         // ... and of the symmetric kernel's (8 channels per wave, 2x2 tile) layout
-  double symCost = 0.0;                                        // its predicted duration for the last planned launch geometry
   size_t offDec = 0; int decKp = 0, decS = 0;                  // decoded code words (qcnn_decoded.hip): conv layer with one sub-space of
                                                                // <= 4 dims (decKp > 0), FC layer with one-dim sub-spaces (decKp = -1); 0: not eligible
-  int segN = 0, segBeg[9] = {0};                               // sliding plan of the last planned launch geometry
   bool hasDmap = false;
   bool loaded = false;
-  int planKey = -1;                                            // conv: split plan of the last planned launch geometry (qk_conv_plan)
-  QkSplitPlan plan = {0, 1, 0};
+  // conv: launch plans by launch geometry and options (panels, sub-batches, split / slide / sym, LUT mode, input in place):
+  // sub-batches of unequal panel counts (3 panels over 2 streams) each keep theirs instead of evicting one another — a plan
+  // is dozens of 256-CU list schedules on the host
+  struct Plan {
+    QkSplitPlan plan = {0, 1, 0, 0.0};                         // split plan (qk_conv_plan)
+    int segN = 0, segBeg[9] = {0};                             // sliding plan (qk_conv_plan_slide)
+    double symCost = 0.0;                                      // predicted duration of the symmetric kernel (0: not eligible)
+  };
+  std::map<long long, Plan> plans;
+  int segN = 0, segBeg[9] = {0};                               // segments of the last launch when it slid (qcnn_get_layer_segments)
   int lastFrom = -1, lastZ = 1;                                // how the last launch was actually cut
 };
 
@@ -51,7 +58,7 @@ constexpr int kMaxStreams = 4;   // sub-batches (streams) of one forward
 constexpr int kSmallBatchMax = QCNN_SMALL_BATCH_MAX;  // batches up to this size run the few-image kernels (QCNN_OPT_SMALL_BATCH): beyond, a
                                    // 128-image panel is cheaper (measured: 1 / 2 / 3 / 4 images 0.58 / 0.85 / 1.15 / 1.47 ms, a panel 1.50 ms)
 constexpr int kMaxFcSplit = 32;  // workgroups along the sub-space axis of an FC layer (partial sums reduced in fixed order)
-constexpr size_t kConvPartialFloats = (size_t)64 << 20;   // 256 MB of partial sums for split conv tiles (all sub-batches)
+constexpr size_t kConvPartialFloats = (size_t)64 << 20;   // 256 MB of partial sums for split conv tiles (all sub-batches), allocated when a plan first splits
 constexpr size_t kSlack = 64 * 1024;   // bytes of slack behind every device buffer: the MFMA operand loads are
                                         // unconditional and may read a few rows past the last dim / sub-space
 
@@ -314,7 +321,7 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
         q.relu = fuseRelu ? 1 : 0; q.panels = panels; q.live = live;
         s.lastFrom = -3; s.lastZ = 1;                     // reported by qcnn_get_layer_split as (-3, 1)
         e = qk_conv_dec(q, st);
-        break;
+        if (e != hipErrorInvalidValue) break;             // (a map beyond the kernel's 32-bit byte offsets: the table kernel below)
       }
       ConvParams p;
       p.src = src; p.dst = dst;
@@ -337,39 +344,47 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
       if (e == hipErrorInvalidValue) {
         // A launch of a few hundred workgroups (one GPU's share of a sharded batch) splits the tail of its tiles over
         // several workgroups (qk_conv_plan).  MFMA builders only: the exact builder keeps the reference's summation order.
-        if (c->lutMode >= 1 && c->convPartial && (c->split || c->slide || c->sym)) {
+        if (c->lutMode >= 1 && (c->split || c->slide || c->sym)) {
           // Plan of this launch geometry (cached): tile kernel whole / with a split tail (QCNN_OPT_SPLIT; changes a cut
           // tile's summation order) / sliding kernel (QCNN_OPT_SLIDE; same order and bits as the tile kernel).
           const size_t share = kConvPartialFloats / (size_t)nsub;
-          const int key = (((panels * 8 + nsub) * 2 + (c->split ? 1 : 0)) * 4 + c->slide) * 4 + c->sym;
-          if (s.planKey != key) {
+          const long long key = ((((((long long)panels * 8 + nsub) * 2 + (c->split ? 1 : 0)) * 4 + c->slide) * 4 + c->sym) * 4 +
+                                 c->lutMode) * 2 + (inNchw ? 1 : 0);
+          auto it = s.plans.find(key);
+          if (it == s.plans.end()) {
+            LayerShape::Plan pl;
             const size_t scratch = c->split ? share : 0;            // no scratch: qk_conv_plan only prices the whole-tile launch
-            s.plan = qk_conv_plan(p, scratch);
-            s.planKey = key;
-            s.segN = 0;
-            s.symCost = (c->sym && s.progYBytes && c->lutMode == 1 && !inNchw) ? qk_conv_sym_cost(p) : 0.0;
+            pl.plan = qk_conv_plan(p, scratch);
+            pl.symCost = (c->sym && s.progYBytes && c->lutMode == 1 && !inNchw) ? qk_conv_sym_cost(p) : 0.0;
             if (c->slide && p.progS) {                // sliding variant where it is predicted to beat the (split) tile kernel
               ConvParams t = p;
-              qk_conv_plan_slide(t, c->slide >= 2 ? 1e30 : s.plan.cost);   // 2: whenever the layer is eligible (tests)
-              s.segN = t.nSeg;
-              for (int i = 0; i <= t.nSeg && i < 9; ++i) s.segBeg[i] = t.segBeg[i];
+              qk_conv_plan_slide(t, c->slide >= 2 ? 1e30 : pl.plan.cost);   // 2: whenever the layer is eligible (tests)
+              pl.segN = t.nSeg;
+              for (int i = 0; i <= t.nSeg && i < 9; ++i) pl.segBeg[i] = t.segBeg[i];
             }
+            it = s.plans.emplace(key, pl).first;
           }
+          const LayerShape::Plan& pl = it->second;
           // symmetric workgroups: 128-channel layers that neither slide nor split, when predicted at least 3 % faster
-          if (s.symCost > 0.0 && s.segN == 0 && s.plan.Z <= 1 && c->lutMode == 1 && !inNchw &&
-              (c->sym >= 2 || s.symCost < 0.97 * s.plan.cost)) {
+          if (pl.symCost > 0.0 && pl.segN == 0 && pl.plan.Z <= 1 && c->lutMode == 1 && !inNchw &&
+              (c->sym >= 2 || pl.symCost < 0.97 * pl.plan.cost)) {
             p.progS = reinterpret_cast<const uint16_t*>(c->arena + s.offProgY);
             s.lastFrom = -4; s.lastZ = 1;             // reported by qcnn_get_layer_split as (-4, 1)
             e = qk_conv_sym(p, st);
             break;
           }
-          if (s.segN > 0) {
-            p.nSeg = s.segN;
-            for (int i = 0; i <= s.segN; ++i) p.segBeg[i] = s.segBeg[i];
-            s.lastFrom = -2; s.lastZ = s.segN;       // reported by qcnn_get_layer_split as (-2, segments per column)
-          } else if (s.plan.Z > 1) {
-            p.splitFrom = s.plan.splitFrom; p.splitZ = s.plan.Z; p.partial = c->convPartial + share * sub;
-            s.lastFrom = s.plan.splitFrom; s.lastZ = s.plan.Z;
+          if (pl.segN > 0) {
+            p.nSeg = pl.segN;
+            s.segN = pl.segN;
+            for (int i = 0; i <= pl.segN; ++i) { p.segBeg[i] = pl.segBeg[i]; s.segBeg[i] = pl.segBeg[i]; }
+            s.lastFrom = -2; s.lastZ = pl.segN;      // reported by qcnn_get_layer_split as (-2, segments per column)
+          } else if (pl.plan.Z > 1) {
+            if (!c->convPartial) {                    // first split launch of this context: the scratch for partial sums
+              const hipError_t ea = hipMalloc(&c->convPartial, kConvPartialFloats * sizeof(float));
+              if (ea != hipSuccess) return fail(c, "layer %d: no scratch for split tiles: %s", l, hipGetErrorString(ea));
+            }
+            p.splitFrom = pl.plan.splitFrom; p.splitZ = pl.plan.Z; p.partial = c->convPartial + share * sub;
+            s.lastFrom = pl.plan.splitFrom; s.lastZ = pl.plan.Z;
           }
         }
         e = qk_conv_aprx(p, c->lutMode, st);
@@ -402,7 +417,9 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
         q.wdec = reinterpret_cast<const float*>(c->arena + s.offDec);
         q.D = a.h * a.w * a.c; q.Ct = b.c; q.S = s.decS;
         q.relu = fuseRelu ? 1 : 0; q.panels = panels; q.halves = 2;
-        int z = qk_fc_dec_slices(q.D, q.Ct, panels, live);
+        // k slices over workgroups change the summation order with the panel count of the launch: QCNN_OPT_SPLIT only (off =
+        // batch-size-invariant bits, as for the split conv tiles and the per-launch FC split below)
+        int z = c->split ? std::min(qk_fc_dec_slices(q.D, q.Ct, panels, live), kMaxFcSplit) : 1;
         const size_t need = (size_t)z * panels * q.Ct * QCNN_PANEL;
         const size_t poff = (size_t)kMaxFcSplit * p0 * c->fcMaxCt * QCNN_PANEL;    // every sub-batch has its own slab
         if (z > 1 && poff + need <= c->fcPartialElems) q.partial = c->fcPartial + poff; else z = 1;
@@ -719,14 +736,14 @@ int qcnn_ctx_destroy(QcnnCtx* c) {
 
 int qcnn_set_option(QcnnCtx* c, int option, int value) {
   switch (option) {
-    case QCNN_OPT_LUT_MODE: if (value < 0 || value > 3) return fail(c, "LUT mode must be 0, 1, 2 or 3"); c->lutMode = value; return 0;
+    case QCNN_OPT_LUT_MODE: if (value < 0 || value > 3) return fail(c, "LUT mode must be 0, 1, 2 or 3"); c->lutMode = value; return 0;   // (part of the plan key)
     case QCNN_OPT_KEEP_ALL: c->keepAll = value ? 1 : 0; return 0;
     case QCNN_OPT_PROFILE: c->profile = value ? 1 : 0; return 0;
     case QCNN_OPT_SMALL_BATCH: c->smallBatch = value ? 1 : 0; return 0;
-    case QCNN_OPT_SPLIT: c->split = value ? 1 : 0; for (LayerShape& ls : c->shapes) ls.planKey = -1; return 0;
+    case QCNN_OPT_SPLIT: c->split = value ? 1 : 0; return 0;
     case QCNN_OPT_DECODE: c->decode = value ? 1 : 0; return 0;
-    case QCNN_OPT_SYM: c->sym = value < 0 ? 0 : (value > 2 ? 2 : value); for (LayerShape& ls : c->shapes) ls.planKey = -1; return 0;
-    case QCNN_OPT_SLIDE: c->slide = value < 0 ? 0 : (value > 2 ? 2 : value); for (LayerShape& ls : c->shapes) ls.planKey = -1; return 0;
+    case QCNN_OPT_SYM: c->sym = value < 0 ? 0 : (value > 2 ? 2 : value); return 0;
+    case QCNN_OPT_SLIDE: c->slide = value < 0 ? 0 : (value > 2 ? 2 : value); return 0;
     case QCNN_OPT_HOST_CHUNK:
       if (value < 0) return fail(c, "host chunk must be >= 0 panels");
       c->hostChunk = value; return 0;
@@ -875,7 +892,6 @@ int qcnn_model_commit(QcnnCtx* c, int max_batch, void* dev_arena) {
     c->fcMaxCt = maxCt;
     c->fcPartialElems = (size_t)kMaxFcSplit * c->maxPanels * maxCt * QCNN_PANEL;
     if (c->fcPartialElems) HIP_TRY(c, hipMalloc(&c->fcPartial, c->fcPartialElems * sizeof(float)));
-    HIP_TRY(c, hipMalloc(&c->convPartial, kConvPartialFloats * sizeof(float)));
     if (c->firstFc >= 0 && c->shapes[c->firstFc].hasDmap)
       HIP_TRY(c, hipMalloc(&c->fcFlat, (size_t)c->maxPanels * fm_elems(c, c->firstFc) * QCNN_PANEL * sizeof(float) + kSlack));
   }

@@ -786,17 +786,18 @@ __device__ __forceinline__ void blk_load(IdxBlk<NB>& o, const char* __restrict__
     o.w[4 * i] = v.x; o.w[4 * i + 1] = v.y; o.w[4 * i + 2] = v.z; o.w[4 * i + 3] = v.w;
   }
 }
-// 16 bytes per lane from gsrc (per lane) to LDS byte ldsDst + 16 * lane (ldsDst wave-uniform); completion = vmcnt
-__device__ __forceinline__ void glds16(const char* gsrc, uint32_t ldsDst) {
+// 16 bytes per lane from row (wave-uniform: an SGPR pair) + off (per lane, 32 bits) to LDS byte ldsDst + 16 * lane (ldsDst
+// wave-uniform); completion = vmcnt.  The scalar-base form costs no 64-bit vector address arithmetic and no VGPR pair.
+__device__ __forceinline__ void glds16(const char* row, uint32_t off, uint32_t ldsDst) {
   uint32_t keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(gsrc), "s"(ldsDst) : "memory");
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(off), "s"(row), "s"(ldsDst) : "memory");
 }
 template <int BYTES>
 __device__ __forceinline__ void idx_row_to_lds(const char* __restrict__ row, uint32_t ldsDst, int lane) {
   static_assert(BYTES <= (int)IDX_BUF && BYTES % 16 == 0, "a workgroup row fits one buffer");
-  if (lane * 16 < BYTES) glds16(row + lane * 16, ldsDst);
-  if (BYTES > 1024 && lane * 16 < BYTES - 1024) glds16(row + 1024 + lane * 16, ldsDst + 1024u);
+  if (lane * 16 < BYTES) glds16(row, (uint32_t)lane * 16u, ldsDst);
+  if (BYTES > 1024 && lane * 16 < BYTES - 1024) glds16(row, (uint32_t)lane * 16u + 1024u, ldsDst + 1024u);
 }
 __device__ __forceinline__ void barrier_after_lds_dma() {
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -1112,14 +1113,17 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
     // a slot restarts from the bias every few stages: waves with few channels keep their bias values in registers, the
     // others (12 channels and more: no register to spare, but also many stages per source column) re-read them
     constexpr bool BIAS_REGS = SLIDE && CPW <= 8 && NP * CPW <= 24;
-    const float* __restrict__ biasP = p.bias + grp * Ctg + (active ? cl0 : 0);
+    // wave-uniform bases (SGPR pairs) + one 32-bit lane offset each: no per-lane 64-bit pointers in the register file
+    const float* __restrict__ biasU = p.bias + grp * Ctg + (active ? cw0 : 0);
+    const uint32_t biasLane = (uint32_t)(half * HC);
     float biasR[BIAS_REGS ? HC : 1];
     if constexpr (BIAS_REGS) {
 #pragma unroll
-      for (int j = 0; j < HC; ++j) biasR[j] = biasP[j];
+      for (int j = 0; j < HC; ++j) biasR[j] = biasU[biasLane + j];
     }
-    float* __restrict__ dstCol = p.dst + ((size_t)panel * p.Ho * p.Wo + (size_t)wo0) * p.Ct * PANEL +
-                                 (size_t)(grp * Ctg + (active ? cl0 : 0)) * PANEL + 4 * quad;
+    float* __restrict__ dstColU = p.dst + ((size_t)panel * p.Ho * p.Wo + (size_t)wo0) * p.Ct * PANEL +
+                                  (size_t)(grp * Ctg + (active ? cw0 : 0)) * PANEL;
+    const uint32_t dstLane = (uint32_t)(half * HC) * PANEL + 4u * (uint32_t)quad;
     // after the last stage of a source row: positions whose window ends with this row (or with the strip) are stored and
     // their slot restarts from the bias for the position TW rows further down
     auto column_end = [&](const StagePos& c, int live) {
@@ -1129,7 +1133,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
         if ((c.hi - xq[q] == p.knl - 1 || c.hi == hiU) && okq[q]) {
 #pragma unroll
           for (int dx = 0; dx < TH; ++dx) {
-            float* o = dstCol + ((size_t)woq[q] * p.Wo + dx) * p.Ct * PANEL;
+            float* o = dstColU + ((size_t)woq[q] * p.Wo + dx) * p.Ct * PANEL;      // uniform
             const bool colReal = wo0 + dx < p.Wo;
 #pragma unroll
             for (int j = 0; j < HC; ++j) {
@@ -1140,9 +1144,9 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
 #pragma unroll
                   for (int e = 0; e < 4; ++e) v[e] = (0.0f < v[e]) ? v[e] : 0.0f;
                 }
-                *reinterpret_cast<f32x4*>(o + j * PANEL) = v;
+                *reinterpret_cast<f32x4*>(o + dstLane + j * PANEL) = v;
               }
-              const float b = BIAS_REGS ? biasR[BIAS_REGS ? j : 0] : biasP[j];
+              const float b = BIAS_REGS ? biasR[BIAS_REGS ? j : 0] : biasU[biasLane + j];
               acc[dx * TW + q][2 * j] = f32x2{b, b}; acc[dx * TW + q][2 * j + 1] = f32x2{b, b};
             }
           }

@@ -4,6 +4,8 @@
 // include/qcnn_hip.h.
 #include "../../include/CaffeEva.h"
 
+#include <algorithm>
+
 #include "../../include/FileIO.h"
 #include "../../include/qcnn_hip.h"
 
@@ -31,7 +33,7 @@ QcnnLayerDesc toDesc(const LayerInfo& li) {
 
 CaffeEva::CaffeEva(void)
     : enblAprx(true), grp_(nullptr), ctx_(nullptr), modelReady_(false), batchSize_(1), batchCnt_(100),
-      inflight_(1), imagesDone_(0), keepAll_(false), pinned_(nullptr), pinnedCopy_(nullptr) {}
+      inflight_(1), imagesDone_(0), keepAll_(false), pinned_(nullptr), pinnedCopy_(nullptr), pinnedImages_(0) {}
 
 CaffeEva::~CaffeEva(void) {
   if (grp_ != nullptr) qcnn_group_destroy(grp_);   // owns the per-device contexts
@@ -44,10 +46,18 @@ CaffeEva::~CaffeEva(void) {
 // (no second copy, about half the transfer rate); "0": plain pageable memory (uploads are staged copies).
 void CaffeEva::pinDataset(void) {
   unpinDataset();
-  if (dataLst.GetEleCnt() <= 0) return;
+  if (dataLst.GetEleCnt() <= 0 || dataLst.GetDimCnt() != 4) return;
   const char* env = getenv("QCNN_PIN_DATASET");
   const std::string mode = (env != nullptr && *env != '\0') ? env : "copy";
-  const size_t bytes = sizeof(float) * static_cast<size_t>(dataLst.GetEleCnt());
+  // Only the images ExecForwardPass(void) will submit are pinned: QCNN_BATCHES x QCNN_BATCH of them from the start of the
+  // dataset (its window rule, src/CaffeEva.cc:170-177: when the batches cover the dataset, all of it) — an ImageNet-sized
+  // dataMatTst is neither doubled in host memory nor page-locked for the 100 images that are classified.
+  const long long dataCnt = dataLst.GetDimLen(0);
+  const long long bs = envInt("QCNN_BATCH", 1), bc = envInt("QCNN_BATCHES", 100);
+  const long long batchesInData = bs > 0 ? (dataCnt + bs - 1) / bs : 0;
+  const long long used = (bs <= 0 || bc >= batchesInData) ? dataCnt : std::min(dataCnt, bs * bc);
+  pinnedImages_ = static_cast<int>(used);
+  const size_t bytes = sizeof(float) * static_cast<size_t>(dataLst.GetDimStp(0)) * static_cast<size_t>(used);
   if (mode == "0" || mode == "off") return;
   if (mode == "register") {
     if (qcnn_host_register(dataLst.GetDataPtr(), bytes) == 0) pinned_ = dataLst.GetDataPtr();
@@ -68,6 +78,7 @@ void CaffeEva::unpinDataset(void) {
   if (pinnedCopy_ != nullptr) qcnn_host_free(pinnedCopy_);
   pinned_ = nullptr;
   pinnedCopy_ = nullptr;
+  pinnedImages_ = 0;
 }
 
 bool CaffeEva::fail(const std::string& what) {
@@ -253,7 +264,11 @@ void CaffeEva::ExecForwardPass(void) {
   if (dataLst.GetDimCnt() != 4) { fail("ExecForwardPass() before a successful LoadDataset()"); return; }
   const int dataCnt = dataLst.GetDimLen(0);
   const size_t perImg = static_cast<size_t>(dataLst.GetDimStp(0));
-  const float* images = pinnedCopy_ != nullptr ? pinnedCopy_ : dataLst.GetDataPtr();   // same values, pinned storage
+  // same values, pinned storage — for the leading pinnedImages_ images (pinDataset); a window beyond them is read from dataLst
+  auto imageAt = [&](int first, int count) -> const float* {
+    const float* base = (pinnedCopy_ != nullptr && first + count <= pinnedImages_) ? pinnedCopy_ : dataLst.GetDataPtr();
+    return base + static_cast<size_t>(first) * perImg;
+  };
   if (dataCnt < batchSize_) { fail("dataset smaller than one batch"); return; }
   lablVecPred.Create(dataCnt, kLablCntPerData, 1, 1);
   memset(lablVecPred.GetDataPtr(), 0, sizeof(uint16_t) * lablVecPred.GetEleCnt());
@@ -280,12 +295,12 @@ void CaffeEva::ExecForwardPass(void) {
     const int nb = (b0 + perChunk <= batchCnt_) ? perChunk : batchCnt_ - b0;
     bool contiguous = true;
     for (int b = 1; b < nb; ++b) contiguous = contiguous && firstOf[b0 + b] == firstOf[b0 + b - 1] + batchSize_;
-    in[k] = images + static_cast<size_t>(firstOf[b0]) * perImg;
+    in[k] = imageAt(firstOf[b0], nb * batchSize_);
     if (!contiguous) {                                   // right-aligned last window: gather the chunk
       staging[k].resize(static_cast<size_t>(nb) * batchSize_ * perImg);
       for (int b = 0; b < nb; ++b)
         memcpy(staging[k].data() + static_cast<size_t>(b) * batchSize_ * perImg,
-               images + static_cast<size_t>(firstOf[b0 + b]) * perImg, sizeof(float) * batchSize_ * perImg);
+               imageAt(firstOf[b0 + b], batchSize_), sizeof(float) * batchSize_ * perImg);
       in[k] = staging[k].data();
     }
     cnt[k] = nb * batchSize_;

@@ -852,16 +852,27 @@ def test_decoded_classifier():
     base.forward_host(imgs)
     want = base.layer_output(5, 200)
     base.close()
-    eng = make_engine(in_chw, layers, params, 200, lut=capi.LUT_MFMA, keep_all=1, decode=1)
+    eng = make_engine(in_chw, layers, params, 200, lut=capi.LUT_MFMA, keep_all=1, decode=1, split=1)
     for n in (200, 3, 1):
         prob, top5 = eng.forward_host(imgs[:n])
         got = eng.layer_output(5, n)
         assert np.abs(got - want[:n]).max() <= 2e-6 * np.abs(want).max(), n
+        assert eng.layer_split(4)[0] == -3 and (n == 200 or eng.layer_split(4)[1] > 1), n   # few images: k slices over workgroups
         m = min(n, 4)
         for l in (5, 6):
             e_inf, e_l2 = rel_err(eng.layer_output(l, m), orc.fm(l)[:m])
             assert e_inf <= TOL and e_l2 <= TOL, "n = %d fm[%d] vs oracle: %g %g" % (n, l, e_inf, e_l2)
     eng.close()
+    # QCNN_OPT_SPLIT = 0 promises batch-size-invariant bits: the decoded classifier then never cuts its k axis over
+    # workgroups (the cut depends on the panels of the launch), so an image's outputs do not depend on its batch
+    inv = make_engine(in_chw, layers, params, 200, lut=capi.LUT_MFMA, keep_all=1, decode=1, split=0)
+    inv.set_option(capi.OPT_SMALL_BATCH, 0)
+    p200, _ = inv.forward_host(imgs)
+    for n in (130, 70, 3, 1):
+        pn, _ = inv.forward_host(imgs[:n])
+        assert inv.layer_split(4) == (-3, 1)
+        assert np.array_equal(pn, p200[:n]), n
+    inv.close()
 
 
 # ---------------------------------------------------------------- symmetric workgroups (128-channel layers) ----
