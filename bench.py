@@ -254,6 +254,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=100, help="images for the CPU baseline (0 = skip)")
     ap.add_argument("--parity-images", type=int, default=8, help="images checked against the CPU reference (0 = skip)")
     ap.add_argument("--extras", type=int, default=1, help="0 = only the headline measurement")
+    ap.add_argument("--sym8", type=int, default=-1,
+                    help="QCNN_OPT_SYM8 (eight-wave symmetric workgroups): -1 = library default (planner), 0 off, 2 forced, 6 forced + staggered phases")
     ap.add_argument("--streams", type=int, default=1,
                     help="sub-batches of whole panels run concurrently on separate HIP streams (QCNN_OPT_STREAMS; the "
                          "library default is 2).  1 keeps one launch per layer, so that the per-kernel HIP-event "
@@ -310,6 +312,8 @@ def main():
     eng.set_option(capi.OPT_KEEP_ALL, 0)
     eng.set_option(capi.OPT_PROFILE, 1)
     eng.set_option(capi.OPT_STREAMS, args.streams)
+    if args.sym8 >= 0:
+        eng.set_option(capi.OPT_SYM8, args.sym8)
     shapes = {i: tuple(int(x) for x in p["ctrd"].shape) for i, p in params.items()}
     eng.configure(in_chw, layers, shapes)
     arena = torch.zeros(eng.arena_bytes(), dtype=torch.uint8, device=dev)
@@ -375,6 +379,7 @@ def main():
     segments = {i: eng.layer_segments(i) for i, l in enumerate(layers) if l["type"] == topo.CONV}   # sliding kernel, per layer
     decoded = {i for i, l in enumerate(layers) if l["type"] in (topo.CONV, topo.FCNT) and eng.layer_split(i)[0] == -3}   # decoded layers
     symmetric = {i for i, l in enumerate(layers) if l["type"] == topo.CONV and eng.layer_split(i)[0] == -4}            # k_conv_sym
+    sym8 = {i for i, l in enumerate(layers) if l["type"] == topo.CONV and eng.layer_split(i)[0] == -5}                 # k_conv_sym8
     ok = bool(torch.isfinite(prob[lo:hi]).all().item())
     images_per_step = B if (strong or world == 1) else B * world
 

@@ -106,6 +106,13 @@ enum {
                               2x2 tile per wave: fewer table builds per output position and no idle gather lane — when the
                               launch planner predicts them faster.  Bit-identical to the tile kernels; f32 MFMA mode only.
                               0 = never; 2 = whenever eligible (tests) */
+  QCNN_OPT_SYM8 = 10,      /* 1 (default): a conv layer with K = 128, complete 4- or 8-dim sub-spaces and more than 64 channels per
+                              group may run EIGHT-wave symmetric workgroups with 256 registers per wave (k_conv_sym8): twice the
+                              accumulators of the 16-wave kernels per CU, i.e. larger output tiles (384 channels x 1x2, 256 x 1x3,
+                              192 x 2x2, 128 x 2x3) and a third fewer table builds per output position — when the launch planner
+                              predicts them faster than the tile / sliding / 16-wave symmetric launch.  Bit-identical to the tile
+                              kernels; f32 MFMA mode only.  0 = never; 2 = whenever eligible (tests); + 4 = the two waves of a SIMD
+                              run their build and gather phases in opposite order (experiments) */
   QCNN_OPT_HOST_CHUNK = 6, /* panels per chunk (default 2) of a qcnn_forward_host batch of at least two chunks: every chunk is
                               uploaded on a copy stream and its layers start when it has arrived, so the upload of chunk
                               k + 1 runs under the layers of chunk k; all chunks fill the same whole-batch feature maps.
@@ -206,7 +213,7 @@ int qcnn_run_layer(QcnnCtx* ctx, int layer, const float* in_host, int n, float* 
  * was split), *tiles_unsplit = tiles of the heaviest-first order that ran whole (-1 when nothing was split); sliding
  * kernel (QCNN_OPT_SLIDE): *tiles_unsplit = -2, *slices = segments per output column; a conv or FC layer that ran through
  * its decoded code words (QCNN_OPT_DECODE): *tiles_unsplit = -3, *slices = 1 (FC: slices of the input axis over workgroups);
- * symmetric workgroups (QCNN_OPT_SYM): *tiles_unsplit = -4. */
+ * symmetric workgroups (QCNN_OPT_SYM): *tiles_unsplit = -4; eight-wave symmetric workgroups (QCNN_OPT_SYM8): -5. */
 int qcnn_get_layer_split(QcnnCtx* ctx, int layer, int* tiles_unsplit, int* slices);
 /* Sliding kernel: the row segments [seg_beg9[i], seg_beg9[i + 1]) every output column of the last launch of `layer` was
  * cut into (*n_seg of them; 0 when the layer ran the tile kernel). */

@@ -25,7 +25,7 @@ BIN_DIR = os.path.join(ROOT, "build", "bin")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
-HIP_SOURCES = ["qcnn_kernels.hip", "qcnn_glue.hip", "qcnn_small.hip", "qcnn_dense.hip", "qcnn_decoded.hip", "qcnn_engine.hip", "qcnn_group.hip"]
+HIP_SOURCES = ["qcnn_kernels.hip", "qcnn_sym8.hip", "qcnn_glue.hip", "qcnn_small.hip", "qcnn_dense.hip", "qcnn_decoded.hip", "qcnn_engine.hip", "qcnn_group.hip"]
 HIP_FLAGS = ["-O3", "-std=c++17", "--offload-arch=" + ARCH, "-fPIC", "-ffp-contract=off", "-Wall",
              "-Wno-unused-function"]
 
@@ -45,7 +45,7 @@ def _run(cmd, **kw):
 def build_hip(force: bool = False, extra_flags=()) -> str:
     """Compile the HIP extension for gfx950 (hipcc cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
-    deps = srcs + [os.path.join(CSRC, "qcnn_kernels.h"), os.path.join(ROOT, "include", "qcnn_hip.h")]
+    deps = srcs + [os.path.join(CSRC, "qcnn_kernels.h"), os.path.join(CSRC, "qcnn_dev.h"), os.path.join(ROOT, "include", "qcnn_hip.h")]
     if force or _newer(HIP_SO, deps):
         objs = []
         for s in srcs:

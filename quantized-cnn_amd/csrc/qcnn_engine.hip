@@ -34,6 +34,7 @@ struct LayerShape {
   size_t offProg = 0, progBytes = 0;                           // conv with K = 128: offsets in consumption order (QkProgram)
   size_t offProgS = 0, progSBytes = 0;                         // ... and in the order of the sliding variant, where it applies
   size_t offProgY = 0, progYBytes = 0;                         // ... and of the symmetric kernel's (8 channels per wave, 2x2 tile) layout
+  size_t offProg8 = 0, prog8Bytes = 0;                         // ... and of the eight-wave symmetric kernel's layout (Qk8Config)
   size_t offDec = 0; int decKp = 0, decS = 0;                  // decoded code words (qcnn_decoded.hip): conv layer with one sub-space of
                                                                // <= 4 dims (decKp > 0), FC layer with one-dim sub-spaces (decKp = -1); 0: not eligible
   bool hasDmap = false;
@@ -44,7 +45,9 @@ struct LayerShape {
   struct Plan {
     QkSplitPlan plan = {0, 1, 0, 0.0};                         // split plan (qk_conv_plan)
     int segN = 0, segBeg[9] = {0};                             // sliding plan (qk_conv_plan_slide)
+    double slideCost = 0.0;                                    // ... and its predicted duration
     double symCost = 0.0;                                      // predicted duration of the symmetric kernel (0: not eligible)
+    double sym8Cost = 0.0;                                     // ... of the eight-wave symmetric kernel
   };
   std::map<long long, Plan> plans;
   int segN = 0, segBeg[9] = {0};                               // segments of the last launch when it slid (qcnn_get_layer_segments)
@@ -59,6 +62,7 @@ constexpr int kSmallBatchMax = QCNN_SMALL_BATCH_MAX;  // batches up to this size
                                    // 128-image panel is cheaper (measured: 1 / 2 / 3 / 4 images 0.58 / 0.85 / 1.15 / 1.47 ms, a panel 1.50 ms)
 constexpr int kMaxFcSplit = 32;  // workgroups along the sub-space axis of an FC layer (partial sums reduced in fixed order)
 constexpr size_t kConvPartialFloats = (size_t)64 << 20;   // 256 MB of partial sums for split conv tiles (all sub-batches), allocated when a plan first splits
+constexpr double kSym8StageFactor = 1.25;   // what a stage of k_conv_sym8 costs against a stage of the tile kernel (it serves twice the look-ups)
 constexpr size_t kSlack = 64 * 1024;   // bytes of slack behind every device buffer: the MFMA operand loads are
                                         // unconditional and may read a few rows past the last dim / sub-space
 
@@ -73,6 +77,7 @@ struct QcnnCtx {
   int nStreams = 2;                  // QCNN_OPT_STREAMS: sub-batches of whole panels run concurrently
   int smallBatch = 1;                // QCNN_OPT_SMALL_BATCH: few-image kernels for batches <= kSmallBatchMax
   int hostChunk = 2;                 // QCNN_OPT_HOST_CHUNK: panels per chunk of a large qcnn_forward_host batch (0: one launch)
+  int sym8 = 1;                      // QCNN_OPT_SYM8: eight-wave symmetric workgroups where predicted faster (2: whenever eligible; +4: staggered phases)
   int sym = 1;                       // QCNN_OPT_SYM: symmetric workgroups for 128-channel layers where predicted faster (2: whenever eligible)
   int decode = 1;                    // QCNN_OPT_DECODE: one-sub-space conv layers through their decoded code words (MFMA builders only)
   int slide = 1;                     // QCNN_OPT_SLIDE: sliding-window conv kernels where they pay (MFMA builders only)
@@ -196,6 +201,12 @@ int plan_arena(QcnnCtx* c) {
       const QkProgram py = qk_conv_program(qk_make_slots(Ct / d.grpCnt, d.grpCnt, 8), d.knlSiz, d.stride);
       s.progYBytes = (size_t)py.rfH * py.rfW * s.M * py.rowU16 * sizeof(uint16_t);
       s.offProgY = off; off = align_up(off + s.progYBytes + QCNN_ROWS_PAD, 256);
+    }
+    s.prog8Bytes = 0;
+    if (d.type == QCNN_CONV) {
+      const Qk8Config c8 = qk_conv_sym8_config(c->dims[l].c, d.grpCnt, Ct, s.M, s.Cs, s.K);
+      s.prog8Bytes = qk_conv_sym8_program_bytes(c8, d.grpCnt, d.knlSiz, d.stride, s.M);
+      if (s.prog8Bytes) { s.offProg8 = off; off = align_up(off + s.prog8Bytes + QCNN_ROWS_PAD, 256); }
     }
     s.decKp = 0;
     s.hasDmap = (d.type == QCNN_FCNT && l == c->firstFc && c->dims[l].h * c->dims[l].w > 1);
@@ -344,27 +355,41 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
       if (e == hipErrorInvalidValue) {
         // A launch of a few hundred workgroups (one GPU's share of a sharded batch) splits the tail of its tiles over
         // several workgroups (qk_conv_plan).  MFMA builders only: the exact builder keeps the reference's summation order.
-        if (c->lutMode >= 1 && (c->split || c->slide || c->sym)) {
+        if (c->lutMode >= 1 && (c->split || c->slide || c->sym || c->sym8)) {
           // Plan of this launch geometry (cached): tile kernel whole / with a split tail (QCNN_OPT_SPLIT; changes a cut
           // tile's summation order) / sliding kernel (QCNN_OPT_SLIDE; same order and bits as the tile kernel).
           const size_t share = kConvPartialFloats / (size_t)nsub;
-          const long long key = ((((((long long)panels * 8 + nsub) * 2 + (c->split ? 1 : 0)) * 4 + c->slide) * 4 + c->sym) * 4 +
-                                 c->lutMode) * 2 + (inNchw ? 1 : 0);
+          const long long key = (((((((long long)panels * 8 + nsub) * 2 + (c->split ? 1 : 0)) * 4 + c->slide) * 4 + c->sym) * 4 +
+                                  c->lutMode) * 2 + (inNchw ? 1 : 0)) * 8 + (c->sym8 & 7);
           auto it = s.plans.find(key);
           if (it == s.plans.end()) {
             LayerShape::Plan pl;
             const size_t scratch = c->split ? share : 0;            // no scratch: qk_conv_plan only prices the whole-tile launch
             pl.plan = qk_conv_plan(p, scratch);
             pl.symCost = (c->sym && s.progYBytes && c->lutMode == 1 && !inNchw) ? qk_conv_sym_cost(p) : 0.0;
+            pl.sym8Cost = ((c->sym8 & 3) && s.prog8Bytes && c->lutMode == 1 && !inNchw)
+                              ? qk_conv_sym8_cost(p, qk_conv_sym8_config(p.Cin, p.grp, p.Ct, p.M, p.Cs, p.K), kSym8StageFactor) : 0.0;
             if (c->slide && p.progS) {                // sliding variant where it is predicted to beat the (split) tile kernel
               ConvParams t = p;
-              qk_conv_plan_slide(t, c->slide >= 2 ? 1e30 : pl.plan.cost);   // 2: whenever the layer is eligible (tests)
+              pl.slideCost = qk_conv_plan_slide(t, c->slide >= 2 ? 1e30 : pl.plan.cost);   // 2: whenever the layer is eligible (tests)
               pl.segN = t.nSeg;
               for (int i = 0; i <= t.nSeg && i < 9; ++i) pl.segBeg[i] = t.segBeg[i];
             }
             it = s.plans.emplace(key, pl).first;
           }
           const LayerShape::Plan& pl = it->second;
+          // eight-wave symmetric workgroups: when forced, or predicted at least 3 % faster than every other plan of the launch
+          if (pl.sym8Cost > 0.0 && c->lutMode == 1 && !inNchw && ((c->sym8 & 3) >= 2 || (c->sym < 2 && c->slide < 2))) {
+            double other = pl.plan.cost;                           // tile kernel, whole or split (in stage-times)
+            if (pl.symCost > 0.0 && pl.symCost < other) other = pl.symCost;
+            if (pl.segN > 0 && pl.slideCost > 0.0 && pl.slideCost < other) other = pl.slideCost;
+            if ((c->sym8 & 3) >= 2 || pl.sym8Cost < 0.97 * other) {
+              p.progS = reinterpret_cast<const uint16_t*>(c->arena + s.offProg8);
+              s.lastFrom = -5; s.lastZ = 1;             // reported by qcnn_get_layer_split as (-5, 1)
+              e = qk_conv_sym8(p, (c->sym8 & 4) ? 1 : 0, st);
+              break;
+            }
+          }
           // symmetric workgroups: 128-channel layers that neither slide nor split, when predicted at least 3 % faster
           if (pl.symCost > 0.0 && pl.segN == 0 && pl.plan.Z <= 1 && c->lutMode == 1 && !inNchw &&
               (c->sym >= 2 || pl.symCost < 0.97 * pl.plan.cost)) {
@@ -742,6 +767,7 @@ int qcnn_set_option(QcnnCtx* c, int option, int value) {
     case QCNN_OPT_SMALL_BATCH: c->smallBatch = value ? 1 : 0; return 0;
     case QCNN_OPT_SPLIT: c->split = value ? 1 : 0; return 0;
     case QCNN_OPT_DECODE: c->decode = value ? 1 : 0; return 0;
+    case QCNN_OPT_SYM8: c->sym8 = value < 0 ? 0 : (value & 7); return 0;
     case QCNN_OPT_SYM: c->sym = value < 0 ? 0 : (value > 2 ? 2 : value); return 0;
     case QCNN_OPT_SLIDE: c->slide = value < 0 ? 0 : (value > 2 ? 2 : value); return 0;
     case QCNN_OPT_HOST_CHUNK:
@@ -972,6 +998,12 @@ hipError_t build_program(QcnnCtx* c, int layer, const QkSlots& sl) {
     e = qk_decode_weights(reinterpret_cast<const uint8_t*>(c->arena + s.offAsmt), reinterpret_cast<const float*>(c->arena + s.offCtrd),
                           reinterpret_cast<float*>(c->arena + s.offDec), sl, d.knlSiz, c->dims[layer].c, s.K,
                           c->dims[layer + 1].c, s.decKp, s.decS, c->stream);
+  if (e == hipSuccess && s.prog8Bytes) {       // eight-wave symmetric kernel: its own layout of the same table
+    const int Ct = c->dims[layer + 1].c;
+    e = qk_build_program8(reinterpret_cast<const uint8_t*>(c->arena + s.offAsmt), reinterpret_cast<uint16_t*>(c->arena + s.offProg8), sl,
+                          qk_conv_sym8_config(c->dims[layer].c, d.grpCnt, Ct, s.M, s.Cs, s.K), Ct / d.grpCnt, d.grpCnt, d.knlSiz,
+                          d.stride, s.M, c->stream);
+  }
   if (e == hipSuccess && s.progYBytes) {       // symmetric kernel: the (8 channels per wave, 2x2 tile) layout of the same table
     const QkSlots s8 = qk_make_slots(sl.C, sl.groups, 8);
     e = qk_build_program(reinterpret_cast<const uint8_t*>(c->arena + s.offAsmt), reinterpret_cast<uint16_t*>(c->arena + s.offProgY),

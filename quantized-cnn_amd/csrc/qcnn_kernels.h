@@ -204,14 +204,27 @@ struct QkSplitPlan {
 // what the caller can offer for partial sums
 QkSplitPlan qk_conv_plan(const ConvParams& p, size_t scratchFloats);
 // Segments of the sliding variant for a launch over p.panels panels: fills p.nSeg / p.segBeg when sliding is predicted to
-// beat `tileCost` (the list-scheduled stage-times of the tile kernel, QkSplitPlan::cost), else leaves nSeg = 0
-void qk_conv_plan_slide(ConvParams& p, double tileCost);
+// beat `tileCost` (the list-scheduled stage-times of the tile kernel, QkSplitPlan::cost), else leaves nSeg = 0; returns the
+// predicted duration of the chosen sliding launch in stage-times (0: none chosen)
+double qk_conv_plan_slide(ConvParams& p, double tileCost);
 // Symmetric workgroups (k_conv_sym: all 16 waves build and gather, 8 channels x a 2x2 tile per wave) for layers with exactly
 // 128 channels per group: eligibility, predicted duration in stage-times, launch (p.progS = the program table of the
 // (8 channels per wave, 2x2 tile) layout: qk_make_slots(128, groups, 8) / qk_conv_program)
 bool qk_conv_sym_shape(int Cin, int grp, int Ct, int M, int Cs, int K);
 double qk_conv_sym_cost(const ConvParams& p);
 hipError_t qk_conv_sym(const ConvParams& p, hipStream_t st);
+
+// Eight-wave symmetric workgroups with 256 registers per wave (qcnn_sym8.hip): all 8 waves build and gather, cpw channels x
+// a th x tw tile per wave (cpw * th * tw = 96 = 192 accumulator registers), `chunks` workgroups along the channel axis.
+// cpw = 0: the layer is not eligible.  Program table of this layout: [rfH][rfW][M][groups * chunks][8 waves][2 halves]
+// [position][cpw / 2] uint16 (ConvParams::progS when the kernel is launched).
+struct Qk8Config { int cpw, th, tw, chunks; };
+Qk8Config qk_conv_sym8_config(int Cin, int grp, int Ct, int M, int Cs, int K);
+size_t qk_conv_sym8_program_bytes(const Qk8Config& cf, int groups, int knl, int stride, int M);
+hipError_t qk_build_program8(const uint8_t* rows, uint16_t* prog, const QkSlots& src, const Qk8Config& cf, int Ctg, int groups,
+                             int knl, int stride, int M, hipStream_t st);
+double qk_conv_sym8_cost(const ConvParams& p, const Qk8Config& cf, double stageFactor);
+hipError_t qk_conv_sym8(const ConvParams& p, int stagger, hipStream_t st);
 
 struct FcParams {
   float* partial;        // [msplit][panels][Ct][128] scratch for split-M partial sums (msplit > 1)

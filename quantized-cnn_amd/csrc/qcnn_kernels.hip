@@ -24,6 +24,7 @@
 // "program" table whose row for a stage is DMA-ed into LDS by one wave (QkProgram), the others straight from the
 // plain table through the vector memory path.
 #include "qcnn_kernels.h"
+#include "qcnn_dev.h"
 
 #include <float.h>
 #include <stdio.h>
@@ -36,19 +37,13 @@
 #include <utility>
 #include <vector>
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int PANEL = QCNN_PANEL;              // images per panel
 constexpr int NW = 16;                         // waves per workgroup of the two hot kernels (4 per SIMD)
 constexpr int NBW = 4;                         // builder waves (one per SIMD) — MFMA + LDS writes
 constexpr int NGW = QCNN_GATHER_WAVES;         // gather waves — LDS reads + packed adds
-constexpr int TILEB = QCNN_TILE_BYTES;         // LDS bytes of one image tile of a stage
 constexpr int STAGE_ROWS = QCNN_STAGE_ROWS;
-constexpr int STAGE_BYTES = QCNN_STAGE_BYTES;  // 64 KB; two stages = 128 KB of the 160 KB LDS
-constexpr int XROWB = PANEL * 4;               // bytes of one activation row in HBM
 // s_setprio of the two wave roles.  Measured (profiles/r2_*/variants.log): any setting with the gather waves
 // ABOVE the builders costs 6 % (the builder's store stream is the pole of most stages); equal priorities and
 // builder-above-gather measure the same.
@@ -60,14 +55,6 @@ constexpr int XROWB = PANEL * 4;               // bytes of one activation row in
 #endif
 static_assert(NW == NBW + NGW, "wave roles");
 
-__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
-
-// Workgroup barrier WITHOUT the implicit "wait for everything" of __syncthreads(): the builder waves
-// wait for their LDS writes only (their operand prefetch of the stage after next stays in flight), the
-// gather waves wait for nothing (their look-ups were consumed by the adds; their index prefetch stays
-// in flight).  The "memory" clobber keeps the compiler from moving LDS accesses across it.
-__device__ __forceinline__ void barrier_after_lds_writes() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-__device__ __forceinline__ void barrier_plain() { asm volatile("s_barrier" ::: "memory"); }
 
 #ifdef QCNN_TRACE
 // Debug build only (scripts/trace_stage.py): workgroup `qcnn_trace_block` records, for every wave and the first
@@ -166,16 +153,6 @@ __device__ __forceinline__ Idx<DW> expand_idx(const IdxB<idx_bytes_dwords(DW)>& 
   return o;
 }
 
-#define Q_AD(a, w, sel) "v_xor_b32_sdwa " a ", %[" w "], %[b] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" sel " src1_sel:DWORD\n\t"
-#define Q_RD(v, a) "ds_read_b128 " v ", " a "\n\t"
-#define Q_ACC(n, c0, c1, lo, hi) \
-  "s_waitcnt lgkmcnt(" n ")\n\tv_pk_add_f32 %[" c0 "], " lo ", %[" c0 "]\n\tv_pk_add_f32 %[" c1 "], " hi ", %[" c1 "]\n\t"
-#define Q_SKIP "s_cmp_eq_u32 %[ok], 0\n\ts_cbranch_scc1 .Lqskip%=\n\t"
-#define Q_CLOB8 "scc", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107",     \
-                "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120",    \
-                "v121", "v122", "v123", "v124", "v125", "v126", "v127"
-#define Q_CLOB4 "scc", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123",   \
-                "v124", "v125", "v126", "v127"
 
 // eight reads = 16 look-ups; acc[2j], acc[2j+1] = the four images of channel j.  The address of a read lives in the
 // first register of its own destination quad (the address is consumed at issue).
@@ -356,8 +333,6 @@ __device__ __forceinline__ XAddr xaddr_nchw(int bw, int lane, int img0, int n, u
   return a;
 }
 
-// LDS slot of a stage row (device copy of qcnn_row_slot)
-__device__ __forceinline__ int row_slot(int r) { return (r & 0x70) | ((r & 3) << 2) | ((r >> 2) & 3); }
 
 // exact: y = ((0 + x0*c0) + x1*c1) + ...  with separately rounded product and sum, the order of the
 // reference's saxpy chain (src/CaffeEva.cc:1284-1289, include/BlasWrapper.h:164-184).  Any K <= 128.
@@ -442,36 +417,6 @@ __device__ __forceinline__ void mfma_load(MfmaOps<KT, KS>& o, const char* __rest
 
 __device__ __forceinline__ f32x4 round_f16(f32x4 v) {
   return f32x4{(float)(_Float16)v[0], (float)(_Float16)v[1], (float)(_Float16)v[2], (float)(_Float16)v[3]};
-}
-
-// Result tile (image tile `it` of this wave, row tile I) -> LDS: element e of the four result registers goes
-// to slots 16I + 4e .. 4e+3 of the tile, 256 contiguous bytes, by ONE ds_write_addtid_b32 (address = M0[15:0] +
-// 16-bit offset + 4 * lane: no address register, half the LDS-path cycles of ds_write_b32).  The position of a
-// slot inside its aligned group of four is XOR-ed with (tile >> 1) (bank spreading for the readers, see
-// qcnn_kernels.h); both tiles of builder wave bw have tile >> 1 == bw, and the wave fetched its code-book rows
-// pre-swizzled (mfma_load), so lane group q already holds the rows that belong at position q.  M0 holds the
-// full byte address of the tile (measured on gfx950: all of M0 is added, not 16 bits of it); an SALU write of
-// M0 needs one wait state before an add-TID LDS instruction reads it (without the s_nop the store uses the
-// previous M0: scripts/ubench/addtid_probe.hip).
-#define QCNN_WR2(ea, eb, oa, ob)                                                                                   \
-  asm volatile("s_mov_b32 m0, %[m]\n\ts_nop 0\n\tds_write_addtid_b32 %[" ea "] offset:%[" oa "]\n\t"              \
-               "ds_write_addtid_b32 %[" eb "] offset:%[" ob "]"                                                      \
-               :: [m] "s"(m0v), [e0] "v"(v[0]), [e1] "v"(v[1]), [e2] "v"(v[2]), [e3] "v"(v[3]),                      \
-                  [o0] "n"(I * 1024), [o1] "n"(I * 1024 + 256), [o2] "n"(I * 1024 + 512), [o3] "n"(I * 1024 + 768)   \
-               : "m0", "memory")
-template <int I>
-__device__ __forceinline__ void store_tile_lo(const f32x4& v, uint32_t m0v) { QCNN_WR2("e0", "e1", "o0", "o1"); }
-template <int I>
-__device__ __forceinline__ void store_tile_hi(const f32x4& v, uint32_t m0v) { QCNN_WR2("e2", "e3", "o2", "o3"); }
-// all four registers of a tile behind ONE M0 write (4-dim first layers: half the scalar instructions of the split form)
-template <int I>
-__device__ __forceinline__ void store_tile_all(const f32x4& v, uint32_t m0v) {
-  asm volatile("s_mov_b32 m0, %[m]\n\ts_nop 0\n\tds_write_addtid_b32 %[e0] offset:%[o0]\n\t"
-               "ds_write_addtid_b32 %[e1] offset:%[o1]\n\tds_write_addtid_b32 %[e2] offset:%[o2]\n\t"
-               "ds_write_addtid_b32 %[e3] offset:%[o3]"
-               :: [m] "s"(m0v), [e0] "v"(v[0]), [e1] "v"(v[1]), [e2] "v"(v[2]), [e3] "v"(v[3]),
-                  [o0] "n"(I * 1024), [o1] "n"(I * 1024 + 256), [o2] "n"(I * 1024 + 512), [o3] "n"(I * 1024 + 768)
-               : "m0", "memory");
 }
 
 // Multiply the stage `o` was loaded for (m0, mEnd, D, Cs) out into stage buffer BUF.  The 16 tiles of the wave
@@ -674,51 +619,6 @@ __device__ __forceinline__ void bf_store(BfSet& o, int bw) {
 // TH*TW x CPW float2 accumulators.  KT = K/16 selects the MFMA builder, KT = 0 the exact builder (any
 // K <= 128).
 // ------------------------------------------------------------------------------------------------
-struct ConvGeom {
-  int W, Cin, knl, M, MG, G, wiL, wiU;
-  int slide, hiL, hiU;  // slide: the workgroup sweeps a strip of source rows under a segment of one output column (k_conv_aprx<.., SLIDE>)
-  int period;           // slide: slots * stride (the slot -> tap-column map repeats with it)
-  uint32_t pixStride;   // bytes from one source pixel to the next: Cin * 512 (panels) or 4 (NCHW input read in place)
-  uint32_t rowStride;   // bytes of one (tap, sub-space) row of the assignment table
-};
-// Workgroups are dispatched in linear order, so the tiles are numbered heaviest first: interior tiles
-// (full receptive field = most stages), then the four edges, then the corners.  With a few workgroups per
-// CU the last dispatch round is then made of the short border tiles (longest-processing-time-first).
-__host__ __device__ __forceinline__ void tile_of_rank(int r, int tilesY, int tilesX, int& ty, int& tx) {
-  if (tilesY < 3 || tilesX < 3) { ty = r / tilesX; tx = r % tilesX; return; }
-  const int iy = tilesY - 2, ix = tilesX - 2;
-  if (r < iy * ix) { ty = 1 + r / ix; tx = 1 + r % ix; return; }
-  r -= iy * ix;
-  if (r < ix) { ty = 0; tx = 1 + r; return; }
-  r -= ix;
-  if (r < ix) { ty = tilesY - 1; tx = 1 + r; return; }
-  r -= ix;
-  if (r < iy) { ty = 1 + r; tx = 0; return; }
-  r -= iy;
-  if (r < iy) { ty = 1 + r; tx = tilesX - 1; return; }
-  r -= iy;
-  ty = (r >> 1) ? tilesY - 1 : 0;
-  tx = (r & 1) ? tilesX - 1 : 0;
-}
-struct StagePos {
-  int hi, wi, mg;
-  int ph;               // sliding variant: source row modulo the slot period (ConvGeom::period); else unused
-};
-__device__ __forceinline__ StagePos next_pos(const StagePos& c, const ConvGeom& g) {
-  StagePos n = c;
-  if (++n.mg == g.MG) {
-    n.mg = 0;
-    if (++n.wi > g.wiU) {
-      n.wi = g.wiL; ++n.hi;
-      if (g.slide && ++n.ph == g.period) n.ph = 0;
-    }
-  }
-  return n;
-}
-__device__ __forceinline__ uint32_t pixel_off(const StagePos& c, const ConvGeom& g) {
-  return (uint32_t)(c.hi * g.W + c.wi) * g.pixStride;
-}
-
 // offsets of the first sub-space of stage c for every position of the tile (taps that do not exist are
 // clamped to an existing one: the load is harmless, the gather skips them)
 template <int TH, int TW, int CPW>
@@ -771,42 +671,6 @@ __device__ __forceinline__ void conv_gather(f32x2 (&acc)[TH * TW][CPW],
 // gathers the current one.  Measured before the change: the per-position table reads and their address arithmetic
 // kept a gather wave busy for 565-1270 cycles per stage (profiles/r2_v7/trace); dropping them altogether (wrong
 // results, timing only) was worth 11 % of the whole forward pass.
-constexpr uint32_t IDX_LDS = 2u * STAGE_BYTES;     // two row buffers behind the two LUT stages
-constexpr uint32_t IDX_BUF = 2048u;
-template <int NB>
-struct IdxBlk {
-  uint32_t w[NB];
-};
-template <int NB>
-__device__ __forceinline__ void blk_load(IdxBlk<NB>& o, const char* __restrict__ src) {
-  const uint4* __restrict__ q = reinterpret_cast<const uint4*>(__builtin_assume_aligned(src, 16));
-#pragma unroll
-  for (int i = 0; i < NB / 4; ++i) {
-    const uint4 v = q[i];
-    o.w[4 * i] = v.x; o.w[4 * i + 1] = v.y; o.w[4 * i + 2] = v.z; o.w[4 * i + 3] = v.w;
-  }
-}
-// 16 bytes per lane from row (wave-uniform: an SGPR pair) + off (per lane, 32 bits) to LDS byte ldsDst + 16 * lane (ldsDst
-// wave-uniform); completion = vmcnt.  The scalar-base form costs no 64-bit vector address arithmetic and no VGPR pair.
-__device__ __forceinline__ void glds16(const char* row, uint32_t off, uint32_t ldsDst) {
-  uint32_t keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(off), "s"(row), "s"(ldsDst) : "memory");
-}
-template <int BYTES>
-__device__ __forceinline__ void idx_row_to_lds(const char* __restrict__ row, uint32_t ldsDst, int lane) {
-  static_assert(BYTES <= (int)IDX_BUF && BYTES % 16 == 0, "a workgroup row fits one buffer");
-  if (lane * 16 < BYTES) glds16(row, (uint32_t)lane * 16u, ldsDst);
-  if (BYTES > 1024 && lane * 16 < BYTES - 1024) glds16(row, (uint32_t)lane * 16u + 1024u, ldsDst + 1024u);
-}
-__device__ __forceinline__ void barrier_after_lds_dma() {
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
-// 1 when 0 <= d < n, else 0 — in integer arithmetic only: a comparison would make hipcc carry the (wave-uniform)
-// result as a lane mask and turn it into the asm blocks' scalar operand through v_cndmask + v_readfirstlane, once per
-// position and stage (measured: the validity logic of the four positions of conv1 alone cost 30 % of the layer)
-__device__ __forceinline__ int in_range(int d, int n) { return (int)(~(uint32_t)(d | (n - 1 - d)) >> 31); }
 
 template <int TH, int TW, int CPW, int NB>
 __device__ __forceinline__ void conv_gather_prog(f32x2 (&acc)[TH * TW][CPW], const IdxBlk<NB>& blk, const StagePos& c,
@@ -1618,27 +1482,6 @@ namespace {
 #endif
 
 
-// hipFuncAttributeMaxDynamicSharedMemorySize has to be raised once per kernel and DEVICE before the 128 KB launch:
-// remember (kernel, device) pairs instead of asking the runtime on every launch.
-hipError_t allow_big_lds(const void* kern, int bytes) {
-  struct Seen { const void* k; std::atomic<unsigned long long> devMask; };
-  static Seen seen[256];
-  static std::atomic<int> used{0};
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  const unsigned long long bit = 1ull << (dev & 63);
-  const int n = used.load(std::memory_order_acquire);
-  for (int i = 0; i < n; ++i)
-    if (seen[i].k == kern && (seen[i].devMask.load(std::memory_order_relaxed) & bit)) return hipSuccess;
-  const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-  if (e != hipSuccess) return e;
-  for (int i = 0; i < n; ++i)
-    if (seen[i].k == kern) { seen[i].devMask.fetch_or(bit); return hipSuccess; }
-  const int slot = used.fetch_add(1);
-  if (slot < 256) { seen[slot].devMask.store(bit); seen[slot].k = kern; }   // a racing duplicate only costs a repeated call
-  return hipSuccess;
-}
-
 // rows (plain table of row slots, [kh][kw][M][rowStride]) -> program table of pre-scaled offsets ([ry][rx][M][rowU16], QkProgram): one thread per entry
 __global__ __launch_bounds__(256) void k_build_program(const uint8_t* __restrict__ rows, uint16_t* __restrict__ prog,
                                                        QkSlots src, QkSlots sl, QkProgram pg, int knl, int stride, int M, size_t n,
@@ -1973,12 +1816,12 @@ QkSplitPlan qk_conv_plan(const ConvParams& p, size_t scratchFloats) {
 // it re-builds knl - stride rows of its upper neighbour's strip: few, long segments build the least, but a launch of
 // columns x segments x groups x panels workgroups must also fill 256 CUs evenly.  Candidates: 1 .. 4 equal segments and
 // "one long + one short" cuts; list-scheduled (longest first) like qk_conv_plan; taken when it beats the tile kernel.
-void qk_conv_plan_slide(ConvParams& p, double tileCost) {
+double qk_conv_plan_slide(ConvParams& p, double tileCost) {
   p.nSeg = 0;
   const int Ctg = p.Ct / p.grp;
   const QkSlide sc = qk_slide_config(Ctg, p.grp, p.knl, p.stride);
   const int ns = sc.ns;
-  if (ns == 0 || p.K != 128 || p.progS == nullptr || p.Ho < 2 * ns) return;
+  if (ns == 0 || p.K != 128 || p.progS == nullptr || p.Ho < 2 * ns) return 0.0;
   const int ny = sc.sl.chunks * p.grp;               // every channel chunk builds the strip's stages again
   const int G = qcnn_stage_group(p.K), MG = (p.M + G - 1) / G;
   const double kFixed = 12.0;
@@ -1994,7 +1837,7 @@ void qk_conv_plan_slide(ConvParams& p, double tileCost) {
   // AlexNet conv1), and every source row ends with the store + restart of a slot.  Measured: AlexNet conv1 (11 stages per column) -10 %, conv5 (72) -15 %,
   // VGG-16 conv1_2 (24) -12 %, its 128-channel layers (24 / 48) -25 %, but conv1_1 (3 stages per column: one sub-space,
   // three rows) +47 % — a column must hold enough stages to carry its restart.
-  if (std::min(p.knl + (sc.nc - 1) * p.stride, p.W) * MG < 6 && tileCost < 1e29) return;      // (forced mode, tests: slides anyway)
+  if (std::min(p.knl + (sc.nc - 1) * p.stride, p.W) * MG < 6 && tileCost < 1e29) return 0.0;      // (forced mode, tests: slides anyway)
   auto segCost = [&](int wo, int a, int b) {
     const int rows = std::min(p.H - 1, (b - 1) * p.stride - p.pad + p.knl - 1) - std::max(0, a * p.stride - p.pad) + 1;
     return segStages(wo, a, b) + 0.3 * std::max(rows, 0);
@@ -2058,6 +1901,7 @@ void qk_conv_plan_slide(ConvParams& p, double tileCost) {
       for (size_t i = 0; i < b.size(); ++i) p.segBeg[i] = b[i];
     }
   }
+  return p.nSeg > 0 ? best : 0.0;
 }
 
 int qk_fc_channels_per_block(int Ct) { return NGW * qk_fc_slots(Ct).cpw; }

@@ -1,0 +1,460 @@
+// qcnn_sym8.hip — k_conv_sym8: the conv table kernel (GetInPdMat src/CaffeEva.cc:1261-1296 fused with
+// CalcFeatMap_ConvAprx :760-868) as an EIGHT-wave symmetric workgroup with 256 registers per wave.
+//
+// Why.  A workgroup's accumulators — 128 images x (position, channel) pairs in registers — bound its output tile, and the
+// tile's receptive field is what it must build tables for: with 16 waves x 128 registers (k_conv_aprx: 12 gather waves x
+// 64 accumulator registers = 384 pairs; k_conv_sym: 16 x 64 = 512) a 384-channel 3x3 layer gets ONE position per
+// workgroup and builds every source pixel's tables 9 times (AlexNet conv3: 8.1 after clipping), a 192-channel one two
+// positions (conv4: 5.5).  The register file of a CU is the same 512 KB however it is cut: EIGHT waves of 256 registers,
+// every wave building AND gathering, spend 192 of them on accumulators — 8 x 96 = 768 pairs, twice k_conv_aprx's — because
+// the per-wave overhead (look-up temporaries, operands, offsets) is paid 8 times instead of 16 and no wave idles in a
+// builder role.  Tiles: 384 channels x 1x2 (6 builds per position instead of 9), 256 x 1x3 (5 instead of 9), 192 x 2x2
+// (4 instead of 6), 128 x 2x3 (7 instead of 9 for a 5x5 kernel).  A stage then serves twice the look-ups, i.e. the fixed
+// cost of a stage (64 KB of LDS stores, the matrix instructions, the barrier) is spread over twice the work.
+//
+// How.  Same stage machine as k_conv_sym (qcnn_kernels.hip): two 64 KB LUT stages in LDS, one s_barrier per stage, stage
+// s + 1 multiplied out while stage s is gathered; same table entries in the same (kh, kw, m) order per output, so the
+// results are BIT-IDENTICAL to the tile kernels.  Per wave and stage: 8 of the 64 result tiles (two image tiles x four row
+// tiles: 16 v_mfma_f32_16x16x4_f32 for 8-dim sub-spaces, 32 ds_write_addtid_b32 behind 8 M0 writes) and 96 (position,
+// channel) look-ups in twelve blocks of four ds_read_b128.  What makes 192 accumulator registers fit: the row offsets of a
+// block (8 bytes per wave half) are read from the program row in LDS right before the block that needs them — one
+// ds_read_b64 issued ahead of the previous block's reads, so it has landed when that block's last counted wait is over —
+// instead of a whole stage's offsets sitting in registers (k_conv_aprx: two sets); ONE operand set; look-up temporaries
+// v[240:255].  Optional stagger (template): the two waves that share a SIMD run their build and gather phases in opposite
+// order, so that one wave's matrix instructions meet the other's look-ups instead of its matrix instructions.
+#include "qcnn_kernels.h"
+#include "qcnn_dev.h"
+
+#include <algorithm>
+#include <functional>
+#include <queue>
+#include <type_traits>
+#include <vector>
+
+namespace {
+
+constexpr int NW8 = 8;                              // waves per workgroup (2 per SIMD: 256 registers each)
+constexpr uint32_t PROG8_LDS = 2u * STAGE_BYTES;    // three program-row buffers behind the two LUT stages
+constexpr uint32_t PROG8_BUF = 2048u;
+
+#define Q8_CLOB4 "scc", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251",   \
+                 "v252", "v253", "v254", "v255"
+
+// four reads = 8 look-ups (gq4 of qcnn_kernels.hip with its temporaries at the top of a 256-register file).  Leaves with
+// lgkmcnt(0) on BOTH paths: the offsets of the next block, fetched by a ds_read_b64 issued before this block, have landed.
+__device__ __forceinline__ void gq4h(f32x2* acc, uint32_t w0, uint32_t w1, uint32_t base, int valid) {
+  asm volatile(Q_SKIP
+               Q_AD("v240", "w0", "WORD_0") Q_AD("v244", "w0", "WORD_1") Q_AD("v248", "w1", "WORD_0") Q_AD("v252", "w1", "WORD_1")
+               Q_RD("v[240:243]", "v240") Q_RD("v[244:247]", "v244") Q_RD("v[248:251]", "v248") Q_RD("v[252:255]", "v252")
+               Q_ACC("3", "c0", "c1", "v[240:241]", "v[242:243]") Q_ACC("2", "c2", "c3", "v[244:245]", "v[246:247]")
+               Q_ACC("1", "c4", "c5", "v[248:249]", "v[250:251]") Q_ACC("0", "c6", "c7", "v[252:253]", "v[254:255]")
+               "\n.Lqskip%=:\n\ts_waitcnt lgkmcnt(0)"
+               : [c0] "+v"(acc[0]), [c1] "+v"(acc[1]), [c2] "+v"(acc[2]), [c3] "+v"(acc[3]), [c4] "+v"(acc[4]),
+                 [c5] "+v"(acc[5]), [c6] "+v"(acc[6]), [c7] "+v"(acc[7])
+               : [w0] "v"(w0), [w1] "v"(w1), [b] "v"(base), [ok] "s"(valid)
+               : Q8_CLOB4);
+}
+
+// 8 bytes of a program row: issued as asm so that it stays where it is written (ahead of the block before the one that
+// consumes it); the consumer relies on the lgkmcnt(0) gq4h leaves with, the first block of a stage on offsets_landed()
+struct Off2 { uint32_t x, y; };
+template <int IMM>
+__device__ __forceinline__ void offsets_fetch(Off2& o, uint32_t addr) {
+  uint64_t v;
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(IMM));
+  o.x = (uint32_t)v; o.y = (uint32_t)(v >> 32);
+}
+__device__ __forceinline__ void offsets_landed(Off2& o) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(o.x), "+v"(o.y)); }
+
+// operands of one stage for this wave: code-book tiles of its four row tiles, activation tiles of its two image tiles
+template <int KS>
+struct Ops8 {
+  float a[4][KS];
+  float b[2][KS];
+};
+template <int KS>
+__device__ __forceinline__ void ops8_load(Ops8<KS>& o, const char* __restrict__ xbase, uint32_t xoff0, uint32_t bLane,
+                                          const float* __restrict__ ctrd, int Cs, int m, uint32_t laneA, int rt0) {
+  constexpr int K = 128;
+  const float* __restrict__ cbU = ctrd + (size_t)m * Cs * K + rt0 * 16;            // uniform
+  const char* __restrict__ xbU = xbase + xoff0 + (uint32_t)(m * Cs) * XROWB;       // uniform
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o.a[i][ks] = (cbU + (ks * 4 * K + i * 16))[laneA];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) o.b[t][ks] = *reinterpret_cast<const float*>(xbU + (uint32_t)(ks * 4) * XROWB + bLane + t * 64);
+  }
+}
+template <int KS>
+__device__ __forceinline__ f32x4 ops8_tile(const Ops8<KS>& o, int t, int i) {
+  const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+  f32x4 c = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a[i][0], o.b[t][0], zero, 0, 0, 0);
+  if (KS > 1) c = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a[i][KS - 1], o.b[t][KS - 1], c, 0, 0, 0);
+  return c;
+}
+// the wave's eight tiles -> stage buffer; mA / mB = LDS byte address of (buffer, image tile, first row tile) of its two
+// image tiles.  The four stores of a tile go out behind ONE M0 write, in the shadow of the next tile's matrix instructions.
+template <int KS>
+__device__ __forceinline__ void ops8_store(const Ops8<KS>& o, uint32_t mA, uint32_t mB) {
+  const f32x4 v0 = ops8_tile<KS>(o, 0, 0);
+  const f32x4 v1 = ops8_tile<KS>(o, 0, 1);
+  __builtin_amdgcn_sched_barrier(0);
+  const f32x4 v2 = ops8_tile<KS>(o, 0, 2);
+  store_tile_all<0>(v0, mA);
+  __builtin_amdgcn_sched_barrier(0);
+  const f32x4 v3 = ops8_tile<KS>(o, 0, 3);
+  store_tile_all<1>(v1, mA);
+  __builtin_amdgcn_sched_barrier(0);
+  const f32x4 v4 = ops8_tile<KS>(o, 1, 0);
+  store_tile_all<2>(v2, mA);
+  __builtin_amdgcn_sched_barrier(0);
+  const f32x4 v5 = ops8_tile<KS>(o, 1, 1);
+  store_tile_all<3>(v3, mA);
+  __builtin_amdgcn_sched_barrier(0);
+  const f32x4 v6 = ops8_tile<KS>(o, 1, 2);
+  store_tile_all<0>(v4, mB);
+  __builtin_amdgcn_sched_barrier(0);
+  const f32x4 v7 = ops8_tile<KS>(o, 1, 3);
+  store_tile_all<1>(v5, mB);
+  __builtin_amdgcn_sched_barrier(0);
+  store_tile_all<2>(v6, mB);
+  store_tile_all<3>(v7, mB);
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// the 96 look-ups of this wave in stage `c`: NP positions x CPW channels in blocks of four reads; blk = LDS byte address of
+// the wave half's block of the stage's program row ([position][CPW / 2] uint16)
+template <int TH, int TW, int CPW>
+__device__ __forceinline__ void gather8(f32x2 (&acc)[TH * TW][CPW], uint32_t blk, const StagePos& c, int knl,
+                                        const int (&rowStart)[TH], const int (&colStart)[TW], uint32_t stage, int live) {
+  constexpr int NP = TH * TW, BPP = CPW / 8;           // blocks per position
+  int ok[NP];
+  {
+    int colOk[TW];
+#pragma unroll
+    for (int dx = 0; dx < TW; ++dx) colOk[dx] = in_range(c.wi - colStart[dx], knl);
+#pragma unroll
+    for (int dy = 0; dy < TH; ++dy) {
+      const int rowOk = live & in_range(c.hi - rowStart[dy], knl);
+#pragma unroll
+      for (int dx = 0; dx < TW; ++dx) ok[dy * TW + dx] = uni(rowOk & colOk[dx]);
+    }
+  }
+  Off2 oa, ob;
+  offsets_fetch<0>(oa, blk);
+  offsets_landed(oa);
+#pragma unroll
+  for (int k = 0; k < NP * BPP; k += 2) {
+    // (an unrolled pair of blocks: the offsets of block k + 1 fly under block k, those of k + 2 under k + 1)
+    if (k + 1 < NP * BPP) {
+      switch (k + 1) {   // compile-time immediate of the fetch
+#define Q8_F(n) case n: offsets_fetch<(n) * 8>(ob, blk); break;
+        Q8_F(1) Q8_F(3) Q8_F(5) Q8_F(7) Q8_F(9) Q8_F(11) Q8_F(13) Q8_F(15) Q8_F(17) Q8_F(19) Q8_F(21) Q8_F(23)
+        default: break;
+      }
+    }
+    gq4h(&acc[k / BPP][(k % BPP) * 8], oa.x, oa.y, stage, ok[k / BPP]);
+    if (k + 1 < NP * BPP) {
+      if (k + 2 < NP * BPP) {
+        switch (k + 2) {
+          Q8_F(2) Q8_F(4) Q8_F(6) Q8_F(8) Q8_F(10) Q8_F(12) Q8_F(14) Q8_F(16) Q8_F(18) Q8_F(20) Q8_F(22)
+          default: break;
+        }
+        { const Off2 t = oa; oa = ob; ob = t; }        // (registers renamed at compile time: the loop is unrolled)
+        gq4h(&acc[(k + 1) / BPP][((k + 1) % BPP) * 8], ob.x, ob.y, stage, ok[(k + 1) / BPP]);
+      } else {
+        gq4h(&acc[(k + 1) / BPP][((k + 1) % BPP) * 8], ob.x, ob.y, stage, ok[(k + 1) / BPP]);
+      }
+    }
+  }
+#undef Q8_F
+}
+
+template <int CPW, int TH, int TW, int KS, bool STAGGER>
+__global__ __launch_bounds__(NW8 * 64) void k_conv_sym8(ConvParams p, int tilesX, int tilesY, int chunks) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  constexpr int NP = TH * TW, HC = CPW / 2;
+  static_assert(CPW % 8 == 0 && NP * CPW == 96, "96 (position, channel) pairs of four images per lane = 192 accumulator registers");
+  constexpr int BLKB = NP * CPW;                       // bytes of a wave half's block of a program row ([NP][HC] uint16)
+  constexpr int ROWB = NW8 * 2 * BLKB;                 // bytes of the workgroup's program row of one entry (1536)
+  const int lane = threadIdx.x & 63;
+  const int wave = uni(threadIdx.x >> 6);
+  const int rank = (int)(blockIdx.x / (unsigned)p.panels), panel = (int)(blockIdx.x % (unsigned)p.panels);
+  int ty, tx;
+  tile_of_rank(rank, tilesY, tilesX, ty, tx);
+  const int grp = (int)blockIdx.y / chunks, chunk = (int)blockIdx.y % chunks;
+  const int Cg = p.Cin / p.grp, Ctg = p.Ct / p.grp;
+  const int M = p.M;
+  const int ho0 = ty * TH, wo0 = tx * TW;
+  const int hoL = min(ho0 + TH, p.Ho) - 1, woL = min(wo0 + TW, p.Wo) - 1;
+  const int hiL = max(0, ho0 * p.stride - p.pad), hiU = min(p.H - 1, hoL * p.stride - p.pad + p.knl - 1);
+  ConvGeom g;
+  g.W = p.W; g.Cin = p.Cin; g.knl = p.knl; g.M = M; g.G = 1; g.rowStride = 0;
+  g.pixStride = (uint32_t)p.Cin * (uint32_t)XROWB;
+  g.MG = M;
+  g.wiL = max(0, wo0 * p.stride - p.pad);
+  g.wiU = min(p.W - 1, woL * p.stride - p.pad + p.knl - 1);
+  g.slide = 0; g.hiL = hiL; g.hiU = hiU; g.period = 1;
+  const int cols = g.wiU - g.wiL + 1;
+  const int S = (hiU - hiL + 1) * cols * g.MG;
+  const int Sp = (S + 1) & ~1;
+  const StagePos first = {hiL, g.wiL, 0, 0};
+  if ((uint32_t)(uintptr_t)lds != 0u) __builtin_trap();   // the stage addressing assumes the dynamic segment starts at LDS byte 0
+
+  // ---- builder side of this wave: image tiles 2 (wave >> 1), + 1 (both with slot swizzle wave >> 1), row tiles 4 (wave & 1) ..
+  const int it0 = (wave >> 1) * 2, rt0 = (wave & 1) * 4, sw = wave >> 1;
+  const uint32_t li = lane & 15, lk = lane >> 4;
+  const uint32_t laneA = lk * 128 + (li ^ ((uint32_t)sw << 2));          // rows pre-swizzled for the tiles' slot order (mfma_load)
+  const uint32_t bLane = lk * XROWB + (uint32_t)it0 * 64 + li * 4;
+  const char* __restrict__ xbase =
+      reinterpret_cast<const char*>(p.src + ((size_t)panel * p.H * p.W * p.Cin + (size_t)grp * Cg) * PANEL);
+  const uint32_t mA0 = (uint32_t)it0 * TILEB + (uint32_t)rt0 * 1024u, mB0 = mA0 + TILEB;
+  const int Cs = p.Cs;
+
+  // ---- gather side: channels cw0 .. cw0 + CPW - 1 of the group for every position of the tile
+  const int half = lane >> 5, quad = lane & 31;
+  const int cw0 = (chunk * NW8 + wave) * CPW;
+  const int activeI = in_range(cw0, Ctg);
+  const int cl0 = cw0 + half * HC;
+  const uint32_t laneLds = (uint32_t)(quad >> 2) * TILEB | (uint32_t)(quad >> 3) * 64 | (uint32_t)(quad & 3) * 16;
+  f32x2 acc[NP][CPW];
+  {
+    const float* __restrict__ bp = p.bias + grp * Ctg + (activeI ? cl0 : 0);
+#pragma unroll
+    for (int j = 0; j < HC; ++j) {
+      const float b = bp[j];
+#pragma unroll
+      for (int q = 0; q < NP; ++q) { acc[q][2 * j] = f32x2{b, b}; acc[q][2 * j + 1] = f32x2{b, b}; }
+    }
+  }
+  int rowStart[TH], colStart[TW];
+#pragma unroll
+  for (int dy = 0; dy < TH; ++dy) rowStart[dy] = (ho0 + dy < p.Ho) ? (ho0 + dy) * p.stride - p.pad : -(1 << 28);
+#pragma unroll
+  for (int dx = 0; dx < TW; ++dx) colStart[dx] = (wo0 + dx < p.Wo) ? (wo0 + dx) * p.stride - p.pad : -(1 << 28);
+  const int rfW = (TW - 1) * p.stride + p.knl;
+  const int ry0 = ho0 * p.stride - p.pad, rx0 = wo0 * p.stride - p.pad;
+  const uint32_t entryB = (uint32_t)(p.grp * chunks) * ROWB;
+  const char* __restrict__ progWg = reinterpret_cast<const char*>(p.progS) + (size_t)(grp * chunks + chunk) * ROWB;
+  auto rowOf = [&](const StagePos& q, int idx) {       // stages past the end: any existing row
+    const StagePos c = (idx < S) ? q : first;
+    return progWg + (size_t)(uint32_t)(((c.hi - ry0) * rfW + (c.wi - rx0)) * M + c.mg) * entryB;
+  };
+  auto posOf = [&](const StagePos& q, int idx) { return (idx < S) ? q : first; };
+  const uint32_t myBlk = PROG8_LDS + (uint32_t)(wave * 2 + half) * BLKB;
+  const bool loader = wave == 0;
+  // waves w and w + 4 share a SIMD (dispatch order 0 -> 2 -> 1 -> 3): with STAGGER the upper four gather first
+  const bool gatherFirst = STAGGER && (wave >> 2) != 0;
+
+  Ops8<KS> ops;
+  StagePos c0 = first;
+  StagePos c1 = next_pos(c0, g);
+  StagePos c2 = next_pos(c1, g);
+  // program rows: three LDS buffers, the row of stage t in buffer t % 3, fetched by LDS-DMA two periods before it is read —
+  // wave 0 never waits for it at a barrier: it has landed when the operands loaded after it are consumed a period later
+  uint32_t rb0 = 0, rb1 = PROG8_BUF, rb2 = 2 * PROG8_BUF;     // buffers of stages s, s + 1, s + 2
+  // prologue: stage 0 -> buffer 0; operands of stage 1; program rows of stages 0 and 1
+  ops8_load<KS>(ops, xbase, pixel_off(c0, g), bLane, p.ctrd, Cs, c0.mg, laneA, rt0);
+  ops8_store<KS>(ops, mA0, mB0);
+  {
+    const StagePos q = posOf(c1, 1);
+    ops8_load<KS>(ops, xbase, pixel_off(q, g), bLane, p.ctrd, Cs, q.mg, laneA, rt0);
+  }
+  if (loader) { idx_row_to_lds<ROWB>(rowOf(c0, 0), PROG8_LDS + rb0, lane); idx_row_to_lds<ROWB>(rowOf(c1, 1), PROG8_LDS + rb1, lane); }
+  barrier_after_lds_dma();
+  // The stage loop and the epilogue exist once per phase order (the accumulators never meet at a join of the two paths:
+  // with a run-time branch inside the loop the compiler gave them different registers on the two sides and spilled 800)
+  auto run = [&](auto order) {
+    constexpr bool GF = decltype(order)::value;          // gather first, then build
+    for (int s = 0; s < Sp; s += 2) {
+      // ---- period s: stage s + 1 -> buffer 1, gather stage s out of buffer 0
+      if (loader) idx_row_to_lds<ROWB>(rowOf(c2, s + 2), PROG8_LDS + rb2, lane);      // row of stage s + 2
+      __builtin_amdgcn_sched_barrier(0);
+      if (GF) {
+        gather8<TH, TW, CPW>(acc, myBlk + rb0, c0, p.knl, rowStart, colStart, laneLds, activeI);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      ops8_store<KS>(ops, mA0 + STAGE_BYTES, mB0 + STAGE_BYTES);
+      {
+        const StagePos q = posOf(c2, s + 2);
+        ops8_load<KS>(ops, xbase, pixel_off(q, g), bLane, p.ctrd, Cs, q.mg, laneA, rt0);
+      }
+      if (!GF) {
+        __builtin_amdgcn_sched_barrier(0);
+        gather8<TH, TW, CPW>(acc, myBlk + rb0, c0, p.knl, rowStart, colStart, laneLds, activeI);
+      }
+      c0 = c1; c1 = c2; c2 = next_pos(c2, g);
+      { const uint32_t t = rb0; rb0 = rb1; rb1 = rb2; rb2 = t; }
+      barrier_after_lds_writes();
+      // ---- period s + 1: stage s + 2 -> buffer 0, gather stage s + 1 out of buffer 1
+      if (loader) idx_row_to_lds<ROWB>(rowOf(c2, s + 3), PROG8_LDS + rb2, lane);
+      __builtin_amdgcn_sched_barrier(0);
+      if (GF) {
+        gather8<TH, TW, CPW>(acc, myBlk + rb0, c0, p.knl, rowStart, colStart, laneLds | STAGE_BYTES, activeI & in_range(s + 1, S));
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      ops8_store<KS>(ops, mA0, mB0);
+      {
+        const StagePos q = posOf(c2, s + 3);
+        ops8_load<KS>(ops, xbase, pixel_off(q, g), bLane, p.ctrd, Cs, q.mg, laneA, rt0);
+      }
+      if (!GF) {
+        __builtin_amdgcn_sched_barrier(0);
+        gather8<TH, TW, CPW>(acc, myBlk + rb0, c0, p.knl, rowStart, colStart, laneLds | STAGE_BYTES, activeI & in_range(s + 1, S));
+      }
+      c0 = c1; c1 = c2; c2 = next_pos(c2, g);
+      { const uint32_t t = rb0; rb0 = rb1; rb1 = rb2; rb2 = t; }
+      barrier_after_lds_writes();
+    }
+    // ---- results
+    if (activeI) {
+      float* __restrict__ dst = p.dst + (size_t)panel * p.Ho * p.Wo * p.Ct * PANEL;
+#pragma unroll
+      for (int q = 0; q < NP; ++q) {
+        const int ho = ho0 + q / TW, wo = wo0 + q % TW;
+        if (ho < p.Ho && wo < p.Wo) {
+          float* o = dst + ((size_t)(ho * p.Wo + wo) * p.Ct + grp * Ctg + cl0) * PANEL + 4 * quad;
+#pragma unroll
+          for (int j = 0; j < HC; ++j) {
+            f32x4 v = {acc[q][2 * j].x, acc[q][2 * j].y, acc[q][2 * j + 1].x, acc[q][2 * j + 1].y};
+            if (p.relu) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = (0.0f < v[e]) ? v[e] : 0.0f;
+            }
+            *reinterpret_cast<f32x4*>(o + j * PANEL) = v;
+          }
+        }
+      }
+    }
+  };
+  if (STAGGER && gatherFirst) run(std::true_type{}); else run(std::false_type{});
+}
+
+// rows (plain table of row slots, [kh][kw][M][rowStride], `src` order) -> program of the eight-wave layout: entry (ry, rx, m)
+// holds per (group, channel chunk), wave and wave half ONE block [position][CPW / 2] of pre-scaled uint16 offsets (0 where
+// the position has no tap at that pixel or the channel does not exist).  One thread per uint16.
+__global__ __launch_bounds__(256) void k_build_program8(const uint8_t* __restrict__ rows, uint16_t* __restrict__ prog, QkSlots src,
+                                                        Qk8Config cf, int Ctg, int groups, int knl, int stride, int M, size_t n) {
+  const int hc = cf.cpw / 2, np = cf.th * cf.tw;
+  const int blkU16 = np * hc, rowU16 = groups * cf.chunks * NW8 * 2 * blkU16;
+  const int rfW = (cf.tw - 1) * stride + knl;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
+    const int r = (int)(e % (size_t)rowU16);
+    const int row = (int)(e / (size_t)rowU16);
+    const int m = row % M, pix = row / M;
+    const int ry = pix / rfW, rx = pix % rfW;
+    const int wh = r / blkU16, r3 = r % blkU16;
+    const int pos = r3 / hc, j = r3 % hc;
+    const int half = wh & 1, waveG = wh >> 1;
+    const int wave = waveG % NW8, gc = waveG / NW8;
+    const int chunk = gc % cf.chunks, g = gc / cf.chunks;
+    const int ch = (chunk * NW8 + wave) * cf.cpw + half * hc + j;
+    const int kh = ry - (pos / cf.tw) * stride, kw = rx - (pos % cf.tw) * stride;
+    uint16_t v = 0;
+    if (ch < Ctg && (unsigned)kh < (unsigned)knl && (unsigned)kw < (unsigned)knl) {
+      const int at = qk_slot_entry(src, g, ch);
+      if (at >= 0) v = (uint16_t)(rows[(size_t)((kh * knl + kw) * M + m) * src.rowStride + at] * 64);
+    }
+    prog[e] = v;
+  }
+}
+
+template <int CPW, int TH, int TW>
+hipError_t launch_sym8(const ConvParams& p, const Qk8Config& cf, int stagger, hipStream_t st) {
+  const int tilesX = (p.Wo + TW - 1) / TW, tilesY = (p.Ho + TH - 1) / TH;
+  const dim3 grid((unsigned)(tilesX * tilesY * p.panels), (unsigned)(p.grp * cf.chunks), 1);
+  const size_t shm = (size_t)2 * STAGE_BYTES + 3 * PROG8_BUF;
+  const bool two = std::min(p.Cin / p.grp, p.Cs) > 4;
+  auto kern = two ? (stagger ? k_conv_sym8<CPW, TH, TW, 2, true> : k_conv_sym8<CPW, TH, TW, 2, false>)
+                  : (stagger ? k_conv_sym8<CPW, TH, TW, 1, true> : k_conv_sym8<CPW, TH, TW, 1, false>);
+  hipError_t e = allow_big_lds(reinterpret_cast<const void*>(kern), (int)shm);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, grid, dim3(NW8 * 64), shm, st, p, tilesX, tilesY, cf.chunks);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+Qk8Config qk_conv_sym8_config(int Cin, int grp, int Ct, int M, int Cs, int K) {
+  Qk8Config cf = {0, 0, 0, 0};
+  if (grp < 1 || Ct % grp || Cin % grp) return cf;
+  const int Cg = Cin / grp, Ctg = Ct / grp;
+  // K = 128, every sub-space complete with 4 or 8 dims (no operand masks in the kernel)
+  if (K != 128 || !(Cs == 4 || Cs == 8) || Cg % Cs || M != Cg / Cs) return cf;
+  // channels per wave x positions = 96: as many channels of the group in ONE workgroup as 8 waves hold (every further
+  // channel chunk builds the same stages again), the tile that goes with it
+  const int chunks = (Ctg + 383) / 384;
+  const int per = (Ctg + chunks - 1) / chunks;
+  if (per <= 64) return cf;                      // narrow layers: the sliding kernels of k_conv_aprx build less
+  if (per <= 128) { cf.cpw = 16; cf.th = 2; cf.tw = 3; }
+  else if (per <= 192) { cf.cpw = 24; cf.th = 2; cf.tw = 2; }
+  else if (per <= 256) { cf.cpw = 32; cf.th = 1; cf.tw = 3; }
+  else { cf.cpw = 48; cf.th = 1; cf.tw = 2; }
+  if (Ctg % cf.cpw) { cf.cpw = 0; return cf; }   // a wave's channels all exist or none does
+  cf.chunks = (Ctg + NW8 * cf.cpw - 1) / (NW8 * cf.cpw);
+  return cf;
+}
+
+size_t qk_conv_sym8_program_bytes(const Qk8Config& cf, int groups, int knl, int stride, int M) {
+  if (!cf.cpw) return 0;
+  const int rfH = (cf.th - 1) * stride + knl, rfW = (cf.tw - 1) * stride + knl;
+  return (size_t)rfH * rfW * M * groups * cf.chunks * NW8 * cf.th * cf.tw * cf.cpw * sizeof(uint16_t);   // 16 half-waves x NP x CPW / 2
+}
+
+hipError_t qk_build_program8(const uint8_t* rows, uint16_t* prog, const QkSlots& src, const Qk8Config& cf, int Ctg, int groups,
+                             int knl, int stride, int M, hipStream_t st) {
+  const size_t n = qk_conv_sym8_program_bytes(cf, groups, knl, stride, M) / sizeof(uint16_t);
+  if (!n) return hipErrorInvalidValue;
+  const int grid = (int)std::min<size_t>((n + 255) / 256, 8192);
+  hipLaunchKernelGGL(k_build_program8, dim3(grid), dim3(256), 0, st, rows, prog, src, cf, Ctg, groups, knl, stride, M, n);
+  return hipGetLastError();
+}
+
+// predicted duration (in stage-times of the tile kernel, like QkSplitPlan::cost) of a launch over p.panels panels: tiles
+// list-scheduled heaviest first on 256 CUs; stageFactor = what a stage of this kernel costs against a tile-kernel stage
+double qk_conv_sym8_cost(const ConvParams& p, const Qk8Config& cf, double stageFactor) {
+  if (!cf.cpw) return 0.0;
+  const int TH = cf.th, TW = cf.tw;
+  const int tilesX = (p.Wo + TW - 1) / TW, tilesY = (p.Ho + TH - 1) / TH, tiles = tilesX * tilesY;
+  std::vector<double> cost((size_t)tiles);
+  for (int r = 0; r < tiles; ++r) {
+    int ty, tx;
+    tile_of_rank(r, tilesY, tilesX, ty, tx);
+    const int ho0 = ty * TH, wo0 = tx * TW;
+    const int hoL = std::min(ho0 + TH, p.Ho) - 1, woL = std::min(wo0 + TW, p.Wo) - 1;
+    const int rows = std::min(p.H - 1, hoL * p.stride - p.pad + p.knl - 1) - std::max(0, ho0 * p.stride - p.pad) + 1;
+    const int cols = std::min(p.W - 1, woL * p.stride - p.pad + p.knl - 1) - std::max(0, wo0 * p.stride - p.pad) + 1;
+    cost[r] = stageFactor * ((double)std::max(rows, 0) * std::max(cols, 0) * p.M) + 10.0;
+  }
+  const int ny = p.grp * cf.chunks;
+  const long long wgs = (long long)tiles * p.panels * ny;
+  if (wgs >= 8 * 256) {
+    double sum = 0.0;
+    for (int r = 0; r < tiles; ++r) sum += cost[r];
+    return sum * p.panels * ny / 256.0;
+  }
+  std::priority_queue<double, std::vector<double>, std::greater<double>> q;
+  for (int i = 0; i < 256; ++i) q.push(0.0);
+  double end = 0.0;
+  for (int y = 0; y < ny; ++y)
+    for (int r = 0; r < tiles; ++r)
+      for (int k = 0; k < p.panels; ++k) {
+        const double t = q.top() + cost[r];
+        q.pop(); q.push(t);
+        end = std::max(end, t);
+      }
+  return end;
+}
+
+hipError_t qk_conv_sym8(const ConvParams& p, int stagger, hipStream_t st) {
+  const Qk8Config cf = qk_conv_sym8_config(p.Cin, p.grp, p.Ct, p.M, p.Cs, p.K);
+  if (!cf.cpw || p.progS == nullptr || p.srcNchw) return hipErrorInvalidValue;
+  switch (cf.cpw) {
+    case 48: return launch_sym8<48, 1, 2>(p, cf, stagger, st);
+    case 32: return launch_sym8<32, 1, 3>(p, cf, stagger, st);
+    case 24: return launch_sym8<24, 2, 2>(p, cf, stagger, st);
+    case 16: return launch_sym8<16, 2, 3>(p, cf, stagger, st);
+    default: return hipErrorInvalidValue;
+  }
+}

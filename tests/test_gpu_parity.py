@@ -26,7 +26,7 @@ SAMPLE_STRIDE = 97
 BITWISE_TYPES = (topo.CONV, topo.FCNT, topo.RELU, topo.POOL, topo.DRPT)
 
 
-def make_engine(in_chw, layers, params, max_batch, lut=capi.LUT_EXACT, keep_all=1, split=0, decode=0):
+def make_engine(in_chw, layers, params, max_batch, lut=capi.LUT_EXACT, keep_all=1, split=0, decode=0, sym8=0):
     """split = 0: one workgroup per tile whatever the batch size (QCNN_OPT_SPLIT off) — the setting under which an image's
     bits do not depend on its batch, which many tests below rely on; the split itself has its own tests.  decode = 0: the
     table kernels for the first layer too (QCNN_OPT_DECODE off) — what these tests are about; the decoded first layer
@@ -36,6 +36,7 @@ def make_engine(in_chw, layers, params, max_batch, lut=capi.LUT_EXACT, keep_all=
     eng.set_option(capi.OPT_KEEP_ALL, keep_all)
     eng.set_option(capi.OPT_SPLIT, split)
     eng.set_option(capi.OPT_DECODE, decode)
+    eng.set_option(capi.OPT_SYM8, sym8)     # eight-wave symmetric workgroups: their own tests below (default on everywhere else)
     eng.load_model(in_chw, layers, params, max_batch)
     return eng
 
@@ -935,6 +936,68 @@ def test_symmetric_workgroups_geometries():
         e_inf, e_l2 = rel_err(eng.layer_output_range(l, 129, 2), orc.fm(l))
         assert e_inf <= TOL and e_l2 <= TOL, "fm[%d] vs oracle: %g %g" % (l, e_inf, e_l2)
     eng.close()
+
+
+# ---------------------------------------------------------------- eight-wave symmetric workgroups (256 registers per wave) ----
+@pytest.mark.parametrize("n_img,mode", [(5, 2), (300, 2), (300, 6)])
+def test_sym8_workgroups_alexnet(n_img, mode):
+    """QCNN_OPT_SYM8 = 2 (forced; 6 = forced + staggered phases): AlexNet conv2 (128 channels per group: 16 channels x a 2x3
+    tile per wave), conv3 (384: 48 x 1x2), conv4 (192: 24 x 2x2) and conv5 (128: 16 x 2x3) run k_conv_sym8 — eight waves of
+    256 registers, all of them building and gathering.  Same table entries in the same (kh, kw, m) order per output:
+    BIT-IDENTICAL to the tile kernels, layer for layer; conv1 (one 3-dim sub-space) is not eligible."""
+    in_chw, layers, _, _ = topo.MODELS["AlexNet"]
+    params = synth.make_params(in_chw, layers, seed=0)
+    imgs = synth.make_images(n_img, in_chw, seed=199)
+    base = make_engine(in_chw, layers, params, n_img, lut=capi.LUT_MFMA, keep_all=1, split=0)
+    base.set_option(capi.OPT_SYM, 0)
+    base.set_option(capi.OPT_SLIDE, 0)
+    p0, t0 = base.forward_host(imgs)
+    fm0 = {l: base.layer_output_range(l, n_img - 2, 2) for l in (5, 9, 11, 13, 15)}
+    assert all(base.layer_split(l)[0] not in (-2, -4, -5) for l in (4, 8, 10, 12))
+    base.close()
+    eng = make_engine(in_chw, layers, params, n_img, lut=capi.LUT_MFMA, keep_all=1, split=0, sym8=mode)
+    p1, t1 = eng.forward_host(imgs)
+    assert [eng.layer_split(l)[0] for l in (0, 4, 8, 10, 12)] == [-1, -5, -5, -5, -5]
+    for l, want in fm0.items():
+        assert np.array_equal(eng.layer_output_range(l, n_img - 2, 2), want), "fm[%d]" % l
+    assert np.array_equal(p0, p1) and np.array_equal(t0, t1)
+    eng.set_option(capi.OPT_LUT_MODE, capi.LUT_EXACT)                  # the exact builder: tile kernels
+    eng.forward_host(imgs[:5])
+    assert eng.layer_split(8)[0] != -5
+    eng.close()
+
+
+def test_sym8_workgroups_geometries():
+    """k_conv_sym8 on shapes AlexNet does not have: 256 channels (32 x 1x3 per wave) and 512 (two channel chunks of 256) behind
+    8- and 16-channel inputs, a padded 5x5 / 2 layer in two groups of 96 channels (16 x 2x3, six of the eight waves with
+    channels), a 4-dim sub-space layer (one k-step), an even kernel, odd maps (tiles hanging over the border), a ragged
+    second panel — forced on, against the tile kernels (bit-identical) and the oracle (<= 1e-4)."""
+    layers = [topo.conv(1, 3, 16, 1, 1), topo.relu(), topo.conv(1, 3, 256, 1, 1), topo.relu(), topo.conv(2, 5, 192, 2, 2),
+              topo.relu(), topo.conv(0, 2, 512, 1, 1), topo.relu(), topo.pool(0, 3, 2), topo.fcnt(40), topo.smax()]
+    in_chw = (3, 21, 17)
+    spec = synth.quant_spec(in_chw, layers)
+    spec[6] = dict(spec[6], Cs=4, M=spec[6]["D"] // 4)                  # 96 inputs per group as 24 sub-spaces of 4 dims
+    params = synth.make_params(in_chw, layers, seed=201, spec=spec)
+    imgs = synth.make_images(131, in_chw, seed=202)
+    orc = po.COracle(in_chw, layers)
+    orc.set_params(params)
+    orc.forward(imgs[129:])
+    base = make_engine(in_chw, layers, params, 131, lut=capi.LUT_MFMA, keep_all=1, split=0)
+    base.set_option(capi.OPT_SYM, 0)
+    base.set_option(capi.OPT_SLIDE, 0)
+    base.forward_host(imgs)
+    want = {l: base.layer_output(l, 131) for l in (3, 5, 7)}
+    base.close()
+    for mode in (2, 6):
+        eng = make_engine(in_chw, layers, params, 131, lut=capi.LUT_MFMA, keep_all=1, split=0, sym8=mode)
+        eng.forward_host(imgs)
+        assert [eng.layer_split(l)[0] for l in (0, 2, 4, 6)] == [-1, -5, -5, -5]
+        for l, w in want.items():
+            assert np.array_equal(eng.layer_output(l, 131), w), "mode %d fm[%d]" % (mode, l)
+        for l in (3, 5, 7, len(layers)):
+            e_inf, e_l2 = rel_err(eng.layer_output_range(l, 129, 2), orc.fm(l))
+            assert e_inf <= TOL and e_l2 <= TOL, "fm[%d] vs oracle: %g %g" % (l, e_inf, e_l2)
+        eng.close()
 
 
 # ---------------------------------------------------------------- sliding-window conv kernels ----
