@@ -45,7 +45,7 @@ def _run(cmd, **kw):
 def build_hip(force: bool = False, extra_flags=()) -> str:
     """Compile the HIP extension for gfx950 (hipcc cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
-    deps = srcs + [os.path.join(CSRC, "qcnn_kernels.h"), os.path.join(CSRC, "qcnn_dev.h"), os.path.join(ROOT, "include", "qcnn_hip.h")]
+    deps = srcs + [os.path.join(CSRC, "qcnn_kernels.h"), os.path.join(CSRC, "qcnn_dev.h"), os.path.join(CSRC, "qcnn_sym8_gather.h"), os.path.join(ROOT, "include", "qcnn_hip.h")]
     if force or _newer(HIP_SO, deps):
         objs = []
         for s in srcs:

@@ -17,10 +17,11 @@
 // results are BIT-IDENTICAL to the tile kernels.  Per wave and stage: 8 of the 64 result tiles (two image tiles x four row
 // tiles: 16 v_mfma_f32_16x16x4_f32 for 8-dim sub-spaces, 32 ds_write_addtid_b32 behind 8 M0 writes) and 96 (position,
 // channel) look-ups in twelve blocks of four ds_read_b128.  What makes 192 accumulator registers fit: the row offsets of a
-// block (8 bytes per wave half) are read from the program row in LDS right before the block that needs them — one
-// ds_read_b64 issued ahead of the previous block's reads, so it has landed when that block's last counted wait is over —
-// instead of a whole stage's offsets sitting in registers (k_conv_aprx: two sets); ONE operand set; look-up temporaries
-// v[240:255].  Optional stagger (template): the two waves that share a SIMD run their build and gather phases in opposite
+// block (8 bytes per wave half) are read from the program row in LDS two blocks before the block that needs them (one
+// ds_read_b64 into one of two fixed register pairs) instead of a whole stage's offsets sitting in registers (k_conv_aprx:
+// two sets); ONE operand set.  With two waves per SIMD nobody hides an LDS round trip per block, so the blocks of a position
+// are software-pipelined inside ONE asm statement (qcnn_sym8_gather.h, generated): two sets of read temporaries
+// (v[224:255]) alternate, the reads of block k + 1 fly while block k is accumulated, every wait is a count.  Optional stagger (template): the two waves that share a SIMD run their build and gather phases in opposite
 // order, so that one wave's matrix instructions meet the other's look-ups instead of its matrix instructions.
 #include "qcnn_kernels.h"
 #include "qcnn_dev.h"
@@ -29,6 +30,7 @@
 #include <functional>
 #include <queue>
 #include <type_traits>
+#include <utility>
 #include <vector>
 
 namespace {
@@ -37,34 +39,7 @@ constexpr int NW8 = 8;                              // waves per workgroup (2 pe
 constexpr uint32_t PROG8_LDS = 2u * STAGE_BYTES;    // three program-row buffers behind the two LUT stages
 constexpr uint32_t PROG8_BUF = 2048u;
 
-#define Q8_CLOB4 "scc", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251",   \
-                 "v252", "v253", "v254", "v255"
-
-// four reads = 8 look-ups (gq4 of qcnn_kernels.hip with its temporaries at the top of a 256-register file).  Leaves with
-// lgkmcnt(0) on BOTH paths: the offsets of the next block, fetched by a ds_read_b64 issued before this block, have landed.
-__device__ __forceinline__ void gq4h(f32x2* acc, uint32_t w0, uint32_t w1, uint32_t base, int valid) {
-  asm volatile(Q_SKIP
-               Q_AD("v240", "w0", "WORD_0") Q_AD("v244", "w0", "WORD_1") Q_AD("v248", "w1", "WORD_0") Q_AD("v252", "w1", "WORD_1")
-               Q_RD("v[240:243]", "v240") Q_RD("v[244:247]", "v244") Q_RD("v[248:251]", "v248") Q_RD("v[252:255]", "v252")
-               Q_ACC("3", "c0", "c1", "v[240:241]", "v[242:243]") Q_ACC("2", "c2", "c3", "v[244:245]", "v[246:247]")
-               Q_ACC("1", "c4", "c5", "v[248:249]", "v[250:251]") Q_ACC("0", "c6", "c7", "v[252:253]", "v[254:255]")
-               "\n.Lqskip%=:\n\ts_waitcnt lgkmcnt(0)"
-               : [c0] "+v"(acc[0]), [c1] "+v"(acc[1]), [c2] "+v"(acc[2]), [c3] "+v"(acc[3]), [c4] "+v"(acc[4]),
-                 [c5] "+v"(acc[5]), [c6] "+v"(acc[6]), [c7] "+v"(acc[7])
-               : [w0] "v"(w0), [w1] "v"(w1), [b] "v"(base), [ok] "s"(valid)
-               : Q8_CLOB4);
-}
-
-// 8 bytes of a program row: issued as asm so that it stays where it is written (ahead of the block before the one that
-// consumes it); the consumer relies on the lgkmcnt(0) gq4h leaves with, the first block of a stage on offsets_landed()
-struct Off2 { uint32_t x, y; };
-template <int IMM>
-__device__ __forceinline__ void offsets_fetch(Off2& o, uint32_t addr) {
-  uint64_t v;
-  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(IMM));
-  o.x = (uint32_t)v; o.y = (uint32_t)(v >> 32);
-}
-__device__ __forceinline__ void offsets_landed(Off2& o) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(o.x), "+v"(o.y)); }
+#include "qcnn_sym8_gather.h"      // gpos2 / gpos3 / gpos4 / gpos6: the look-ups of one position, software-pipelined (generated)
 
 // operands of one stage for this wave: code-book tiles of its four row tiles, activation tiles of its two image tiles
 template <int KS>
@@ -123,52 +98,38 @@ __device__ __forceinline__ void ops8_store(const Ops8<KS>& o, uint32_t mA, uint3
   __builtin_amdgcn_sched_barrier(0);
 }
 
-// the 96 look-ups of this wave in stage `c`: NP positions x CPW channels in blocks of four reads; blk = LDS byte address of
-// the wave half's block of the stage's program row ([position][CPW / 2] uint16)
+// the 96 look-ups of this wave in stage `c`: NP positions x CPW channels, one pipelined asm statement per position (a
+// position that does not look at the stage's pixel is skipped inside it); blk = LDS byte address of the wave half's block
+// of the stage's program row ([position][CPW / 2] uint16)
+template <int CPW, int P>
+__device__ __forceinline__ void gather8_pos(f32x2* acc, uint32_t blk, uint32_t stage, int ok) {
+  constexpr int B = CPW / 8;
+  static_assert(B == 2 || B == 3 || B == 4 || B == 6, "blocks per position");
+  if constexpr (B == 6) gpos6<P * CPW>(acc, blk, stage, ok);
+  else if constexpr (B == 4) gpos4<P * CPW>(acc, blk, stage, ok);
+  else if constexpr (B == 3) gpos3<P * CPW>(acc, blk, stage, ok);
+  else gpos2<P * CPW>(acc, blk, stage, ok);
+}
+template <int TH, int TW, int CPW, int... Ps>
+__device__ __forceinline__ void gather8_all(f32x2 (&acc)[TH * TW][CPW], uint32_t blk, uint32_t stage, const int (&ok)[TH * TW],
+                                            std::integer_sequence<int, Ps...>) {
+  (gather8_pos<CPW, Ps>(&acc[Ps][0], blk, stage, ok[Ps]), ...);
+}
 template <int TH, int TW, int CPW>
 __device__ __forceinline__ void gather8(f32x2 (&acc)[TH * TW][CPW], uint32_t blk, const StagePos& c, int knl,
                                         const int (&rowStart)[TH], const int (&colStart)[TW], uint32_t stage, int live) {
-  constexpr int NP = TH * TW, BPP = CPW / 8;           // blocks per position
+  constexpr int NP = TH * TW;
   int ok[NP];
-  {
-    int colOk[TW];
+  int colOk[TW];
 #pragma unroll
-    for (int dx = 0; dx < TW; ++dx) colOk[dx] = in_range(c.wi - colStart[dx], knl);
+  for (int dx = 0; dx < TW; ++dx) colOk[dx] = in_range(c.wi - colStart[dx], knl);
 #pragma unroll
-    for (int dy = 0; dy < TH; ++dy) {
-      const int rowOk = live & in_range(c.hi - rowStart[dy], knl);
+  for (int dy = 0; dy < TH; ++dy) {
+    const int rowOk = live & in_range(c.hi - rowStart[dy], knl);
 #pragma unroll
-      for (int dx = 0; dx < TW; ++dx) ok[dy * TW + dx] = uni(rowOk & colOk[dx]);
-    }
+    for (int dx = 0; dx < TW; ++dx) ok[dy * TW + dx] = uni(rowOk & colOk[dx]);
   }
-  Off2 oa, ob;
-  offsets_fetch<0>(oa, blk);
-  offsets_landed(oa);
-#pragma unroll
-  for (int k = 0; k < NP * BPP; k += 2) {
-    // (an unrolled pair of blocks: the offsets of block k + 1 fly under block k, those of k + 2 under k + 1)
-    if (k + 1 < NP * BPP) {
-      switch (k + 1) {   // compile-time immediate of the fetch
-#define Q8_F(n) case n: offsets_fetch<(n) * 8>(ob, blk); break;
-        Q8_F(1) Q8_F(3) Q8_F(5) Q8_F(7) Q8_F(9) Q8_F(11) Q8_F(13) Q8_F(15) Q8_F(17) Q8_F(19) Q8_F(21) Q8_F(23)
-        default: break;
-      }
-    }
-    gq4h(&acc[k / BPP][(k % BPP) * 8], oa.x, oa.y, stage, ok[k / BPP]);
-    if (k + 1 < NP * BPP) {
-      if (k + 2 < NP * BPP) {
-        switch (k + 2) {
-          Q8_F(2) Q8_F(4) Q8_F(6) Q8_F(8) Q8_F(10) Q8_F(12) Q8_F(14) Q8_F(16) Q8_F(18) Q8_F(20) Q8_F(22)
-          default: break;
-        }
-        { const Off2 t = oa; oa = ob; ob = t; }        // (registers renamed at compile time: the loop is unrolled)
-        gq4h(&acc[(k + 1) / BPP][((k + 1) % BPP) * 8], ob.x, ob.y, stage, ok[(k + 1) / BPP]);
-      } else {
-        gq4h(&acc[(k + 1) / BPP][((k + 1) % BPP) * 8], ob.x, ob.y, stage, ok[(k + 1) / BPP]);
-      }
-    }
-  }
-#undef Q8_F
+  gather8_all<TH, TW, CPW>(acc, blk, stage, ok, std::make_integer_sequence<int, NP>{});
 }
 
 template <int CPW, int TH, int TW, int KS, bool STAGGER>
