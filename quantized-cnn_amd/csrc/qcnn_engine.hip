@@ -35,6 +35,7 @@ struct LayerShape {
   size_t offProgS = 0, progSBytes = 0;                         // ... and in the order of the sliding variant, where it applies
   size_t offProgY = 0, progYBytes = 0;                         // ... and of the symmetric kernel's (8 channels per wave, 2x2 tile) layout
   size_t offProg8 = 0, prog8Bytes = 0;                         // ... and of the eight-wave symmetric kernel's layout (Qk8Config)
+  size_t offCtrd8 = 0;                                         // ... with the code book in that kernel's operand order (qk_ctrd8_index)
   size_t offDec = 0; int decKp = 0, decS = 0;                  // decoded code words (qcnn_decoded.hip): conv layer with one sub-space of
                                                                // <= 4 dims (decKp > 0), FC layer with one-dim sub-spaces (decKp = -1); 0: not eligible
   bool hasDmap = false;
@@ -206,7 +207,10 @@ int plan_arena(QcnnCtx* c) {
     if (d.type == QCNN_CONV) {
       const Qk8Config c8 = qk_conv_sym8_config(c->dims[l].c, d.grpCnt, Ct, s.M, s.Cs, s.K);
       s.prog8Bytes = qk_conv_sym8_program_bytes(c8, d.grpCnt, d.knlSiz, d.stride, s.M);
-      if (s.prog8Bytes) { s.offProg8 = off; off = align_up(off + s.prog8Bytes + QCNN_ROWS_PAD, 256); }
+      if (s.prog8Bytes) {
+        s.offProg8 = off; off = align_up(off + s.prog8Bytes + QCNN_ROWS_PAD, 256);
+        s.offCtrd8 = off; off = align_up(off + sizeof(float) * (size_t)s.M * s.Cs * s.K, 256);
+      }
     }
     s.decKp = 0;
     s.hasDmap = (d.type == QCNN_FCNT && l == c->firstFc && c->dims[l].h * c->dims[l].w > 1);
@@ -341,6 +345,7 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
       p.bias = reinterpret_cast<const float*>(c->arena + s.offBias);
       p.ctrd = reinterpret_cast<const float*>(c->arena + s.offCtrd);
       p.ctrd2 = s.hasCtrd2 ? c->arena + s.offCtrd2 : nullptr;
+      p.ctrd8 = s.prog8Bytes ? reinterpret_cast<const float*>(c->arena + s.offCtrd8) : nullptr;
       p.rows = reinterpret_cast<const uint8_t*>(c->arena + s.offAsmt);
       p.prog = s.progBytes ? reinterpret_cast<const uint16_t*>(c->arena + s.offProg) : nullptr;
       p.H = a.h; p.W = a.w; p.Cin = a.c; p.Ho = b.h; p.Wo = b.w; p.Ct = b.c;
@@ -976,6 +981,14 @@ int upload_bias_ctrd(QcnnCtx* c, int layer, const float* bias, const float* ctrd
               split[((((size_t)m * 8 + i) * 4 + g4) * 16 + row) * 8 + dd] = (g4 < 2) ? a1 : a2;
             }
     HIP_TRY(c, hipMemcpyAsync(c->arena + s.offCtrd2, split.data(), split.size() * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
+  }
+  std::vector<float> ctrd8;
+  if (s.prog8Bytes) {                 // the eight-wave symmetric kernel's operand order (K = 128, Cs = 4 or 8)
+    ctrd8.resize((size_t)M * Cs * K);
+    for (int m = 0; m < M; ++m)
+      for (int dd = 0; dd < Cs; ++dd)
+        for (int k = 0; k < K; ++k) ctrd8[qk_ctrd8_index(m, dd, k, Cs / 4)] = ctrd[((size_t)m * Cs + dd) * K + k];
+    HIP_TRY(c, hipMemcpyAsync(c->arena + s.offCtrd8, ctrd8.data(), ctrd8.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
   }
   HIP_TRY(c, hipMemcpyAsync(c->arena + s.offBias, bias, sizeof(float) * Ct, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipMemcpyAsync(c->arena + s.offCtrd, ctrd.data(), sizeof(float) * ctrd.size(), hipMemcpyHostToDevice, c->stream));

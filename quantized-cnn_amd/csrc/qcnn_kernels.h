@@ -171,6 +171,8 @@ struct ConvParams {
   const float* ctrd;     // [M][Cs][K]      (PrepCtrdBuf layout, src/CaffeEva.cc:556-557)
   const void* ctrd2;     // [M][8 row tiles][4 k-slices][16 rows][8 bf16]: code book split in two bf16 parts (slices 0, 1:
                          // leading part, 2, 3: remainder) in v_mfma_f32_16x16x32_bf16 operand order; K = 128 layers only, else NULL
+  const float* ctrd8;    // eight-wave symmetric kernel: the code book in its operand order [M][2 halves of the row tiles][k-steps][64 lanes]
+                         // [4 row tiles] (qk_ctrd8_index): a lane's four code-book operands of a k-step are ONE 16-byte load; else NULL
   const uint8_t* rows;   // [kh][kw][M][rowStride] (PrepAsmtBuf order, src/CaffeEva.cc:585-586): row slots, QkSlots order
   const uint16_t* prog;  // [rfH][rfW][M][rowU16]: the same offsets in consumption order (QkProgram); panel kernels only
   int H, W, Cin, Ho, Wo, Ct;
@@ -219,6 +221,11 @@ hipError_t qk_conv_sym(const ConvParams& p, hipStream_t st);
 // cpw = 0: the layer is not eligible.  Program table of this layout: [rfH][rfW][M][groups * chunks][8 waves][2 halves]
 // [position][cpw / 2] uint16 (ConvParams::progS when the kernel is launched).
 struct Qk8Config { int cpw, th, tw, chunks; };
+// position (in floats) inside ConvParams::ctrd8 of code word k (0..127), dim d of sub-space m; ks = Cs / 4 k-steps
+__host__ __device__ static inline size_t qk_ctrd8_index(int m, int d, int k, int ks) {
+  const int h = k >> 6, i = (k >> 4) & 3, li = k & 15, step = d >> 2, lk = d & 3;
+  return ((((size_t)m * 2 + h) * ks + step) * 64 + lk * 16 + li) * 4 + i;
+}
 Qk8Config qk_conv_sym8_config(int Cin, int grp, int Ct, int M, int Cs, int K);
 size_t qk_conv_sym8_program_bytes(const Qk8Config& cf, int groups, int knl, int stride, int M);
 hipError_t qk_build_program8(const uint8_t* rows, uint16_t* prog, const QkSlots& src, const Qk8Config& cf, int Ctg, int groups,

@@ -33,6 +33,32 @@
 #include <utility>
 #include <vector>
 
+#ifndef S8_VAR
+#define S8_VAR 0      // timing experiments only (scripts/variants_sym8.sh; results wrong): 1 no LUT stores, 2 no matrix instructions, 4 no look-ups
+#endif
+
+#ifdef S8_TRACE
+// Debug build only (scripts/trace_sym8.py): every wave of workgroup `s8_trace_block` sums, in scalar registers, the cycles
+// between its phase marks — period start / build done (matrix instructions + stores issued, next operand loads issued) /
+// look-ups done / barrier left — and writes the sums once at the end (marks cost an s_memtime + s_waitcnt lgkmcnt(0) each).
+__device__ unsigned long long s8_trace_buf[8 * 8];
+__device__ int s8_trace_block = 0;
+#define S8_DECL unsigned long long s8_t = __builtin_readcyclecounter(), s8_sum[6] = {0, 0, 0, 0, 0, 0}
+#define S8_T(k, s) do { const unsigned long long now_ = __builtin_readcyclecounter(); s8_sum[k] += now_ - s8_t; s8_t = now_; } while (0)
+#define S8_DUMP do { if ((int)blockIdx.x == s8_trace_block && blockIdx.y == 0 && (threadIdx.x & 63) == 0) \
+    for (int k_ = 0; k_ < 6; ++k_) s8_trace_buf[(threadIdx.x >> 6) * 8 + k_] = s8_sum[k_]; } while (0)
+extern "C" int qcnn_debug_trace8_read(unsigned long long* host, int block) {
+  hipError_t e = hipMemcpyFromSymbol(host, HIP_SYMBOL(s8_trace_buf), sizeof(unsigned long long) * 8 * 8);
+  if (e != hipSuccess) return 1;
+  e = hipMemcpyToSymbol(HIP_SYMBOL(s8_trace_block), &block, sizeof(int));
+  return e == hipSuccess ? 0 : 1;
+}
+#else
+#define S8_DECL do {} while (0)
+#define S8_T(k, s) do {} while (0)
+#define S8_DUMP do {} while (0)
+#endif
+
 namespace {
 
 constexpr int NW8 = 8;                              // waves per workgroup (2 per SIMD: 256 registers each)
@@ -49,20 +75,25 @@ struct Ops8 {
 };
 template <int KS>
 __device__ __forceinline__ void ops8_load(Ops8<KS>& o, const char* __restrict__ xbase, uint32_t xoff0, uint32_t bLane,
-                                          const float* __restrict__ ctrd, int Cs, int m, uint32_t laneA, int rt0) {
-  constexpr int K = 128;
-  const float* __restrict__ cbU = ctrd + (size_t)m * Cs * K + rt0 * 16;            // uniform
+                                          const float* __restrict__ ctrd8, int Cs, int m, uint32_t laneA8, int rt0) {
+  // code book in operand order (ConvParams::ctrd8): the four row tiles of a k-step are ONE 16-byte load per lane (issuing a
+  // vector memory instruction costs ~30 cycles of the wave's time: 2 + 4 loads per stage instead of 8 + 4)
+  const char* __restrict__ cbU = reinterpret_cast<const char*>(ctrd8) + ((size_t)m * 2 + (rt0 >> 2)) * KS * 1024;   // uniform
   const char* __restrict__ xbU = xbase + xoff0 + (uint32_t)(m * Cs) * XROWB;       // uniform
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
+    const f32x4 a4 = *reinterpret_cast<const f32x4*>(cbU + ks * 1024 + laneA8);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) o.a[i][ks] = (cbU + (ks * 4 * K + i * 16))[laneA];
+    for (int i = 0; i < 4; ++i) o.a[i][ks] = a4[i];
 #pragma unroll
     for (int t = 0; t < 2; ++t) o.b[t][ks] = *reinterpret_cast<const float*>(xbU + (uint32_t)(ks * 4) * XROWB + bLane + t * 64);
   }
 }
 template <int KS>
 __device__ __forceinline__ f32x4 ops8_tile(const Ops8<KS>& o, int t, int i) {
+#if S8_VAR & 2
+  return f32x4{o.a[i][0], o.b[t][0], o.a[i][KS - 1], o.b[t][KS - 1]};
+#endif
   const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
   f32x4 c = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a[i][0], o.b[t][0], zero, 0, 0, 0);
   if (KS > 1) c = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a[i][KS - 1], o.b[t][KS - 1], c, 0, 0, 0);
@@ -70,31 +101,37 @@ __device__ __forceinline__ f32x4 ops8_tile(const Ops8<KS>& o, int t, int i) {
 }
 // the wave's eight tiles -> stage buffer; mA / mB = LDS byte address of (buffer, image tile, first row tile) of its two
 // image tiles.  The four stores of a tile go out behind ONE M0 write, in the shadow of the next tile's matrix instructions.
+#if S8_VAR & 1
+#define S8_ST(I, v, m) asm volatile("" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "s"(m))
+#else
+#define S8_ST(I, v, m) store_tile_all<I>(v, m)
+#endif
 template <int KS>
 __device__ __forceinline__ void ops8_store(const Ops8<KS>& o, uint32_t mA, uint32_t mB) {
   const f32x4 v0 = ops8_tile<KS>(o, 0, 0);
   const f32x4 v1 = ops8_tile<KS>(o, 0, 1);
   __builtin_amdgcn_sched_barrier(0);
+
   const f32x4 v2 = ops8_tile<KS>(o, 0, 2);
-  store_tile_all<0>(v0, mA);
+  S8_ST(0, v0, mA);
   __builtin_amdgcn_sched_barrier(0);
   const f32x4 v3 = ops8_tile<KS>(o, 0, 3);
-  store_tile_all<1>(v1, mA);
+  S8_ST(1, v1, mA);
   __builtin_amdgcn_sched_barrier(0);
   const f32x4 v4 = ops8_tile<KS>(o, 1, 0);
-  store_tile_all<2>(v2, mA);
+  S8_ST(2, v2, mA);
   __builtin_amdgcn_sched_barrier(0);
   const f32x4 v5 = ops8_tile<KS>(o, 1, 1);
-  store_tile_all<3>(v3, mA);
+  S8_ST(3, v3, mA);
   __builtin_amdgcn_sched_barrier(0);
   const f32x4 v6 = ops8_tile<KS>(o, 1, 2);
-  store_tile_all<0>(v4, mB);
+  S8_ST(0, v4, mB);
   __builtin_amdgcn_sched_barrier(0);
   const f32x4 v7 = ops8_tile<KS>(o, 1, 3);
-  store_tile_all<1>(v5, mB);
+  S8_ST(1, v5, mB);
   __builtin_amdgcn_sched_barrier(0);
-  store_tile_all<2>(v6, mB);
-  store_tile_all<3>(v7, mB);
+  S8_ST(2, v6, mB);
+  S8_ST(3, v7, mB);
   __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -129,7 +166,9 @@ __device__ __forceinline__ void gather8(f32x2 (&acc)[TH * TW][CPW], uint32_t blk
 #pragma unroll
     for (int dx = 0; dx < TW; ++dx) ok[dy * TW + dx] = uni(rowOk & colOk[dx]);
   }
+#if !(S8_VAR & 4)
   gather8_all<TH, TW, CPW>(acc, blk, stage, ok, std::make_integer_sequence<int, NP>{});
+#endif
 }
 
 template <int CPW, int TH, int TW, int KS, bool STAGGER>
@@ -166,7 +205,7 @@ __global__ __launch_bounds__(NW8 * 64) void k_conv_sym8(ConvParams p, int tilesX
   // ---- builder side of this wave: image tiles 2 (wave >> 1), + 1 (both with slot swizzle wave >> 1), row tiles 4 (wave & 1) ..
   const int it0 = (wave >> 1) * 2, rt0 = (wave & 1) * 4, sw = wave >> 1;
   const uint32_t li = lane & 15, lk = lane >> 4;
-  const uint32_t laneA = lk * 128 + (li ^ ((uint32_t)sw << 2));          // rows pre-swizzled for the tiles' slot order (mfma_load)
+  const uint32_t laneA = (lk * 16 + (li ^ ((uint32_t)sw << 2))) * 16;    // byte offset in a 1 KB operand block: rows pre-swizzled for the tiles' slot order (mfma_load)
   const uint32_t bLane = lk * XROWB + (uint32_t)it0 * 64 + li * 4;
   const char* __restrict__ xbase =
       reinterpret_cast<const char*>(p.src + ((size_t)panel * p.H * p.W * p.Cin + (size_t)grp * Cg) * PANEL);
@@ -207,6 +246,9 @@ __global__ __launch_bounds__(NW8 * 64) void k_conv_sym8(ConvParams p, int tilesX
   const bool loader = wave == 0;
   // waves w and w + 4 share a SIMD (dispatch order 0 -> 2 -> 1 -> 3): with STAGGER the upper four gather first
   const bool gatherFirst = STAGGER && (wave >> 2) != 0;
+#ifdef S8_PRIO
+  if (wave >> 2) __builtin_amdgcn_s_setprio(S8_PRIO);    // experiment: the second wave of every SIMD is the slower one
+#endif
 
   Ops8<KS> ops;
   StagePos c0 = first;
@@ -216,11 +258,11 @@ __global__ __launch_bounds__(NW8 * 64) void k_conv_sym8(ConvParams p, int tilesX
   // wave 0 never waits for it at a barrier: it has landed when the operands loaded after it are consumed a period later
   uint32_t rb0 = 0, rb1 = PROG8_BUF, rb2 = 2 * PROG8_BUF;     // buffers of stages s, s + 1, s + 2
   // prologue: stage 0 -> buffer 0; operands of stage 1; program rows of stages 0 and 1
-  ops8_load<KS>(ops, xbase, pixel_off(c0, g), bLane, p.ctrd, Cs, c0.mg, laneA, rt0);
+  ops8_load<KS>(ops, xbase, pixel_off(c0, g), bLane, p.ctrd8, Cs, c0.mg, laneA, rt0);
   ops8_store<KS>(ops, mA0, mB0);
   {
     const StagePos q = posOf(c1, 1);
-    ops8_load<KS>(ops, xbase, pixel_off(q, g), bLane, p.ctrd, Cs, q.mg, laneA, rt0);
+    ops8_load<KS>(ops, xbase, pixel_off(q, g), bLane, p.ctrd8, Cs, q.mg, laneA, rt0);
   }
   if (loader) { idx_row_to_lds<ROWB>(rowOf(c0, 0), PROG8_LDS + rb0, lane); idx_row_to_lds<ROWB>(rowOf(c1, 1), PROG8_LDS + rb1, lane); }
   barrier_after_lds_dma();
@@ -228,46 +270,60 @@ __global__ __launch_bounds__(NW8 * 64) void k_conv_sym8(ConvParams p, int tilesX
   // with a run-time branch inside the loop the compiler gave them different registers on the two sides and spilled 800)
   auto run = [&](auto order) {
     constexpr bool GF = decltype(order)::value;          // gather first, then build
+    S8_DECL;
     for (int s = 0; s < Sp; s += 2) {
       // ---- period s: stage s + 1 -> buffer 1, gather stage s out of buffer 0
-      if (loader) idx_row_to_lds<ROWB>(rowOf(c2, s + 2), PROG8_LDS + rb2, lane);      // row of stage s + 2
-      __builtin_amdgcn_sched_barrier(0);
       if (GF) {
         gather8<TH, TW, CPW>(acc, myBlk + rb0, c0, p.knl, rowStart, colStart, laneLds, activeI);
         __builtin_amdgcn_sched_barrier(0);
+        S8_T(1, s);
       }
       ops8_store<KS>(ops, mA0 + STAGE_BYTES, mB0 + STAGE_BYTES);
+      S8_T(4, s);
+      // program row of stage s + 2, AFTER the build (whose counted vmcnt waits would otherwise wait for this fresh transfer)
+      // and BEFORE the operand loads (whose wait, a period later, then covers it)
+      if (loader) idx_row_to_lds<ROWB>(rowOf(c2, s + 2), PROG8_LDS + rb2, lane);
+      __builtin_amdgcn_sched_barrier(0);
       {
         const StagePos q = posOf(c2, s + 2);
-        ops8_load<KS>(ops, xbase, pixel_off(q, g), bLane, p.ctrd, Cs, q.mg, laneA, rt0);
+        ops8_load<KS>(ops, xbase, pixel_off(q, g), bLane, p.ctrd8, Cs, q.mg, laneA, rt0);
       }
       if (!GF) {
         __builtin_amdgcn_sched_barrier(0);
+        S8_T(1, s);
         gather8<TH, TW, CPW>(acc, myBlk + rb0, c0, p.knl, rowStart, colStart, laneLds, activeI);
       }
+      S8_T(2, s);
       c0 = c1; c1 = c2; c2 = next_pos(c2, g);
       { const uint32_t t = rb0; rb0 = rb1; rb1 = rb2; rb2 = t; }
       barrier_after_lds_writes();
+      S8_T(3, s);
       // ---- period s + 1: stage s + 2 -> buffer 0, gather stage s + 1 out of buffer 1
-      if (loader) idx_row_to_lds<ROWB>(rowOf(c2, s + 3), PROG8_LDS + rb2, lane);
-      __builtin_amdgcn_sched_barrier(0);
       if (GF) {
         gather8<TH, TW, CPW>(acc, myBlk + rb0, c0, p.knl, rowStart, colStart, laneLds | STAGE_BYTES, activeI & in_range(s + 1, S));
         __builtin_amdgcn_sched_barrier(0);
+        S8_T(1, s + 1);
       }
       ops8_store<KS>(ops, mA0, mB0);
+      S8_T(4, s + 1);
+      if (loader) idx_row_to_lds<ROWB>(rowOf(c2, s + 3), PROG8_LDS + rb2, lane);
+      __builtin_amdgcn_sched_barrier(0);
       {
         const StagePos q = posOf(c2, s + 3);
-        ops8_load<KS>(ops, xbase, pixel_off(q, g), bLane, p.ctrd, Cs, q.mg, laneA, rt0);
+        ops8_load<KS>(ops, xbase, pixel_off(q, g), bLane, p.ctrd8, Cs, q.mg, laneA, rt0);
       }
       if (!GF) {
         __builtin_amdgcn_sched_barrier(0);
+        S8_T(1, s + 1);
         gather8<TH, TW, CPW>(acc, myBlk + rb0, c0, p.knl, rowStart, colStart, laneLds | STAGE_BYTES, activeI & in_range(s + 1, S));
       }
+      S8_T(2, s + 1);
       c0 = c1; c1 = c2; c2 = next_pos(c2, g);
       { const uint32_t t = rb0; rb0 = rb1; rb1 = rb2; rb2 = t; }
       barrier_after_lds_writes();
+      S8_T(3, s + 1);
     }
+    S8_DUMP;
     // ---- results
     if (activeI) {
       float* __restrict__ dst = p.dst + (size_t)panel * p.Ho * p.Wo * p.Ct * PANEL;
@@ -410,7 +466,7 @@ double qk_conv_sym8_cost(const ConvParams& p, const Qk8Config& cf, double stageF
 
 hipError_t qk_conv_sym8(const ConvParams& p, int stagger, hipStream_t st) {
   const Qk8Config cf = qk_conv_sym8_config(p.Cin, p.grp, p.Ct, p.M, p.Cs, p.K);
-  if (!cf.cpw || p.progS == nullptr || p.srcNchw) return hipErrorInvalidValue;
+  if (!cf.cpw || p.progS == nullptr || p.ctrd8 == nullptr || p.srcNchw) return hipErrorInvalidValue;
   switch (cf.cpw) {
     case 48: return launch_sym8<48, 1, 2>(p, cf, stagger, st);
     case 32: return launch_sym8<32, 1, 3>(p, cf, stagger, st);
