@@ -584,13 +584,14 @@ def main():
         vdt = timed(torch, dev, vf, 2)
         vms, _ = ve.layer_ms()
         vdom = int(np.argmax(vms))
-        rep = perf.layer_report(v_sizes, v_layers, v_params, vdom, vb, float(vms[vdom]), ve.layer_segments(vdom))
+        rep = perf.layer_report(v_sizes, v_layers, v_params, vdom, vb, float(vms[vdom]), ve.layer_segments(vdom),
+                                8 if ve.layer_split(vdom)[0] == -5 else ve.layer_split(vdom)[0] == -4)
         conv_total = sum(float(vms[i]) for i, l in enumerate(v_layers) if l["type"] == topo.CONV)
         slow = {}
         for i in sorted((i for i, l in enumerate(v_layers) if l["type"] in (topo.CONV, topo.FCNT)), key=lambda i: -vms[i])[:5]:
             split = ve.layer_split(i)[0]
             r = (perf.decoded_report(v_sizes, v_layers, i, vb, float(vms[i])) if (split == -3 and v_layers[i]["type"] == topo.CONV) else
-                 perf.layer_report(v_sizes, v_layers, v_params, i, vb, float(vms[i]), ve.layer_segments(i), split == -4))
+                 perf.layer_report(v_sizes, v_layers, v_params, i, vb, float(vms[i]), ve.layer_segments(i), 8 if split == -5 else split == -4))
             r["ms"] = round(float(vms[i]), 4)
             r["in_hwc"], r["out_hwc"] = list(v_sizes[i]), list(v_sizes[i + 1])
             slow["%02d_%s" % (i, topo.TYPE_NAMES[v_layers[i]["type"]])] = r
@@ -628,7 +629,7 @@ def main():
                      dict(tile="decoded code words: x @ w on the matrix pipe, 64 channels x 64 images per workgroup",
                           issued_mfma_flop_per_image=2 * sizes[i][0] * sizes[i][1] * sizes[i][2] * ((l["nod"] + 63) // 64 * 64),
                           lookups_replaced_per_image=sizes[i][0] * sizes[i][1] * sizes[i][2] * l["nod"]) if i in decoded else
-                     perf.layer_report(sizes, layers, params, i, launch_images, float(layer_ms[i]), segments.get(i), i in symmetric))
+                     perf.layer_report(sizes, layers, params, i, launch_images, float(layer_ms[i]), segments.get(i), 8 if i in sym8 else (i in symmetric)))
                 r["ms"] = round(float(layer_ms[i]), 4)
                 per_layer["%02d_%s" % (i, topo.TYPE_NAMES[l["type"]])] = r
         table_lk = 0                                    # look-ups of the layers that really ran as table look-ups
@@ -664,6 +665,7 @@ def main():
                                       written=ent.get("write_bytes"), algorithmic_bytes_per_launch=int(ab),
                                       traffic_over_algorithmic=round(ent["bytes"] / ab, 2))
         roof = dict(bound, kernel=("k_conv_dec (layer %d, %s)" % (dom, name)) if dom in decoded else
+                    ("k_conv_sym8 (layer %d, %s)" % (dom, name)) if dom in sym8 else
                     ("k_conv_sym (layer %d, %s)" % (dom, name)) if dom in symmetric else
                     "k_%s_aprx (layer %d, %s)" % ("conv" if dom in conv_idx else "fc", dom, name),
                     traffic=traffic, traffic_source=tsrc,

@@ -63,7 +63,7 @@ constexpr int kSmallBatchMax = QCNN_SMALL_BATCH_MAX;  // batches up to this size
                                    // 128-image panel is cheaper (measured: 1 / 2 / 3 / 4 images 0.58 / 0.85 / 1.15 / 1.47 ms, a panel 1.50 ms)
 constexpr int kMaxFcSplit = 32;  // workgroups along the sub-space axis of an FC layer (partial sums reduced in fixed order)
 constexpr size_t kConvPartialFloats = (size_t)64 << 20;   // 256 MB of partial sums for split conv tiles (all sub-batches), allocated when a plan first splits
-constexpr double kSym8StageFactor = 1.25;   // what a stage of k_conv_sym8 costs against a stage of the tile kernel (it serves twice the look-ups)
+constexpr double kSym8StageFactor = 1.0;    // scale of qk_conv_sym8_cost's stage price (1.0 = its calibration)
 constexpr size_t kSlack = 64 * 1024;   // bytes of slack behind every device buffer: the MFMA operand loads are
                                         // unconditional and may read a few rows past the last dim / sub-space
 

@@ -65,7 +65,7 @@ constexpr int NW8 = 8;                              // waves per workgroup (2 pe
 constexpr uint32_t PROG8_LDS = 2u * STAGE_BYTES;    // three program-row buffers behind the two LUT stages
 constexpr uint32_t PROG8_BUF = 2048u;
 
-#include "qcnn_sym8_gather.h"      // gpos2 / gpos3 / gpos4 / gpos6: the look-ups of one position, software-pipelined (generated)
+#include "qcnn_sym8_gather.h"
 
 // operands of one stage for this wave: code-book tiles of its four row tiles, activation tiles of its two image tiles
 template <int KS>
@@ -429,12 +429,15 @@ hipError_t qk_build_program8(const uint8_t* rows, uint16_t* prog, const QkSlots&
 }
 
 // predicted duration (in stage-times of the tile kernel, like QkSplitPlan::cost) of a launch over p.panels panels: tiles
-// list-scheduled heaviest first on 256 CUs; stageFactor = what a stage of this kernel costs against a tile-kernel stage
-double qk_conv_sym8_cost(const ConvParams& p, const Qk8Config& cf, double stageFactor) {
+// list-scheduled heaviest first on 256 CUs.  A stage of this kernel is priced by its look-ups: measured (AlexNet conv2 - 5,
+// 1000 images, profiles/r4_*) 2540 + 1.97 x (row look-ups per stage) cycles against ~2500 for a stage of the tile kernel,
+// whose look-ups run beside its builder waves; `scale` corrects the whole (1.0 = that calibration)
+double qk_conv_sym8_cost(const ConvParams& p, const Qk8Config& cf, double scale) {
   if (!cf.cpw) return 0.0;
   const int TH = cf.th, TW = cf.tw;
   const int tilesX = (p.Wo + TW - 1) / TW, tilesY = (p.Ho + TH - 1) / TH, tiles = tilesX * tilesY;
-  std::vector<double> cost((size_t)tiles);
+  std::vector<double> stages((size_t)tiles);
+  double total = 0.0;
   for (int r = 0; r < tiles; ++r) {
     int ty, tx;
     tile_of_rank(r, tilesY, tilesX, ty, tx);
@@ -442,22 +445,27 @@ double qk_conv_sym8_cost(const ConvParams& p, const Qk8Config& cf, double stageF
     const int hoL = std::min(ho0 + TH, p.Ho) - 1, woL = std::min(wo0 + TW, p.Wo) - 1;
     const int rows = std::min(p.H - 1, hoL * p.stride - p.pad + p.knl - 1) - std::max(0, ho0 * p.stride - p.pad) + 1;
     const int cols = std::min(p.W - 1, woL * p.stride - p.pad + p.knl - 1) - std::max(0, wo0 * p.stride - p.pad) + 1;
-    cost[r] = stageFactor * ((double)std::max(rows, 0) * std::max(cols, 0) * p.M) + 10.0;
+    stages[r] = (double)std::max(rows, 0) * std::max(cols, 0) * p.M;
+    total += stages[r];
   }
+  // row look-ups of one group and channel chunk per panel (border-clipped taps x sub-spaces x channels) per built stage
+  auto taps = [&](int n, int nIn) {
+    long long t = 0;
+    for (int o = 0; o < n; ++o) t += std::min(p.knl - 1, nIn - 1 - (o * p.stride - p.pad)) - std::max(0, -(o * p.stride - p.pad)) + 1;
+    return (double)t;
+  };
+  const double perStage = total > 0.0 ? taps(p.Ho, p.H) * taps(p.Wo, p.W) * p.M * std::min(p.Ct / p.grp, NW8 * cf.cpw) / total : 0.0;
+  const double factor = scale * (2540.0 + 1.97 * perStage) / 2500.0;
   const int ny = p.grp * cf.chunks;
   const long long wgs = (long long)tiles * p.panels * ny;
-  if (wgs >= 8 * 256) {
-    double sum = 0.0;
-    for (int r = 0; r < tiles; ++r) sum += cost[r];
-    return sum * p.panels * ny / 256.0;
-  }
+  if (wgs >= 8 * 256) return (factor * total + 10.0 * tiles) * p.panels * ny / 256.0;
   std::priority_queue<double, std::vector<double>, std::greater<double>> q;
   for (int i = 0; i < 256; ++i) q.push(0.0);
   double end = 0.0;
   for (int y = 0; y < ny; ++y)
     for (int r = 0; r < tiles; ++r)
       for (int k = 0; k < p.panels; ++k) {
-        const double t = q.top() + cost[r];
+        const double t = q.top() + factor * stages[r] + 10.0;
         q.pop(); q.push(t);
         end = std::max(end, t);
       }

@@ -29,13 +29,22 @@ def stage_group(k: int) -> int:
     return 128 // k if k <= 64 else 1
 
 
-def conv_work(in_hwc, out_hwc, ly, m: int, k: int, cs: int, sym: bool = False):
+def sym8_tile(ctg: int):
+    """(TH, TW, channels per wave, channel chunks) of the eight-wave symmetric kernel (qk_conv_sym8_config)."""
+    chunks = (ctg + 383) // 384
+    per = (ctg + chunks - 1) // chunks
+    cpw, th, tw = (16, 2, 3) if per <= 128 else (24, 2, 2) if per <= 192 else (32, 1, 3) if per <= 256 else (48, 1, 2)
+    return th, tw, cpw, (ctg + 8 * cpw - 1) // (8 * cpw)
+
+
+def conv_work(in_hwc, out_hwc, ly, m: int, k: int, cs: int, sym=False):
     """Per 128-image panel: stages built, look-ups (border clipped), ideal stages (every (pixel, sub-space group)
-    once per group), f32 MFMA FLOP issued.  sym: the symmetric kernel's 2x2 tile of all 128 channels (k_conv_sym)."""
+    once per group), f32 MFMA FLOP issued.  sym: True = the 16-wave symmetric kernel's 2x2 tile of all 128 channels
+    (k_conv_sym), 8 = the eight-wave symmetric kernel's tile (k_conv_sym8)."""
     h, w, cin = in_hwc
     ho, wo, ct = out_hwc
     knl, s, p, grp = ly["knl"], ly["stride"], ly["pad"], ly["grp"]
-    th, tw, cpw, chunks = (2, 2, 8, 1) if sym else conv_tile(ct // grp)
+    th, tw, cpw, chunks = sym8_tile(ct // grp) if sym == 8 else (2, 2, 8, 1) if sym else conv_tile(ct // grp)
     g = stage_group(k)
     mg = (m + g - 1) // g
     stages = 0
@@ -55,7 +64,8 @@ def conv_work(in_hwc, out_hwc, ly, m: int, k: int, cs: int, sym: bool = False):
     # algorithmic LUT build (SURVEY.md §8 table "LUT-MAC/img"): every (pixel, sub-space) table once, over the dims it has
     alg_flop = 2 * h * w * grp * k * sum(min(cs, cin // grp - i * cs) for i in range(m)) * 128
     return dict(stages=stages, lookups=lookups, ideal_stages=ideal, mfma_flop=stages * 128 * 128 * 4 * ks * 2, alg_flop=alg_flop,
-                tile=("symmetric %dx%dx%d" % (th, tw, 16 * cpw)) if sym else "%dx%dx%d" % (th, tw, GATHER_WAVES * cpw), ks=ks)
+                tile=("symmetric 8 waves %dx%dx%d" % (th, tw, 8 * cpw)) if sym == 8 else
+                     ("symmetric %dx%dx%d" % (th, tw, 16 * cpw)) if sym else "%dx%dx%d" % (th, tw, GATHER_WAVES * cpw), ks=ks)
 
 
 def conv_work_slide(in_hwc, out_hwc, ly, m: int, k: int, cs: int, seg_beg):
@@ -108,7 +118,7 @@ def decoded_report(sizes, layers, l: int, images: float, ms: float):
                 lookups_replaced_per_image=int(conv_work(sizes[l], sizes[l + 1], ly, 1, 128, c)["lookups"]))
 
 
-def layer_report(sizes, layers, params, l: int, images: float, ms: float, seg_beg=None, sym: bool = False):
+def layer_report(sizes, layers, params, l: int, images: float, ms: float, seg_beg=None, sym=False):
     """Roofline-style figures of conv/FC layer l for a launch over `images` images that took `ms` milliseconds; seg_beg:
     the sliding kernel's row segments when the layer ran it (QcnnEngine.layer_segments)."""
     ly = layers[l]

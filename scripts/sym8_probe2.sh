@@ -1,12 +1,8 @@
 set -x
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_parity.py -q -x -k "sym8" 2>&1 | tail -5
-for v in 0 2 6; do
+timeout 900 python -m pytest tests/test_gpu_parity.py -q -x -k "sym8" 2>&1 | tail -8
+for v in 2 6; do
   timeout 600 python bench.py --steps 5 --warmup 2 --extras 0 --cpu-sample 0 --parity-images 4 --sym8 $v 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.readline()); print('sym8=$v', d['value'], {k:v for k,v in d['roofline']['layer_ms'].items() if 'conv' in k}, d['parity']['ok'])"
 done
-QCNN_HIP_LIB=$PWD/quantized-cnn_amd/libqcnn_hip_s8prio.so timeout 600 python bench.py --steps 5 --warmup 2 --extras 0 --cpu-sample 0 --parity-images 4 --sym8 2 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.readline()); print('prio1 sym8=2', d['value'], {k:v for k,v in d['roofline']['layer_ms'].items() if 'conv' in k}, d['parity']['ok'])"
-python scripts/trace_sym8.py 8 300 1000 2

@@ -5,7 +5,7 @@ inputs".  The ten shipped Bmp.Files/*.BMP (decoded by the reference's own BmpImg
 panels + a ragged one of 104, and every feature map the configuration materialises is compared with what the COMPILED
 reference produced for that image (tests/golden/alexnet_real10_ref.npz, oracle/make_golden.py) — for images of the
 first panel, of a middle one and of the ragged last one.  Configurations: the library defaults (decoded conv1 / fc8,
-split, sliding and symmetric kernels as the planner picks them), layer-for-layer and fast path (fused ReLU, fused
+split, sliding, symmetric and eight-wave symmetric kernels as the planner picks them), layer-for-layer and fast path (fused ReLU, fused
 LRN + pool, one stream = what bench.py times), every eligible layer forced through the symmetric / sliding kernels, and
 every layer through tables (QCNN_OPT_DECODE = 0).  The fc6 assignment file is missing from the reference mount
 (SURVEY.md §0 fact 3): fixture 1 (SURVEY's recipe) leaves fc7 / fc8 degenerate, so the tail fm[16..23], the soft-max
@@ -31,13 +31,13 @@ N = 1000
 BLOCKS = ((0, 10), (500, 10), (990, 10))       # (first image, count): first panel, a middle one, the ragged last one
 
 
-def _engine(params, keep_all, streams=None, host_chunk=None, sym=None, slide=None, decode=None, split=None):
+def _engine(params, keep_all, streams=None, host_chunk=None, sym=None, slide=None, decode=None, split=None, sym8=None):
     in_chw, layers, _, _ = topo.MODELS["AlexNet"]
     eng = pkg("engine").QcnnEngine(0)
     eng.set_option(capi.OPT_LUT_MODE, capi.LUT_MFMA)
     eng.set_option(capi.OPT_KEEP_ALL, keep_all)
     for opt, v in ((capi.OPT_STREAMS, streams), (capi.OPT_HOST_CHUNK, host_chunk), (capi.OPT_SYM, sym),
-                   (capi.OPT_SLIDE, slide), (capi.OPT_DECODE, decode), (capi.OPT_SPLIT, split)):
+                   (capi.OPT_SLIDE, slide), (capi.OPT_DECODE, decode), (capi.OPT_SPLIT, split), (capi.OPT_SYM8, sym8)):
         if v is not None:
             eng.set_option(opt, v)
     eng.load_model(in_chw, layers, params, N)
@@ -84,8 +84,10 @@ CONFIGS = {
     "defaults_layer_for_layer": dict(keep_all=1),
     # what bench.py times: fast path (fused ReLU, fused LRN + pool), one stream, one launch per layer
     "headline_fast_path": dict(keep_all=0, streams=1, host_chunk=0),
-    # every eligible layer through the symmetric / sliding kernels whatever the planner would pick
+    # every eligible layer through the (16-wave) symmetric / sliding kernels whatever the planner would pick
     "forced_sym_slide": dict(keep_all=1, sym=2, slide=2),
+    # every eligible layer (conv2 - conv5) through the eight-wave symmetric kernel
+    "forced_sym8": dict(keep_all=1, sym8=2),
     # the north star's scheme for all eight conv / FC layers (bench key value_tables_only)
     "tables_only_fast_path": dict(keep_all=0, streams=1, host_chunk=0, decode=0),
 }
@@ -104,9 +106,9 @@ def test_shipped_parameters_headline_kernels_match_reference(golden_alex_real10,
     n_maps = _check_maps(eng, z, 1, range(0, L + 1), name)
     _check_outputs(prob, top5, z, 1, name)
     if name == "headline_fast_path":
-        # which kernels ran (qcnn_get_layer_split: -3 decoded, -4 symmetric, -2 sliding): the ones the headline is made of
+        # which kernels ran (qcnn_get_layer_split: -3 decoded, -5 eight-wave symmetric, -2 sliding): the ones the headline is made of
         assert eng.layer_split(0)[0] == -3 and eng.layer_split(21)[0] == -3      # conv1, fc8 decoded
-        assert eng.layer_split(4)[0] == -4                                       # conv2 symmetric workgroups
+        assert eng.layer_split(4)[0] == -5 and eng.layer_split(10)[0] == -5      # conv2, conv4: eight-wave symmetric workgroups
         assert eng.layer_split(12)[0] == -2                                      # conv5 sliding
         with pytest.raises(pkg("engine").QcnnError):
             eng.layer_output_range(3, 0, 1)                                      # LRN1 fused into the pool behind it
