@@ -63,7 +63,7 @@ constexpr int kSmallBatchMax = QCNN_SMALL_BATCH_MAX;  // batches up to this size
                                    // 128-image panel is cheaper (measured: 1 / 2 / 3 / 4 images 0.58 / 0.85 / 1.15 / 1.47 ms, a panel 1.50 ms)
 constexpr int kMaxFcSplit = 32;  // workgroups along the sub-space axis of an FC layer (partial sums reduced in fixed order)
 constexpr size_t kConvPartialFloats = (size_t)64 << 20;   // 256 MB of partial sums for split conv tiles (all sub-batches), allocated when a plan first splits
-constexpr double kSym8StageFactor = 1.0;    // scale of qk_conv_sym8_cost's stage price (1.0 = its calibration)
+constexpr double kSym8StageFactor = 0.97;   // scale of qk_conv_sym8_cost's stage price (its list schedule over-prices the last round by ~3 %)
 constexpr size_t kSlack = 64 * 1024;   // bytes of slack behind every device buffer: the MFMA operand loads are
                                         // unconditional and may read a few rows past the last dim / sub-space
 
@@ -380,14 +380,21 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
               pl.segN = t.nSeg;
               for (int i = 0; i <= t.nSeg && i < 9; ++i) pl.segBeg[i] = t.segBeg[i];
             }
+            if (const char* dbg = getenv("QCNN_DEBUG_PLAN"); dbg && atoi(dbg))
+              fprintf(stderr, "[qcnn plan] layer %d panels %d: tile %.0f (Z %d) | slide %.0f (%d segments) | sym %.0f | sym8 %.0f stage-times\n",
+                      l, panels, pl.plan.cost, pl.plan.Z, pl.slideCost, pl.segN, pl.symCost, pl.sym8Cost);
             it = s.plans.emplace(key, pl).first;
           }
           const LayerShape::Plan& pl = it->second;
           // eight-wave symmetric workgroups: when forced, or predicted at least 3 % faster than every other plan of the launch
           if (pl.sym8Cost > 0.0 && c->lutMode == 1 && !inNchw && ((c->sym8 & 3) >= 2 || (c->sym < 2 && c->slide < 2))) {
             double other = pl.plan.cost;                           // tile kernel, whole or split (in stage-times)
-            if (pl.symCost > 0.0 && pl.symCost < other) other = pl.symCost;
-            if (pl.segN > 0 && pl.slideCost > 0.0 && pl.slideCost < other) other = pl.slideCost;
+            // (qk_conv_sym_cost prices a 16-wave symmetric stage at 1.09 tile stages — enough to rank it against the tile kernel;
+            // measured 1.18: 2952 against 2508 cycles on AlexNet conv2)
+            if (pl.symCost > 0.0 && 1.08 * pl.symCost < other) other = 1.08 * pl.symCost;
+            // (a sliding stage is priced 3 % above a tile stage; measured 3330 against 2500 cycles with 12 channels per wave, i.e.
+            // ~1.05 us per planner unit against ~0.92 for this kernel on AlexNet conv5 and VGG-16's 256 / 512-channel layers)
+            if (pl.segN > 0 && pl.slideCost > 0.0) other = std::min(other, 1.10 * pl.slideCost);
             if ((c->sym8 & 3) >= 2 || pl.sym8Cost < 0.97 * other) {
               p.progS = reinterpret_cast<const uint16_t*>(c->arena + s.offProg8);
               s.lastFrom = -5; s.lastZ = 1;             // reported by qcnn_get_layer_split as (-5, 1)
