@@ -36,6 +36,8 @@ struct LayerShape {
   size_t offProgY = 0, progYBytes = 0;                         // ... and of the symmetric kernel's (8 channels per wave, 2x2 tile) layout
   size_t offProg8 = 0, prog8Bytes = 0;                         // ... and of the eight-wave symmetric kernel's layout (Qk8Config)
   size_t offCtrd8 = 0;                                         // ... with the code book in that kernel's operand order (qk_ctrd8_index)
+  size_t offCbn = 0, cbnBytes = 0; int cbnBits = 0;            // FC: the assignments bit-packed as the .cbn payload holds them (file order
+                                                               // [Ct][M], include/FileIO.h:128-166), read in place by the few-image kernel
   size_t offDec = 0; int decKp = 0, decS = 0;                  // decoded code words (qcnn_decoded.hip): conv layer with one sub-space of
                                                                // <= 4 dims (decKp > 0), FC layer with one-dim sub-spaces (decKp = -1); 0: not eligible
   bool hasDmap = false;
@@ -78,6 +80,7 @@ struct QcnnCtx {
   int nStreams = 2;                  // QCNN_OPT_STREAMS: sub-batches of whole panels run concurrently
   int smallBatch = 1;                // QCNN_OPT_SMALL_BATCH: few-image kernels for batches <= kSmallBatchMax
   int hostChunk = 2;                 // QCNN_OPT_HOST_CHUNK: panels per chunk of a large qcnn_forward_host batch (0: one launch)
+  int packedFc = 1;                  // QCNN_OPT_PACKED_FC: the few-image FC kernel reads the bit-packed assignment stream in place
   int sym8 = 1;                      // QCNN_OPT_SYM8: eight-wave symmetric workgroups where predicted faster (2: whenever eligible; +4: staggered phases)
   int sym = 1;                       // QCNN_OPT_SYM: symmetric workgroups for 128-channel layers where predicted faster (2: whenever eligible)
   int decode = 1;                    // QCNN_OPT_DECODE: one-sub-space conv layers through their decoded code words (MFMA builders only)
@@ -202,6 +205,14 @@ int plan_arena(QcnnCtx* c) {
       const QkProgram py = qk_conv_program(qk_make_slots(Ct / d.grpCnt, d.grpCnt, 8), d.knlSiz, d.stride);
       s.progYBytes = (size_t)py.rfH * py.rfW * s.M * py.rowU16 * sizeof(uint16_t);
       s.offProgY = off; off = align_up(off + s.progYBytes + QCNN_ROWS_PAD, 256);
+    }
+    s.cbnBytes = 0;
+    if (d.type == QCNN_FCNT) {           // bits = the reference's CalcBitCntPerEle for K code words (src/CaffePara.cc:360-380)
+      s.cbnBits = 1;
+      while ((1 << s.cbnBits) < s.K) ++s.cbnBits;
+      const size_t per = 4096 * 8 / (size_t)s.cbnBits;
+      s.cbnBytes = ((size_t)Ct * s.M + per - 1) / per * 4096;
+      s.offCbn = off; off = align_up(off + s.cbnBytes + 256, 256);
     }
     s.prog8Bytes = 0;
     if (d.type == QCNN_CONV) {
@@ -472,6 +483,8 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
       p.bias = reinterpret_cast<const float*>(c->arena + s.offBias);
       p.ctrd = reinterpret_cast<const float*>(c->arena + s.offCtrd);
       p.rows = reinterpret_cast<const uint8_t*>(c->arena + s.offAsmt);
+      p.cbn = (s.cbnBytes && c->packedFc) ? reinterpret_cast<const uint8_t*>(c->arena + s.offCbn) : nullptr;
+      p.cbnBits = s.cbnBits;
       if (s.hasDmap && !flatFcInput) {   // NHWC -> consumption order (NCHW flatten) into the scratch map
         float* flat = c->fcFlat + (size_t)p0 * fm_elems(c, l) * QCNN_PANEL;
         e = qk_permute_rows(src, flat, reinterpret_cast<const int*>(c->arena + s.offDmap), a.h * a.w * a.c,
@@ -780,6 +793,7 @@ int qcnn_set_option(QcnnCtx* c, int option, int value) {
     case QCNN_OPT_SPLIT: c->split = value ? 1 : 0; return 0;
     case QCNN_OPT_DECODE: c->decode = value ? 1 : 0; return 0;
     case QCNN_OPT_SYM8: c->sym8 = value < 0 ? 0 : (value & 7); return 0;
+    case QCNN_OPT_PACKED_FC: c->packedFc = value ? 1 : 0; return 0;
     case QCNN_OPT_SYM: c->sym = value < 0 ? 0 : (value > 2 ? 2 : value); return 0;
     case QCNN_OPT_SLIDE: c->slide = value < 0 ? 0 : (value > 2 ? 2 : value); return 0;
     case QCNN_OPT_HOST_CHUNK:
@@ -1005,6 +1019,28 @@ int upload_bias_ctrd(QcnnCtx* c, int layer, const float* bias, const float* ctrd
 }  // namespace
 
 namespace {
+// FC layer: the assignments (file order [Ct][M], 0-based code words) bit-packed exactly as a .cbn payload of `bits` bits per
+// element (include/FileIO.h:299-341: 4096-byte blocks of floor(32768 / bits) values, MSB first, no value across a block)
+// into the arena: the resident form the few-image kernel reads in place
+int upload_packed_assignments(QcnnCtx* c, int layer, const uint8_t* asmt_file) {
+  const LayerShape& s = c->shapes[layer];
+  if (!s.cbnBytes) return 0;
+  const size_t n = (size_t)c->dims[layer + 1].c * s.M;
+  const int bits = s.cbnBits;
+  const size_t per = 4096 * 8 / (size_t)bits;
+  std::vector<uint8_t> blocks(s.cbnBytes, 0);
+  for (size_t e = 0; e < n; ++e) {
+    const size_t bit0 = (e % per) * bits;
+    uint8_t* b = blocks.data() + (e / per) * 4096 + (bit0 >> 3);
+    const unsigned w = (unsigned)asmt_file[e] << (16 - (bit0 & 7) - bits);      // <= 8 bits: at most two bytes
+    b[0] |= (uint8_t)(w >> 8);
+    if (w & 0xffu) b[1] |= (uint8_t)(w & 0xffu);
+  }
+  HIP_TRY(c, hipMemcpyAsync(c->arena + s.offCbn, blocks.data(), blocks.size(), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
 // rows table of a conv layer (already in the arena, same stream) -> program table
 hipError_t build_program(QcnnCtx* c, int layer, const QkSlots& sl) {
   const QcnnLayerDesc& d = c->layers[layer];
@@ -1071,6 +1107,7 @@ int qcnn_model_set_layer_params(QcnnCtx* c, int layer, const float* bias, const 
       }
   }
   if (upload_bias_ctrd(c, layer, bias, ctrd_file)) return 1;
+  if (upload_packed_assignments(c, layer, asmt_file)) return 1;
   HIP_TRY(c, hipMemcpyAsync(c->arena + s.offAsmt, asmt.data(), asmt.size(), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, build_program(c, layer, sl));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -1096,11 +1133,26 @@ int qcnn_model_set_layer_params_cbn(QcnnCtx* c, int layer, const float* bias, co
   const size_t need = (n + per - 1) / per * 4096;
   if (cbn_bytes < need) return fail(c, "layer %d: %zu bytes of packed assignments, %zu needed", layer, cbn_bytes, need);
   if (upload_bias_ctrd(c, layer, bias, ctrd_file)) return 1;
+  if (s.cbnBytes && bits != s.cbnBits) {           // a stream of another width: re-packed at the layer's own width for the resident copy
+    std::vector<uint8_t> vals(n);
+    bool bad = false;
+    for (size_t e = 0; e < n; ++e) {
+      const size_t bit0 = (e % per) * bits;
+      const uint8_t* b = cbn_blocks + (e / per) * 4096 + (bit0 >> 3);
+      const unsigned w = ((unsigned)b[0] << 8) | (unsigned)b[(bit0 & 7) + bits > 8 ? 1 : 0];
+      vals[e] = (uint8_t)((w >> (16 - (bit0 & 7) - bits)) & ((1u << bits) - 1u));
+      bad = bad || vals[e] >= s.K;
+    }
+    if (bad) return fail(c, "layer %d: an assignment >= K = %d in the packed stream", layer, s.K);
+    if (upload_packed_assignments(c, layer, vals.data())) return 1;
+  }
   uint8_t* dev = nullptr;
   int* bad = nullptr;
   HIP_TRY(c, hipMalloc(&dev, need + sizeof(int)));
   bad = reinterpret_cast<int*>(dev + need);
   hipError_t e = hipMemcpyAsync(dev, cbn_blocks, need, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess && s.cbnBytes && bits == s.cbnBits)       // the payload itself is the resident packed form
+    e = hipMemcpyAsync(c->arena + s.offCbn, dev, std::min(need, s.cbnBytes), hipMemcpyDeviceToDevice, c->stream);
   if (e == hipSuccess) e = hipMemsetAsync(bad, 0, sizeof(int), c->stream);
   if (e == hipSuccess) e = hipMemsetAsync(c->arena + s.offAsmt, 0, s.asmtBytes + QCNN_ROWS_PAD, c->stream);   // padding entries -> row 0
   if (e == hipSuccess)

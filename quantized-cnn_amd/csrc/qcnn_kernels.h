@@ -241,6 +241,9 @@ struct FcParams {
   const float* bias;
   const float* ctrd;     // [M][Cs][K]
   const uint8_t* rows;   // [M][rowStride]  (src/CaffeEva.cc:610-611): row slots, QkSlots order
+  const uint8_t* cbn;    // the same assignments BIT-PACKED as the reference's .cbn payload holds them (include/FileIO.h:128-166: file
+                         // order [Ct][M], 4096-byte blocks of floor(32768 / bits) values, MSB first, 0-based code words), or NULL;
+  int cbnBits;           // read in place by the few-image kernel (qk_fc_small): 4 / 5 bits per assignment instead of a byte
   int D, Ct, M, Cs, K;
   int relu;
   int panels;

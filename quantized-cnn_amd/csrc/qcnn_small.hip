@@ -252,6 +252,8 @@ struct SmallFc {
   const float* bias;
   const float* ctrd;
   const uint8_t* rows;     // [M][rowStride]: row slots
+  const uint8_t* cbn;      // or: the .cbn payload ([Ct][M] code words, `bits` each, 4096-byte blocks of `per` values), read in place
+  int bits, per;
   int D, Ct, M, Cs, K, G, relu, rowStride, MC;
   QkSlots sl;
 };
@@ -299,6 +301,37 @@ __global__ __launch_bounds__(NT) void k_fc_small(SmallFc p) {
     if (chOk) {
       const int per = (mc + FC_SLICES - 1) / FC_SLICES;
       const int a0 = slice * per, a1 = min(mc, a0 + per);
+      if (p.cbn != nullptr) {
+        // Packed stream in place: the channel's assignments of this slice are CONSECUTIVE values of the
+        // file order [Ct][M] — (a1 - a0) x bits contiguous bits, at most one 4096-byte block boundary inside.  A value
+        // = the `bits` bits at bit (index in block) x bits, MSB first: two byte loads and a shift (values never
+        // straddle a block; a second byte that is not needed is not read past the block).
+        if (a0 < a1) {
+          const size_t e0 = (size_t)c * p.M + (size_t)(m0 + a0);
+          const uint8_t* __restrict__ blk = p.cbn + (e0 / (size_t)p.per) * 4096;
+          const int r0 = (int)(e0 % (size_t)p.per);
+          const unsigned mask = (1u << p.bits) - 1u;
+          for (int ml = a0; ml < a1; ml += 8) {                       // eight independent look-ups at a time
+            unsigned code[8];
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              int rr = r0 + (min(ml + u, a1 - 1) - a0);
+              const uint8_t* __restrict__ b = blk;
+              if (rr >= p.per) { rr -= p.per; b += 4096; }
+              const int bit0 = rr * p.bits;
+              const uint8_t* __restrict__ q = b + (bit0 >> 3);
+              const unsigned w = ((unsigned)q[0] << 8) | (unsigned)q[(bit0 & 7) + p.bits > 8 ? 1 : 0];
+              code[u] = (w >> (16 - (bit0 & 7) - p.bits)) & mask;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = lut[min(ml + u, a1 - 1) * K + (int)code[u]];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+              if (ml + u < a1) acc += v[u];
+          }
+        }
+      } else {
       const uint8_t* rr = p.rows + (size_t)m0 * p.rowStride + entry;
       for (int ml = a0; ml < a1; ml += 8) {                         // eight independent look-ups at a time
         uint8_t o[8];
@@ -313,6 +346,7 @@ __global__ __launch_bounds__(NT) void k_fc_small(SmallFc p) {
 #pragma unroll
         for (int u = 0; u < 8; ++u)
           if (ml + u < a1) acc += v[u];
+      }
       }
     }
     __syncthreads();
@@ -380,6 +414,8 @@ hipError_t qk_fc_small(const FcParams& fp, int n, hipStream_t st) {
   if (fp.K % 4 || fp.partial == nullptr) return hipErrorInvalidValue;
   SmallFc p;
   p.src = fp.src; p.dst = fp.dst; p.lut = fp.partial; p.bias = fp.bias; p.ctrd = fp.ctrd; p.rows = fp.rows;
+  p.cbn = (fp.cbnBits >= 1 && fp.cbnBits <= 8) ? fp.cbn : nullptr;
+  p.bits = fp.cbnBits; p.per = p.cbn ? 4096 * 8 / fp.cbnBits : 1;
   p.D = fp.D; p.Ct = fp.Ct; p.M = fp.M; p.Cs = fp.Cs; p.K = fp.K; p.G = qcnn_stage_group(fp.K); p.relu = fp.relu;
   p.sl = qk_fc_slots(fp.Ct);
   p.rowStride = p.sl.rowStride;

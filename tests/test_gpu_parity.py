@@ -546,6 +546,46 @@ def test_cbn_payload_decoded_on_the_device(golden_tiny):
     e1.close(); e2.close()
 
 
+def test_packed_assignment_stream_read_in_place():
+    """SURVEY.md §8f-3, second half: for batches of a few images the FC layers read their assignments from the bit-packed
+    stream of the reference's .cbn files (file order [Ct][M], 5 / 4 bits, values across byte but never across 4096-byte block
+    boundaries), resident beside the byte table, and unpack them in the kernel (QCNN_OPT_PACKED_FC, default on).  Same
+    bits as the byte path (QCNN_OPT_PACKED_FC = 0) for 1, 2 and 3 images — AlexNet sizes: fc6 = 9.4 M values in 1441
+    blocks —, whether the parameters came as bytes (packed on the host), as a .cbn payload of the layer's own width (kept as
+    it is) or of another width (re-packed), and within 1e-4 of the oracle."""
+    in_chw, layers, _, _ = topo.MODELS["AlexNet"]
+    params = synth.make_params(in_chw, layers, seed=31)
+    imgs = synth.make_images(3, in_chw, seed=32)
+    orc = po.COracle(in_chw, layers)
+    orc.set_params(params)
+    orc.forward(imgs)
+    L = len(layers)
+    shapes = {i: tuple(int(x) for x in p["ctrd"].shape) for i, p in params.items()}
+
+    def engine(upload, packed):
+        e = pkg("engine").QcnnEngine(0)
+        e.set_option(capi.OPT_PACKED_FC, packed)
+        e.configure(in_chw, layers, shapes)
+        e.commit(4)
+        upload(e)
+        return e
+    wide = {i: dict(p, bits=p["bits"] + 1) if layers[i]["type"] == topo.FCNT else p for i, p in params.items()}   # 6 / 5 bits
+    ref = engine(lambda e: e.upload(params), 0)
+    variants = [engine(lambda e: e.upload(params), 1), engine(lambda e: e.upload_cbn(params), 1),
+                engine(lambda e: e.upload_cbn(wide), 1)]
+    for n in (1, 2, 3):
+        p0, t0 = ref.forward_host(imgs[:n])
+        for k, eng in enumerate(variants):
+            p1, t1 = eng.forward_host(imgs[:n])
+            assert np.array_equal(p0, p1) and np.array_equal(t0, t1), (n, k)
+            for l in (16, 19, 22):
+                assert np.array_equal(eng.layer_output(l, n), ref.layer_output(l, n)), (n, k, l)
+        e_inf, e_l2 = rel_err(p0, orc.fm(L).reshape(3, -1)[:n])
+        assert e_inf <= TOL and e_l2 <= TOL
+    for e in [ref] + variants:
+        e.close()
+
+
 def test_cbn_payload_with_an_index_beyond_k_is_rejected():
     in_chw = (3, 8, 8)
     layers = [topo.conv(0, 3, 8, 1, 1), topo.relu(), topo.fcnt(10), topo.smax()]
