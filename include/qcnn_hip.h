@@ -113,11 +113,12 @@ enum {
                               predicts them faster than the tile / sliding / 16-wave symmetric launch.  Bit-identical to the tile
                               kernels; f32 MFMA mode only.  0 = never; 2 = whenever eligible (tests); + 4 = the two waves of a SIMD
                               run their build and gather phases in opposite order (experiments) */
-  QCNN_OPT_PACKED_FC = 11, /* 1 (default): for batches of up to QCNN_SMALL_BATCH_MAX images the FC layers read their assignments from the
+  QCNN_OPT_PACKED_FC = 11, /* 1: for batches of up to QCNN_SMALL_BATCH_MAX images the FC layers read their assignments from the
                               BIT-PACKED stream the reference's .cbn files hold (4 / 5 bits per assignment, file order [Ct][M], kept
                               resident in the arena beside the one-byte table of the panel kernels) and unpack them in the kernel:
                               AlexNet streams 10.5 MB of FC assignments per image instead of 16.8 MB of bytes (of which the strided
-                              byte reads fetched 64-byte lines: 4x).  Same bits as the byte path.  0 = bytes */
+                              byte reads fetched 64-byte lines: 4x).  Same bits as the byte path.  0 (default) = bytes: the unpack arithmetic of the
+                              block-structured stream costs more than the traffic it saves (fc6 0.056 against 0.035 ms at one image) */
   QCNN_OPT_HOST_CHUNK = 6, /* panels per chunk (default 2) of a qcnn_forward_host batch of at least two chunks: every chunk is
                               uploaded on a copy stream and its layers start when it has arrived, so the upload of chunk
                               k + 1 runs under the layers of chunk k; all chunks fill the same whole-batch feature maps.

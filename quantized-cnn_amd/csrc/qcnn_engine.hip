@@ -80,7 +80,7 @@ struct QcnnCtx {
   int nStreams = 2;                  // QCNN_OPT_STREAMS: sub-batches of whole panels run concurrently
   int smallBatch = 1;                // QCNN_OPT_SMALL_BATCH: few-image kernels for batches <= kSmallBatchMax
   int hostChunk = 2;                 // QCNN_OPT_HOST_CHUNK: panels per chunk of a large qcnn_forward_host batch (0: one launch)
-  int packedFc = 1;                  // QCNN_OPT_PACKED_FC: the few-image FC kernel reads the bit-packed assignment stream in place
+  int packedFc = 0;                  // QCNN_OPT_PACKED_FC (default off: measured 0.056 against 0.035 ms for AlexNet fc6 at one image): the few-image FC kernel reads the bit-packed assignment stream in place
   int sym8 = 1;                      // QCNN_OPT_SYM8: eight-wave symmetric workgroups where predicted faster (2: whenever eligible; +4: staggered phases)
   int sym = 1;                       // QCNN_OPT_SYM: symmetric workgroups for 128-channel layers where predicted faster (2: whenever eligible)
   int decode = 1;                    // QCNN_OPT_DECODE: one-sub-space conv layers through their decoded code words (MFMA builders only)

@@ -549,7 +549,7 @@ def test_cbn_payload_decoded_on_the_device(golden_tiny):
 def test_packed_assignment_stream_read_in_place():
     """SURVEY.md §8f-3, second half: for batches of a few images the FC layers read their assignments from the bit-packed
     stream of the reference's .cbn files (file order [Ct][M], 5 / 4 bits, values across byte but never across 4096-byte block
-    boundaries), resident beside the byte table, and unpack them in the kernel (QCNN_OPT_PACKED_FC, default on).  Same
+    boundaries), resident beside the byte table, and unpack them in the kernel (QCNN_OPT_PACKED_FC = 1).  Same
     bits as the byte path (QCNN_OPT_PACKED_FC = 0) for 1, 2 and 3 images — AlexNet sizes: fc6 = 9.4 M values in 1441
     blocks —, whether the parameters came as bytes (packed on the host), as a .cbn payload of the layer's own width (kept as
     it is) or of another width (re-packed), and within 1e-4 of the oracle."""
