@@ -111,8 +111,9 @@ enum {
                               accumulators of the 16-wave kernels per CU, i.e. larger output tiles (384 channels x 1x2, 256 x 1x3,
                               192 x 2x2, 128 x 2x3) and a third fewer table builds per output position — when the launch planner
                               predicts them faster than the tile / sliding / 16-wave symmetric launch.  Bit-identical to the tile
-                              kernels; f32 MFMA mode only.  0 = never; 2 = whenever eligible (tests); + 4 = the two waves of a SIMD
-                              run their build and gather phases in opposite order (experiments) */
+                              kernels; f32 MFMA mode only.  0 = never; 2 = whenever eligible (tests).  FC layers with 32 code words of 4 dims
+                              (AlexNet / VGG-16 fc6, fc7) run the same eight waves (k_fc_sym8: 96 channels per wave, offsets through
+                              LDS-DMA, software-pipelined look-ups) unless the option is 0 */
   QCNN_OPT_PACKED_FC = 11, /* 1: for batches of up to QCNN_SMALL_BATCH_MAX images the FC layers read their assignments from the
                               BIT-PACKED stream the reference's .cbn files hold (4 / 5 bits per assignment, file order [Ct][M], kept
                               resident in the arena beside the one-byte table of the panel kernels) and unpack them in the kernel:

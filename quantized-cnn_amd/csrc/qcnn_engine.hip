@@ -36,6 +36,7 @@ struct LayerShape {
   size_t offProgY = 0, progYBytes = 0;                         // ... and of the symmetric kernel's (8 channels per wave, 2x2 tile) layout
   size_t offProg8 = 0, prog8Bytes = 0;                         // ... and of the eight-wave symmetric kernel's layout (Qk8Config)
   size_t offCtrd8 = 0;                                         // ... with the code book in that kernel's operand order (qk_ctrd8_index)
+  size_t offProgF8 = 0, progF8Bytes = 0, offCtrdF = 0;         // FC with 32 code words of 4 dims: program + code book of the eight-wave kernel (k_fc_sym8)
   size_t offCbn = 0, cbnBytes = 0; int cbnBits = 0;            // FC: the assignments bit-packed as the .cbn payload holds them (file order
                                                                // [Ct][M], include/FileIO.h:128-166), read in place by the few-image kernel
   size_t offDec = 0; int decKp = 0, decS = 0;                  // decoded code words (qcnn_decoded.hip): conv layer with one sub-space of
@@ -81,7 +82,7 @@ struct QcnnCtx {
   int smallBatch = 1;                // QCNN_OPT_SMALL_BATCH: few-image kernels for batches <= kSmallBatchMax
   int hostChunk = 2;                 // QCNN_OPT_HOST_CHUNK: panels per chunk of a large qcnn_forward_host batch (0: one launch)
   int packedFc = 0;                  // QCNN_OPT_PACKED_FC (default off: measured 0.056 against 0.035 ms for AlexNet fc6 at one image): the few-image FC kernel reads the bit-packed assignment stream in place
-  int sym8 = 1;                      // QCNN_OPT_SYM8: eight-wave symmetric workgroups where predicted faster (2: whenever eligible; +4: staggered phases)
+  int sym8 = 1;                      // QCNN_OPT_SYM8: eight-wave symmetric workgroups where predicted faster (2: whenever eligible)
   int sym = 1;                       // QCNN_OPT_SYM: symmetric workgroups for 128-channel layers where predicted faster (2: whenever eligible)
   int decode = 1;                    // QCNN_OPT_DECODE: one-sub-space conv layers through their decoded code words (MFMA builders only)
   int slide = 1;                     // QCNN_OPT_SLIDE: sliding-window conv kernels where they pay (MFMA builders only)
@@ -205,6 +206,12 @@ int plan_arena(QcnnCtx* c) {
       const QkProgram py = qk_conv_program(qk_make_slots(Ct / d.grpCnt, d.grpCnt, 8), d.knlSiz, d.stride);
       s.progYBytes = (size_t)py.rfH * py.rfW * s.M * py.rowU16 * sizeof(uint16_t);
       s.offProgY = off; off = align_up(off + s.progYBytes + QCNN_ROWS_PAD, 256);
+    }
+    s.progF8Bytes = 0;
+    if (d.type == QCNN_FCNT && qk_fc_sym8_shape((int)fm_elems(c, l), Ct, s.M, s.Cs, s.K)) {
+      s.progF8Bytes = qk_fc_sym8_program_bytes(Ct, s.M);
+      s.offProgF8 = off; off = align_up(off + s.progF8Bytes + QCNN_ROWS_PAD, 256);
+      s.offCtrdF = off; off = align_up(off + sizeof(float) * (size_t)s.M * s.Cs * s.K, 256);
     }
     s.cbnBytes = 0;
     if (d.type == QCNN_FCNT) {           // bits = the reference's CalcBitCntPerEle for K code words (src/CaffePara.cc:360-380)
@@ -376,14 +383,14 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
           // tile's summation order) / sliding kernel (QCNN_OPT_SLIDE; same order and bits as the tile kernel).
           const size_t share = kConvPartialFloats / (size_t)nsub;
           const long long key = (((((((long long)panels * 8 + nsub) * 2 + (c->split ? 1 : 0)) * 4 + c->slide) * 4 + c->sym) * 4 +
-                                  c->lutMode) * 2 + (inNchw ? 1 : 0)) * 8 + (c->sym8 & 7);
+                                  c->lutMode) * 2 + (inNchw ? 1 : 0)) * 8 + c->sym8;
           auto it = s.plans.find(key);
           if (it == s.plans.end()) {
             LayerShape::Plan pl;
             const size_t scratch = c->split ? share : 0;            // no scratch: qk_conv_plan only prices the whole-tile launch
             pl.plan = qk_conv_plan(p, scratch);
             pl.symCost = (c->sym && s.progYBytes && c->lutMode == 1 && !inNchw) ? qk_conv_sym_cost(p) : 0.0;
-            pl.sym8Cost = ((c->sym8 & 3) && s.prog8Bytes && c->lutMode == 1 && !inNchw)
+            pl.sym8Cost = (c->sym8 && s.prog8Bytes && c->lutMode == 1 && !inNchw)
                               ? qk_conv_sym8_cost(p, qk_conv_sym8_config(p.Cin, p.grp, p.Ct, p.M, p.Cs, p.K), kSym8StageFactor) : 0.0;
             if (c->slide && p.progS) {                // sliding variant where it is predicted to beat the (split) tile kernel
               ConvParams t = p;
@@ -398,7 +405,7 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
           }
           const LayerShape::Plan& pl = it->second;
           // eight-wave symmetric workgroups: when forced, or predicted at least 3 % faster than every other plan of the launch
-          if (pl.sym8Cost > 0.0 && c->lutMode == 1 && !inNchw && ((c->sym8 & 3) >= 2 || (c->sym < 2 && c->slide < 2))) {
+          if (pl.sym8Cost > 0.0 && c->lutMode == 1 && !inNchw && (c->sym8 >= 2 || (c->sym < 2 && c->slide < 2))) {
             double other = pl.plan.cost;                           // tile kernel, whole or split (in stage-times)
             // (qk_conv_sym_cost prices a 16-wave symmetric stage at 1.09 tile stages — enough to rank it against the tile kernel;
             // measured 1.18: 2952 against 2508 cycles on AlexNet conv2)
@@ -406,10 +413,10 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
             // (a sliding stage is priced 3 % above a tile stage; measured 3330 against 2500 cycles with 12 channels per wave, i.e.
             // ~1.05 us per planner unit against ~0.92 for this kernel on AlexNet conv5 and VGG-16's 256 / 512-channel layers)
             if (pl.segN > 0 && pl.slideCost > 0.0) other = std::min(other, 1.10 * pl.slideCost);
-            if ((c->sym8 & 3) >= 2 || pl.sym8Cost < 0.97 * other) {
+            if (c->sym8 >= 2 || pl.sym8Cost < 0.97 * other) {
               p.progS = reinterpret_cast<const uint16_t*>(c->arena + s.offProg8);
               s.lastFrom = -5; s.lastZ = 1;             // reported by qcnn_get_layer_split as (-5, 1)
-              e = qk_conv_sym8(p, (c->sym8 & 4) ? 1 : 0, st);
+              e = qk_conv_sym8(p, st);
               break;
             }
           }
@@ -503,6 +510,7 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
         if (e != hipErrorInvalidValue) break;
         p.partial = nullptr;
       }
+      const bool fc8 = s.progF8Bytes && c->sym8 && c->lutMode == 1 && !small;     // k_fc_sym8: 768 channels per workgroup
       if (c->lutMode >= 1) {
         const int G = qcnn_stage_group(s.K);
         const int stages = (s.M + G - 1) / G;
@@ -512,7 +520,7 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
         // CUs); ties go to fewer splits.  (A grid of chunks x splits x panels workgroups runs in
         // ceil(grid / 256) rounds: 528 workgroups cost as much as 768.)
         const int cpb = qk_fc_channels_per_block(p.Ct);
-        const int chunks = (p.Ct + cpb - 1) / cpb;
+        const int chunks = fc8 ? qk_fc_sym8_chunks(p.Ct) : (p.Ct + cpb - 1) / cpb;
         auto pick = [&](int minStages) {
           int best = 1;
           double bestFill = 0.0;
@@ -544,7 +552,16 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
         const size_t poff = (size_t)kMaxFcSplit * p0 * c->fcMaxCt * QCNN_PANEL;    // every sub-batch has its own slab
         if (ms > 1 && poff + need <= c->fcPartialElems) { p.msplit = ms; p.partial = c->fcPartial + poff; }
       }
-      e = qk_fc_aprx(p, c->lutMode, st);
+      if (fc8) {
+        // every workgroup along the sub-space axis needs a stage: the count the launcher will accept for this split
+        const int stagesF = s.M / 4, per = (stagesF + p.msplit - 1) / p.msplit;
+        p.msplit = (stagesF + per - 1) / per;
+        if (p.msplit == 1) p.partial = nullptr;
+        s.lastFrom = -5; s.lastZ = p.msplit;            // reported by qcnn_get_layer_split as (-5, splits of the sub-space axis)
+        e = qk_fc_sym8(p, reinterpret_cast<const uint16_t*>(c->arena + s.offProgF8), reinterpret_cast<const float*>(c->arena + s.offCtrdF), st);
+      } else {
+        e = qk_fc_aprx(p, c->lutMode, st);
+      }
       if (e == hipSuccess && p.msplit > 1)
         e = qk_sum_partials(p.partial, dst, p.msplit, (size_t)panels * p.Ct * QCNN_PANEL, p.relu, st);
       break;
@@ -792,7 +809,7 @@ int qcnn_set_option(QcnnCtx* c, int option, int value) {
     case QCNN_OPT_SMALL_BATCH: c->smallBatch = value ? 1 : 0; return 0;
     case QCNN_OPT_SPLIT: c->split = value ? 1 : 0; return 0;
     case QCNN_OPT_DECODE: c->decode = value ? 1 : 0; return 0;
-    case QCNN_OPT_SYM8: c->sym8 = value < 0 ? 0 : (value & 7); return 0;
+    case QCNN_OPT_SYM8: c->sym8 = value < 0 ? 0 : (value > 2 ? 2 : value); return 0;
     case QCNN_OPT_PACKED_FC: c->packedFc = value ? 1 : 0; return 0;
     case QCNN_OPT_SYM: c->sym = value < 0 ? 0 : (value > 2 ? 2 : value); return 0;
     case QCNN_OPT_SLIDE: c->slide = value < 0 ? 0 : (value > 2 ? 2 : value); return 0;
@@ -1003,6 +1020,14 @@ int upload_bias_ctrd(QcnnCtx* c, int layer, const float* bias, const float* ctrd
             }
     HIP_TRY(c, hipMemcpyAsync(c->arena + s.offCtrd2, split.data(), split.size() * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
   }
+  std::vector<float> ctrdF;
+  if (s.progF8Bytes) {                // the eight-wave FC kernel's operand order (K = 32, Cs = 4)
+    ctrdF.resize((size_t)M * Cs * K);
+    for (int m = 0; m < M; ++m)
+      for (int dd = 0; dd < Cs; ++dd)
+        for (int k = 0; k < K; ++k) ctrdF[qk_ctrdf_index(m, dd, k)] = ctrd[((size_t)m * Cs + dd) * K + k];
+    HIP_TRY(c, hipMemcpyAsync(c->arena + s.offCtrdF, ctrdF.data(), ctrdF.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  }
   std::vector<float> ctrd8;
   if (s.prog8Bytes) {                 // the eight-wave symmetric kernel's operand order (K = 128, Cs = 4 or 8)
     ctrd8.resize((size_t)M * Cs * K);
@@ -1054,6 +1079,9 @@ hipError_t build_program(QcnnCtx* c, int layer, const QkSlots& sl) {
     e = qk_decode_weights(reinterpret_cast<const uint8_t*>(c->arena + s.offAsmt), reinterpret_cast<const float*>(c->arena + s.offCtrd),
                           reinterpret_cast<float*>(c->arena + s.offDec), sl, d.knlSiz, c->dims[layer].c, s.K,
                           c->dims[layer + 1].c, s.decKp, s.decS, c->stream);
+  if (e == hipSuccess && s.progF8Bytes)        // eight-wave FC kernel: uint16 offsets in its channel order
+    e = qk_build_program_fc8(reinterpret_cast<const uint8_t*>(c->arena + s.offAsmt), reinterpret_cast<uint16_t*>(c->arena + s.offProgF8), sl,
+                             c->dims[layer + 1].c, s.M, c->stream);
   if (e == hipSuccess && s.prog8Bytes) {       // eight-wave symmetric kernel: its own layout of the same table
     const int Ct = c->dims[layer + 1].c;
     e = qk_build_program8(reinterpret_cast<const uint8_t*>(c->arena + s.offAsmt), reinterpret_cast<uint16_t*>(c->arena + s.offProg8), sl,

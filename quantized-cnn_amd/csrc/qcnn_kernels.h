@@ -231,7 +231,7 @@ size_t qk_conv_sym8_program_bytes(const Qk8Config& cf, int groups, int knl, int 
 hipError_t qk_build_program8(const uint8_t* rows, uint16_t* prog, const QkSlots& src, const Qk8Config& cf, int Ctg, int groups,
                              int knl, int stride, int M, hipStream_t st);
 double qk_conv_sym8_cost(const ConvParams& p, const Qk8Config& cf, double stageFactor);
-hipError_t qk_conv_sym8(const ConvParams& p, int stagger, hipStream_t st);
+hipError_t qk_conv_sym8(const ConvParams& p, hipStream_t st);
 
 struct FcParams {
   float* partial;        // [msplit][panels][Ct][128] scratch for split-M partial sums (msplit > 1)
@@ -249,6 +249,19 @@ struct FcParams {
   int panels;
   int lutF16;            // as ConvParams::lutF16
 };
+
+// Eight-wave FC kernel (qcnn_sym8.hip, k_fc_sym8): K = 32, Cs = 4, complete sub-spaces; 96 channels per wave, 768 per workgroup.
+// prog: [M][chunks][8 waves][2 halves][48] pre-scaled uint16 offsets; ctrdF: the code book in operand order (qk_ctrdf_index).
+bool qk_fc_sym8_shape(int D, int Ct, int M, int Cs, int K);
+int qk_fc_sym8_chunks(int Ct);
+size_t qk_fc_sym8_program_bytes(int Ct, int M);
+hipError_t qk_build_program_fc8(const uint8_t* rows, uint16_t* prog, const QkSlots& src, int Ct, int M, hipStream_t st);
+hipError_t qk_fc_sym8(const FcParams& p, const uint16_t* prog, const float* ctrdF, hipStream_t st);
+// position (in floats) inside ctrdF of code word k (0..31), dim d (0..3) of sub-space m: stage m / 4, row tile 2 (m % 4) + k / 16
+__host__ __device__ static inline size_t qk_ctrdf_index(int m, int d, int k) {
+  const int stage = m >> 2, rt = 2 * (m & 3) + (k >> 4), h = rt >> 2, i = rt & 3, li = k & 15;
+  return ((((size_t)stage * 2 + h) * 64) + d * 16 + li) * 4 + i;
+}
 
 // Precise path (qcnn_dense.hip): conv and FC layers with dense weights (FC = 1x1 conv on a 1x1 map, Cin = D).
 struct DenseParams {

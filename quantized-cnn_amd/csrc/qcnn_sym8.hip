@@ -20,9 +20,10 @@
 // block (8 bytes per wave half) are read from the program row in LDS two blocks before the block that needs them (one
 // ds_read_b64 into one of two fixed register pairs) instead of a whole stage's offsets sitting in registers (k_conv_aprx:
 // two sets); ONE operand set.  With two waves per SIMD nobody hides an LDS round trip per block, so the blocks of a position
-// are software-pipelined inside ONE asm statement (qcnn_sym8_gather.h, generated): two sets of read temporaries
-// (v[224:255]) alternate, the reads of block k + 1 fly while block k is accumulated, every wait is a count.  Optional stagger (template): the two waves that share a SIMD run their build and gather phases in opposite
-// order, so that one wave's matrix instructions meet the other's look-ups instead of its matrix instructions.
+// are software-pipelined inside ONE asm statement (qcnn_sym8_gather.h, generated): three sets of two-read temporaries
+// (v[232:255]) rotate, the reads of blocks k + 1, k + 2 fly while block k is accumulated, every wait is a count.  The code
+// book comes in operand order (ConvParams::ctrd8: one 16-byte load per k-step).  Measured and dropped
+// (profiles/r4_sym8/experiments): the two waves of a SIMD in opposite phase order; the build interleaved into the look-ups.
 #include "qcnn_kernels.h"
 #include "qcnn_dev.h"
 
@@ -171,7 +172,7 @@ __device__ __forceinline__ void gather8(f32x2 (&acc)[TH * TW][CPW], uint32_t blk
 #endif
 }
 
-template <int CPW, int TH, int TW, int KS, bool STAGGER>
+template <int CPW, int TH, int TW, int KS>
 __global__ __launch_bounds__(NW8 * 64) void k_conv_sym8(ConvParams p, int tilesX, int tilesY, int chunks) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   constexpr int NP = TH * TW, HC = CPW / 2;
@@ -244,12 +245,6 @@ __global__ __launch_bounds__(NW8 * 64) void k_conv_sym8(ConvParams p, int tilesX
   auto posOf = [&](const StagePos& q, int idx) { return (idx < S) ? q : first; };
   const uint32_t myBlk = PROG8_LDS + (uint32_t)(wave * 2 + half) * BLKB;
   const bool loader = wave == 0;
-  // waves w and w + 4 share a SIMD (dispatch order 0 -> 2 -> 1 -> 3): with STAGGER the upper four gather first
-  const bool gatherFirst = STAGGER && (wave >> 2) != 0;
-#ifdef S8_PRIO
-  if (wave >> 2) __builtin_amdgcn_s_setprio(S8_PRIO);    // experiment: the second wave of every SIMD is the slower one
-#endif
-
   Ops8<KS> ops;
   StagePos c0 = first;
   StagePos c1 = next_pos(c0, g);
@@ -266,18 +261,10 @@ __global__ __launch_bounds__(NW8 * 64) void k_conv_sym8(ConvParams p, int tilesX
   }
   if (loader) { idx_row_to_lds<ROWB>(rowOf(c0, 0), PROG8_LDS + rb0, lane); idx_row_to_lds<ROWB>(rowOf(c1, 1), PROG8_LDS + rb1, lane); }
   barrier_after_lds_dma();
-  // The stage loop and the epilogue exist once per phase order (the accumulators never meet at a join of the two paths:
-  // with a run-time branch inside the loop the compiler gave them different registers on the two sides and spilled 800)
-  auto run = [&](auto order) {
-    constexpr bool GF = decltype(order)::value;          // gather first, then build
+  {
     S8_DECL;
     for (int s = 0; s < Sp; s += 2) {
       // ---- period s: stage s + 1 -> buffer 1, gather stage s out of buffer 0
-      if (GF) {
-        gather8<TH, TW, CPW>(acc, myBlk + rb0, c0, p.knl, rowStart, colStart, laneLds, activeI);
-        __builtin_amdgcn_sched_barrier(0);
-        S8_T(1, s);
-      }
       ops8_store<KS>(ops, mA0 + STAGE_BYTES, mB0 + STAGE_BYTES);
       S8_T(4, s);
       // program row of stage s + 2, AFTER the build (whose counted vmcnt waits would otherwise wait for this fresh transfer)
@@ -288,22 +275,15 @@ __global__ __launch_bounds__(NW8 * 64) void k_conv_sym8(ConvParams p, int tilesX
         const StagePos q = posOf(c2, s + 2);
         ops8_load<KS>(ops, xbase, pixel_off(q, g), bLane, p.ctrd8, Cs, q.mg, laneA, rt0);
       }
-      if (!GF) {
-        __builtin_amdgcn_sched_barrier(0);
-        S8_T(1, s);
-        gather8<TH, TW, CPW>(acc, myBlk + rb0, c0, p.knl, rowStart, colStart, laneLds, activeI);
-      }
+      __builtin_amdgcn_sched_barrier(0);
+      S8_T(1, s);
+      gather8<TH, TW, CPW>(acc, myBlk + rb0, c0, p.knl, rowStart, colStart, laneLds, activeI);
       S8_T(2, s);
       c0 = c1; c1 = c2; c2 = next_pos(c2, g);
       { const uint32_t t = rb0; rb0 = rb1; rb1 = rb2; rb2 = t; }
       barrier_after_lds_writes();
       S8_T(3, s);
       // ---- period s + 1: stage s + 2 -> buffer 0, gather stage s + 1 out of buffer 1
-      if (GF) {
-        gather8<TH, TW, CPW>(acc, myBlk + rb0, c0, p.knl, rowStart, colStart, laneLds | STAGE_BYTES, activeI & in_range(s + 1, S));
-        __builtin_amdgcn_sched_barrier(0);
-        S8_T(1, s + 1);
-      }
       ops8_store<KS>(ops, mA0, mB0);
       S8_T(4, s + 1);
       if (loader) idx_row_to_lds<ROWB>(rowOf(c2, s + 3), PROG8_LDS + rb2, lane);
@@ -312,11 +292,9 @@ __global__ __launch_bounds__(NW8 * 64) void k_conv_sym8(ConvParams p, int tilesX
         const StagePos q = posOf(c2, s + 3);
         ops8_load<KS>(ops, xbase, pixel_off(q, g), bLane, p.ctrd8, Cs, q.mg, laneA, rt0);
       }
-      if (!GF) {
-        __builtin_amdgcn_sched_barrier(0);
-        S8_T(1, s + 1);
-        gather8<TH, TW, CPW>(acc, myBlk + rb0, c0, p.knl, rowStart, colStart, laneLds | STAGE_BYTES, activeI & in_range(s + 1, S));
-      }
+      __builtin_amdgcn_sched_barrier(0);
+      S8_T(1, s + 1);
+      gather8<TH, TW, CPW>(acc, myBlk + rb0, c0, p.knl, rowStart, colStart, laneLds | STAGE_BYTES, activeI & in_range(s + 1, S));
       S8_T(2, s + 1);
       c0 = c1; c1 = c2; c2 = next_pos(c2, g);
       { const uint32_t t = rb0; rb0 = rb1; rb1 = rb2; rb2 = t; }
@@ -344,8 +322,185 @@ __global__ __launch_bounds__(NW8 * 64) void k_conv_sym8(ConvParams p, int tilesX
         }
       }
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// k_fc_sym8: the FC table kernel (GetInPdMat :1261-1296 fused with CalcFeatMap_FCntAprx :968-1025) with the same eight
+// waves of 256 registers.  An FC stage (four sub-spaces of 32 code words) is built once for 128 images and then serves
+// 4 x (channels of the workgroup) look-ups: the kernel is its look-up stream.  k_fc_aprx runs that stream at 4.9 cycles per
+// row look-up (offset bytes through the vector memory path, expanded with two VALU instructions per dword, blocks of eight
+// reads with a round trip each); here the offsets come as uint16 through LDS-DMA like the conv program rows, a wave owns
+// 96 channels (768 per workgroup: 6 instead of 11 channel chunks for 4096 outputs) and runs the software-pipelined position
+// statements of k_conv_sym8 (a sub-space of the stage = a "position" accumulating into the same registers).
+// K = 32, Cs = 4, M a multiple of 4, D = 4 M (AlexNet / VGG-16 fc6, fc7); everything else stays with k_fc_aprx.
+// Stage loop, barriers and add-TID stores as in k_conv_sym8; the sub-space axis is split over blockIdx.z like k_fc_aprx's.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int FC8_CPW = 96;                               // channels per wave (192 accumulator registers)
+constexpr int FC8_SUBB = NW8 * 2 * (FC8_CPW / 2) * 2;     // program bytes of one sub-space for the workgroup: 16 x 48 uint16 = 1536
+constexpr uint32_t FC8_ROWBUF = 4u * FC8_SUBB;            // a stage's four sub-spaces: 6 KB
+
+struct FcOps8 {
+  float a[4];        // code-book tiles of the wave's four row tiles (two sub-spaces x two tiles of 16 code words)
+  float b[2][2];     // activation tiles [image tile][sub-space of the pair]
+};
+// ctrdF: the code book in operand order [stage][2 halves of the row tiles][64 lanes][4 row tiles] (qk_ctrdf_index)
+__device__ __forceinline__ void fc8_load(FcOps8& o, const char* __restrict__ xbase, const float* __restrict__ ctrdF, int stage,
+                                         int subA, uint32_t bLane, uint32_t laneA16, int h) {
+  const f32x4 a4 = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(ctrdF) + ((size_t)stage * 2 + h) * 1024 + laneA16);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o.a[i] = a4[i];
+  const char* __restrict__ xbU = xbase + (uint32_t)(subA * 4) * XROWB;           // uniform: dims of the pair's first sub-space
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) o.b[t][j] = *reinterpret_cast<const float*>(xbU + (uint32_t)(j * 4) * XROWB + bLane + t * 64);
+}
+__device__ __forceinline__ void fc8_store(const FcOps8& o, uint32_t mA, uint32_t mB) {
+  const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+  auto tile = [&](int t, int i) { return __builtin_amdgcn_mfma_f32_16x16x4f32(o.a[i], o.b[t][i >> 1], zero, 0, 0, 0); };
+  const f32x4 v0 = tile(0, 0), v1 = tile(0, 1), v2 = tile(0, 2);
+  __builtin_amdgcn_sched_barrier(0);
+  const f32x4 v3 = tile(0, 3);
+  S8_ST(0, v0, mA);
+  __builtin_amdgcn_sched_barrier(0);
+  const f32x4 v4 = tile(1, 0);
+  S8_ST(1, v1, mA);
+  __builtin_amdgcn_sched_barrier(0);
+  const f32x4 v5 = tile(1, 1);
+  S8_ST(2, v2, mA);
+  __builtin_amdgcn_sched_barrier(0);
+  const f32x4 v6 = tile(1, 2);
+  S8_ST(3, v3, mA);
+  __builtin_amdgcn_sched_barrier(0);
+  const f32x4 v7 = tile(1, 3);
+  S8_ST(0, v4, mB);
+  __builtin_amdgcn_sched_barrier(0);
+  S8_ST(1, v5, mB);
+  S8_ST(2, v6, mB);
+  S8_ST(3, v7, mB);
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// the look-ups of a stage: four sub-spaces x two halves of the wave's 96 channels, each the 24-read position statement of
+// k_conv_sym8 accumulating into the same registers
+__device__ __forceinline__ void fc8_gather(f32x2 (&acc)[FC8_CPW], uint32_t blk, uint32_t stageBase, int live) {
+  const int ok = uni(live);
+  gpos6<0 * FC8_SUBB>(&acc[0], blk, stageBase, ok);
+  gpos6<0 * FC8_SUBB + 48>(&acc[48], blk, stageBase, ok);
+  gpos6<1 * FC8_SUBB>(&acc[0], blk, stageBase, ok);
+  gpos6<1 * FC8_SUBB + 48>(&acc[48], blk, stageBase, ok);
+  gpos6<2 * FC8_SUBB>(&acc[0], blk, stageBase, ok);
+  gpos6<2 * FC8_SUBB + 48>(&acc[48], blk, stageBase, ok);
+  gpos6<3 * FC8_SUBB>(&acc[0], blk, stageBase, ok);
+  gpos6<3 * FC8_SUBB + 48>(&acc[48], blk, stageBase, ok);
+}
+
+__global__ __launch_bounds__(NW8 * 64) void k_fc_sym8(FcParams p, const uint16_t* __restrict__ prog, const float* __restrict__ ctrdF,
+                                                       int chunks, int stagesPerSplit) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  constexpr int HC = FC8_CPW / 2;
+  const int lane = threadIdx.x & 63;
+  const int wave = uni(threadIdx.x >> 6);
+  const int chunk = blockIdx.x, panel = blockIdx.y, split = blockIdx.z;
+  const int stagesAll = p.M / 4;
+  const int sBeg = split * stagesPerSplit;
+  const int S = min(stagesAll, sBeg + stagesPerSplit) - sBeg;       // stages of this workgroup (>= 1 by the launcher)
+  const int Sp = (S + 1) & ~1;
+  if ((uint32_t)(uintptr_t)lds != 0u) __builtin_trap();
+
+  // ---- build side (see k_conv_sym8): image tiles 2 (wave >> 1), + 1; row tiles 4 (wave & 1) .. + 3 = sub-spaces 2 (wave & 1), + 1 of the stage
+  const int it0 = (wave >> 1) * 2, h = wave & 1, sw = wave >> 1;
+  const uint32_t li = lane & 15, lk = lane >> 4;
+  const uint32_t laneA16 = (lk * 16 + (li ^ ((uint32_t)sw << 2))) * 16;
+  const uint32_t bLane = lk * XROWB + (uint32_t)it0 * 64 + li * 4;
+  const char* __restrict__ xbase = reinterpret_cast<const char*>(p.src + (size_t)panel * p.D * PANEL);
+  const uint32_t mA0 = (uint32_t)it0 * TILEB + (uint32_t)(h * 4) * 1024u, mB0 = mA0 + TILEB;
+
+  // ---- gather side
+  const int half = lane >> 5, quad = lane & 31;
+  const int cw0 = (chunk * NW8 + wave) * FC8_CPW;
+  const int activeI = in_range(cw0, p.Ct);
+  const int cl0 = cw0 + half * HC;
+  const uint32_t laneLds = (uint32_t)(quad >> 2) * TILEB | (uint32_t)(quad >> 3) * 64 | (uint32_t)(quad & 3) * 16;
+  f32x2 acc[FC8_CPW];
+#pragma unroll
+  for (int c = 0; c < FC8_CPW; ++c) acc[c] = f32x2{0.0f, 0.0f};
+  if (split == 0) {
+    const float* __restrict__ bp = p.bias + (activeI ? cl0 : 0);
+#pragma unroll
+    for (int j = 0; j < HC; ++j) {
+      const float b = (cl0 + j < p.Ct) ? bp[j] : 0.0f;
+      acc[2 * j] = f32x2{b, b}; acc[2 * j + 1] = f32x2{b, b};
+    }
+  }
+  // program: [M][chunks][16 wave halves][48] uint16; a stage = four consecutive sub-spaces
+  const char* __restrict__ progWg = reinterpret_cast<const char*>(prog) + (size_t)chunk * FC8_SUBB;
+  const uint32_t subStride = (uint32_t)chunks * FC8_SUBB;
+  auto stageOf = [&](int idx) { return sBeg + min(idx, S - 1); };                 // stages past the end: the last one again
+  const uint32_t myBlk = PROG8_LDS + (uint32_t)(wave * 2 + half) * (HC * 2);
+  // waves 0 .. 3 each fetch one sub-space's 1536 bytes of a stage's program rows (two DMA instructions)
+  auto dma_rows = [&](int stage, uint32_t rowBuf) {
+    if (wave < 4) idx_row_to_lds<FC8_SUBB>(progWg + (size_t)(stage * 4 + wave) * subStride, PROG8_LDS + rowBuf + (uint32_t)wave * FC8_SUBB, lane);
   };
-  if (STAGGER && gatherFirst) run(std::true_type{}); else run(std::false_type{});
+
+  FcOps8 ops;
+  uint32_t rb0 = 0, rb1 = FC8_ROWBUF, rb2 = 2 * FC8_ROWBUF;
+  fc8_load(ops, xbase, ctrdF, stageOf(0), stageOf(0) * 4 + 2 * h, bLane, laneA16, h);
+  fc8_store(ops, mA0, mB0);
+  fc8_load(ops, xbase, ctrdF, stageOf(1), stageOf(1) * 4 + 2 * h, bLane, laneA16, h);
+  dma_rows(stageOf(0), rb0);
+  dma_rows(stageOf(1), rb1);
+  barrier_after_lds_dma();
+  for (int s = 0; s < Sp; s += 2) {
+    // ---- period s: stage s + 1 -> buffer 1, gather stage s out of buffer 0
+    fc8_store(ops, mA0 + STAGE_BYTES, mB0 + STAGE_BYTES);
+    dma_rows(stageOf(s + 2), rb2);
+    __builtin_amdgcn_sched_barrier(0);
+    fc8_load(ops, xbase, ctrdF, stageOf(s + 2), stageOf(s + 2) * 4 + 2 * h, bLane, laneA16, h);
+    __builtin_amdgcn_sched_barrier(0);
+    fc8_gather(acc, myBlk + rb0, laneLds, activeI);
+    { const uint32_t t = rb0; rb0 = rb1; rb1 = rb2; rb2 = t; }
+    barrier_after_lds_writes();
+    // ---- period s + 1: stage s + 2 -> buffer 0, gather stage s + 1 out of buffer 1
+    fc8_store(ops, mA0, mB0);
+    dma_rows(stageOf(s + 3), rb2);
+    __builtin_amdgcn_sched_barrier(0);
+    fc8_load(ops, xbase, ctrdF, stageOf(s + 3), stageOf(s + 3) * 4 + 2 * h, bLane, laneA16, h);
+    __builtin_amdgcn_sched_barrier(0);
+    fc8_gather(acc, myBlk + rb0, laneLds | STAGE_BYTES, activeI & in_range(s + 1, S));
+    { const uint32_t t = rb0; rb0 = rb1; rb1 = rb2; rb2 = t; }
+    barrier_after_lds_writes();
+  }
+  if (activeI) {
+    float* base = (p.msplit > 1) ? p.partial + (size_t)split * p.panels * p.Ct * PANEL : p.dst;
+    float* o = base + ((size_t)panel * p.Ct + cl0) * PANEL + 4 * quad;
+#pragma unroll
+    for (int j = 0; j < HC; ++j) {
+      if (cl0 + j < p.Ct) {
+        f32x4 v = {acc[2 * j].x, acc[2 * j].y, acc[2 * j + 1].x, acc[2 * j + 1].y};
+        if (p.relu && p.msplit == 1) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (0.0f < v[e]) ? v[e] : 0.0f;
+        }
+        *reinterpret_cast<f32x4*>(o + j * PANEL) = v;
+      }
+    }
+  }
+}
+
+// rows ([M][rowStride] slot bytes, FC QkSlots order) -> [M][chunks][8 waves][2 halves][48] pre-scaled uint16 offsets
+__global__ __launch_bounds__(256) void k_build_program_fc8(const uint8_t* __restrict__ rows, uint16_t* __restrict__ prog, QkSlots src,
+                                                           int Ct, int chunks, size_t n) {
+  const int hc = FC8_CPW / 2, subU16 = chunks * NW8 * 2 * hc;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
+    const int r = (int)(e % (size_t)subU16), m = (int)(e / (size_t)subU16);
+    const int j = r % hc, wh = r / hc;
+    const int half = wh & 1, wave = (wh >> 1) % NW8, chunk = (wh >> 1) / NW8;
+    const int ch = (chunk * NW8 + wave) * FC8_CPW + half * hc + j;
+    const int at = ch < Ct ? qk_slot_entry(src, 0, ch) : -1;
+    prog[e] = at >= 0 ? (uint16_t)(rows[(size_t)m * src.rowStride + at] * 64) : (uint16_t)0;
+  }
 }
 
 // rows (plain table of row slots, [kh][kw][M][rowStride], `src` order) -> program of the eight-wave layout: entry (ry, rx, m)
@@ -378,13 +533,12 @@ __global__ __launch_bounds__(256) void k_build_program8(const uint8_t* __restric
 }
 
 template <int CPW, int TH, int TW>
-hipError_t launch_sym8(const ConvParams& p, const Qk8Config& cf, int stagger, hipStream_t st) {
+hipError_t launch_sym8(const ConvParams& p, const Qk8Config& cf, hipStream_t st) {
   const int tilesX = (p.Wo + TW - 1) / TW, tilesY = (p.Ho + TH - 1) / TH;
   const dim3 grid((unsigned)(tilesX * tilesY * p.panels), (unsigned)(p.grp * cf.chunks), 1);
   const size_t shm = (size_t)2 * STAGE_BYTES + 3 * PROG8_BUF;
   const bool two = std::min(p.Cin / p.grp, p.Cs) > 4;
-  auto kern = two ? (stagger ? k_conv_sym8<CPW, TH, TW, 2, true> : k_conv_sym8<CPW, TH, TW, 2, false>)
-                  : (stagger ? k_conv_sym8<CPW, TH, TW, 1, true> : k_conv_sym8<CPW, TH, TW, 1, false>);
+  auto kern = two ? k_conv_sym8<CPW, TH, TW, 2> : k_conv_sym8<CPW, TH, TW, 1>;
   hipError_t e = allow_big_lds(reinterpret_cast<const void*>(kern), (int)shm);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, grid, dim3(NW8 * 64), shm, st, p, tilesX, tilesY, cf.chunks);
@@ -472,14 +626,42 @@ double qk_conv_sym8_cost(const ConvParams& p, const Qk8Config& cf, double scale)
   return end;
 }
 
-hipError_t qk_conv_sym8(const ConvParams& p, int stagger, hipStream_t st) {
+hipError_t qk_conv_sym8(const ConvParams& p, hipStream_t st) {
   const Qk8Config cf = qk_conv_sym8_config(p.Cin, p.grp, p.Ct, p.M, p.Cs, p.K);
   if (!cf.cpw || p.progS == nullptr || p.ctrd8 == nullptr || p.srcNchw) return hipErrorInvalidValue;
   switch (cf.cpw) {
-    case 48: return launch_sym8<48, 1, 2>(p, cf, stagger, st);
-    case 32: return launch_sym8<32, 1, 3>(p, cf, stagger, st);
-    case 24: return launch_sym8<24, 2, 2>(p, cf, stagger, st);
-    case 16: return launch_sym8<16, 2, 3>(p, cf, stagger, st);
+    case 48: return launch_sym8<48, 1, 2>(p, cf, st);
+    case 32: return launch_sym8<32, 1, 3>(p, cf, st);
+    case 24: return launch_sym8<24, 2, 2>(p, cf, st);
+    case 16: return launch_sym8<16, 2, 3>(p, cf, st);
     default: return hipErrorInvalidValue;
   }
+}
+
+bool qk_fc_sym8_shape(int D, int Ct, int M, int Cs, int K) {
+  return K == 32 && Cs == 4 && M % 4 == 0 && D == 4 * M && Ct >= 2 * FC8_CPW && Ct % 2 == 0;
+}
+int qk_fc_sym8_chunks(int Ct) { return (Ct + NW8 * FC8_CPW - 1) / (NW8 * FC8_CPW); }
+size_t qk_fc_sym8_program_bytes(int Ct, int M) { return (size_t)M * qk_fc_sym8_chunks(Ct) * FC8_SUBB; }
+
+hipError_t qk_build_program_fc8(const uint8_t* rows, uint16_t* prog, const QkSlots& src, int Ct, int M, hipStream_t st) {
+  const size_t n = qk_fc_sym8_program_bytes(Ct, M) / sizeof(uint16_t);
+  const int grid = (int)std::min<size_t>((n + 255) / 256, 8192);
+  hipLaunchKernelGGL(k_build_program_fc8, dim3(grid), dim3(256), 0, st, rows, prog, src, Ct, qk_fc_sym8_chunks(Ct), n);
+  return hipGetLastError();
+}
+
+// p.msplit = workgroups along the sub-space axis (partial sums in p.partial when > 1, reduced by qk_sum_partials)
+hipError_t qk_fc_sym8(const FcParams& p, const uint16_t* prog, const float* ctrdF, hipStream_t st) {
+  if (!qk_fc_sym8_shape(p.D, p.Ct, p.M, p.Cs, p.K) || prog == nullptr || ctrdF == nullptr || p.msplit < 1) return hipErrorInvalidValue;
+  const int stages = p.M / 4;
+  const int per = (stages + p.msplit - 1) / p.msplit;
+  const int splits = (stages + per - 1) / per;                 // every workgroup along z has at least one stage
+  if (splits != p.msplit) return hipErrorInvalidValue;
+  const size_t shm = (size_t)2 * STAGE_BYTES + 3 * FC8_ROWBUF;
+  hipError_t e = allow_big_lds(reinterpret_cast<const void*>(k_fc_sym8), (int)shm);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_fc_sym8, dim3((unsigned)qk_fc_sym8_chunks(p.Ct), (unsigned)p.panels, (unsigned)p.msplit), dim3(NW8 * 64), shm, st,
+                     p, prog, ctrdF, qk_fc_sym8_chunks(p.Ct), per);
+  return hipGetLastError();
 }

@@ -35,17 +35,21 @@ def kernels_of(obj_path):
         if not dev:
             return out
         notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", dev[0]], check=True, capture_output=True, text=True).stdout
+    # one metadata entry per kernel, its keys in alphabetical order: ".args" opens an entry, ".name" sits in the middle of it
     cur = None
     for line in notes.splitlines():
-        m = re.match(r"\s+\.(\w+):\s+(\S+)", line)
-        if not m:
+        if re.match(r"  - \.\w+:", line):             # a new kernel of `amdhsa.kernels` (argument lists are indented deeper)
+            cur = {}
+            out.append(cur)
+        m = re.match(r"\s+(?:-\s+)?\.(\w+):\s+(\S+)", line)
+        if not m or cur is None:
             continue
         key, val = m.group(1), m.group(2)
-        if key == "name":
-            cur = {}
-            out.append([val, cur])
-        elif cur is not None and key in FIELDS:
+        if key == "name" and "name" not in cur:
+            cur["name"] = val
+        elif key in FIELDS and key not in cur:
             cur[key] = int(val)
+    out = [[d.pop("name"), d] for d in out if "name" in d]
     if out:
         names = subprocess.run(["c++filt"] + [n for n, _ in out], check=True, capture_output=True, text=True).stdout.splitlines()
         for ent, nm in zip(out, names):

@@ -33,21 +33,42 @@ def main():
     table = list(csv.DictReader(io.StringIO(pmc)))
     bench = json.loads(open(os.path.join(src, "trace_bench.json")).readline())
     dom_layer = int(bench["roofline"]["kernel"].split("layer ")[1].split(",")[0])
-    # the table-kernel family (tile / sliding / symmetric conv, FC): the dominant one by wave cycles is the layer the bench names
-    dom = max((r for r in table if r["kernel"].startswith(("k_conv_aprx", "k_conv_sym", "k_fc_aprx"))),
-              key=lambda r: float(r["SQ_WAVE_CYCLES"] or 0))
-    fetch_kib, write_kib = float(dom["FETCH_SIZE"]), float(dom["WRITE_SIZE"])
+
+    def kernel_prefix(tile):
+        """bench `roofline.layers[*].tile` -> how the kernel's name starts in the counter tables"""
+        import re
+        m = re.match(r"symmetric 8 waves (\d+)x(\d+)x(\d+)", tile)
+        if m:
+            return "k_conv_sym8<%d.%s.%s." % (int(m.group(3)) // 8, m.group(1), m.group(2))
+        if tile.startswith("symmetric"):
+            return "k_conv_sym<"
+        m = re.match(r"slide (\d+) column\(s\) x (\d+) slots x (\d+)", tile)
+        if m:
+            return "k_conv_aprx<%s.%s.%d.8." % (m.group(1), m.group(2), int(m.group(3)) // 12)
+        if tile.startswith("decoded code words: x @ w"):
+            return "k_fc_dec"
+        if tile.startswith("decoded"):
+            return "k_conv_dec"
+        m = re.match(r"(\d+)x(\d+)x(\d+)$", tile)
+        if m:
+            return "k_conv_aprx<%s.%s.%d.8." % (m.group(1), m.group(2), int(m.group(3)) // 12)
+        return None
+
+    kernels = {}
+    for key, rep in bench["roofline"]["layers"].items():
+        pre = kernel_prefix(rep.get("tile", ""))
+        rows = [r for r in table if pre and r["kernel"].startswith(pre) and r.get("FETCH_SIZE") and r.get("WRITE_SIZE")]
+        if key.endswith("_conv") and len(rows) >= 1:
+            r = max(rows, key=lambda r: float(r["SQ_WAVE_CYCLES"] or 0))
+            f, w = float(r["FETCH_SIZE"]), float(r["WRITE_SIZE"])
+            kernels[str(int(key[:2]))] = dict(kernel=r["kernel"], bytes=int((2.0 * f + w) * 1024), fetch_bytes=int(2.0 * f * 1024),
+                                              write_bytes=int(w * 1024))
+    dom = kernels[str(dom_layer)]
+    fetch_kib, write_kib = dom["fetch_bytes"] / 2048.0, dom["write_bytes"] / 1024.0
+    dom = dict(kernel=dom["kernel"])
     sys.path.insert(0, ROOT)
     import bench as bench_mod
     h = bench_mod.kernel_hash()          # every device source under quantized-cnn_amd/csrc
-    # per-layer table: the dominant table kernel and the decoded first layer (k_conv_dec runs layer 0 only)
-    kernels = {str(dom_layer): dict(kernel=dom["kernel"], bytes=int((2.0 * fetch_kib + write_kib) * 1024),
-                                    fetch_bytes=int(2.0 * fetch_kib * 1024), write_bytes=int(write_kib * 1024))}
-    for r in table:
-        if r["kernel"].startswith("k_conv_dec") and r.get("FETCH_SIZE") and r.get("WRITE_SIZE"):
-            f, w = float(r["FETCH_SIZE"]), float(r["WRITE_SIZE"])
-            kernels.setdefault("0", dict(kernel=r["kernel"], bytes=int((2.0 * f + w) * 1024), fetch_bytes=int(2.0 * f * 1024),
-                                         write_bytes=int(w * 1024)))
     json.dump({"kernel": dom["kernel"], "layer": dom_layer, "launches_per_forward": 1, "kernels": kernels,
                "bytes": int((2.0 * fetch_kib + write_kib) * 1024),
                "fetch_size_kib_raw": fetch_kib, "write_size_kib_raw": write_kib, "kernel_hash": h,
