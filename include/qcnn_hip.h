@@ -120,6 +120,10 @@ enum {
                               AlexNet streams 10.5 MB of FC assignments per image instead of 16.8 MB of bytes (of which the strided
                               byte reads fetched 64-byte lines: 4x).  Same bits as the byte path.  0 (default) = bytes: the unpack arithmetic of the
                               block-structured stream costs more than the traffic it saves (fc6 0.056 against 0.035 ms at one image) */
+  QCNN_OPT_DIRECT_DEC = 12, /* 1 (default): on the fast path (QCNN_OPT_KEEP_ALL = 0) an unpadded first conv layer that runs through its
+                              decoded code words (QCNN_OPT_DECODE) reads the caller's NCHW batch in place (k_conv_dec_nchw: k over the
+                              columns of a kernel row) — no pack pass into panels (AlexNet: 1.24 GB of HBM traffic per 1000 images).
+                              0 = pack, then the panel kernel.  qcnn_get_layer_split reports (-3, 2) against (-3, 1) */
   QCNN_OPT_HOST_CHUNK = 6, /* panels per chunk (default 2) of a qcnn_forward_host batch of at least two chunks: every chunk is
                               uploaded on a copy stream and its layers start when it has arrived, so the upload of chunk
                               k + 1 runs under the layers of chunk k; all chunks fill the same whole-batch feature maps.

@@ -274,6 +274,176 @@ hipError_t launch_dec(const DecParams& p, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// k_conv_dec_nchw: the same products with the operands taken straight from the NCHW network input — no pack pass (0.24 ms
+// per 1000 AlexNet images: 1.24 GB through HBM) in front of the first layer, and k FLAT over the window: k = (c knl + kh) knl
+// + kw runs 0 .. Cin knl^2 - 1 in fours whatever the length of a kernel row, so the matrix pipe multiplies 364 (368 with the
+// steps padded to a multiple of four; not 11 x 36 = 396) products per output for AlexNet conv1.  Lane (k row kq, li) of step
+// s needs element k = 4 s + kq of a window: byte offset c H W 4 + kh W 4 + kw 4 from the window's corner — a table of steps
+// x 4 ints the workgroup computes once into LDS — plus the lane's image and position; the item's position group, image tile
+// and panel travel in the scalar offset.
+// Work item of a wave: 16 images x FOUR NEIGHBOURING POSITIONS of an output row x 96 channels (24 accumulator tiles).  In
+// NCHW the images are C H W floats apart, so the 16 rows of a product tile are 2 positions x 8 images: with stride 4 the
+// lanes of one image read 4 k x 2 positions = 8 consecutive floats, a dword load touches 8 lines of 32 useful bytes, and the
+// four loads of a step and the steps of a kernel row hit the same lines again.  The image values are the A operand (rows of
+// the product), the code words B: a lane ends up with FOUR CONSECUTIVE IMAGES of one channel — 24 16-byte stores per item.
+// Eight waves of up to 256 registers per CU, a ring of four steps' operands (three in flight, counted s_waitcnt).
+// Measured, AlexNet conv1 at 1000 images (scripts/variants_nchw.sh; pack + k_conv_dec: 0.24 + 1.76 ms):
+//   tile = 16 images x 1 position, item = 64 images (dword stores)      2.34 ms   (L1: 8 waves x 64 lines per kernel row)
+//   tile = 16 images x 1 position, item = 16 images x 4 positions       1.98 ms, 16-byte stores 1.86 ms (loads alone 1.37 ms)
+//   tile = 4 images x 4 positions                                       1.96 ms   (loads alone 0.67 ms, 16-byte store fragments)
+//   tile = 8 images x 2 positions                                       1.85 ms   (everything but the products 1.10 ms,
+//                                                                                  everything but loads or but stores 1.68 ms)
+// the matrix pipe alone would need 1.42 ms at 2.4 GHz; what is left is the stores and loads of a wave's item boundary that
+// its SIMD neighbour's products do not cover.
+// ------------------------------------------------------------------------------------------------------------------
+template <int CT>
+__global__ __launch_bounds__(512) void k_conv_dec_nchw(DecParams p) {
+  extern __shared__ __attribute__((aligned(16))) float ldsW[];          // [steps][Ct / 16][4 k][16]: a wave's read of one channel tile is
+                                                                        // 64 consecutive floats (no bank conflicts); then int [steps + 4][4]
+  constexpr int IT = 4;
+  const int lane = threadIdx.x & 63, wave = uni(threadIdx.x >> 6);
+  const int P = p.Ho * p.Wo;
+  const int steps = p.Kp >> 2;                                          // Kp: Cin knl^2 padded to a multiple of 16
+  const uint32_t imgBytes = (uint32_t)p.Cin * p.H * p.W * 4u, planeBytes = (uint32_t)p.H * p.W * 4u, rowBytes = (uint32_t)p.W * 4u;
+  int* ldsOff = reinterpret_cast<int*>(ldsW + (size_t)steps * 4 * p.S);
+  {
+    const int wq = steps * p.S;
+    const f32x4* __restrict__ wsrc = reinterpret_cast<const f32x4*>(p.wdec);
+    f32x4* ldsW4 = reinterpret_cast<f32x4*>(ldsW);
+    for (int i = threadIdx.x; i < wq; i += 512) ldsW4[i] = wsrc[i];
+    for (int i = threadIdx.x; i < (steps + 4) * 4; i += 512) {
+      const int k = min(i, p.Kr - 1);                                   // Kr: Cin knl^2
+      const int kw = k % p.knl, kh = (k / p.knl) % p.knl, c = k / (p.knl * p.knl);
+      ldsOff[i] = (int)((uint32_t)c * planeBytes + (uint32_t)kh * rowBytes + (uint32_t)kw * 4u);
+    }
+  }
+  __syncthreads();
+  const int tiles = (p.live + 15) / 16;                                 // image tiles a panel has (a small batch: fewer)
+  const int chunks = p.Ct / (16 * CT);
+  const int WoG = (p.Wo + IT - 1) / IT, PG = p.Ho * WoG;                // position groups: IT consecutive positions of an output row
+  const int nItems = p.panels * PG * tiles * chunks;
+  const unsigned long long total = (unsigned long long)p.nImages * imgBytes;
+  typedef int i32x4_t __attribute__((ext_vector_type(4)));
+  const unsigned long long srcA = reinterpret_cast<unsigned long long>(p.src);
+  // buffer resource: base, stride 0, the batch's bytes (reads past the batch return 0), raw 32-bit data format
+  const i32x4_t rsrc4 = {(int)(unsigned)srcA, (int)((unsigned)(srcA >> 32) & 0xffffu),
+                         (int)(total < 0xffffffffull ? (unsigned)total : 0xffffffffu), 0x00020000};
+  const int xcd = blockIdx.x & 7, nX = gridDim.x < 8 ? gridDim.x : 8;
+  const int wgX = (gridDim.x - xcd + 7) >> 3;
+  const int itemBeg = (int)((long long)nItems * xcd / nX), itemEnd = (int)((long long)nItems * (xcd + 1) / nX);
+  for (int item = itemBeg + (blockIdx.x >> 3) * 8 + wave; item < itemEnd; item += wgX * 8) {
+    int laneI = lane;
+    asm volatile("" : "+v"(laneI));                                     // lane-derived constants re-derived per item (registers)
+    const int li = laneI & 15, kq = laneI >> 4;
+    // image tiles fastest: the eight waves of a workgroup write the 128 images of the same (position, channel) rows at about
+    // the same time, so that L2 sees whole lines (position groups fastest: 2.03 against 1.98 ms with dword stores)
+    const int it = item % tiles, cc = (item / tiles) % chunks, pg = (item / (tiles * chunks)) % PG, panel = item / (chunks * tiles * PG);
+    const int orow = pg / WoG, ocol = (pg % WoG) * IT;
+    const int r0 = orow * p.stride, c0 = ocol * p.stride;                        // unpadded layers
+    const uint32_t img0 = (uint32_t)(p.panel0 + panel) * PANEL + (uint32_t)it * 16u;
+    // row li of a product tile: image li & 7 of the tile's eight, position li >> 3 of its two.  Positions past the end of the
+    // output row read columns of the next image row, of the next plane ... finite values or the buffer's zeros, never stored.
+    const int laneOff = (int)((uint32_t)(li & 7) * imgBytes + (uint32_t)((li >> 3) * p.stride) * 4u);
+    const uint32_t base0 = img0 * imgBytes + (uint32_t)(r0 * p.W + c0) * 4u;      // tile ti: + 8 (ti & 1) images, + 2 (ti >> 1) positions
+    const int* __restrict__ offT = ldsOff + kq;
+    // Operand loads as inline assembly with counted waits: the compiler's own vmcnt bookkeeping drains the ring to one
+    // step at every loop back edge (s_waitcnt vmcnt(4) in front of the first of four steps).  Loads return in order, so
+    // "at most 12 outstanding" = everything but the three newest steps has arrived — whatever else (the previous item's
+    // stores) is still in flight only makes the wait stricter.
+#ifndef NCHW_VAR
+#define NCHW_VAR 0                      // timing experiments (scripts/variants_nchw.sh): 1 no operand loads, 2 no products, 4 no stores
+#endif
+    auto issue = [&](int s, float (&bb)[IT]) {                          // the operands of step s
+      const int vo = offT[s * 4] + laneOff;
+#pragma unroll
+      for (int ti = 0; ti < IT; ++ti)
+        if (NCHW_VAR & 1) asm volatile("v_mov_b32 %0, %1" : "=v"(bb[ti]) : "v"(vo)); else
+        asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(bb[ti]) : "v"(vo), "s"(rsrc4), "s"(base0 + (uint32_t)(ti & 1) * 8u * imgBytes + (uint32_t)((ti >> 1) * 2 * p.stride) * 4u));
+    };
+    f32x4 acc[CT][IT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      const float b1 = p.bias[(cc * CT + ct) * 16 + li];
+#pragma unroll
+      for (int ti = 0; ti < IT; ++ti) acc[ct][ti] = f32x4{b1, b1, b1, b1};
+    }
+    const float* __restrict__ wl = ldsW + cc * 64 * CT + laneI;
+    const int aStep = 4 * p.S;
+    float a[2][CT], b[4][IT];                                           // b: a ring of four steps' operands, three in flight (a ring
+                                                                        // of eight: 256 registers, spills, no faster)
+    auto load_a = [&](const float* __restrict__ w, float (&aa)[CT]) {
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) aa[ct] = w[ct * 64];
+    };
+    issue(0, b[0]);
+    issue(1, b[1]);
+    issue(2, b[2]);
+    load_a(wl, a[0]);
+#define NCHW_WAIT(n, bb) asm volatile("s_waitcnt vmcnt(" #n ")" : "+v"(bb[0]), "+v"(bb[1]), "+v"(bb[2]), "+v"(bb[3]))
+#define NCHW_STEP(u, n) /* step s + u; at most n loads may still be in flight */                                       \
+  {                                                                                                                   \
+    wl += aStep;                                                                                                      \
+    load_a(wl, a[((u) + 1) & 1]); /* code words of the next step */                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                                \
+    NCHW_WAIT(n, b[u]);                                                                                               \
+    _Pragma("unroll") for (int ti = 0; ti < IT; ++ti)                                                                 \
+      _Pragma("unroll") for (int ct = 0; ct < CT; ++ct)                                                               \
+        if (NCHW_VAR & 2) asm volatile("" : "+v"(acc[ct][ti]) : "v"(a[(u) & 1][ct]), "v"(b[u][ti])); else             \
+        acc[ct][ti] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[u][ti], a[(u) & 1][ct], acc[ct][ti], 0, 0, 0);           \
+    __builtin_amdgcn_sched_barrier(0);                                                                                \
+  }
+    int s = 0;
+    for (; s < steps - 4; s += 4) {                                     // three steps ahead, into the set the step before released
+      issue(s + 3, b[3]); NCHW_STEP(0, 12)
+      issue(s + 4, b[0]); NCHW_STEP(1, 12)
+      issue(s + 5, b[1]); NCHW_STEP(2, 12)
+      issue(s + 6, b[2]); NCHW_STEP(3, 12)
+    }
+    issue(s + 3, b[3]); NCHW_STEP(0, 12)                                // the last four steps: one more to fetch
+    NCHW_STEP(1, 8) NCHW_STEP(2, 4) NCHW_STEP(3, 0)
+#undef NCHW_STEP
+#undef NCHW_WAIT
+    // The image values are the A operand, the code words B (the lane layouts of the two operands of a 16x16x4 instruction
+    // are the same: this is the order of the arguments only): lane (li, kq) holds channel li of the tile at position kq >> 1
+    // of the tile's two for the FOUR CONSECUTIVE images 4 (kq & 1) .. + 3 of its eight — one 16-byte store per tile
+    {
+      const int nPos = (NCHW_VAR & 4) ? (p.Wo < 0 ? IT : 0) : min(IT, p.Wo - ocol);
+      float* __restrict__ dst = p.dst + (((size_t)panel * P + orow * p.Wo + ocol + (kq >> 1)) * p.Ct + li) * PANEL + it * 16 + 4 * (kq & 1);
+#pragma unroll
+      for (int ti = 0; ti < IT; ++ti)
+        if ((ti >> 1) * 2 + (kq >> 1) < nPos) {
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct) {
+            f32x4 v = acc[ct][ti];
+            if (p.relu)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = (0.0f < v[e]) ? v[e] : 0.0f;
+            *reinterpret_cast<f32x4*>(dst + ((size_t)(ti >> 1) * 2 * p.Ct + (cc * CT + ct) * 16) * PANEL + 8 * (ti & 1)) = v;
+          }
+        }
+    }
+  }
+}
+
+// rows: [kh][kw][1][rowStride] slot bytes; ctrd: [Cs][K]; out: [step][S / 16][4 kq][16]: the code word of window element
+// k = 4 step + kq = (c knl + kh) knl + kw, zero past the window
+__global__ void k_decode_weights_nchw(const uint8_t* __restrict__ rows, const float* __restrict__ ctrd, float* __restrict__ out,
+                                      QkSlots sl, int knl, int Cin, int K, int Ct, int steps, int S) {
+  const int total = steps * 4 * S;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int ch = (i % 16) + 16 * ((i / 64) % (S / 16)), kq = (i / 16) % 4, step = i / (4 * S);
+    const int k = 4 * step + kq;
+    float w = 0.0f;
+    if (ch < Ct && k < Cin * knl * knl) {
+      const int kw = k % knl, kh = (k / knl) % knl, c = k / (knl * knl);
+      const int slot = rows[(size_t)(kh * knl + kw) * sl.rowStride + qk_slot_entry(sl, 0, ch)];
+      w = ctrd[(size_t)c * K + qcnn_row_slot(slot)];
+    }
+    out[i] = w;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // FC layers whose sub-spaces have ONE dim (a 1000-way classifier behind 4096 features: AlexNet / VGG-16 fc8, 16 code
 // words of one float each): a look-up there stands for one multiply-add, so the table build — 4096 sub-spaces x 16 code
 // words x 128 images per panel — is pure overhead.  out[c] = bias[c] + sum_k x[k] * w[k][c], w[k][c] = ctrd[k][asmt[k][c]].
@@ -469,5 +639,34 @@ hipError_t qk_fc_dec(const FcDecParams& p, int slices, int live, hipStream_t st)
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fc_dec), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_fc_dec, grid, dim3(1024), shm, st, q);
+  return hipGetLastError();
+}
+
+bool qk_conv_dec_nchw_shape(int Cin, int grp, int M, int Ct, int knl, int pad, int* Kp, int* S) {
+  if (grp != 1 || M != 1 || Cin < 1 || Cin > 4 || pad != 0 || Ct % 96) return false;
+  const int kp = (Cin * knl * knl + 15) / 16 * 16;            // steps in fours
+  if ((size_t)kp * Ct * sizeof(float) + (kp / 4 + 4) * 16 > 160 * 1024) return false;
+  *Kp = kp; *S = Ct;
+  return true;
+}
+
+hipError_t qk_decode_weights_nchw(const uint8_t* rows, const float* ctrd, float* out, const QkSlots& sl, int knl, int Cin, int K,
+                                  int Ct, int Kp, int S, hipStream_t st) {
+  const int total = Kp * S;
+  hipLaunchKernelGGL(k_decode_weights_nchw, dim3((total + 255) / 256), dim3(256), 0, st, rows, ctrd, out, sl, knl, Cin, K, Ct, Kp / 4, S);
+  return hipGetLastError();
+}
+
+// p.Kr = Cin knl^2, p.Kp = qk_conv_dec_nchw_shape's, p.S = Ct
+hipError_t qk_conv_dec_nchw(const DecParams& p, hipStream_t st) {
+  if (!p.srcNchw || p.pad != 0 || p.Ct % 96 || p.S != p.Ct || (unsigned long long)p.nImages * p.Cin * p.H * p.W * 4ull >= (1ull << 32))
+    return hipErrorInvalidValue;
+  const long long items = (long long)p.panels * p.Ho * ((p.Wo + 3) / 4) * ((p.live + 15) / 16) * (p.Ct / 96);
+  const int blocks = (int)std::min<long long>(256, (items + 7) / 8);
+  const size_t shm = (size_t)p.Kp * p.S * sizeof(float) + (size_t)(p.Kp / 4 + 4) * 16;
+  auto kern = k_conv_dec_nchw<6>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), shm, st, p);
   return hipGetLastError();
 }

@@ -39,6 +39,7 @@ struct LayerShape {
   size_t offProgF8 = 0, progF8Bytes = 0, offCtrdF = 0;         // FC with 32 code words of 4 dims: program + code book of the eight-wave kernel (k_fc_sym8)
   size_t offCbn = 0, cbnBytes = 0; int cbnBits = 0;            // FC: the assignments bit-packed as the .cbn payload holds them (file order
                                                                // [Ct][M], include/FileIO.h:128-166), read in place by the few-image kernel
+  size_t offDecN = 0; int decNV = 0;                          // first layer: the same code words in k_conv_dec_nchw's order; decNV: its padded k (0: not eligible)
   size_t offDec = 0; int decKp = 0, decS = 0;                  // decoded code words (qcnn_decoded.hip): conv layer with one sub-space of
                                                                // <= 4 dims (decKp > 0), FC layer with one-dim sub-spaces (decKp = -1); 0: not eligible
   bool hasDmap = false;
@@ -81,6 +82,7 @@ struct QcnnCtx {
   int nStreams = 2;                  // QCNN_OPT_STREAMS: sub-batches of whole panels run concurrently
   int smallBatch = 1;                // QCNN_OPT_SMALL_BATCH: few-image kernels for batches <= kSmallBatchMax
   int hostChunk = 2;                 // QCNN_OPT_HOST_CHUNK: panels per chunk of a large qcnn_forward_host batch (0: one launch)
+  int directDec = 1;                 // QCNN_OPT_DIRECT_DEC: a decoded first layer reads the NCHW input in place (k_conv_dec_nchw) on the fast path
   int packedFc = 0;                  // QCNN_OPT_PACKED_FC (default off: measured 0.056 against 0.035 ms for AlexNet fc6 at one image): the few-image FC kernel reads the bit-packed assignment stream in place
   int sym8 = 1;                      // QCNN_OPT_SYM8: eight-wave symmetric workgroups where predicted faster (2: whenever eligible)
   int sym = 1;                       // QCNN_OPT_SYM: symmetric workgroups for 128-channel layers where predicted faster (2: whenever eligible)
@@ -234,6 +236,13 @@ int plan_arena(QcnnCtx* c) {
     s.hasDmap = (d.type == QCNN_FCNT && l == c->firstFc && c->dims[l].h * c->dims[l].w > 1);
     if (d.type == QCNN_CONV && qk_conv_dec_shape(c->dims[l].c, d.grpCnt, s.M, Ct, d.knlSiz, &s.decKp, &s.decS)) {
       s.offDec = off; off = align_up(off + sizeof(float) * (size_t)d.knlSiz * s.decKp * s.decS, 256);
+      int nS = 0;
+      s.decNV = 0;
+      if (l == 0 && qk_conv_dec_nchw_shape(c->dims[l].c, d.grpCnt, s.M, Ct, d.knlSiz, d.padSiz, &s.decNV, &nS)) {
+        s.offDecN = off; off = align_up(off + sizeof(float) * (size_t)s.decNV * nS, 256);
+      } else {
+        s.decNV = 0;
+      }
     } else if (d.type == QCNN_FCNT && !s.hasDmap && qk_fc_dec_shape((int)fm_elems(c, l), s.M, s.Cs, Ct, &s.decS)) {
       s.decKp = -1;                   // FC layer with one-dim sub-spaces: [D][decS] decoded code words
       s.offDec = off; off = align_up(off + sizeof(float) * fm_elems(c, l) * s.decS, 256);
@@ -343,17 +352,20 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
         e = qk_dense(q, st);
         break;
       }
-      if (decoded_layer(c, l) && !small && !inNchw) {     // one sub-space of <= 4 dims: decoded code words on the matrix pipe
+      if (decoded_layer(c, l) && !small && (!inNchw || s.decNV)) {   // one sub-space of <= 4 dims: decoded code words on the matrix pipe
         DecParams q;
         q.src = src; q.dst = dst;
+        q.srcNchw = 0; q.nImages = 0; q.panel0 = 0;
+        if (inNchw) { q.src = inNchw; q.srcNchw = 1; q.nImages = nImages; q.panel0 = p0; }   // network input read in place
         q.bias = reinterpret_cast<const float*>(c->arena + s.offBias);
-        q.wdec = reinterpret_cast<const float*>(c->arena + s.offDec);
+        q.wdec = reinterpret_cast<const float*>(c->arena + (inNchw ? s.offDecN : s.offDec));
         q.H = a.h; q.W = a.w; q.Cin = a.c; q.Ho = b.h; q.Wo = b.w; q.Ct = b.c;
         q.knl = d.knlSiz; q.stride = d.stride; q.pad = d.padSiz;
         q.Kr = d.knlSiz * a.c; q.Kp = s.decKp; q.S = s.decS;
+        if (inNchw) { q.Kr = d.knlSiz * d.knlSiz * a.c; q.Kp = s.decNV; q.S = b.c; }
         q.relu = fuseRelu ? 1 : 0; q.panels = panels; q.live = live;
-        s.lastFrom = -3; s.lastZ = 1;                     // reported by qcnn_get_layer_split as (-3, 1)
-        e = qk_conv_dec(q, st);
+        s.lastFrom = -3; s.lastZ = inNchw ? 2 : 1;        // reported by qcnn_get_layer_split as (-3, 1), NCHW in place: (-3, 2)
+        e = inNchw ? qk_conv_dec_nchw(q, st) : qk_conv_dec(q, st);
         if (e != hipErrorInvalidValue) break;             // (a map beyond the kernel's 32-bit byte offsets: the table kernel below)
       }
       ConvParams p;
@@ -623,7 +635,9 @@ bool direct_input(const QcnnCtx* c, int n) {
   if (c->keepAll || c->L == 0 || c->layers[0].type != QCNN_CONV) return false;
   // a first layer that runs through its decoded code words reads packed panels (the few-image kernels do not take that
   // path: one or two images in a 128-image panel layout are 64-byte segments with one float each, they read NCHW densely)
-  if (decoded_layer(c, 0) && !(c->smallBatch && c->lutMode == 1 && n <= kSmallBatchMax)) return false;
+  // path: one or two images in a 128-image panel layout ...) — unless its kernel has the NCHW form (k_conv_dec_nchw)
+  if ((unsigned long long)c->maxBatch * c->inC * c->inH * c->inW * sizeof(float) >= (1ull << 32)) return false;
+  if (decoded_layer(c, 0) && !(c->smallBatch && c->lutMode == 1 && n <= kSmallBatchMax)) return c->directDec && c->shapes[0].decNV > 0;
   const QcnnLayerDesc& d = c->layers[0];
   // ONE sub-space (a second one would be fetched from channel planes past the group's own, for the last image past the
   // caller's buffer), and the whole batch inside 4 GiB: the builders keep per-lane image offsets in 32 bits
@@ -811,6 +825,7 @@ int qcnn_set_option(QcnnCtx* c, int option, int value) {
     case QCNN_OPT_DECODE: c->decode = value ? 1 : 0; return 0;
     case QCNN_OPT_SYM8: c->sym8 = value < 0 ? 0 : (value > 2 ? 2 : value); return 0;
     case QCNN_OPT_PACKED_FC: c->packedFc = value ? 1 : 0; return 0;
+    case QCNN_OPT_DIRECT_DEC: c->directDec = value ? 1 : 0; return 0;
     case QCNN_OPT_SYM: c->sym = value < 0 ? 0 : (value > 2 ? 2 : value); return 0;
     case QCNN_OPT_SLIDE: c->slide = value < 0 ? 0 : (value > 2 ? 2 : value); return 0;
     case QCNN_OPT_HOST_CHUNK:
@@ -1079,6 +1094,10 @@ hipError_t build_program(QcnnCtx* c, int layer, const QkSlots& sl) {
     e = qk_decode_weights(reinterpret_cast<const uint8_t*>(c->arena + s.offAsmt), reinterpret_cast<const float*>(c->arena + s.offCtrd),
                           reinterpret_cast<float*>(c->arena + s.offDec), sl, d.knlSiz, c->dims[layer].c, s.K,
                           c->dims[layer + 1].c, s.decKp, s.decS, c->stream);
+  if (e == hipSuccess && s.decKp > 0 && s.decNV)
+    e = qk_decode_weights_nchw(reinterpret_cast<const uint8_t*>(c->arena + s.offAsmt), reinterpret_cast<const float*>(c->arena + s.offCtrd),
+                               reinterpret_cast<float*>(c->arena + s.offDecN), sl, d.knlSiz, c->dims[layer].c, s.K,
+                               c->dims[layer + 1].c, s.decNV, c->dims[layer + 1].c, c->stream);
   if (e == hipSuccess && s.progF8Bytes)        // eight-wave FC kernel: uint16 offsets in its channel order
     e = qk_build_program_fc8(reinterpret_cast<const uint8_t*>(c->arena + s.offAsmt), reinterpret_cast<uint16_t*>(c->arena + s.offProgF8), sl,
                              c->dims[layer + 1].c, s.M, c->stream);

@@ -321,6 +321,8 @@ hipError_t qk_pool(const float* src, float* dst, int panels, int H, int W, int C
 // Quantised conv layer with one sub-space of <= 4 dims evaluated through its decoded code words on the matrix pipe
 // (qcnn_decoded.hip).  wdec: [knl][Kp][S] — kernel row, k = column * Cin + d (padded to Kp, zeros), channel (row stride S)
 struct DecParams {
+  int srcNchw;           // 1: src is the network input [nImages][Cin][H][W] read in place (qk_conv_dec_nchw); 0: panels
+  int nImages, panel0;   // srcNchw: images of the batch, index of the launch's first panel inside it
   const float* src;      // [panels][H*W*Cin][128]
   float* dst;            // [panels][Ho*Wo*Ct][128]
   const float* bias;     // [Ct]
@@ -334,6 +336,12 @@ bool qk_conv_dec_shape(int Cin, int grp, int M, int Ct, int knl, int* Kp, int* S
 hipError_t qk_decode_weights(const uint8_t* rows, const float* ctrd, float* out, const QkSlots& sl, int knl, int Cin, int K,
                              int Ct, int Kp, int S, hipStream_t st);
 hipError_t qk_conv_dec(const DecParams& p, hipStream_t st);
+// The same layer reading the NCHW network input in place (no pack pass), k flat over the window (Cin knl^2 products in
+// fours, padded to Kp = a multiple of 16): unpadded layers.  wdec: [Kp / 4 steps][S / 16][4 k][16], S = Ct.
+bool qk_conv_dec_nchw_shape(int Cin, int grp, int M, int Ct, int knl, int pad, int* Kp, int* S);
+hipError_t qk_decode_weights_nchw(const uint8_t* rows, const float* ctrd, float* out, const QkSlots& sl, int knl, int Cin, int K,
+                                  int Ct, int Kp, int S, hipStream_t st);
+hipError_t qk_conv_dec_nchw(const DecParams& p, hipStream_t st);   // p.Kr = Cin knl^2, p.Kp and p.S from qk_conv_dec_nchw_shape
 // FC layer with one-dim sub-spaces through its decoded code words (qcnn_decoded.hip).  wdec: [D][S], S = Ct rounded up to 64
 struct FcDecParams {
   const float* src;      // [panels][D][128]

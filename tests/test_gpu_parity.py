@@ -787,7 +787,7 @@ def test_decoded_first_layer_alexnet():
     for keep in (1, 0):
         eng = make_engine(in_chw, layers, params, 131, lut=capi.LUT_MFMA, keep_all=keep, decode=1)
         p1, t1 = eng.forward_host(imgs)
-        assert eng.layer_split(0) == (-3, 1)
+        assert eng.layer_split(0) == (-3, 1 if keep else 2)        # fast path: the NCHW batch read in place (k_conv_dec_nchw)
         if keep:
             for l, want in fm0.items():
                 got = eng.layer_output(l, 131)
@@ -844,6 +844,48 @@ def test_decoded_first_layer_geometries(cin, knl, stride, pad, ct):
         e_inf, e_l2 = rel_err(eng.layer_output_range(l, 126, 5), orc.fm(l))
         assert e_inf <= TOL and e_l2 <= TOL, "fm[%d] vs oracle: %g %g" % (l, e_inf, e_l2)
     eng.close()
+
+
+@pytest.mark.parametrize("cin,knl,stride,ct", [(3, 11, 4, 96), (3, 7, 2, 96), (1, 3, 1, 96), (4, 4, 2, 192), (2, 8, 3, 96), (2, 12, 5, 96)])
+def test_decoded_first_layer_reads_nchw_in_place(cin, knl, stride, ct):
+    """QCNN_OPT_DIRECT_DEC (default on): on the fast path an unpadded decoded first layer takes its operands straight
+    from the caller's NCHW batch (k over the columns of a kernel row: 1, 2 or 3 steps per row, the last lane group
+    overlapping the one before it with zero code words) — no pack pass.  Kernel sizes 3 ... 12, 1 - 4 input channels,
+    strides 1 - 5, 5 / 70 / 200 images (one ragged 64-image block; a full panel + a ragged one).  Against the packed
+    decoded kernel (QCNN_OPT_DIRECT_DEC = 0) within 2e-6 of the map's largest value — the same products summed in another
+    order — and against the oracle within 1e-4; device-resident input (qcnn_forward) as well as the host pipeline."""
+    layers = [topo.conv(0, knl, ct, 1, stride), topo.relu(), topo.pool(0, 2, 2), topo.fcnt(40), topo.smax()]
+    in_chw = (cin, 29, 31)
+    params = synth.make_params(in_chw, layers, seed=190 + cin)
+    rng = np.random.default_rng(191)
+    imgs = (rng.integers(0, 256, size=(200,) + in_chw).astype(np.float32) - 120.0)
+    orc = po.COracle(in_chw, layers)
+    orc.set_params(params)
+    for n in (200, 70, 5):                  # (5: beyond QCNN_SMALL_BATCH_MAX, one live image tile)
+        orc.forward(imgs[n - 3:n])
+        outs = {}
+        for direct in (0, 1):
+            eng = pkg("engine").QcnnEngine(0)
+            eng.set_option(capi.OPT_LUT_MODE, capi.LUT_MFMA)
+            eng.set_option(capi.OPT_KEEP_ALL, 0)
+            eng.set_option(capi.OPT_DIRECT_DEC, direct)
+            eng.load_model(in_chw, layers, params, 200)
+            prob, top5 = eng.forward_host(imgs[:n])
+            assert eng.layer_split(0) == (-3, 1 + direct)
+            outs[direct] = (eng.layer_output(3, n), prob, top5)
+            if direct:
+                import torch
+                x = torch.from_numpy(imgs[:n]).to("cuda:0")
+                prob_d = torch.empty((n, 40), dtype=torch.float32, device="cuda:0")
+                eng.forward_dev(x.data_ptr(), n, prob_d.data_ptr())
+                eng.sync()
+                assert np.array_equal(prob_d.cpu().numpy(), prob)
+                for l in (3, 4, 5):
+                    e_inf, e_l2 = rel_err(eng.layer_output_range(l, n - 3, 3), orc.fm(l))
+                    assert e_inf <= TOL and e_l2 <= TOL, "n = %d fm[%d] vs oracle: %g %g" % (n, l, e_inf, e_l2)
+            eng.close()
+        assert np.abs(outs[1][0] - outs[0][0]).max() <= 2e-6 * np.abs(outs[0][0]).max()
+        assert np.abs(outs[1][1] - outs[0][1]).max() <= 1e-5 * outs[0][1].max()
 
 
 def test_decoded_first_layer_vgg16_shape():

@@ -107,7 +107,7 @@ def test_shipped_parameters_headline_kernels_match_reference(golden_alex_real10,
     _check_outputs(prob, top5, z, 1, name)
     if name == "headline_fast_path":
         # which kernels ran (qcnn_get_layer_split: -3 decoded, -5 eight-wave symmetric, -2 sliding): the ones the headline is made of
-        assert eng.layer_split(0)[0] == -3 and eng.layer_split(21)[0] == -3      # conv1, fc8 decoded
+        assert eng.layer_split(0) == (-3, 2) and eng.layer_split(21)[0] == -3        # conv1 decoded, NCHW in place; fc8 decoded
         assert eng.layer_split(4)[0] == -5 and eng.layer_split(10)[0] == -5      # conv2, conv4: eight-wave symmetric workgroups
         assert eng.layer_split(12)[0] == -2                                      # conv5 sliding
         with pytest.raises(pkg("engine").QcnnError):
