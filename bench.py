@@ -378,6 +378,7 @@ def main():
     layer_ms, recorded = eng.layer_ms()
     segments = {i: eng.layer_segments(i) for i, l in enumerate(layers) if l["type"] == topo.CONV}   # sliding kernel, per layer
     decoded = {i for i, l in enumerate(layers) if l["type"] in (topo.CONV, topo.FCNT) and eng.layer_split(i)[0] == -3}   # decoded layers
+    dec_nchw = {i for i in decoded if eng.layer_split(i)[1] == 2}                                                      # k_conv_dec_nchw
     symmetric = {i for i, l in enumerate(layers) if l["type"] == topo.CONV and eng.layer_split(i)[0] == -4}            # k_conv_sym
     sym8 = {i for i, l in enumerate(layers) if l["type"] == topo.CONV and eng.layer_split(i)[0] == -5}                 # k_conv_sym8
     ok = bool(torch.isfinite(prob[lo:hi]).all().item())
@@ -590,7 +591,7 @@ def main():
         slow = {}
         for i in sorted((i for i, l in enumerate(v_layers) if l["type"] in (topo.CONV, topo.FCNT)), key=lambda i: -vms[i])[:5]:
             split = ve.layer_split(i)[0]
-            r = (perf.decoded_report(v_sizes, v_layers, i, vb, float(vms[i])) if (split == -3 and v_layers[i]["type"] == topo.CONV) else
+            r = (perf.decoded_report(v_sizes, v_layers, i, vb, float(vms[i]), ve.layer_split(i)[1] == 2) if (split == -3 and v_layers[i]["type"] == topo.CONV) else
                  perf.layer_report(v_sizes, v_layers, v_params, i, vb, float(vms[i]), ve.layer_segments(i), 8 if split == -5 else split == -4))
             r["ms"] = round(float(vms[i]), 4)
             r["in_hwc"], r["out_hwc"] = list(v_sizes[i]), list(v_sizes[i + 1])
@@ -625,7 +626,7 @@ def main():
         total_lk = 0
         for i, l in enumerate(layers):
             if l["type"] in (topo.CONV, topo.FCNT) and layer_ms[i] > 0:
-                r = (perf.decoded_report(sizes, layers, i, launch_images, float(layer_ms[i])) if (i in decoded and l["type"] == topo.CONV) else
+                r = (perf.decoded_report(sizes, layers, i, launch_images, float(layer_ms[i]), i in dec_nchw) if (i in decoded and l["type"] == topo.CONV) else
                      dict(tile="decoded code words: x @ w on the matrix pipe, 64 channels x 64 images per workgroup",
                           issued_mfma_flop_per_image=2 * sizes[i][0] * sizes[i][1] * sizes[i][2] * ((l["nod"] + 63) // 64 * 64),
                           lookups_replaced_per_image=sizes[i][0] * sizes[i][1] * sizes[i][2] * l["nod"]) if i in decoded else

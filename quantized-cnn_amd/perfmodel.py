@@ -101,20 +101,30 @@ def fc_work(d: int, ct: int, m: int, k: int, cs: int, msplit_chunks: int):
                 alg_flop=alg_flop, tile="fc", ks=ks)
 
 
-def decoded_report(sizes, layers, l: int, images: float, ms: float):
-    """A conv layer that ran through its decoded code words (qcnn_decoded.hip): products issued on the matrix pipe — kernel
-    rows of knl * Cin products padded to fours, positions x channels x images — against the dense f32 peak and against
-    what `scripts/ubench/mfma_clock.hip` sustains on all CUs (145 TFLOP/s at the 2.29 GHz the chip holds under that load)."""
+def decoded_report(sizes, layers, l: int, images: float, ms: float, nchw: bool = False):
+    """A conv layer that ran through its decoded code words (qcnn_decoded.hip): products issued on the matrix pipe against
+    the dense f32 peak and against what `scripts/ubench/mfma_clock.hip` sustains on all CUs (145 TFLOP/s at the 2.29 GHz the
+    chip holds under that load).  Panel kernel (k_conv_dec): kernel rows of knl * Cin products padded to fours, positions x
+    channels x images.  nchw (k_conv_dec_nchw, the network input read in place): Cin * knl^2 products flat, padded to 16;
+    output rows in groups of four positions, images in sixteens."""
     ly = layers[l]
     h, w, c = sizes[l]
     ho, wo, ct = sizes[l + 1]
-    kp = (ly["knl"] * c + 3) // 4 * 4
-    flop = 2.0 * ho * wo * ct * ly["knl"] * kp * images
+    if nchw:
+        kflat = (ly["knl"] * ly["knl"] * c + 15) // 16 * 16
+        flop = 2.0 * ho * ((wo + 3) // 4 * 4) * ct * kflat * ((images + 15) // 16 * 16)
+        tile = ("decoded code words, NCHW input in place: %d (of %d) products per output, 16 images x 4 positions x 96 channels per wave"
+                % (kflat, ly["knl"] * ly["knl"] * c))
+    else:
+        kp = (ly["knl"] * c + 3) // 4 * 4
+        flop = 2.0 * ho * wo * ct * ly["knl"] * kp * images
+        tile = "decoded code words: %d x %d products per output, 64 images x %d channels per wave" % (
+            ly["knl"], kp, 96 if ct % 96 == 0 else (64 if ct % 64 == 0 else 32))
     t = ms * 1e-3
-    return dict(tile="decoded code words: %d x %d products per output, 64 images x %d channels per wave" %
-                     (ly["knl"], kp, 96 if ct % 96 == 0 else (64 if ct % 64 == 0 else 32)),
+    return dict(tile=tile,
                 issued_mfma_flop_per_image=int(flop / images), mfma_util=round(flop / t / F32_MFMA_FLOPS, 4) if t > 0 else 0.0,
                 mfma_util_of_sustained=round(flop / t / 145.0e12, 4) if t > 0 else 0.0,
+                mfma_algorithmic_frac=round(2.0 * ho * wo * ct * ly["knl"] * ly["knl"] * c * images / t / F32_MFMA_FLOPS, 4) if t > 0 else 0.0,
                 lookups_replaced_per_image=int(conv_work(sizes[l], sizes[l + 1], ly, 1, 128, c)["lookups"]))
 
 

@@ -47,8 +47,10 @@ def main():
             return "k_conv_aprx<%s.%s.%d.8." % (m.group(1), m.group(2), int(m.group(3)) // 12)
         if tile.startswith("decoded code words: x @ w"):
             return "k_fc_dec"
+        if tile.startswith("decoded code words, NCHW"):
+            return "k_conv_dec_nchw"
         if tile.startswith("decoded"):
-            return "k_conv_dec"
+            return "k_conv_dec<"
         m = re.match(r"(\d+)x(\d+)x(\d+)$", tile)
         if m:
             return "k_conv_aprx<%s.%s.%d.8." % (m.group(1), m.group(2), int(m.group(3)) // 12)
