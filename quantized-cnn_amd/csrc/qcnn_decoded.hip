@@ -293,14 +293,29 @@ hipError_t launch_dec(const DecParams& p, hipStream_t st) {
 //   tile = 4 images x 4 positions                                       1.96 ms   (loads alone 0.67 ms, 16-byte store fragments)
 //   tile = 8 images x 2 positions                                       1.85 ms   (everything but the products 1.10 ms,
 //                                                                                  everything but loads or but stores 1.68 ms)
+//   one loop body (no peeled tail, no zero-trip path: 225 -> 133 registers), then 5 / 6 positions of 16 images per item
+//   1.86 / 2.06 ms, 12 / 16 waves per workgroup 1.86 / 1.88 ms against 1.81 (synthetic parameters): eight waves, four positions
 // the matrix pipe alone would need 1.42 ms at 2.4 GHz; what is left is the stores and loads of a wave's item boundary that
 // its SIMD neighbour's products do not cover.
 // ------------------------------------------------------------------------------------------------------------------
-template <int CT>
-__global__ __launch_bounds__(512) void k_conv_dec_nchw(DecParams p) {
+// s_waitcnt vmcnt(N) that the operands of a step pass through (the compiler must not move their uses above it)
+template <int N, int IT>
+__device__ __forceinline__ void nchw_wait_impl(float (&bb)[IT]) {
+  if constexpr (IT == 4) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(bb[0]), "+v"(bb[1]), "+v"(bb[2]), "+v"(bb[3]) : "n"(N));
+  else if constexpr (IT == 5) asm volatile("s_waitcnt vmcnt(%5)" : "+v"(bb[0]), "+v"(bb[1]), "+v"(bb[2]), "+v"(bb[3]), "+v"(bb[4]) : "n"(N));
+  else asm volatile("s_waitcnt vmcnt(%6)" : "+v"(bb[0]), "+v"(bb[1]), "+v"(bb[2]), "+v"(bb[3]), "+v"(bb[4]), "+v"(bb[5]) : "n"(N));
+}
+template <int N, int IT>
+__device__ __forceinline__ void nchw_wait(float (&bb)[IT]) { nchw_wait_impl<N, IT>(bb); }
+
+#ifndef NCHW_WAVES
+#define NCHW_WAVES 8
+#endif
+template <int CT, int IT>
+__global__ __launch_bounds__(64 * NCHW_WAVES) void k_conv_dec_nchw(DecParams p) {
+  static_assert(IT == 4, "a product tile is 2 positions x 8 images, an item two pairs of positions x two image halves");
   extern __shared__ __attribute__((aligned(16))) float ldsW[];          // [steps][Ct / 16][4 k][16]: a wave's read of one channel tile is
                                                                         // 64 consecutive floats (no bank conflicts); then int [steps + 4][4]
-  constexpr int IT = 4;
   const int lane = threadIdx.x & 63, wave = uni(threadIdx.x >> 6);
   const int P = p.Ho * p.Wo;
   const int steps = p.Kp >> 2;                                          // Kp: Cin knl^2 padded to a multiple of 16
@@ -310,8 +325,8 @@ __global__ __launch_bounds__(512) void k_conv_dec_nchw(DecParams p) {
     const int wq = steps * p.S;
     const f32x4* __restrict__ wsrc = reinterpret_cast<const f32x4*>(p.wdec);
     f32x4* ldsW4 = reinterpret_cast<f32x4*>(ldsW);
-    for (int i = threadIdx.x; i < wq; i += 512) ldsW4[i] = wsrc[i];
-    for (int i = threadIdx.x; i < (steps + 4) * 4; i += 512) {
+    for (int i = threadIdx.x; i < wq; i += 64 * NCHW_WAVES) ldsW4[i] = wsrc[i];
+    for (int i = threadIdx.x; i < (steps + 4) * 4; i += 64 * NCHW_WAVES) {
       const int k = min(i, p.Kr - 1);                                   // Kr: Cin knl^2
       const int kw = k % p.knl, kh = (k / p.knl) % p.knl, c = k / (p.knl * p.knl);
       ldsOff[i] = (int)((uint32_t)c * planeBytes + (uint32_t)kh * rowBytes + (uint32_t)kw * 4u);
@@ -331,7 +346,7 @@ __global__ __launch_bounds__(512) void k_conv_dec_nchw(DecParams p) {
   const int xcd = blockIdx.x & 7, nX = gridDim.x < 8 ? gridDim.x : 8;
   const int wgX = (gridDim.x - xcd + 7) >> 3;
   const int itemBeg = (int)((long long)nItems * xcd / nX), itemEnd = (int)((long long)nItems * (xcd + 1) / nX);
-  for (int item = itemBeg + (blockIdx.x >> 3) * 8 + wave; item < itemEnd; item += wgX * 8) {
+  for (int item = itemBeg + (blockIdx.x >> 3) * NCHW_WAVES + wave; item < itemEnd; item += wgX * NCHW_WAVES) {
     int laneI = lane;
     asm volatile("" : "+v"(laneI));                                     // lane-derived constants re-derived per item (registers)
     const int li = laneI & 15, kq = laneI >> 4;
@@ -370,7 +385,7 @@ __global__ __launch_bounds__(512) void k_conv_dec_nchw(DecParams p) {
     const float* __restrict__ wl = ldsW + cc * 64 * CT + laneI;
     const int aStep = 4 * p.S;
     float a[2][CT], b[4][IT];                                           // b: a ring of four steps' operands, three in flight (a ring
-                                                                        // of eight: 256 registers, spills, no faster)
+                                                                        // of eight: no faster)
     auto load_a = [&](const float* __restrict__ w, float (&aa)[CT]) {
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) aa[ct] = w[ct * 64];
@@ -379,8 +394,8 @@ __global__ __launch_bounds__(512) void k_conv_dec_nchw(DecParams p) {
     issue(1, b[1]);
     issue(2, b[2]);
     load_a(wl, a[0]);
-#define NCHW_WAIT(n, bb) asm volatile("s_waitcnt vmcnt(" #n ")" : "+v"(bb[0]), "+v"(bb[1]), "+v"(bb[2]), "+v"(bb[3]))
-#define NCHW_STEP(u, n) /* step s + u; at most n loads may still be in flight */                                       \
+#define NCHW_WAIT(n, bb) nchw_wait<n * IT>(bb)
+#define NCHW_STEP(u, n) /* step s + u; the loads of at most n steps may still be in flight */                                       \
   {                                                                                                                   \
     wl += aStep;                                                                                                      \
     load_a(wl, a[((u) + 1) & 1]); /* code words of the next step */                                                   \
@@ -392,15 +407,18 @@ __global__ __launch_bounds__(512) void k_conv_dec_nchw(DecParams p) {
         acc[ct][ti] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[u][ti], a[(u) & 1][ct], acc[ct][ti], 0, 0, 0);           \
     __builtin_amdgcn_sched_barrier(0);                                                                                \
   }
+    // three steps ahead, into the set the step before released.  The last iteration fetches three steps past the end (the
+    // offset table repeats the window's last element there): 12 loads of 4 steps x IT per item that nobody reads — the
+    // price of ONE loop body: a peeled tail with decreasing wait counts made the compiler keep the accumulators in a
+    // second register block (225 registers; 5 positions per item did not fit)
     int s = 0;
-    for (; s < steps - 4; s += 4) {                                     // three steps ahead, into the set the step before released
-      issue(s + 3, b[3]); NCHW_STEP(0, 12)
-      issue(s + 4, b[0]); NCHW_STEP(1, 12)
-      issue(s + 5, b[1]); NCHW_STEP(2, 12)
-      issue(s + 6, b[2]); NCHW_STEP(3, 12)
-    }
-    issue(s + 3, b[3]); NCHW_STEP(0, 12)                                // the last four steps: one more to fetch
-    NCHW_STEP(1, 8) NCHW_STEP(2, 4) NCHW_STEP(3, 0)
+    do {                                                                // (at least four steps: no zero-trip copy of the accumulators)
+      issue(s + 3, b[3]); NCHW_STEP(0, 3)
+      issue(s + 4, b[0]); NCHW_STEP(1, 3)
+      issue(s + 5, b[1]); NCHW_STEP(2, 3)
+      issue(s + 6, b[2]); NCHW_STEP(3, 3)
+    } while ((s += 4) < steps);
+    NCHW_WAIT(0, b[0]); NCHW_WAIT(0, b[1]); NCHW_WAIT(0, b[2]);         // nothing in flight into registers the stores may reuse
 #undef NCHW_STEP
 #undef NCHW_WAIT
     // The image values are the A operand, the code words B (the lane layouts of the two operands of a 16x16x4 instruction
@@ -409,18 +427,30 @@ __global__ __launch_bounds__(512) void k_conv_dec_nchw(DecParams p) {
     {
       const int nPos = (NCHW_VAR & 4) ? (p.Wo < 0 ? IT : 0) : min(IT, p.Wo - ocol);
       float* __restrict__ dst = p.dst + (((size_t)panel * P + orow * p.Wo + ocol + (kq >> 1)) * p.Ct + li) * PANEL + it * 16 + 4 * (kq & 1);
+      // two copies of the store loop under one uniform branch: a ReLU applied under a branch INSIDE the loop made the compiler
+      // keep a second set of result registers (225 instead of 140)
+      if (p.relu) {
 #pragma unroll
-      for (int ti = 0; ti < IT; ++ti)
-        if ((ti >> 1) * 2 + (kq >> 1) < nPos) {
+        for (int ti = 0; ti < IT; ++ti)
+          if ((ti >> 1) * 2 + (kq >> 1) < nPos) {
 #pragma unroll
-          for (int ct = 0; ct < CT; ++ct) {
-            f32x4 v = acc[ct][ti];
-            if (p.relu)
+            for (int ct = 0; ct < CT; ++ct) {
+              f32x4 v;
 #pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = (0.0f < v[e]) ? v[e] : 0.0f;
-            *reinterpret_cast<f32x4*>(dst + ((size_t)(ti >> 1) * 2 * p.Ct + (cc * CT + ct) * 16) * PANEL + 8 * (ti & 1)) = v;
+              for (int e = 0; e < 4; ++e) v[e] = (0.0f < acc[ct][ti][e]) ? acc[ct][ti][e] : 0.0f;
+              *reinterpret_cast<f32x4*>(dst + ((size_t)(ti >> 1) * 2 * p.Ct + (cc * CT + ct) * 16) * PANEL + 8 * (ti & 1)) = v;
+              __builtin_amdgcn_sched_barrier(0);
+            }
           }
-        }
+      } else {
+#pragma unroll
+        for (int ti = 0; ti < IT; ++ti)
+          if ((ti >> 1) * 2 + (kq >> 1) < nPos) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+              *reinterpret_cast<f32x4*>(dst + ((size_t)(ti >> 1) * 2 * p.Ct + (cc * CT + ct) * 16) * PANEL + 8 * (ti & 1)) = acc[ct][ti];
+          }
+      }
     }
   }
 }
@@ -662,11 +692,11 @@ hipError_t qk_conv_dec_nchw(const DecParams& p, hipStream_t st) {
   if (!p.srcNchw || p.pad != 0 || p.Ct % 96 || p.S != p.Ct || (unsigned long long)p.nImages * p.Cin * p.H * p.W * 4ull >= (1ull << 32))
     return hipErrorInvalidValue;
   const long long items = (long long)p.panels * p.Ho * ((p.Wo + 3) / 4) * ((p.live + 15) / 16) * (p.Ct / 96);
-  const int blocks = (int)std::min<long long>(256, (items + 7) / 8);
+  const int blocks = (int)std::min<long long>(256, (items + NCHW_WAVES - 1) / NCHW_WAVES);
   const size_t shm = (size_t)p.Kp * p.S * sizeof(float) + (size_t)(p.Kp / 4 + 4) * 16;
-  auto kern = k_conv_dec_nchw<6>;
+  auto kern = k_conv_dec_nchw<6, 4>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), shm, st, p);
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * NCHW_WAVES), shm, st, p);
   return hipGetLastError();
 }

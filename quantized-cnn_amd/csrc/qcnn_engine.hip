@@ -522,7 +522,10 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
         if (e != hipErrorInvalidValue) break;
         p.partial = nullptr;
       }
-      const bool fc8 = s.progF8Bytes && c->sym8 && c->lutMode == 1 && !small;     // k_fc_sym8: 768 channels per workgroup
+      // k_fc_sym8: 768 channels per workgroup.  A launch of one or two panels stays with the 12-wave kernel's 384 (measured,
+      // AlexNet fc6 / fc7 per 125 images: 0.092 / 0.053 against 0.108 / 0.070 ms; 250: 0.148 / 0.076 against 0.150 / 0.082; 500:
+      // 0.304 / 0.135 against 0.259 / 0.129) — under QCNN_OPT_SPLIT only, whose results may depend on the batch size
+      const bool fc8 = s.progF8Bytes && c->sym8 && c->lutMode == 1 && !small && (c->sym8 >= 2 || !c->split || panels >= 3);
       if (c->lutMode >= 1) {
         const int G = qcnn_stage_group(s.K);
         const int stages = (s.M + G - 1) / G;
