@@ -423,8 +423,9 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
             // measured 1.18: 2952 against 2508 cycles on AlexNet conv2)
             if (pl.symCost > 0.0 && 1.08 * pl.symCost < other) other = 1.08 * pl.symCost;
             // (a sliding stage is priced 3 % above a tile stage; measured 3330 against 2500 cycles with 12 channels per wave, i.e.
-            // ~1.05 us per planner unit against ~0.92 for this kernel on AlexNet conv5 and VGG-16's 256 / 512-channel layers)
-            if (pl.segN > 0 && pl.slideCost > 0.0) other = std::min(other, 1.10 * pl.slideCost);
+            // 1.04 - 1.08 us per planner unit against 0.89 - 0.91 for this kernel on VGG-16's 256 / 512-channel layers: x 1.17;
+            // AlexNet conv5, which must keep sliding — 0.99 against 1.04 ms —, sits at a cost ratio of 1.157)
+            if (pl.segN > 0 && pl.slideCost > 0.0) other = std::min(other, 1.15 * pl.slideCost);
             if (c->sym8 >= 2 || pl.sym8Cost < 0.97 * other) {
               p.progS = reinterpret_cast<const uint16_t*>(c->arena + s.offProg8);
               s.lastFrom = -5; s.lastZ = 1;             // reported by qcnn_get_layer_split as (-5, 1)
@@ -629,8 +630,10 @@ int drain_profile(QcnnCtx* c) {
 // Fast path only (layer-for-layer mode keeps fm[0] for dumps); a conv layer with <= 4 input channels per group (one
 // sub-space of <= 4 dims: exactly what the operand loads of one stage touch) and K = 128 or the exact builder.
 // workgroups a fused LRN + pool launch must have (QCNN_LRNPOOL_MIN overrides it for experiments)
+// (192: one panel of AlexNet's LRN1 + pool1 — 196 workgroups — fuses: 0.091 against 0.104 ms; LRN2 + pool2 at one / two panels —
+// 64 / 128 workgroups — must not: 0.21 against 0.065 ms)
 int lrn_pool_min_blocks() {
-  static const int v = [] { const char* e = getenv("QCNN_LRNPOOL_MIN"); return (e && atoi(e) > 0) ? atoi(e) : 256; }();
+  static const int v = [] { const char* e = getenv("QCNN_LRNPOOL_MIN"); return (e && atoi(e) > 0) ? atoi(e) : 192; }();
   return v;
 }
 
