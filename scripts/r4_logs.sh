@@ -4,7 +4,7 @@
 O=gpurun_out/r4; mkdir -p $O
 F='^layerInd|^\[INFO\]|^\[CHECK|amdgpu.ids'
 bash scripts/shard_sweep.sh > /dev/null 2>&1; cp gpurun_out/shard_sweep.log $O/shard_sweep.log
-bash scripts/b1_probe.sh > $O/b1.log 2>&1
+for b in 1 2; do QCNN_SPLIT=1 timeout 300 python scripts/layer_times.py $b 50 1; done 2>&1 | grep -vE "$F" > $O/b1.log
 for b in 125 1000; do for y in 0 2 1; do
 echo "QCNN_SYM8=$y"; QCNN_SYM8=$y timeout 300 python scripts/layer_times.py $b 10 1
 done; done 2>&1 | grep -vE "$F" > $O/sym8_sweep.log
