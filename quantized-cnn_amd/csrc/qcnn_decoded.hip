@@ -346,7 +346,11 @@ __global__ __launch_bounds__(64 * NCHW_WAVES) void k_conv_dec_nchw(DecParams p) 
   const int xcd = blockIdx.x & 7, nX = gridDim.x < 8 ? gridDim.x : 8;
   const int wgX = (gridDim.x - xcd + 7) >> 3;
   const int itemBeg = (int)((long long)nItems * xcd / nX), itemEnd = (int)((long long)nItems * (xcd + 1) / nX);
-  for (int item = itemBeg + (blockIdx.x >> 3) * NCHW_WAVES + wave; item < itemEnd; item += wgX * NCHW_WAVES) {
+  // a launch of less than one item per wave (a few images) spreads its items over the SIMDs of ALL workgroups — wave w of
+  // workgroup g takes item w wgX + g — instead of filling the eight waves of a few: an item then has a matrix pipe to itself
+  const bool sparse = itemEnd - itemBeg <= wgX * NCHW_WAVES;
+  for (int item = itemBeg + (sparse ? wave * wgX + (int)(blockIdx.x >> 3) : (int)(blockIdx.x >> 3) * NCHW_WAVES + wave); item < itemEnd;
+       item += wgX * NCHW_WAVES) {
     int laneI = lane;
     asm volatile("" : "+v"(laneI));                                     // lane-derived constants re-derived per item (registers)
     const int li = laneI & 15, kq = laneI >> 4;
@@ -692,7 +696,7 @@ hipError_t qk_conv_dec_nchw(const DecParams& p, hipStream_t st) {
   if (!p.srcNchw || p.pad != 0 || p.Ct % 96 || p.S != p.Ct || (unsigned long long)p.nImages * p.Cin * p.H * p.W * 4ull >= (1ull << 32))
     return hipErrorInvalidValue;
   const long long items = (long long)p.panels * p.Ho * ((p.Wo + 3) / 4) * ((p.live + 15) / 16) * (p.Ct / 96);
-  const int blocks = (int)std::min<long long>(256, (items + NCHW_WAVES - 1) / NCHW_WAVES);
+  const int blocks = (int)std::min<long long>(256, items);           // (few items: one per workgroup, see `sparse`)
   const size_t shm = (size_t)p.Kp * p.S * sizeof(float) + (size_t)(p.Kp / 4 + 4) * 16;
   auto kern = k_conv_dec_nchw<6, 4>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);

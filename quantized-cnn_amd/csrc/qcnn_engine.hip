@@ -352,7 +352,10 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
         e = qk_dense(q, st);
         break;
       }
-      if (decoded_layer(c, l) && !small && (!inNchw || s.decNV)) {   // one sub-space of <= 4 dims: decoded code words on the matrix pipe
+      // one sub-space of <= 4 dims: decoded code words on the matrix pipe.  Batches of one to three images too when the layer
+      // reads the NCHW input in place: a 16-image tile with one live image still beats the few-image table kernel, whose
+      // workgroups rebuild the pixel tables five times (AlexNet conv1 at one image: 0.126 -> 0.0xx ms)
+      if (decoded_layer(c, l) && (small ? (inNchw && s.decNV && c->directDec) : (!inNchw || s.decNV))) {
         DecParams q;
         q.src = src; q.dst = dst;
         q.srcNchw = 0; q.nImages = 0; q.panel0 = 0;
