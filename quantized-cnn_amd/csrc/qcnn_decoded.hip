@@ -294,7 +294,9 @@ hipError_t launch_dec(const DecParams& p, hipStream_t st) {
 //   tile = 8 images x 2 positions                                       1.85 ms   (everything but the products 1.10 ms,
 //                                                                                  everything but loads or but stores 1.68 ms)
 //   one loop body (no peeled tail, no zero-trip path: 225 -> 133 registers), then 5 / 6 positions of 16 images per item
-//   1.86 / 2.06 ms, 12 / 16 waves per workgroup 1.86 / 1.88 ms against 1.81 (synthetic parameters): eight waves, four positions
+//   1.86 / 2.06 ms, 12 / 16 waves per workgroup 1.86 / 1.88 ms against 1.81 (synthetic parameters): eight waves, four positions;
+//   the two 32-byte halves of a row stored back to back 1.79 ms; non-temporal stores 1.86; item = 32 images x 2 positions
+//   (whole 128-byte lines per wave) 1.82
 // the matrix pipe alone would need 1.42 ms at 2.4 GHz; what is left is the stores and loads of a wave's item boundary that
 // its SIMD neighbour's products do not cover.
 // ------------------------------------------------------------------------------------------------------------------
@@ -377,7 +379,8 @@ __global__ __launch_bounds__(64 * NCHW_WAVES) void k_conv_dec_nchw(DecParams p) 
 #pragma unroll
       for (int ti = 0; ti < IT; ++ti)
         if (NCHW_VAR & 1) asm volatile("v_mov_b32 %0, %1" : "=v"(bb[ti]) : "v"(vo)); else
-        asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(bb[ti]) : "v"(vo), "s"(rsrc4), "s"(base0 + (uint32_t)(ti & 1) * 8u * imgBytes + (uint32_t)((ti >> 1) * 2 * p.stride) * 4u));
+        asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(bb[ti]) : "v"(vo), "s"(rsrc4),
+                     "s"(base0 + (uint32_t)(ti & 1) * 8u * imgBytes + (uint32_t)((ti >> 1) * 2 * p.stride) * 4u));
     };
     f32x4 acc[CT][IT];
 #pragma unroll
@@ -434,17 +437,21 @@ __global__ __launch_bounds__(64 * NCHW_WAVES) void k_conv_dec_nchw(DecParams p) 
       // two copies of the store loop under one uniform branch: a ReLU applied under a branch INSIDE the loop made the compiler
       // keep a second set of result registers (225 instead of 140)
       if (p.relu) {
+        // the two halves (images 0-7, 8-15) of a row's 64 bytes leave back to back (1.81 -> 1.79 ms)
 #pragma unroll
-        for (int ti = 0; ti < IT; ++ti)
-          if ((ti >> 1) * 2 + (kq >> 1) < nPos) {
+        for (int tp = 0; tp < IT / 2; ++tp)
+          if (tp * 2 + (kq >> 1) < nPos) {
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) {
-              f32x4 v;
+            for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = (0.0f < acc[ct][ti][e]) ? acc[ct][ti][e] : 0.0f;
-              *reinterpret_cast<f32x4*>(dst + ((size_t)(ti >> 1) * 2 * p.Ct + (cc * CT + ct) * 16) * PANEL + 8 * (ti & 1)) = v;
-              __builtin_amdgcn_sched_barrier(0);
-            }
+              for (int h = 0; h < 2; ++h) {
+                const int ti = tp * 2 + h;
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (0.0f < acc[ct][ti][e]) ? acc[ct][ti][e] : 0.0f;
+                *reinterpret_cast<f32x4*>(dst + ((size_t)tp * 2 * p.Ct + (cc * CT + ct) * 16) * PANEL + 8 * h) = v;
+                __builtin_amdgcn_sched_barrier(0);
+              }
           }
       } else {
 #pragma unroll
