@@ -890,6 +890,25 @@ def test_decoded_first_layer_reads_nchw_in_place(cin, knl, stride, ct):
             eng.close()
         assert np.abs(outs[1][0] - outs[0][0]).max() <= (2e-6 if n > capi.SMALL_BATCH_MAX else 1e-5) * np.abs(outs[0][0]).max()
         assert np.abs(outs[1][1] - outs[0][1]).max() <= 1e-5 * outs[0][1].max()
+    # a host batch of three panels goes through in chunks of two (QCNN_OPT_HOST_CHUNK default): the first layer then reads
+    # the staged NCHW chunks at their panel offsets — same bits as one launch, on one stream and on two
+    big = np.concatenate([imgs, imgs[:110]])
+    res = []
+    for chunk, streams in ((0, 1), (2, 1), (2, 2), (1, 2)):
+        eng = pkg("engine").QcnnEngine(0)
+        eng.set_option(capi.OPT_LUT_MODE, capi.LUT_MFMA)
+        eng.set_option(capi.OPT_KEEP_ALL, 0)
+        eng.set_option(capi.OPT_SPLIT, 0)                       # (the planner's cuts may differ with the panels per launch)
+        eng.set_option(capi.OPT_HOST_CHUNK, chunk)
+        eng.set_option(capi.OPT_STREAMS, streams)
+        eng.load_model(in_chw, layers, params, 310)
+        prob, top5 = eng.forward_host(big)
+        assert eng.layer_split(0) == (-3, 2)
+        res.append((eng.layer_output(3, 310), prob, top5))
+        eng.close()
+    for r in res[1:]:
+        assert all(np.array_equal(a, b) for a, b in zip(res[0], r))
+    assert np.array_equal(res[0][1][200:], res[0][1][:110])
 
 
 def test_decoded_first_layer_vgg16_shape():
