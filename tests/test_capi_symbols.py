@@ -46,3 +46,14 @@ def test_topology_matches_survey_sizes():
     assert {i: (v["M"], v["K"], v["Cs"]) for i, v in spec.items()} == {
         0: (1, 128, 8), 4: (6, 128, 8), 8: (32, 128, 8), 10: (24, 128, 8), 12: (24, 128, 8),
         15: (2304, 32, 4), 18: (1024, 32, 4), 21: (4096, 16, 1)}
+
+
+def test_python_option_constants_match_the_header():
+    """quantized-cnn_amd/capi.py restates the QCNN_OPT_* / QCNN_SMALL_BATCH_MAX values of include/qcnn_hip.h."""
+    import re
+    text = open(capi.HEADER_PATH).read()
+    enum = dict((m.group(1), int(m.group(2))) for m in re.finditer(r"\bQCNN_OPT_([A-Z0-9_]+)\s*=\s*(\d+)", text))
+    assert len(enum) >= 13
+    for name, value in enum.items():
+        assert getattr(capi, "OPT_" + name) == value, name
+    assert capi.SMALL_BATCH_MAX == int(re.search(r"#define\s+QCNN_SMALL_BATCH_MAX\s+(\d+)", text).group(1))
