@@ -52,7 +52,7 @@ def test_python_option_constants_match_the_header():
     """quantized-cnn_amd/capi.py restates the QCNN_OPT_* / QCNN_SMALL_BATCH_MAX values of include/qcnn_hip.h."""
     import re
     text = open(capi.HEADER_PATH).read()
-    enum = dict((m.group(1), int(m.group(2))) for m in re.finditer(r"\bQCNN_OPT_([A-Z0-9_]+)\s*=\s*(\d+)", text))
+    enum = dict((m.group(1), int(m.group(2))) for m in re.finditer(r"^\s+QCNN_OPT_([A-Z0-9_]+)\s*=\s*(\d+),?\s*/\*", text, re.M))
     assert len(enum) >= 13
     for name, value in enum.items():
         assert getattr(capi, "OPT_" + name) == value, name
