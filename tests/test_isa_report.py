@@ -54,3 +54,12 @@ def test_register_budgets(rows):
         limit = {1024: 128, 512: 256}.get(d.get("max_flat_workgroup_size", 0))
         if limit and name.startswith(("k_conv_", "k_fc_")):
             assert d.get("vgpr_count", 0) + d.get("agpr_count", 0) <= limit, (name, d)
+
+
+def test_generated_gather_header_is_current():
+    """quantized-cnn_amd/csrc/qcnn_sym8_gather.h is what scripts/gen/gen_sym8_gather.py (2 reads per block, 3 register sets) emits."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.check_output([sys.executable, os.path.join(root, "scripts", "gen", "gen_sym8_gather.py"), "2", "3"], text=True)
+    assert out == open(os.path.join(root, "quantized-cnn_amd", "csrc", "qcnn_sym8_gather.h")).read()
