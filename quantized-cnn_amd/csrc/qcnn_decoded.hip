@@ -76,7 +76,6 @@ template <int CT, int PW, bool PADDED, int R, int IT>
 __global__ __launch_bounds__(1024) void k_conv_dec(DecParams p) {
   extern __shared__ __attribute__((aligned(16))) float ldsW[];          // [knl * Kp][S]
   const int lane = threadIdx.x & 63, wave = uni(threadIdx.x >> 6);
-  const int li = lane & 15, kq = lane >> 4;
   const int P = p.Ho * p.Wo;
   {
     const int wq = (p.knl * p.Kp * p.S) >> 2;
