@@ -35,6 +35,7 @@ struct LayerShape {
   size_t offProgS = 0, progSBytes = 0;                         // ... and in the order of the sliding variant, where it applies
   size_t offProgY = 0, progYBytes = 0;                         // ... and of the symmetric kernel's (8 channels per wave, 2x2 tile) layout
   size_t offProg8 = 0, prog8Bytes = 0;                         // ... and of the eight-wave symmetric kernel's layout (Qk8Config)
+  size_t offProg8S = 0, prog8SBytes = 0;                       // ... and of its sliding form (qk_conv_sym8_slide_config)
   size_t offCtrd8 = 0;                                         // ... with the code book in that kernel's operand order (qk_ctrd8_index)
   size_t offProgF8 = 0, progF8Bytes = 0, offCtrdF = 0;         // FC with 32 code words of 4 dims: program + code book of the eight-wave kernel (k_fc_sym8)
   size_t offCbn = 0, cbnBytes = 0; int cbnBits = 0;            // FC: the assignments bit-packed as the .cbn payload holds them (file order
@@ -53,6 +54,8 @@ struct LayerShape {
     double slideCost = 0.0;                                    // ... and its predicted duration
     double symCost = 0.0;                                      // predicted duration of the symmetric kernel (0: not eligible)
     double sym8Cost = 0.0;                                     // ... of the eight-wave symmetric kernel
+    double sym8sCost = 0.0;                                    // ... of its sliding form, with the segments it would run
+    int seg8N = 0, seg8Beg[9] = {0};
   };
   std::map<long long, Plan> plans;
   int segN = 0, segBeg[9] = {0};                               // segments of the last launch when it slid (qcnn_get_layer_segments)
@@ -223,14 +226,15 @@ int plan_arena(QcnnCtx* c) {
       s.cbnBytes = ((size_t)Ct * s.M + per - 1) / per * 4096;
       s.offCbn = off; off = align_up(off + s.cbnBytes + 256, 256);
     }
-    s.prog8Bytes = 0;
+    s.prog8Bytes = 0; s.prog8SBytes = 0;
     if (d.type == QCNN_CONV) {
       const Qk8Config c8 = qk_conv_sym8_config(c->dims[l].c, d.grpCnt, Ct, s.M, s.Cs, s.K);
       s.prog8Bytes = qk_conv_sym8_program_bytes(c8, d.grpCnt, d.knlSiz, d.stride, s.M);
-      if (s.prog8Bytes) {
-        s.offProg8 = off; off = align_up(off + s.prog8Bytes + QCNN_ROWS_PAD, 256);
-        s.offCtrd8 = off; off = align_up(off + sizeof(float) * (size_t)s.M * s.Cs * s.K, 256);
-      }
+      const Qk8Config c8s = qk_conv_sym8_slide_config(c->dims[l].c, d.grpCnt, Ct, s.M, s.Cs, s.K, d.knlSiz, d.stride);
+      s.prog8SBytes = qk_conv_sym8_program_bytes(c8s, d.grpCnt, d.knlSiz, d.stride, s.M);
+      if (s.prog8Bytes) { s.offProg8 = off; off = align_up(off + s.prog8Bytes + QCNN_ROWS_PAD, 256); }
+      if (s.prog8SBytes) { s.offProg8S = off; off = align_up(off + s.prog8SBytes + QCNN_ROWS_PAD, 256); }
+      if (s.prog8Bytes || s.prog8SBytes) { s.offCtrd8 = off; off = align_up(off + sizeof(float) * (size_t)s.M * s.Cs * s.K, 256); }
     }
     s.decKp = 0;
     s.hasDmap = (d.type == QCNN_FCNT && l == c->firstFc && c->dims[l].h * c->dims[l].w > 1);
@@ -378,7 +382,7 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
       p.bias = reinterpret_cast<const float*>(c->arena + s.offBias);
       p.ctrd = reinterpret_cast<const float*>(c->arena + s.offCtrd);
       p.ctrd2 = s.hasCtrd2 ? c->arena + s.offCtrd2 : nullptr;
-      p.ctrd8 = s.prog8Bytes ? reinterpret_cast<const float*>(c->arena + s.offCtrd8) : nullptr;
+      p.ctrd8 = (s.prog8Bytes || s.prog8SBytes) ? reinterpret_cast<const float*>(c->arena + s.offCtrd8) : nullptr;
       p.rows = reinterpret_cast<const uint8_t*>(c->arena + s.offAsmt);
       p.prog = s.progBytes ? reinterpret_cast<const uint16_t*>(c->arena + s.offProg) : nullptr;
       p.H = a.h; p.W = a.w; p.Cin = a.c; p.Ho = b.h; p.Wo = b.w; p.Ct = b.c;
@@ -407,6 +411,13 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
             pl.symCost = (c->sym && s.progYBytes && c->lutMode == 1 && !inNchw) ? qk_conv_sym_cost(p) : 0.0;
             pl.sym8Cost = (c->sym8 && s.prog8Bytes && c->lutMode == 1 && !inNchw)
                               ? qk_conv_sym8_cost(p, qk_conv_sym8_config(p.Cin, p.grp, p.Ct, p.M, p.Cs, p.K), kSym8StageFactor) : 0.0;
+            if (c->sym8 && s.prog8SBytes && c->lutMode == 1 && !inNchw) {
+              ConvParams t = p;
+              pl.sym8sCost = qk_conv_sym8_slide_plan(t, qk_conv_sym8_slide_config(p.Cin, p.grp, p.Ct, p.M, p.Cs, p.K, p.knl, p.stride),
+                                                     kSym8StageFactor);
+              pl.seg8N = t.nSeg;
+              for (int i = 0; i <= t.nSeg && i < 9; ++i) pl.seg8Beg[i] = t.segBeg[i];
+            }
             if (c->slide && p.progS) {                // sliding variant where it is predicted to beat the (split) tile kernel
               ConvParams t = p;
               pl.slideCost = qk_conv_plan_slide(t, c->slide >= 2 ? 1e30 : pl.plan.cost);   // 2: whenever the layer is eligible (tests)
@@ -414,13 +425,33 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
               for (int i = 0; i <= t.nSeg && i < 9; ++i) pl.segBeg[i] = t.segBeg[i];
             }
             if (const char* dbg = getenv("QCNN_DEBUG_PLAN"); dbg && atoi(dbg))
-              fprintf(stderr, "[qcnn plan] layer %d panels %d: tile %.0f (Z %d) | slide %.0f (%d segments) | sym %.0f | sym8 %.0f stage-times\n",
-                      l, panels, pl.plan.cost, pl.plan.Z, pl.slideCost, pl.segN, pl.symCost, pl.sym8Cost);
+              fprintf(stderr, "[qcnn plan] layer %d panels %d: tile %.0f (Z %d) | slide %.0f (%d segments) | sym %.0f | sym8 %.0f | sym8 sliding %.0f (%d segments) stage-times\n",
+                      l, panels, pl.plan.cost, pl.plan.Z, pl.slideCost, pl.segN, pl.symCost, pl.sym8Cost, pl.sym8sCost, pl.seg8N);
             it = s.plans.emplace(key, pl).first;
           }
           const LayerShape::Plan& pl = it->second;
-          // eight-wave symmetric workgroups: when forced, or predicted at least 3 % faster than every other plan of the launch
-          if (pl.sym8Cost > 0.0 && c->lutMode == 1 && !inNchw && (c->sym8 >= 2 || (c->sym < 2 && c->slide < 2))) {
+          // eight-wave symmetric workgroups, tile or sliding form: when forced (QCNN_OPT_SYM8 = 2: tile form, 3: sliding form where
+          // eligible), or predicted at least 3 % faster than every other plan of the launch
+          const bool may8 = c->lutMode == 1 && !inNchw && (c->sym8 >= 2 || (c->sym < 2 && c->slide < 2));
+          if (may8 && pl.sym8sCost > 0.0 && pl.seg8N > 0 && c->sym8 != 2) {
+            double other = pl.plan.cost;
+            if (pl.symCost > 0.0 && 1.08 * pl.symCost < other) other = 1.08 * pl.symCost;
+            if (pl.segN > 0 && pl.slideCost > 0.0) other = std::min(other, 1.15 * pl.slideCost);
+            if (pl.sym8Cost > 0.0) other = std::min(other, pl.sym8Cost);
+            // (measured per planner unit, 1000 images: the sliding form 1.04 - 1.11 us — VGG-16's layers, AlexNet conv2 / conv5 —,
+            // the tile form 0.89 - 0.93: x 1.17.  With it the sliding form takes VGG-16's 256- and 512-channel layers and conv2_1,
+            // none of AlexNet's: 13 x 13 maps leave too few strips — 208 workgroups for conv4)
+            if (c->sym8 >= 3 || 1.17 * pl.sym8sCost < 0.97 * other) {
+              p.progS = reinterpret_cast<const uint16_t*>(c->arena + s.offProg8S);
+              p.nSeg = pl.seg8N;
+              s.segN = pl.seg8N;
+              for (int i = 0; i <= pl.seg8N; ++i) { p.segBeg[i] = pl.seg8Beg[i]; s.segBeg[i] = pl.seg8Beg[i]; }
+              s.lastFrom = -6; s.lastZ = pl.seg8N;      // reported by qcnn_get_layer_split as (-6, segments per column)
+              e = qk_conv_sym8_slide(p, st);
+              break;
+            }
+          }
+          if (pl.sym8Cost > 0.0 && may8) {
             double other = pl.plan.cost;                           // tile kernel, whole or split (in stage-times)
             // (qk_conv_sym_cost prices a 16-wave symmetric stage at 1.09 tile stages — enough to rank it against the tile kernel;
             // measured 1.18: 2952 against 2508 cycles on AlexNet conv2)
@@ -832,7 +863,7 @@ int qcnn_set_option(QcnnCtx* c, int option, int value) {
     case QCNN_OPT_SMALL_BATCH: c->smallBatch = value ? 1 : 0; return 0;
     case QCNN_OPT_SPLIT: c->split = value ? 1 : 0; return 0;
     case QCNN_OPT_DECODE: c->decode = value ? 1 : 0; return 0;
-    case QCNN_OPT_SYM8: c->sym8 = value < 0 ? 0 : (value > 2 ? 2 : value); return 0;
+    case QCNN_OPT_SYM8: c->sym8 = value < 0 ? 0 : (value > 3 ? 3 : value); return 0;
     case QCNN_OPT_PACKED_FC: c->packedFc = value ? 1 : 0; return 0;
     case QCNN_OPT_DIRECT_DEC: c->directDec = value ? 1 : 0; return 0;
     case QCNN_OPT_SYM: c->sym = value < 0 ? 0 : (value > 2 ? 2 : value); return 0;
@@ -1053,7 +1084,7 @@ int upload_bias_ctrd(QcnnCtx* c, int layer, const float* bias, const float* ctrd
     HIP_TRY(c, hipMemcpyAsync(c->arena + s.offCtrdF, ctrdF.data(), ctrdF.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
   }
   std::vector<float> ctrd8;
-  if (s.prog8Bytes) {                 // the eight-wave symmetric kernel's operand order (K = 128, Cs = 4 or 8)
+  if (s.prog8Bytes || s.prog8SBytes) {  // the eight-wave symmetric kernel's operand order (K = 128, Cs = 4 or 8)
     ctrd8.resize((size_t)M * Cs * K);
     for (int m = 0; m < M; ++m)
       for (int dd = 0; dd < Cs; ++dd)
@@ -1115,6 +1146,12 @@ hipError_t build_program(QcnnCtx* c, int layer, const QkSlots& sl) {
     e = qk_build_program8(reinterpret_cast<const uint8_t*>(c->arena + s.offAsmt), reinterpret_cast<uint16_t*>(c->arena + s.offProg8), sl,
                           qk_conv_sym8_config(c->dims[layer].c, d.grpCnt, Ct, s.M, s.Cs, s.K), Ct / d.grpCnt, d.grpCnt, d.knlSiz,
                           d.stride, s.M, c->stream);
+  }
+  if (e == hipSuccess && s.prog8SBytes) {      // ... and the program of its sliding form
+    const int Ct = c->dims[layer + 1].c;
+    e = qk_build_program8(reinterpret_cast<const uint8_t*>(c->arena + s.offAsmt), reinterpret_cast<uint16_t*>(c->arena + s.offProg8S), sl,
+                          qk_conv_sym8_slide_config(c->dims[layer].c, d.grpCnt, Ct, s.M, s.Cs, s.K, d.knlSiz, d.stride), Ct / d.grpCnt,
+                          d.grpCnt, d.knlSiz, d.stride, s.M, c->stream);
   }
   if (e == hipSuccess && s.progYBytes) {       // symmetric kernel: the (8 channels per wave, 2x2 tile) layout of the same table
     const QkSlots s8 = qk_make_slots(sl.C, sl.groups, 8);
@@ -1527,7 +1564,7 @@ int qcnn_get_layer_split(QcnnCtx* c, int layer, int* tiles_unsplit, int* slices)
 int qcnn_get_layer_segments(QcnnCtx* c, int layer, int* seg_beg9, int* n_seg) {
   if (layer < 0 || layer >= c->L) return fail(c, "layer %d out of range", layer);
   const LayerShape& s = c->shapes[layer];
-  const int n = (s.lastFrom == -2) ? s.segN : 0;
+  const int n = (s.lastFrom == -2 || s.lastFrom == -6) ? s.segN : 0;
   if (n_seg) *n_seg = n;
   if (seg_beg9)
     for (int i = 0; i < 9; ++i) seg_beg9[i] = (i <= n) ? s.segBeg[i] : 0;

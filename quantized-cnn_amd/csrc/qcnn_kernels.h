@@ -220,7 +220,7 @@ hipError_t qk_conv_sym(const ConvParams& p, hipStream_t st);
 // a th x tw tile per wave (cpw * th * tw = 96 = 192 accumulator registers), `chunks` workgroups along the channel axis.
 // cpw = 0: the layer is not eligible.  Program table of this layout: [rfH][rfW][M][groups * chunks][8 waves][2 halves]
 // [position][cpw / 2] uint16 (ConvParams::progS when the kernel is launched).
-struct Qk8Config { int cpw, th, tw, chunks; };
+struct Qk8Config { int cpw, th, tw, chunks, slide; };   // slide: th = accumulator slots per column, tw = columns of a strip
 // position (in floats) inside ConvParams::ctrd8 of code word k (0..127), dim d of sub-space m; ks = Cs / 4 k-steps
 __host__ __device__ static inline size_t qk_ctrd8_index(int m, int d, int k, int ks) {
   const int h = k >> 6, i = (k >> 4) & 3, li = k & 15, step = d >> 2, lk = d & 3;
@@ -232,6 +232,11 @@ hipError_t qk_build_program8(const uint8_t* rows, uint16_t* prog, const QkSlots&
                              int knl, int stride, int M, hipStream_t st);
 double qk_conv_sym8_cost(const ConvParams& p, const Qk8Config& cf, double stageFactor);
 hipError_t qk_conv_sym8(const ConvParams& p, hipStream_t st);
+// The sliding form of the eight-wave kernel (k_conv_sym8<.., SLIDE>): config (cpw = 0: not eligible), segments + predicted
+// duration, launch.  Program table: qk_conv_sym8_program_bytes / qk_build_program8 with this config.
+Qk8Config qk_conv_sym8_slide_config(int Cin, int grp, int Ct, int M, int Cs, int K, int knl, int stride);
+double qk_conv_sym8_slide_plan(ConvParams& p, const Qk8Config& cf, double stageFactor);
+hipError_t qk_conv_sym8_slide(const ConvParams& p, hipStream_t st);
 
 struct FcParams {
   float* partial;        // [msplit][panels][Ct][128] scratch for split-M partial sums (msplit > 1)

@@ -68,6 +68,26 @@ constexpr uint32_t PROG8_BUF = 2048u;
 
 #include "qcnn_sym8_gather.h"
 
+// the lane index from the execution mask (two VALU instructions): where a value derived from it is needed once per stage
+// period or less, re-deriving beats keeping it — the 96-pair instantiations have no register to spare
+// (volatile asm: the builtin form is loop-invariant to the compiler, which hoists it and keeps what is derived from it)
+__device__ __forceinline__ int lane_now() {
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+}
+
+// wave 0 test on an opaque scalar copy (the compiler otherwise carries the uniform condition as a lane mask in a VGPR across
+// the stage loop), and the LDS address of a wave half's block of a program row from the lane index of the moment
+__device__ __forceinline__ bool is_wave0(int wave) {
+  int w = wave;
+  asm volatile("" : "+s"(w));
+  return w == 0;
+}
+__device__ __forceinline__ uint32_t my_blk(int wave, int blkBytes) {
+  return PROG8_LDS + (uint32_t)(wave * 2 + (lane_now() >> 5)) * (uint32_t)blkBytes;
+}
+
 // operands of one stage for this wave: code-book tiles of its four row tiles, activation tiles of its two image tiles
 template <int KS>
 struct Ops8 {
@@ -172,23 +192,39 @@ __device__ __forceinline__ void gather8(f32x2 (&acc)[TH * TW][CPW], uint32_t blk
 #endif
 }
 
-template <int CPW, int TH, int TW, int KS>
+// SLIDE (the eight-wave form of k_conv_aprx<.., SLIDE>): the workgroup owns a SEGMENT of output rows of a strip of TW output
+// columns and sweeps the source rows under it; TH = ceil(knl / stride) accumulator SLOTS per column hold the output rows
+// whose windows contain the current source row — when a window closes its sums are stored and the slot restarts from the
+// bias TH rows further down.  Every source pixel of the strip is built once per segment: 3 table builds per output position
+// for a 3x3 / 1 layer with 192 or 256 channels per workgroup (2x2 / 1x3 tiles: 4 and 5), 2 with 128 channels (two columns),
+// 5 for a 5x5 / 1 layer with 128 (2x3 tile: 7).  Positions are [slot][column] — the tile kernel's [row][column] with a
+// slot's first source row (xq) in the place of a tile row's; program rows are indexed by the source row modulo TH * stride.
+template <int CPW, int TH, int TW, int KS, bool SLIDE = false>
 __global__ __launch_bounds__(NW8 * 64) void k_conv_sym8(ConvParams p, int tilesX, int tilesY, int chunks) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   constexpr int NP = TH * TW, HC = CPW / 2;
-  static_assert(CPW % 8 == 0 && NP * CPW == 96, "96 (position, channel) pairs of four images per lane = 192 accumulator registers");
+  static_assert(CPW % 8 == 0 && NP * CPW <= 96 && (SLIDE || NP * CPW == 96),
+                "96 (position, channel) pairs of four images per lane = 192 accumulator registers");
   constexpr int BLKB = NP * CPW;                       // bytes of a wave half's block of a program row ([NP][HC] uint16)
-  constexpr int ROWB = NW8 * 2 * BLKB;                 // bytes of the workgroup's program row of one entry (1536)
+  constexpr int ROWB = NW8 * 2 * BLKB;                 // bytes of the workgroup's program row of one entry (<= 1536)
   const int lane = threadIdx.x & 63;
   const int wave = uni(threadIdx.x >> 6);
   const int rank = (int)(blockIdx.x / (unsigned)p.panels), panel = (int)(blockIdx.x % (unsigned)p.panels);
-  int ty, tx;
-  tile_of_rank(rank, tilesY, tilesX, ty, tx);
+  int ty = 0, tx = 0, segBeg = 0, segEnd = 0;
+  if constexpr (SLIDE) {
+    // rank = segment-major unit (longest segments first): segment x strip of TW output columns
+    const unsigned colGroups = (unsigned)(p.Wo + TW - 1) / TW;
+    const int seg = (int)((unsigned)rank / colGroups);
+    tx = (int)((unsigned)rank % colGroups);
+    segBeg = p.segBeg[seg]; segEnd = p.segBeg[seg + 1];
+  } else {
+    tile_of_rank(rank, tilesY, tilesX, ty, tx);
+  }
   const int grp = (int)blockIdx.y / chunks, chunk = (int)blockIdx.y % chunks;
   const int Cg = p.Cin / p.grp, Ctg = p.Ct / p.grp;
   const int M = p.M;
-  const int ho0 = ty * TH, wo0 = tx * TW;
-  const int hoL = min(ho0 + TH, p.Ho) - 1, woL = min(wo0 + TW, p.Wo) - 1;
+  const int ho0 = SLIDE ? segBeg : ty * TH, wo0 = tx * TW;
+  const int hoL = SLIDE ? segEnd - 1 : min(ho0 + TH, p.Ho) - 1, woL = min(wo0 + TW, p.Wo) - 1;
   const int hiL = max(0, ho0 * p.stride - p.pad), hiU = min(p.H - 1, hoL * p.stride - p.pad + p.knl - 1);
   ConvGeom g;
   g.W = p.W; g.Cin = p.Cin; g.knl = p.knl; g.M = M; g.G = 1; g.rowStride = 0;
@@ -196,11 +232,11 @@ __global__ __launch_bounds__(NW8 * 64) void k_conv_sym8(ConvParams p, int tilesX
   g.MG = M;
   g.wiL = max(0, wo0 * p.stride - p.pad);
   g.wiU = min(p.W - 1, woL * p.stride - p.pad + p.knl - 1);
-  g.slide = 0; g.hiL = hiL; g.hiU = hiU; g.period = 1;
+  g.slide = SLIDE ? 1 : 0; g.hiL = hiL; g.hiU = hiU; g.period = SLIDE ? TH * p.stride : 1;
   const int cols = g.wiU - g.wiL + 1;
   const int S = (hiU - hiL + 1) * cols * g.MG;
   const int Sp = (S + 1) & ~1;
-  const StagePos first = {hiL, g.wiL, 0, 0};
+  const StagePos first = {hiL, g.wiL, 0, SLIDE ? (int)((unsigned)(hiL - (ho0 * p.stride - p.pad)) % (unsigned)(TH * p.stride)) : 0};
   if ((uint32_t)(uintptr_t)lds != 0u) __builtin_trap();   // the stage addressing assumes the dynamic segment starts at LDS byte 0
 
   // ---- builder side of this wave: image tiles 2 (wave >> 1), + 1 (both with slot swizzle wave >> 1), row tiles 4 (wave & 1) ..
@@ -229,9 +265,15 @@ __global__ __launch_bounds__(NW8 * 64) void k_conv_sym8(ConvParams p, int tilesX
       for (int q = 0; q < NP; ++q) { acc[q][2 * j] = f32x2{b, b}; acc[q][2 * j + 1] = f32x2{b, b}; }
     }
   }
+  // first source row of every tile row's (SLIDE: every slot's current) window, first source column of every tile column's;
+  // positions outside the map / slots past the segment get a start that can never match a tap
   int rowStart[TH], colStart[TW];
+  int woq[TH];                                         // SLIDE: the output row a slot holds
 #pragma unroll
-  for (int dy = 0; dy < TH; ++dy) rowStart[dy] = (ho0 + dy < p.Ho) ? (ho0 + dy) * p.stride - p.pad : -(1 << 28);
+  for (int dy = 0; dy < TH; ++dy) {
+    woq[dy] = ho0 + dy;
+    rowStart[dy] = (ho0 + dy <= hoL) ? (ho0 + dy) * p.stride - p.pad : -(1 << 28);
+  }
 #pragma unroll
   for (int dx = 0; dx < TW; ++dx) colStart[dx] = (wo0 + dx < p.Wo) ? (wo0 + dx) * p.stride - p.pad : -(1 << 28);
   const int rfW = (TW - 1) * p.stride + p.knl;
@@ -240,11 +282,48 @@ __global__ __launch_bounds__(NW8 * 64) void k_conv_sym8(ConvParams p, int tilesX
   const char* __restrict__ progWg = reinterpret_cast<const char*>(p.progS) + (size_t)(grp * chunks + chunk) * ROWB;
   auto rowOf = [&](const StagePos& q, int idx) {       // stages past the end: any existing row
     const StagePos c = (idx < S) ? q : first;
-    return progWg + (size_t)(uint32_t)(((c.hi - ry0) * rfW + (c.wi - rx0)) * M + c.mg) * entryB;
+    const int row = SLIDE ? c.ph : c.hi - ry0;
+    return progWg + (size_t)(uint32_t)((row * rfW + (c.wi - rx0)) * M + c.mg) * entryB;
+  };
+  // SLIDE: after the last stage of a source row the positions whose window ends with this row (or with the strip) are stored
+  // and their slot restarts from the bias for the output row TH further down
+  auto column_end = [&](const StagePos& c, int live) {
+    if (!(live && c.wi == g.wiU && c.mg == g.MG - 1)) return;
+    // everything lane-dependent is re-derived HERE from an opaque copy of the lane index: hoisted out of the stage loop these
+    // values cost the 96-pair instantiations ten spilled registers, reloaded in every stage period (measured +20 % per stage)
+    const int laneC = lane_now();
+    const uint32_t halfC = (uint32_t)laneC >> 5, quadC = (uint32_t)laneC & 31u;
+    // wave-uniform bases + one 32-bit lane offset each (no per-lane 64-bit pointers)
+    float* __restrict__ dstU = p.dst + (size_t)panel * p.Ho * p.Wo * p.Ct * PANEL + (size_t)(grp * Ctg + cw0) * PANEL;
+    const float* __restrict__ biasU = p.bias + grp * Ctg + cw0;
+    const uint32_t dstLane = halfC * (uint32_t)(HC * PANEL) + 4u * quadC, biasLane = halfC * (uint32_t)HC;
+#pragma unroll
+    for (int q = 0; q < TH; ++q) {
+      if (rowStart[q] > -(1 << 27) && (c.hi - rowStart[q] == p.knl - 1 || c.hi == hiU)) {
+#pragma unroll
+        for (int dx = 0; dx < TW; ++dx) {
+          const bool colReal = wo0 + dx < p.Wo;
+          float* __restrict__ o = dstU + (size_t)(woq[q] * p.Wo + wo0 + dx) * p.Ct * PANEL;   // uniform
+#pragma unroll
+          for (int j = 0; j < HC; ++j) {
+            if (colReal) {
+              f32x4 v = {acc[q * TW + dx][2 * j].x, acc[q * TW + dx][2 * j].y, acc[q * TW + dx][2 * j + 1].x, acc[q * TW + dx][2 * j + 1].y};
+              if (p.relu) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (0.0f < v[e]) ? v[e] : 0.0f;
+              }
+              *reinterpret_cast<f32x4*>(o + dstLane + j * PANEL) = v;
+            }
+            const float b = biasU[biasLane + j];
+            acc[q * TW + dx][2 * j] = f32x2{b, b}; acc[q * TW + dx][2 * j + 1] = f32x2{b, b};
+          }
+        }
+        woq[q] += TH;
+        rowStart[q] = (woq[q] <= hoL) ? rowStart[q] + TH * p.stride : -(1 << 28);
+      }
+    }
   };
   auto posOf = [&](const StagePos& q, int idx) { return (idx < S) ? q : first; };
-  const uint32_t myBlk = PROG8_LDS + (uint32_t)(wave * 2 + half) * BLKB;
-  const bool loader = wave == 0;
   Ops8<KS> ops;
   StagePos c0 = first;
   StagePos c1 = next_pos(c0, g);
@@ -259,17 +338,19 @@ __global__ __launch_bounds__(NW8 * 64) void k_conv_sym8(ConvParams p, int tilesX
     const StagePos q = posOf(c1, 1);
     ops8_load<KS>(ops, xbase, pixel_off(q, g), bLane, p.ctrd8, Cs, q.mg, laneA, rt0);
   }
-  if (loader) { idx_row_to_lds<ROWB>(rowOf(c0, 0), PROG8_LDS + rb0, lane); idx_row_to_lds<ROWB>(rowOf(c1, 1), PROG8_LDS + rb1, lane); }
+  if (wave == 0) { idx_row_to_lds<ROWB>(rowOf(c0, 0), PROG8_LDS + rb0, lane); idx_row_to_lds<ROWB>(rowOf(c1, 1), PROG8_LDS + rb1, lane); }
   barrier_after_lds_dma();
   {
     S8_DECL;
+    StagePos cEnd = first;                              // SLIDE: the stage gathered last (its source row may have ended)
+    int liveEnd = 0;
     for (int s = 0; s < Sp; s += 2) {
       // ---- period s: stage s + 1 -> buffer 1, gather stage s out of buffer 0
       ops8_store<KS>(ops, mA0 + STAGE_BYTES, mB0 + STAGE_BYTES);
       S8_T(4, s);
       // program row of stage s + 2, AFTER the build (whose counted vmcnt waits would otherwise wait for this fresh transfer)
       // and BEFORE the operand loads (whose wait, a period later, then covers it)
-      if (loader) idx_row_to_lds<ROWB>(rowOf(c2, s + 2), PROG8_LDS + rb2, lane);
+      if (is_wave0(wave)) idx_row_to_lds<ROWB>(rowOf(c2, s + 2), PROG8_LDS + rb2, lane_now());
       __builtin_amdgcn_sched_barrier(0);
       {
         const StagePos q = posOf(c2, s + 2);
@@ -277,7 +358,9 @@ __global__ __launch_bounds__(NW8 * 64) void k_conv_sym8(ConvParams p, int tilesX
       }
       __builtin_amdgcn_sched_barrier(0);
       S8_T(1, s);
-      gather8<TH, TW, CPW>(acc, myBlk + rb0, c0, p.knl, rowStart, colStart, laneLds, activeI);
+      if constexpr (SLIDE) column_end(cEnd, liveEnd);       // what the previous stage finished (its stores have this period to drain)
+      gather8<TH, TW, CPW>(acc, my_blk(wave, BLKB) + rb0, c0, p.knl, rowStart, colStart, laneLds, activeI);
+      if constexpr (SLIDE) { cEnd = c0; liveEnd = activeI; }
       S8_T(2, s);
       c0 = c1; c1 = c2; c2 = next_pos(c2, g);
       { const uint32_t t = rb0; rb0 = rb1; rb1 = rb2; rb2 = t; }
@@ -286,7 +369,7 @@ __global__ __launch_bounds__(NW8 * 64) void k_conv_sym8(ConvParams p, int tilesX
       // ---- period s + 1: stage s + 2 -> buffer 0, gather stage s + 1 out of buffer 1
       ops8_store<KS>(ops, mA0, mB0);
       S8_T(4, s + 1);
-      if (loader) idx_row_to_lds<ROWB>(rowOf(c2, s + 3), PROG8_LDS + rb2, lane);
+      if (is_wave0(wave)) idx_row_to_lds<ROWB>(rowOf(c2, s + 3), PROG8_LDS + rb2, lane_now());
       __builtin_amdgcn_sched_barrier(0);
       {
         const StagePos q = posOf(c2, s + 3);
@@ -294,7 +377,9 @@ __global__ __launch_bounds__(NW8 * 64) void k_conv_sym8(ConvParams p, int tilesX
       }
       __builtin_amdgcn_sched_barrier(0);
       S8_T(1, s + 1);
-      gather8<TH, TW, CPW>(acc, myBlk + rb0, c0, p.knl, rowStart, colStart, laneLds | STAGE_BYTES, activeI & in_range(s + 1, S));
+      if constexpr (SLIDE) column_end(cEnd, liveEnd);
+      gather8<TH, TW, CPW>(acc, my_blk(wave, BLKB) + rb0, c0, p.knl, rowStart, colStart, laneLds | STAGE_BYTES, activeI & in_range(s + 1, S));
+      if constexpr (SLIDE) { cEnd = c0; liveEnd = activeI & in_range(s + 1, S); }
       S8_T(2, s + 1);
       c0 = c1; c1 = c2; c2 = next_pos(c2, g);
       { const uint32_t t = rb0; rb0 = rb1; rb1 = rb2; rb2 = t; }
@@ -302,8 +387,9 @@ __global__ __launch_bounds__(NW8 * 64) void k_conv_sym8(ConvParams p, int tilesX
       S8_T(3, s + 1);
     }
     S8_DUMP;
-    // ---- results
-    if (activeI) {
+    if constexpr (SLIDE) column_end(cEnd, liveEnd);           // the strip's last source row
+    // ---- results (SLIDE: every position was stored when its window closed)
+    if (activeI && !SLIDE) {
       float* __restrict__ dst = p.dst + (size_t)panel * p.Ho * p.Wo * p.Ct * PANEL;
 #pragma unroll
       for (int q = 0; q < NP; ++q) {
@@ -522,7 +608,11 @@ __global__ __launch_bounds__(256) void k_build_program8(const uint8_t* __restric
     const int wave = waveG % NW8, gc = waveG / NW8;
     const int chunk = gc % cf.chunks, g = gc / cf.chunks;
     const int ch = (chunk * NW8 + wave) * cf.cpw + half * hc + j;
-    const int kh = ry - (pos / cf.tw) * stride, kw = rx - (pos % cf.tw) * stride;
+    // tile: position (dy, dx) looks at tap (ry - dy * stride, rx - dx * stride); sliding: slot dy at tap row (ry - dy * stride)
+    // modulo the period th * stride (ry = source row modulo that period)
+    const int period = cf.th * stride;
+    const int kh = cf.slide ? ((ry - (pos / cf.tw) * stride) % period + period) % period : ry - (pos / cf.tw) * stride;
+    const int kw = rx - (pos % cf.tw) * stride;
     uint16_t v = 0;
     if (ch < Ctg && (unsigned)kh < (unsigned)knl && (unsigned)kw < (unsigned)knl) {
       const int at = qk_slot_entry(src, g, ch);
@@ -532,13 +622,14 @@ __global__ __launch_bounds__(256) void k_build_program8(const uint8_t* __restric
   }
 }
 
-template <int CPW, int TH, int TW>
+template <int CPW, int TH, int TW, bool SLIDE = false>
 hipError_t launch_sym8(const ConvParams& p, const Qk8Config& cf, hipStream_t st) {
   const int tilesX = (p.Wo + TW - 1) / TW, tilesY = (p.Ho + TH - 1) / TH;
-  const dim3 grid((unsigned)(tilesX * tilesY * p.panels), (unsigned)(p.grp * cf.chunks), 1);
+  // SLIDE: grid.x = (segments x strips of TW output columns, longest segments first) x panels
+  const dim3 grid((unsigned)((SLIDE ? p.nSeg * tilesX : tilesX * tilesY) * p.panels), (unsigned)(p.grp * cf.chunks), 1);
   const size_t shm = (size_t)2 * STAGE_BYTES + 3 * PROG8_BUF;
   const bool two = std::min(p.Cin / p.grp, p.Cs) > 4;
-  auto kern = two ? k_conv_sym8<CPW, TH, TW, 2> : k_conv_sym8<CPW, TH, TW, 1>;
+  auto kern = two ? k_conv_sym8<CPW, TH, TW, 2, SLIDE> : k_conv_sym8<CPW, TH, TW, 1, SLIDE>;
   hipError_t e = allow_big_lds(reinterpret_cast<const void*>(kern), (int)shm);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, grid, dim3(NW8 * 64), shm, st, p, tilesX, tilesY, cf.chunks);
@@ -548,7 +639,7 @@ hipError_t launch_sym8(const ConvParams& p, const Qk8Config& cf, hipStream_t st)
 }  // namespace
 
 Qk8Config qk_conv_sym8_config(int Cin, int grp, int Ct, int M, int Cs, int K) {
-  Qk8Config cf = {0, 0, 0, 0};
+  Qk8Config cf = {0, 0, 0, 0, 0};
   if (grp < 1 || Ct % grp || Cin % grp) return cf;
   const int Cg = Cin / grp, Ctg = Ct / grp;
   // K = 128, every sub-space complete with 4 or 8 dims (no operand masks in the kernel)
@@ -569,7 +660,7 @@ Qk8Config qk_conv_sym8_config(int Cin, int grp, int Ct, int M, int Cs, int K) {
 
 size_t qk_conv_sym8_program_bytes(const Qk8Config& cf, int groups, int knl, int stride, int M) {
   if (!cf.cpw) return 0;
-  const int rfH = (cf.th - 1) * stride + knl, rfW = (cf.tw - 1) * stride + knl;
+  const int rfH = cf.slide ? cf.th * stride : (cf.th - 1) * stride + knl, rfW = (cf.tw - 1) * stride + knl;
   return (size_t)rfH * rfW * M * groups * cf.chunks * NW8 * cf.th * cf.tw * cf.cpw * sizeof(uint16_t);   // 16 half-waves x NP x CPW / 2
 }
 
@@ -624,6 +715,104 @@ double qk_conv_sym8_cost(const ConvParams& p, const Qk8Config& cf, double scale)
         end = std::max(end, t);
       }
   return end;
+}
+
+// Sliding form: th = slots = ceil(knl / stride) (3 or 5 built), tw = output columns of a strip; channels per wave as above
+// for layers of up to 256 channels per workgroup (48 channels per wave would need 144 pairs for three slots).
+Qk8Config qk_conv_sym8_slide_config(int Cin, int grp, int Ct, int M, int Cs, int K, int knl, int stride) {
+  Qk8Config cf = {0, 0, 0, 0, 0};
+  if (grp < 1 || Ct % grp || Cin % grp) return cf;
+  const int Cg = Cin / grp, Ctg = Ct / grp;
+  if (K != 128 || !(Cs == 4 || Cs == 8) || Cg % Cs || M != Cg / Cs) return cf;
+  const int ns = (knl + stride - 1) / stride;
+  const int chunks = (Ctg + 255) / 256;
+  const int per = (Ctg + chunks - 1) / chunks;
+  int cpw = 0, nc = 0;
+  if (ns == 3) {
+    if (per <= 64) return cf;
+    if (per <= 128) { cpw = 16; nc = 2; } else if (per <= 192) { cpw = 24; nc = 1; } else { cpw = 32; nc = 1; }
+  } else if (ns == 5) {
+    if (per <= 64 || per > 128) return cf;
+    cpw = 16; nc = 1;
+  } else {
+    return cf;
+  }
+  if (Ctg % cpw) return cf;
+  cf.cpw = cpw; cf.th = ns; cf.tw = nc; cf.slide = 1;
+  cf.chunks = (Ctg + NW8 * cpw - 1) / (NW8 * cpw);
+  return cf;
+}
+
+// Segments of the sliding form for a launch over p.panels panels (p.nSeg / p.segBeg are filled) and its predicted duration in
+// stage-times: the candidates of qk_conv_plan_slide — one to four equal segments per column, or a long and a short one —
+// list-scheduled on 256 CUs with this kernel's stage price (qk_conv_sym8_cost).  0: the layer cannot slide.
+double qk_conv_sym8_slide_plan(ConvParams& p, const Qk8Config& cf, double scale) {
+  p.nSeg = 0;
+  if (!cf.cpw || !cf.slide || p.Ho < 2 * cf.th) return 0.0;
+  const int ns = cf.th, nc = cf.tw;
+  const int colGroups = (p.Wo + nc - 1) / nc;
+  const int ny = p.grp * cf.chunks;
+  auto segStages = [&](int cgi, int a, int b) {        // strip of output columns [cgi * nc, ..), output rows [a, b)
+    const int wA = cgi * nc, wB = std::min(p.Wo, wA + nc) - 1;
+    const int cols = std::min(p.W - 1, wB * p.stride - p.pad + p.knl - 1) - std::max(0, wA * p.stride - p.pad) + 1;
+    const int rows = std::min(p.H - 1, (b - 1) * p.stride - p.pad + p.knl - 1) - std::max(0, a * p.stride - p.pad) + 1;
+    return (double)std::max(rows, 0) * std::max(cols, 0) * p.M;
+  };
+  auto taps = [&](int n, int nIn) {
+    long long t = 0;
+    for (int o = 0; o < n; ++o) t += std::min(p.knl - 1, nIn - 1 - (o * p.stride - p.pad)) - std::max(0, -(o * p.stride - p.pad)) + 1;
+    return (double)t;
+  };
+  const double lookups = taps(p.Ho, p.H) * taps(p.Wo, p.W) * p.M * std::min(p.Ct / p.grp, NW8 * cf.cpw);   // per group, chunk and panel
+  std::vector<std::vector<int> > cands;
+  for (int n = 1; n <= 4 && n * ns <= p.Ho; ++n) {
+    std::vector<int> b(n + 1);
+    for (int i = 0; i <= n; ++i) b[i] = (int)(((long long)p.Ho * i + n - 1) / n);   // the longer ones first
+    cands.push_back(b);
+  }
+  for (int shortLen = ns; shortLen * 2 < p.Ho; shortLen += std::max(1, p.Ho / 16)) cands.push_back({0, p.Ho - shortLen, p.Ho});
+  double best = 0.0;
+  std::vector<double> cu(256);
+  for (const std::vector<int>& b : cands) {
+    const int nSeg = (int)b.size() - 1;
+    if (nSeg > QK_MAX_SEGS) continue;
+    double total = 0.0;
+    for (int sgi = 0; sgi < nSeg; ++sgi)
+      for (int wo = 0; wo < colGroups; ++wo) total += segStages(wo, b[sgi], b[sgi + 1]);
+    if (total <= 0.0) continue;
+    // a stage's price by its look-ups (2540 + 1.97 x look-ups cycles against 2500 of a tile stage) + the store / restart of
+    // the slots at every source row's end
+    const double factor = scale * (2540.0 + 1.97 * lookups / total) / 2500.0;
+    std::fill(cu.begin(), cu.end(), 0.0);
+    std::make_heap(cu.begin(), cu.end(), std::greater<double>());
+    for (int y = 0; y < ny; ++y)
+      for (int sgi = 0; sgi < nSeg; ++sgi)
+        for (int wo = 0; wo < colGroups; ++wo)
+          for (int pn = 0; pn < p.panels; ++pn) {
+            std::pop_heap(cu.begin(), cu.end(), std::greater<double>());
+            const int rows = std::min(p.H - 1, (b[sgi + 1] - 1) * p.stride - p.pad + p.knl - 1) - std::max(0, b[sgi] * p.stride - p.pad) + 1;
+            cu.back() += factor * segStages(wo, b[sgi], b[sgi + 1]) + 0.3 * std::max(rows, 0) + 12.0;
+            std::push_heap(cu.begin(), cu.end(), std::greater<double>());
+          }
+    const double c = *std::max_element(cu.begin(), cu.end());
+    if (best == 0.0 || c < best) {
+      best = c;
+      p.nSeg = nSeg;
+      for (size_t i = 0; i < b.size(); ++i) p.segBeg[i] = b[i];
+    }
+  }
+  return best;
+}
+
+// p.nSeg / p.segBeg from qk_conv_sym8_slide_plan, p.progS = the sliding program (qk_build_program8 with the sliding config)
+hipError_t qk_conv_sym8_slide(const ConvParams& p, hipStream_t st) {
+  const Qk8Config cf = qk_conv_sym8_slide_config(p.Cin, p.grp, p.Ct, p.M, p.Cs, p.K, p.knl, p.stride);
+  if (!cf.cpw || p.progS == nullptr || p.ctrd8 == nullptr || p.srcNchw || p.nSeg < 1 || p.nSeg > QK_MAX_SEGS) return hipErrorInvalidValue;
+  if (cf.th == 3 && cf.cpw == 16) return launch_sym8<16, 3, 2, true>(p, cf, st);
+  if (cf.th == 3 && cf.cpw == 24) return launch_sym8<24, 3, 1, true>(p, cf, st);
+  if (cf.th == 3 && cf.cpw == 32) return launch_sym8<32, 3, 1, true>(p, cf, st);
+  if (cf.th == 5 && cf.cpw == 16) return launch_sym8<16, 5, 1, true>(p, cf, st);
+  return hipErrorInvalidValue;
 }
 
 hipError_t qk_conv_sym8(const ConvParams& p, hipStream_t st) {

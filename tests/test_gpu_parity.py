@@ -1044,9 +1044,11 @@ def test_symmetric_workgroups_geometries():
 
 
 # ---------------------------------------------------------------- eight-wave symmetric workgroups (256 registers per wave) ----
-@pytest.mark.parametrize("n_img,mode", [(5, 2), (300, 2)])
+@pytest.mark.parametrize("n_img,mode", [(5, 2), (300, 2), (5, 3), (300, 3)])
 def test_sym8_workgroups_alexnet(n_img, mode):
-    """QCNN_OPT_SYM8 = 2 (forced): AlexNet conv2 (128 channels per group: 16 channels x a 2x3
+    """QCNN_OPT_SYM8 = 3: the SLIDING form of the eight-wave kernel wherever it is built — conv2 (5 slots x 1 column x 16 channels
+    per wave), conv3 (3 x 1 x 24 in two channel chunks of 192), conv4 (3 x 1 x 24), conv5 (3 slots x 2 columns x 16) sweep segments
+    of output columns.  QCNN_OPT_SYM8 = 2 (forced): AlexNet conv2 (128 channels per group: 16 channels x a 2x3
     tile per wave), conv3 (384: 48 x 1x2), conv4 (192: 24 x 2x2) and conv5 (128: 16 x 2x3) run k_conv_sym8 — eight waves of
     256 registers, all of them building and gathering.  Same table entries in the same (kh, kw, m) order per output:
     BIT-IDENTICAL to the tile kernels, layer for layer; conv1 (one 3-dim sub-space) is not eligible."""
@@ -1062,7 +1064,9 @@ def test_sym8_workgroups_alexnet(n_img, mode):
     base.close()
     eng = make_engine(in_chw, layers, params, n_img, lut=capi.LUT_MFMA, keep_all=1, split=0, sym8=mode)
     p1, t1 = eng.forward_host(imgs)
-    assert [eng.layer_split(l)[0] for l in (4, 8, 10, 12)] == [-5, -5, -5, -5] and eng.layer_split(0)[0] != -5
+    assert [eng.layer_split(l)[0] for l in (4, 8, 10, 12)] == ([-5, -5, -5, -5] if mode == 2 else [-6, -6, -6, -6]) and eng.layer_split(0)[0] not in (-5, -6)
+    if mode == 3:
+        assert all(len(eng.layer_segments(l)) >= 2 for l in (4, 10, 12))
     for l, want in fm0.items():
         assert np.array_equal(eng.layer_output_range(l, n_img - 2, 2), want), "fm[%d]" % l
     # fc6 / fc7 ran the eight-wave FC kernel (768 instead of 384 channels per workgroup: another split of the sub-space axis,
@@ -1136,10 +1140,10 @@ def test_sym8_workgroups_geometries():
     base.forward_host(imgs)
     want = {l: base.layer_output(l, 131) for l in (3, 5, 7)}
     base.close()
-    for mode in (2,):
+    for mode in (2, 3):      # 3: the sliding form where it exists (3x3 / 1 with 256 channels, 5x5 / 2 — three slots — in two groups of 96)
         eng = make_engine(in_chw, layers, params, 131, lut=capi.LUT_MFMA, keep_all=1, split=0, sym8=mode)
         eng.forward_host(imgs)
-        assert [eng.layer_split(l)[0] for l in (2, 4, 6)] == [-5, -5, -5] and eng.layer_split(0)[0] != -5
+        assert [eng.layer_split(l)[0] for l in (2, 4, 6)] == ([-5, -5, -5] if mode == 2 else [-6, -6, -5]) and eng.layer_split(0)[0] not in (-5, -6)
         for l, w in want.items():
             assert np.array_equal(eng.layer_output(l, 131), w), "mode %d fm[%d]" % (mode, l)
         for l in (3, 5, 7, len(layers)):
