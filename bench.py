@@ -380,7 +380,7 @@ def main():
     decoded = {i for i, l in enumerate(layers) if l["type"] in (topo.CONV, topo.FCNT) and eng.layer_split(i)[0] == -3}   # decoded layers
     dec_nchw = {i for i in decoded if eng.layer_split(i)[1] == 2}                                                      # k_conv_dec_nchw
     symmetric = {i for i, l in enumerate(layers) if l["type"] == topo.CONV and eng.layer_split(i)[0] == -4}            # k_conv_sym
-    sym8 = {i for i, l in enumerate(layers) if l["type"] == topo.CONV and eng.layer_split(i)[0] == -5}                 # k_conv_sym8
+    sym8 = {i for i, l in enumerate(layers) if l["type"] == topo.CONV and eng.layer_split(i)[0] in (-5, -6)}           # k_conv_sym8 (-6: sliding form)
     ok = bool(torch.isfinite(prob[lo:hi]).all().item())
     images_per_step = B if (strong or world == 1) else B * world
 
@@ -586,13 +586,13 @@ def main():
         vms, _ = ve.layer_ms()
         vdom = int(np.argmax(vms))
         rep = perf.layer_report(v_sizes, v_layers, v_params, vdom, vb, float(vms[vdom]), ve.layer_segments(vdom),
-                                8 if ve.layer_split(vdom)[0] == -5 else ve.layer_split(vdom)[0] == -4)
+                                8 if ve.layer_split(vdom)[0] in (-5, -6) else ve.layer_split(vdom)[0] == -4)
         conv_total = sum(float(vms[i]) for i, l in enumerate(v_layers) if l["type"] == topo.CONV)
         slow = {}
         for i in sorted((i for i, l in enumerate(v_layers) if l["type"] in (topo.CONV, topo.FCNT)), key=lambda i: -vms[i])[:5]:
             split = ve.layer_split(i)[0]
             r = (perf.decoded_report(v_sizes, v_layers, i, vb, float(vms[i]), ve.layer_split(i)[1] == 2) if (split == -3 and v_layers[i]["type"] == topo.CONV) else
-                 perf.layer_report(v_sizes, v_layers, v_params, i, vb, float(vms[i]), ve.layer_segments(i), 8 if split == -5 else split == -4))
+                 perf.layer_report(v_sizes, v_layers, v_params, i, vb, float(vms[i]), ve.layer_segments(i), 8 if split in (-5, -6) else split == -4))
             r["ms"] = round(float(vms[i]), 4)
             r["in_hwc"], r["out_hwc"] = list(v_sizes[i]), list(v_sizes[i + 1])
             slow["%02d_%s" % (i, topo.TYPE_NAMES[v_layers[i]["type"]])] = r

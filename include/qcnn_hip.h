@@ -111,7 +111,12 @@ enum {
                               accumulators of the 16-wave kernels per CU, i.e. larger output tiles (384 channels x 1x2, 256 x 1x3,
                               192 x 2x2, 128 x 2x3) and a third fewer table builds per output position — when the launch planner
                               predicts them faster than the tile / sliding / 16-wave symmetric launch.  Bit-identical to the tile
-                              kernels; f32 MFMA mode only.  0 = never; 2 = whenever eligible (tests).  FC layers with 32 code words of 4 dims
+                              kernels; f32 MFMA mode only.  The same workgroups also SLIDE (segments of strips of one or two output
+                              columns with 3 or 5 accumulator slots: 3x3 / 1 and 5x5 / 1 layers of up to 256 channels per workgroup build
+                              every source pixel of a strip once: 3 or 2 table builds per output position instead of 4 - 5) where the
+                              planner predicts that faster: VGG-16's 256- / 512-channel layers.  0 = never; 2 = tile form whenever
+                              eligible, 3 = sliding form whenever eligible (tests).  qcnn_get_layer_split reports (-5, 1) for the tile
+                              form, (-6, segments per column) for the sliding form.  FC layers with 32 code words of 4 dims
                               (AlexNet / VGG-16 fc6, fc7) run the same eight waves (k_fc_sym8: 96 channels per wave, offsets through
                               LDS-DMA, software-pipelined look-ups) unless the option is 0 */
   QCNN_OPT_PACKED_FC = 11, /* 1: for batches of up to QCNN_SMALL_BATCH_MAX images the FC layers read their assignments from the

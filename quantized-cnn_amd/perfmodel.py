@@ -92,6 +92,37 @@ def conv_work_slide(in_hwc, out_hwc, ly, m: int, k: int, cs: int, seg_beg):
                 tile="slide %d column(s) x %d slots x %d, %d segment(s) per column" % (nc, slots, GATHER_WAVES * cpw, len(seg_beg) - 1))
 
 
+def sym8_slide_cfg(ctg: int, knl: int, stride: int):
+    """(slots, columns per strip, channels per wave, channel chunks) of the sliding eight-wave kernel (qk_conv_sym8_slide_config)."""
+    ns = (knl + stride - 1) // stride
+    chunks = (ctg + 255) // 256
+    per = (ctg + chunks - 1) // chunks
+    if ns == 3:
+        cpw, nc = (16, 2) if per <= 128 else (24, 1) if per <= 192 else (32, 1)
+    else:
+        cpw, nc = 16, 1
+    return ns, nc, cpw, (ctg + 8 * cpw - 1) // (8 * cpw)
+
+
+def conv_work_slide8(in_hwc, out_hwc, ly, m: int, k: int, cs: int, seg_beg):
+    """conv_work_slide for k_conv_sym8<.., SLIDE>: strips of nc output columns, row segments [seg_beg[i], seg_beg[i + 1])."""
+    h, w, cin = in_hwc
+    ho, wo, ct = out_hwc
+    knl, s, p, grp = ly["knl"], ly["stride"], ly["pad"], ly["grp"]
+    base = conv_work(in_hwc, out_hwc, ly, m, k, cs)
+    ns, nc, cpw, chunks = sym8_slide_cfg(ct // grp, knl, s)
+    stages = 0
+    for x0 in range(0, wo, nc):
+        x1 = min(wo, x0 + nc) - 1
+        cols = min(w - 1, x1 * s - p + knl - 1) - max(0, x0 * s - p) + 1
+        for a, b in zip(seg_beg[:-1], seg_beg[1:]):
+            rows = min(h - 1, (b - 1) * s - p + knl - 1) - max(0, a * s - p) + 1
+            stages += max(rows, 0) * max(cols, 0) * m
+    stages *= chunks * grp
+    return dict(base, stages=stages, mfma_flop=stages * 128 * 128 * 4 * base["ks"] * 2,
+                tile="slide 8 waves %d column(s) x %d slots x %d, %d segment(s) per column" % (nc, ns, 8 * cpw, len(seg_beg) - 1))
+
+
 def fc_work(d: int, ct: int, m: int, k: int, cs: int, msplit_chunks: int):
     g = stage_group(k)
     stages = (m + g - 1) // g * msplit_chunks
@@ -133,7 +164,9 @@ def layer_report(sizes, layers, params, l: int, images: float, ms: float, seg_be
     the sliding kernel's row segments when the layer ran it (QcnnEngine.layer_segments)."""
     ly = layers[l]
     mm, kk, cc = (int(x) for x in params[l]["ctrd"].shape)
-    if ly["type"] == CONV and seg_beg:
+    if ly["type"] == CONV and seg_beg and sym == 8:
+        wk = conv_work_slide8(sizes[l], sizes[l + 1], ly, mm, kk, cc, seg_beg)
+    elif ly["type"] == CONV and seg_beg:
         wk = conv_work_slide(sizes[l], sizes[l + 1], ly, mm, kk, cc, seg_beg)
     elif ly["type"] == CONV:
         wk = conv_work(sizes[l], sizes[l + 1], ly, mm, kk, cc, sym)

@@ -88,6 +88,8 @@ CONFIGS = {
     "forced_sym_slide": dict(keep_all=1, sym=2, slide=2),
     # every eligible layer (conv2 - conv5) through the eight-wave symmetric kernel
     "forced_sym8": dict(keep_all=1, sym8=2),
+    # ... and through its sliding form (segments of column strips)
+    "forced_sym8_slide": dict(keep_all=0, streams=1, host_chunk=0, sym8=3),
     # the north star's scheme for all eight conv / FC layers (bench key value_tables_only)
     "tables_only_fast_path": dict(keep_all=0, streams=1, host_chunk=0, decode=0),
 }
@@ -112,6 +114,8 @@ def test_shipped_parameters_headline_kernels_match_reference(golden_alex_real10,
         assert eng.layer_split(12)[0] == -2                                      # conv5 sliding
         with pytest.raises(pkg("engine").QcnnError):
             eng.layer_output_range(3, 0, 1)                                      # LRN1 fused into the pool behind it
+    if name == "forced_sym8_slide":
+        assert [eng.layer_split(l)[0] for l in (4, 8, 10, 12)] == [-6, -6, -6, -6]
     if CONFIGS[name]["keep_all"]:
         assert n_maps == L + 1
     else:
