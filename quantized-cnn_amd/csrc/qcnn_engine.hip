@@ -439,9 +439,9 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
             if (pl.segN > 0 && pl.slideCost > 0.0) other = std::min(other, 1.15 * pl.slideCost);
             if (pl.sym8Cost > 0.0) other = std::min(other, pl.sym8Cost);
             // (measured per planner unit, 1000 images: the sliding form 1.04 - 1.11 us — VGG-16's layers, AlexNet conv2 / conv5 —,
-            // the tile form 0.89 - 0.93: x 1.17.  With it the sliding form takes VGG-16's 256- and 512-channel layers and conv2_1,
+            // the tile form 0.89 - 0.93: x 1.15 - 1.2.  With 1.15 the sliding form takes VGG-16's 128-, 256- and 512-channel layers,
             // none of AlexNet's: 13 x 13 maps leave too few strips — 208 workgroups for conv4)
-            if (c->sym8 >= 3 || 1.17 * pl.sym8sCost < 0.97 * other) {
+            if (c->sym8 >= 3 || 1.15 * pl.sym8sCost < 0.97 * other) {
               p.progS = reinterpret_cast<const uint16_t*>(c->arena + s.offProg8S);
               p.nSeg = pl.seg8N;
               s.segN = pl.seg8N;
