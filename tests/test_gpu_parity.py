@@ -1152,6 +1152,50 @@ def test_sym8_workgroups_geometries():
         eng.close()
 
 
+def test_sym8_sliding_form_unpadded_and_short_maps():
+    """The sliding form on what the other tests do not have: an UNPADDED 3x3 / 1 layer with 128 channels (two-column strips
+    on an odd map: the last strip is one column wide), an unpadded 5x5 / 1 layer with 128 channels (five slots), a map with
+    fewer than 2 x slots output rows (the planner must fall back to the tile form) — QCNN_OPT_SYM8 = 3 against the tile
+    kernels (bit-identical) and the oracle, 131 images."""
+    layers = [topo.conv(1, 3, 16, 1, 1), topo.relu(), topo.conv(0, 3, 128, 1, 1), topo.relu(), topo.conv(0, 5, 128, 1, 1),
+              topo.relu(), topo.conv(0, 3, 256, 1, 1), topo.relu(), topo.pool(0, 2, 2), topo.fcnt(40), topo.smax()]
+    in_chw = (3, 17, 19)                       # maps: 17x19 -> 15x17 -> 11x13 -> 9x11: every layer has >= 2 x slots output rows
+    params = synth.make_params(in_chw, layers, seed=211)
+    imgs = synth.make_images(131, in_chw, seed=212)
+    orc = po.COracle(in_chw, layers)
+    orc.set_params(params)
+    orc.forward(imgs[129:])
+    base = make_engine(in_chw, layers, params, 131, lut=capi.LUT_MFMA, keep_all=1, split=0)
+    base.set_option(capi.OPT_SYM, 0)
+    base.set_option(capi.OPT_SLIDE, 0)
+    base.forward_host(imgs)
+    want = {l: base.layer_output(l, 131) for l in (3, 5, 7)}
+    base.close()
+    eng = make_engine(in_chw, layers, params, 131, lut=capi.LUT_MFMA, keep_all=1, split=0, sym8=3)
+    eng.forward_host(imgs)
+    assert [eng.layer_split(l)[0] for l in (2, 4, 6)] == [-6, -6, -6]
+    for l, w in want.items():
+        assert np.array_equal(eng.layer_output(l, 131), w), "fm[%d]" % l
+    for l in (3, 5, 7, len(layers)):
+        e_inf, e_l2 = rel_err(eng.layer_output_range(l, 129, 2), orc.fm(l))
+        assert e_inf <= TOL and e_l2 <= TOL, "fm[%d] vs oracle: %g %g" % (l, e_inf, e_l2)
+    eng.close()
+    # a 3x3 layer on a map of 5 output rows (< 2 x 3 slots): no sliding plan, the tile form runs
+    layers2 = [topo.conv(1, 3, 16, 1, 1), topo.relu(), topo.conv(0, 3, 128, 1, 1), topo.relu(), topo.pool(0, 2, 2), topo.fcnt(40), topo.smax()]
+    in2 = (3, 7, 9)
+    params2 = synth.make_params(in2, layers2, seed=213)
+    imgs2 = synth.make_images(20, in2, seed=214)
+    outs = []
+    for mode in (0, 3):
+        e2 = make_engine(in2, layers2, params2, 20, lut=capi.LUT_MFMA, keep_all=1, split=0, sym8=mode)
+        e2.forward_host(imgs2)
+        if mode == 3:
+            assert e2.layer_split(2)[0] == -5
+        outs.append(e2.layer_output(3, 20))
+        e2.close()
+    assert np.array_equal(outs[0], outs[1])
+
+
 # ---------------------------------------------------------------- sliding-window conv kernels ----
 @pytest.mark.parametrize("n_img", [5, 300])
 def test_sliding_kernels_alexnet(n_img):
