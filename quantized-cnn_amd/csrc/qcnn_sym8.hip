@@ -27,6 +27,9 @@
 #include "qcnn_kernels.h"
 #include "qcnn_dev.h"
 
+#include <stdio.h>
+#include <stdlib.h>
+
 #include <algorithm>
 #include <functional>
 #include <queue>
@@ -771,6 +774,12 @@ double qk_conv_sym8_slide_plan(ConvParams& p, const Qk8Config& cf, double scale)
     cands.push_back(b);
   }
   for (int shortLen = ns; shortLen * 2 < p.Ho; shortLen += std::max(1, p.Ho / 16)) cands.push_back({0, p.Ho - shortLen, p.Ho});
+  if (const char* e = getenv("QCNN_SYM8_SEGS")) {            // experiments: exactly that many equal segments
+    const int n = std::max(1, std::min(atoi(e), std::min(QK_MAX_SEGS, p.Ho / ns)));
+    std::vector<int> b(n + 1);
+    for (int i = 0; i <= n; ++i) b[i] = (int)(((long long)p.Ho * i + n - 1) / n);
+    cands.assign(1, b);
+  }
   double best = 0.0;
   std::vector<double> cu(256);
   for (const std::vector<int>& b : cands) {
@@ -795,6 +804,11 @@ double qk_conv_sym8_slide_plan(ConvParams& p, const Qk8Config& cf, double scale)
             std::push_heap(cu.begin(), cu.end(), std::greater<double>());
           }
     const double c = *std::max_element(cu.begin(), cu.end());
+    if (const char* dbg = getenv("QCNN_DEBUG_PLAN"); dbg && atoi(dbg) > 1) {
+      fprintf(stderr, "[qcnn plan] sym8 slide Ho=%d Wo=%d panels=%d ny=%d factor %.3f: segs", p.Ho, p.Wo, p.panels, ny, factor);
+      for (int v : b) fprintf(stderr, " %d", v);
+      fprintf(stderr, " -> %.0f stage-times\n", c);
+    }
     if (best == 0.0 || c < best) {
       best = c;
       p.nSeg = nSeg;
