@@ -380,7 +380,7 @@ def main():
     decoded = {i for i, l in enumerate(layers) if l["type"] in (topo.CONV, topo.FCNT) and eng.layer_split(i)[0] == -3}   # decoded layers
     dec_nchw = {i for i in decoded if eng.layer_split(i)[1] == 2}                                                      # k_conv_dec_nchw
     symmetric = {i for i, l in enumerate(layers) if l["type"] == topo.CONV and eng.layer_split(i)[0] == -4}            # k_conv_sym
-    sym8 = {i for i, l in enumerate(layers) if l["type"] == topo.CONV and eng.layer_split(i)[0] in (-5, -6)}           # k_conv_sym8 (-6: sliding form)
+    sym8 = {i for i, l in enumerate(layers) if l["type"] in (topo.CONV, topo.FCNT) and eng.layer_split(i)[0] in (-5, -6)}   # k_conv_sym8 (-6: sliding form), k_fc_sym8
     ok = bool(torch.isfinite(prob[lo:hi]).all().item())
     images_per_step = B if (strong or world == 1) else B * world
 

@@ -174,7 +174,11 @@ def layer_report(sizes, layers, params, l: int, images: float, ms: float, seg_be
         e = sizes[l][0] * sizes[l][1] * sizes[l][2]
         cpw = 32 if ly["nod"] >= 384 else (8 if ly["nod"] >= 96 else 4)
         chunks = (ly["nod"] + GATHER_WAVES * cpw - 1) // (GATHER_WAVES * cpw)
+        if sym == 8:                                        # k_fc_sym8: eight waves x 96 channels per workgroup
+            chunks = (ly["nod"] + 767) // 768
         wk = fc_work(e, ly["nod"], mm, kk, cc, chunks)
+        if sym == 8:
+            wk["tile"] = "fc, 8 waves x 96 channels"
     else:
         return None
     panels = (images + PANEL - 1) // PANEL
