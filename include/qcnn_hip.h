@@ -229,7 +229,9 @@ int qcnn_run_layer(QcnnCtx* ctx, int layer, const float* in_host, int n, float* 
  * was split), *tiles_unsplit = tiles of the heaviest-first order that ran whole (-1 when nothing was split); sliding
  * kernel (QCNN_OPT_SLIDE): *tiles_unsplit = -2, *slices = segments per output column; a conv or FC layer that ran through
  * its decoded code words (QCNN_OPT_DECODE): *tiles_unsplit = -3, *slices = 1 (FC: slices of the input axis over workgroups);
- * symmetric workgroups (QCNN_OPT_SYM): *tiles_unsplit = -4; eight-wave symmetric workgroups (QCNN_OPT_SYM8): -5. */
+ * (a conv layer that read the NCHW batch in place: *slices = 2); symmetric workgroups (QCNN_OPT_SYM): *tiles_unsplit = -4;
+ * eight-wave symmetric workgroups (QCNN_OPT_SYM8): -5 (conv tile form, *slices = 1; FC: *slices = splits of the sub-space axis),
+ * -6 in their sliding form (*slices = segments per output column; qcnn_get_layer_segments reports the boundaries). */
 int qcnn_get_layer_split(QcnnCtx* ctx, int layer, int* tiles_unsplit, int* slices);
 /* Sliding kernel: the row segments [seg_beg9[i], seg_beg9[i + 1]) every output column of the last launch of `layer` was
  * cut into (*n_seg of them; 0 when the layer ran the tile kernel). */
