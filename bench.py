@@ -150,16 +150,61 @@ def parity_check(kind, cpu, layers, imgs_host, gpu_prob, gpu_top5, gpu_fms):
                 ok=bool(agree == n and worst_prob <= TOL and all(v <= TOL for v in worst_fm.values())))
 
 
-def cpu_baseline(kind, cpu, imgs_host):
+def cpu_workers(so_path, pdir, n_proc, n_img, lead_s):
+    """n_proc processes of oracle/ref_worker.py (the reference is single-threaded and not re-entrant: one process per
+    core), all starting their timed forwards at the same wall-clock instant.  Returns (images/s over the window from the
+    first start to the last finish, per-process records) or None."""
+    worker = os.path.join(ROOT, "oracle", "ref_worker.py")
+    start = time.time() + lead_s
+    procs = [subprocess.Popen([sys.executable, worker, so_path, pdir, "bench", str(n_img), repr(start)],
+                              stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for _ in range(n_proc)]
+    recs = []
+    for pr in procs:
+        try:
+            out, _ = pr.communicate(timeout=lead_s + 120)
+            recs.append(json.loads(out.strip().splitlines()[-1]))
+        except Exception:
+            pr.kill()
+    if len(recs) != n_proc:
+        return None
+    t0, t1 = min(r["t0"] for r in recs), max(r["t1"] for r in recs)
+    return sum(r["n"] for r in recs) / (t1 - t0), recs
+
+
+def cpu_baseline(kind, cpu, imgs_host, params=None):
     sample = imgs_host.shape[0]
     if kind == "reference":
         cpu.time_forward(imgs_host[:2])                      # page in
         wall, cpu_s = cpu.time_forward(imgs_host)
-        return dict(value=sample / cpu_s, unit="images/s", cores=1, kind="reference",
-                    sample="%d images, batch 1 (the reference's own regime), single thread; %.2f s CPU time by the "
-                           "reference's swAllLayers stop-watch (clock()), %.2f s wall; g++ -O2 Makefile.native flags "
-                           "(ATLAS/OpenVML not installed)" % (sample, cpu_s, wall),
-                    host_cores=os.cpu_count(), ms_per_image=1000.0 * cpu_s / sample)
+        cb = dict(value=sample / cpu_s, unit="images/s", cores=1, kind="reference",
+                  sample="%d images, batch 1 (the reference's own regime), single thread; %.2f s CPU time by the "
+                         "reference's swAllLayers stop-watch (clock()), %.2f s wall; g++ -O2 Makefile.native flags "
+                         "(ATLAS/OpenVML not installed)" % (sample, cpu_s, wall),
+                  host_cores=os.cpu_count(), ms_per_image=1000.0 * cpu_s / sample)
+        # stronger comparators beside the stated baseline (SURVEY.md §8d): the same sources at -O3 -march=znver3, and one
+        # process of the -O2 build per core (the reference is single-threaded by construction)
+        import pyoracle as po
+        if params is not None:
+            try:
+                with tempfile.TemporaryDirectory() as d:
+                    pkg("synth").write_param_dir(d, "bench", params)
+                    if os.path.exists(po.REF_O3_SO):
+                        r = cpu_workers(po.REF_O3_SO, d, 1, 40, 6.0)
+                        if r:
+                            cb["o3"] = dict(value=round(r[1][0]["n"] / r[1][0]["cpu"], 2), unit="images/s", cores=1,
+                                            build="g++ -O3 -march=znver3 (oracle/Makefile ref_o3; the host is Zen 5, gcc 11.4 "
+                                                  "knows no newer AMD target)", sample="40 images, one process")
+                    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+                    per = 12
+                    r = cpu_workers(po.REF_SO, d, ncpu, per, 8.0 + 0.05 * ncpu)
+                    if r:
+                        cb["all_cores"] = dict(value=round(r[0], 1), unit="images/s", cores=ncpu, processes=ncpu,
+                                               sample="%d processes (one per logical core) x %d images of the -O2 reference, common "
+                                                      "start; images / (last finish - first start)" % (ncpu, per),
+                                               mean_ms_per_image_per_process=round(1000.0 * sum(x["wall"] for x in r[1]) / (ncpu * per), 2))
+            except Exception as e:                           # comparators only: never fail the bench line
+                cb["extras_error"] = repr(e)[:200]
+        return cb
     cpu.forward(imgs_host[:1])
     t0 = time.perf_counter()
     for i in range(sample):
@@ -242,8 +287,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=1000, help="images of one (global) batch")
     ap.add_argument("--model", default="AlexNet")
-    ap.add_argument("--lut", default="mfma", choices=["mfma", "exact", "bf16"],
-                    help="LUT builder: f32 MFMA (default), exact VALU (bit-identical conv/FC), bf16 = opt-in bf16-pair MFMA for the 8-dim conv layers")
+    ap.add_argument("--lut", default="mfma", choices=["mfma", "exact", "f16"],
+                    help="LUT builder: f32 MFMA (default), exact VALU (bit-identical conv/FC), f16 = opt-in fp16 table storage (configs[4] study)")
     ap.add_argument("--params", default="auto", choices=["auto", "shipped", "synthetic"],
                     help="AlexNet parameters: shipped = the reference's own files staged under oracle/_ref/data (+ the fc6 table the "
                          "mount lacks, SURVEY.md §8c fixture 1) and inputs minus the shipped mean image (SURVEY.md §8d); synthetic = "
@@ -255,7 +300,7 @@ def main():
     ap.add_argument("--parity-images", type=int, default=8, help="images checked against the CPU reference (0 = skip)")
     ap.add_argument("--extras", type=int, default=1, help="0 = only the headline measurement")
     ap.add_argument("--sym8", type=int, default=-1,
-                    help="QCNN_OPT_SYM8 (eight-wave symmetric workgroups): -1 = library default (planner), 0 off, 2 forced, 6 forced + staggered phases")
+                    help="QCNN_OPT_SYM8 (eight-wave symmetric workgroups): -1 = library default (1 = planner), 0 off, 2 forced tile form, 3 forced sliding form")
     ap.add_argument("--streams", type=int, default=1,
                     help="sub-batches of whole panels run concurrently on separate HIP streams (QCNN_OPT_STREAMS; the "
                          "library default is 2).  1 keeps one launch per layer, so that the per-kernel HIP-event "
@@ -308,7 +353,7 @@ def main():
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
     eng = pkg("engine").QcnnEngine(local, stream.cuda_stream)
-    eng.set_option(capi.OPT_LUT_MODE, {"mfma": capi.LUT_MFMA, "exact": capi.LUT_EXACT, "bf16": capi.LUT_MFMA_BF16X2}[args.lut])
+    eng.set_option(capi.OPT_LUT_MODE, {"mfma": capi.LUT_MFMA, "exact": capi.LUT_EXACT, "f16": capi.LUT_MFMA_F16}[args.lut])
     eng.set_option(capi.OPT_KEEP_ALL, 0)
     eng.set_option(capi.OPT_PROFILE, 1)
     eng.set_option(capi.OPT_STREAMS, args.streams)
@@ -374,13 +419,21 @@ def main():
             dt = float(t.item())
         return dt
 
+    def snapshot():
+        """Per-layer HIP-event times of the forwards since the last reset + which kernel family every conv / FC layer ran."""
+        ms, rec = eng.layer_ms()
+        cf = [i for i, l in enumerate(layers) if l["type"] in (topo.CONV, topo.FCNT)]
+        split = {i: eng.layer_split(i) for i in cf}
+        dec = {i for i in cf if split[i][0] == -3}                                       # decoded layers
+        return dict(layer_ms=ms, recorded=rec,
+                    segments={i: eng.layer_segments(i) for i in cf if layers[i]["type"] == topo.CONV},   # sliding kernel, per layer
+                    decoded=dec, dec_nchw={i for i in dec if split[i][1] == 2},                          # k_conv_dec_nchw
+                    symmetric={i for i in cf if layers[i]["type"] == topo.CONV and split[i][0] == -4},   # k_conv_sym
+                    sym8={i for i in cf if split[i][0] in (-5, -6)})                                     # k_conv_sym8 (-6: sliding form), k_fc_sym8
+
     dt = measure(step, args.steps, args.warmup)
-    layer_ms, recorded = eng.layer_ms()
-    segments = {i: eng.layer_segments(i) for i, l in enumerate(layers) if l["type"] == topo.CONV}   # sliding kernel, per layer
-    decoded = {i for i, l in enumerate(layers) if l["type"] in (topo.CONV, topo.FCNT) and eng.layer_split(i)[0] == -3}   # decoded layers
-    dec_nchw = {i for i in decoded if eng.layer_split(i)[1] == 2}                                                      # k_conv_dec_nchw
-    symmetric = {i for i, l in enumerate(layers) if l["type"] == topo.CONV and eng.layer_split(i)[0] == -4}            # k_conv_sym
-    sym8 = {i for i, l in enumerate(layers) if l["type"] in (topo.CONV, topo.FCNT) and eng.layer_split(i)[0] in (-5, -6)}   # k_conv_sym8 (-6: sliding form), k_fc_sym8
+    snap = snapshot()
+    decoded = snap["decoded"]
     ok = bool(torch.isfinite(prob[lo:hi]).all().item())
     images_per_step = B if (strong or world == 1) else B * world
 
@@ -393,6 +446,7 @@ def main():
 
     extras = {}
     bf_prob = None
+    dt_tab, snap_tab = None, None
     if args.extras and rank == 0 and world == 1:
         eng.set_option(capi.OPT_PROFILE, 0)
         if args.streams == 1:
@@ -406,17 +460,32 @@ def main():
             # the two degenerate layers too (conv1: one sub-space of 3 dims; fc8: one-dim sub-spaces), which `value` evaluates
             # through the code words their assignments name
             eng.set_option(capi.OPT_DECODE, 0)
-            step()
-            extras["value_tables_only"] = round(B * 3 / timed(torch, dev, step, 3), 2)
+            eng.set_option(capi.OPT_PROFILE, 1)
+            dt_tab = measure(step, args.steps, 1)
+            snap_tab = snapshot()
+            eng.set_option(capi.OPT_PROFILE, 0)
             eng.set_option(capi.OPT_DECODE, 1)
             step()
-        # opt-in bf16-pair LUT builder for the 8-dim conv layers (QCNN_OPT_LUT_MODE = 3): rate and its own parity figures
-        if args.lut == "mfma":
-            eng.set_option(capi.OPT_LUT_MODE, capi.LUT_MFMA_BF16X2)
+        # BASELINE configs[4]: fp16 LUT STORAGE (QCNN_OPT_LUT_MODE = 2, opt-in: outside the 1e-4 bar): half-size tables in LDS,
+        # fp32 sums — the rate next to the error it costs (against value_tables_only: both run every layer through tables)
+        if args.lut == "mfma" and args.model == "AlexNet":
+            eng.set_option(capi.OPT_LUT_MODE, capi.LUT_MFMA_F16)
             step()
-            extras["value_bf16_pairs"] = round(B * 3 / timed(torch, dev, step, 3), 2)
+            extras["value_fp16_lut"] = round(B * 3 / timed(torch, dev, step, 3), 2)
             bf_prob = prob[: args.parity_images].cpu().numpy() if args.parity_images > 0 else None
+            f16_split = {str(i): list(eng.layer_split(i)) for i, l in enumerate(layers) if l["type"] in (topo.CONV, topo.FCNT)}
+            eng.set_option(capi.OPT_PROFILE, 1)
+            eng.reset_layer_ms()
+            step(); step()
+            f16_ms, _ = eng.layer_ms()
+            eng.set_option(capi.OPT_PROFILE, 0)
+            extras["fp16_lut"] = dict(layer_ms={"%02d_%s" % (i, topo.TYPE_NAMES[layers[i]["type"]]): round(float(m), 4)
+                                                for i, m in enumerate(f16_ms) if m > 0 and layers[i]["type"] in (topo.CONV, topo.FCNT)},
+                                      kernels=f16_split,
+                                      note="fp16 table entries (round to nearest even), fp32 sums; kernels: qcnn_get_layer_split codes "
+                                           "(-7: fp16-storage form of the eight-wave kernels; others: entries rounded, f32 slots)")
             eng.set_option(capi.OPT_LUT_MODE, capi.LUT_MFMA)
+            step()
         # small batches: one image (the reference's own regime) and one 128-image panel (an 8-GPU shard of the batch)
         for nb, reps, key in ((1, 20, "value_b1"), (128, 10, "value_b128")):
             if nb <= B:
@@ -549,12 +618,12 @@ def main():
                 eng.upload({fc6: params[fc6]})
                 step()
                 torch.cuda.synchronize(dev)
-            if bf_prob is not None:                      # the opt-in builder's probabilities against the same reference
+            if bf_prob is not None:                      # fp16 table storage: its soft-max outputs against the f32 tables' (same images)
                 ref = prob[lo:lo + bf_prob.shape[0]].cpu().numpy()
-                extras["bf16_pairs_max_rel_diff_vs_f32_builder"] = float(
+                extras["fp16_lut"]["max_rel_diff_prob_vs_f32_tables"] = float(
                     max(np.abs(bf_prob[i] - ref[i]).max() / np.abs(ref[i]).max() for i in range(bf_prob.shape[0])))
         if args.cpu_sample > 0 and world == 1:
-            cb = cpu_baseline(kind, cpu, imgs[: args.cpu_sample].cpu().numpy())
+            cb = cpu_baseline(kind, cpu, imgs[: args.cpu_sample].cpu().numpy(), params)
 
     ref_main = None
     if args.extras and rank == 0 and world == 1 and args.model == "AlexNet" and B <= 1024:
@@ -598,7 +667,24 @@ def main():
             slow["%02d_%s" % (i, topo.TYPE_NAMES[v_layers[i]["type"]])] = r
         v_lut_flop = sum(perf.conv_work(v_sizes[i], v_sizes[i + 1], l, *[int(x) for x in v_params[i]["ctrd"].shape])["alg_flop"] / 128.0
                          for i, l in enumerate(v_layers) if l["type"] == topo.CONV)
-        vgg = dict(value=round(vb * 2 / vdt, 2), unit="images/s", batch=vb, steps=2,
+        # parity of THIS configuration (library defaults, batch vb, the kernels timed above): the first and the last image of
+        # the batch (first panel / ragged last panel) through the CPU reference — soft-max outputs, top-5, the last pooling
+        # map and the hidden FC maps (tests/test_gpu_vgg16_config3.py checks every materialised map of three images)
+        v_parity = None
+        if args.parity_images > 0:
+            vkind, vcpu, _ = cpu_side(v_chw, v_layers, v_params)
+            vidx = [0, vb - 1] if vb > 1 else [0]
+            vsel = torch.tensor(vidx, device=dev)
+            vfcs = [i for i, l in enumerate(v_layers) if l["type"] == topo.FCNT]
+            vfm = [max(i + 1 for i, l in enumerate(v_layers) if l["type"] == topo.POOL)] + [i + 2 for i in vfcs[:-1]]
+            v_parity = parity_check(vkind, vcpu, v_layers, vi[vsel].cpu().numpy(), vp[vsel].cpu().numpy(),
+                                    vt[vsel].cpu().numpy().view(np.uint16),
+                                    {l: np.concatenate([ve.layer_output_range(l, i, 1) for i in vidx]) for l in vfm})
+            v_parity["image_indices"] = vidx
+            v_parity["kernels"] = {str(i): list(ve.layer_split(i)) for i, l in enumerate(v_layers) if l["type"] in (topo.CONV, topo.FCNT)}
+            v_parity["kernels_note"] = ("qcnn_get_layer_split codes of the timed forwards: -3 decoded code words, -2 16-wave sliding, "
+                                        "-5 / -6 eight-wave tile / sliding form (second number: segments per column)")
+        vgg = dict(value=round(vb * 2 / vdt, 2), unit="images/s", batch=vb, steps=2, parity=v_parity,
                    outputs_finite=bool(torch.isfinite(vp).all().item()), conv_ms_per_batch=round(conv_total, 3),
                    dominant_layer=vdom, dominant_ms=round(float(vms[vdom]), 4), dominant=rep, slowest_layers=slow,
                    lut_build_algorithmic_tflops=round(v_lut_flop * vb * 2 / vdt / 1e12, 2),
@@ -606,9 +692,10 @@ def main():
                    parameters="seeded synthetic, conv Cs=8 K=128, fc Cs=4 K=32, classifier Cs=1 K=16")
         ve.close()
 
-    if rank == 0:
-        ms_step = 1000.0 * dt / args.steps
-        value = images_per_step * args.steps / dt
+    def roofline_for(snap_, value_, ms_step_, profiled=True):
+        """The `roofline` object of one measured configuration (snapshot() of its forwards)."""
+        layer_ms, recorded = snap_["layer_ms"], snap_["recorded"]
+        decoded, dec_nchw, symmetric, sym8, segments = (snap_[k] for k in ("decoded", "dec_nchw", "symmetric", "sym8", "segments"))
         dom = int(np.argmax(layer_ms))
         dom_ms = float(layer_ms[dom])
         # a layer is launched once per sub-batch (QCNN_OPT_STREAMS): layer_ms is the mean duration of ONE launch,
@@ -620,10 +707,10 @@ def main():
         achieved = abytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         conv_idx = [i for i, l in enumerate(layers) if l["type"] == topo.CONV]
         name = "%s%d" % (topo.TYPE_NAMES[layers[dom]["type"]], (conv_idx.index(dom) + 1) if dom in conv_idx else dom)
-        traffic, tsrc, ttable = (pmc_traffic(dom, ns) if (n_local == 1000 and args.model == "AlexNet")
-                                 else (None, "batch/model differ from the profiled run", {}))
+        traffic, tsrc, ttable = (pmc_traffic(dom, ns) if (n_local == 1000 and args.model == "AlexNet" and profiled)
+                                 else (None, "batch / model / options differ from the profiled run (the committed PMC passes are "
+                                             "of the default configuration)", {}))
         per_layer = {}
-        total_lk = 0
         for i, l in enumerate(layers):
             if l["type"] in (topo.CONV, topo.FCNT) and layer_ms[i] > 0:
                 r = (perf.decoded_report(sizes, layers, i, launch_images, float(layer_ms[i]), i in dec_nchw) if (i in decoded and l["type"] == topo.CONV) else
@@ -633,7 +720,7 @@ def main():
                      perf.layer_report(sizes, layers, params, i, launch_images, float(layer_ms[i]), segments.get(i), 8 if i in sym8 else (i in symmetric)))
                 r["ms"] = round(float(layer_ms[i]), 4)
                 per_layer["%02d_%s" % (i, topo.TYPE_NAMES[l["type"]])] = r
-        table_lk = 0                                    # look-ups of the layers that really ran as table look-ups
+        total_lk, table_lk = 0, 0                       # all look-ups / those of the layers that really ran as table look-ups
         for i, l in enumerate(layers):
             lk = 0
             if l["type"] == topo.CONV:
@@ -664,7 +751,12 @@ def main():
                 ab = algorithmic_bytes(sizes, layers, params, l2, launch_images)
                 other[str(l2)] = dict(kernel=ent.get("kernel"), traffic=int(ent["bytes"]), fetched=ent.get("fetch_bytes"),
                                       written=ent.get("write_bytes"), algorithmic_bytes_per_launch=int(ab),
-                                      traffic_over_algorithmic=round(ent["bytes"] / ab, 2))
+                                      traffic_over_algorithmic=round(ent["bytes"] / ab, 2),
+                                      rocprof_avg_ms=ent.get("rocprof_avg_ms"))
+        # rocprofv3 --kernel-trace --stats average of the same kernel from the committed profile of THIS kernel source
+        # (profiles/*/kernel_stats.csv via traffic.json; hash-checked like `traffic`): the live HIP-event time must agree
+        dom_ent = ttable.get(dom, {})
+        rp_ms = dom_ent.get("rocprof_avg_ms")
         roof = dict(bound, kernel=("k_conv_dec (layer %d, %s)" % (dom, name)) if dom in decoded else
                     ("k_conv_sym8 (layer %d, %s)" % (dom, name)) if dom in sym8 else
                     ("k_conv_sym (layer %d, %s)" % (dom, name)) if dom in symmetric else
@@ -673,13 +765,28 @@ def main():
                     traffic_over_algorithmic=round(traffic / abytes, 2) if traffic else None, other_kernels_traffic=other,
                     hbm_achieved=round(achieved, 2), hbm_peak=HBM_PEAK_GBS, hbm_frac=round(achieved / HBM_PEAK_GBS, 5),
                     ms_per_launch=round(dom_ms, 4), launches_timed=recorded * ns, launches_per_step=ns,
+                    rocprof_avg_ms_per_launch=rp_ms, rocprof_kernel=dom_ent.get("kernel") if rp_ms else None,
+                    rocprof_over_hip_events=round(rp_ms / dom_ms, 3) if (rp_ms and dom_ms > 0) else None,
                     images_per_launch=launch_images, algorithmic_bytes_per_launch=int(abytes),
-                    whole_step_hbm_frac=round(step_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                    whole_step_lds_frac=round(table_lk * 4 * value / 1e9 / lds_peak_gbs, 4),
+                    whole_step_hbm_frac=round(step_bytes / (ms_step_ * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    whole_step_lds_frac=round(table_lk * 4 * value_ / 1e9 / lds_peak_gbs, 4),
                     lds_read_peak="256 CUs x 256 B/clk x 2.4 GHz (ds_read_b64/b128)",
                     layers=per_layer,
                     layer_ms={"%02d_%s" % (i, topo.TYPE_NAMES[layers[i]["type"]]): round(float(m), 4)
                               for i, m in enumerate(layer_ms) if m > 0})
+        return roof, total_lk, table_lk, ns
+
+    if rank == 0:
+        ms_step = 1000.0 * dt / args.steps
+        value = images_per_step * args.steps / dt
+        roof, total_lk, table_lk, ns = roofline_for(snap, value, ms_step)
+        conv_fc = [i for i, l in enumerate(layers) if l["type"] in (topo.CONV, topo.FCNT)]
+        lname = lambda i: "%s%d" % ("conv" if layers[i]["type"] == topo.CONV else "fc", conv_fc.index(i) + 1)
+        dec_names = [lname(i) for i in sorted(decoded)]
+        scheme = ("fp32 LUT + uint8 indices for %s; %s — one sub-space of 3 dims / one-dim sub-spaces — evaluate the same sums as "
+                  "f32 MFMA products of the code words their uint8 assignments name (QCNN_OPT_DECODE, library default); "
+                  "every layer through LUTs: value_tables_only" % (", ".join(lname(i) for i in conv_fc if i not in decoded),
+                                                                   " and ".join(dec_names))) if decoded else "fp32 LUT + uint8 indices, every conv / FC layer"
         par = ("one %d-image batch sharded over %d GPU(s) in contiguous blocks, parameters replicated by one RCCL "
                "broadcast" % (B, world)) if (strong or world == 1) else (
             "%d images per GPU on %d GPUs, parameters replicated by one RCCL broadcast" % (B, world))
@@ -689,8 +796,9 @@ def main():
             "ms_per_step": round(ms_step, 4), "higher_is_better": True,
             "scaling": "strong" if (strong or world == 1) else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s Q-CNN approximate forward (fp32 LUT + uint8 indices), one batch of %d synthetic %dx%d "
-                                   "images per step, device-resident" % (args.model, images_per_step, in_chw[1], in_chw[2]),
+            "config": {"workload": "%s Q-CNN approximate forward (%s), one batch of %d synthetic %dx%d "
+                                   "images per step, device-resident" % (args.model, scheme, images_per_step, in_chw[1], in_chw[2]),
+                       "decoded_layers": dec_names,
                        "global_batch": images_per_step, "images_on_rank0": n_local, "lut_builder": args.lut,
                        "parameters": ("the reference's shipped AlexNet files (oracle/_ref/data) + fc6 assignments of SURVEY.md §8c "
                                       "fixture 1 (the mount lacks that file); inputs U{0..255} minus the shipped mean image") if shipped
@@ -706,6 +814,14 @@ def main():
                              % (table_lk, sorted(decoded), total_lk - table_lk)) if decoded else "all evaluated as table look-ups",
             "roofline": roof,
         }
+        if snap_tab is not None:
+            # the north star's scheme for ALL eight conv / FC layers (QCNN_OPT_DECODE = 0): its own rate and roofline block
+            v_tab = images_per_step * args.steps / dt_tab
+            r_tab, _, lk_tab, _ = roofline_for(snap_tab, v_tab, 1000.0 * dt_tab / args.steps, profiled=False)
+            out["value_tables_only"] = round(v_tab, 2)
+            out["ms_per_step_tables_only"] = round(1000.0 * dt_tab / args.steps, 4)
+            out["lookups_per_s_tables_only"] = round(lk_tab * v_tab, 0)
+            out["roofline_tables_only"] = r_tab
         out.update(extras)
         if value_weak is not None:
             out["value_weak"] = round(value_weak, 2)
@@ -720,12 +836,15 @@ def main():
         if cb is not None:
             out["cpu_baseline"] = cb
             out["speedup_vs_cpu_baseline"] = round(value / cb["value"], 1)
+            if "all_cores" in cb:
+                out["speedup_vs_cpu_all_cores"] = round(value / cb["all_cores"]["value"], 1)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()                      # rank 0 may still have been busy with the CPU reference
         dist.destroy_process_group()
-    if rank == 0 and (not ok or (parity is not None and not parity["ok"])):
-        raise SystemExit("bench.py: outputs differ from the CPU reference beyond %g (see `parity`)" % TOL)
+    if rank == 0 and (not ok or (parity is not None and not parity["ok"]) or
+                      (vgg is not None and vgg.get("parity") is not None and not vgg["parity"]["ok"])):
+        raise SystemExit("bench.py: outputs differ from the CPU reference beyond %g (see `parity` / `vgg16.parity`)" % TOL)
 
 
 if __name__ == "__main__":

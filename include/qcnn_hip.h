@@ -64,12 +64,12 @@ typedef struct {
 enum {
   QCNN_OPT_LUT_MODE = 0,   /* 0 = exact (VALU mul+add in the reference's order: conv/FC outputs are
                               bit-identical to the reference's -O2 native build); 1 = MFMA
-                              (v_mfma_f32_16x16x4_f32, fused multiply-add chain; default); 2 = as 1 with every
-                              table entry rounded to fp16 before it is stored (accumulation stays fp32): the
-                              tolerance study of BASELINE.json configs[4], not a faster path; 3 = as 1, but the conv
-                              layers with K = 128 and 5..8 dims per sub-space build their tables with ONE
-                              v_mfma_f32_16x16x32_bf16 per tile on operands split in two bf16 parts (16 mantissa
-                              bits per operand, fp32 accumulation and fp32 table entries): opt-in, ~1e-5 per layer */
+                              (v_mfma_f32_16x16x4_f32, fused multiply-add chain; default); 2 = fp16 LUT STORAGE
+                              (BASELINE.json configs[4], opt-in study: outside the 1e-4 bar): every table entry is
+                              rounded to fp16 when it is stored, sums stay fp32 — conv layers with K = 128 and complete
+                              4- / 8-dim sub-spaces and FC layers with 32 code words of 4 dims keep half-size tables in
+                              LDS (256-byte rows, ds_read_b64 look-ups: k_conv_sym8 / k_fc_sym8 in their fp16 form),
+                              every other layer rounds the entries and keeps them in f32 slots (same values) */
   QCNN_OPT_KEEP_ALL = 1,   /* 1 = every layer writes its own feature map (layer-for-layer dumps, default);
                               0 = fast path: ReLU fused into the producing conv/FC epilogue, the first conv layer
                               reads the NCHW input in place, and an LRN layer followed by a 3x3 / stride 2 / pad 0

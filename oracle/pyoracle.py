@@ -19,6 +19,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_SO = os.path.join(HERE, "libqcnn_oracle.so")
 REF_DIR = os.path.join(HERE, "_ref")
 REF_SO = os.path.join(REF_DIR, "libqcnn_ref.so")
+REF_O3_SO = os.path.join(REF_DIR, "libqcnn_ref_o3.so")     # same sources, -O3 -march=znver3: timing comparator only (make ref_o3)
 REF_DATA = os.path.join(REF_DIR, "data")
 
 _f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
@@ -161,10 +162,10 @@ def have_ref() -> bool:
 class RefLib:
     """The compiled reference (batch 1 only, as the reference is: src/CaffeEva.cc:23)."""
 
-    def __init__(self):
-        if not have_ref():
-            raise FileNotFoundError(REF_SO)
-        self.lib = lib = C.CDLL(REF_SO)
+    def __init__(self, so_path: str = REF_SO):
+        if not os.path.exists(so_path):
+            raise FileNotFoundError(so_path)
+        self.lib = lib = C.CDLL(so_path)
         lib.qref_create.restype = C.c_void_p
         lib.qref_destroy.argtypes = [C.c_void_p]
         lib.qref_load_named.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p]

@@ -19,6 +19,7 @@
 // whose sub-spaces have ONE dim, k_fc_dec (further down).  Both are opt-out (QCNN_OPT_DECODE = 0: table kernels).
 #include "qcnn_kernels.h"
 #include <algorithm>
+#include <type_traits>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -321,7 +322,9 @@ __global__ __launch_bounds__(64 * NCHW_WAVES) void k_conv_dec_nchw(DecParams p) 
   const int P = p.Ho * p.Wo;
   const int steps = p.Kp >> 2;                                          // Kp: Cin knl^2 padded to a multiple of 16
   const uint32_t imgBytes = (uint32_t)p.Cin * p.H * p.W * 4u, planeBytes = (uint32_t)p.H * p.W * 4u, rowBytes = (uint32_t)p.W * 4u;
-  int* ldsOff = reinterpret_cast<int*>(ldsW + (size_t)steps * 4 * p.S);
+  // (one step of slack behind the code words: the last step of an item pre-loads "the next step's" code words, which nobody
+  // uses — the offset table sits behind that slack, inside the allocation)
+  int* ldsOff = reinterpret_cast<int*>(ldsW + (size_t)(steps + 1) * 4 * p.S);
   {
     const int wq = steps * p.S;
     const f32x4* __restrict__ wsrc = reinterpret_cast<const f32x4*>(p.wdec);
@@ -341,7 +344,8 @@ __global__ __launch_bounds__(64 * NCHW_WAVES) void k_conv_dec_nchw(DecParams p) 
   const unsigned long long total = (unsigned long long)p.nImages * imgBytes;
   typedef int i32x4_t __attribute__((ext_vector_type(4)));
   const unsigned long long srcA = reinterpret_cast<unsigned long long>(p.src);
-  // buffer resource: base, stride 0, the batch's bytes (reads past the batch return 0), raw 32-bit data format
+  // buffer resource: base, stride 0, the batch's bytes, raw 32-bit data format.  No load below depends on the range check:
+  // every address is inside the batch by construction (see `edge`)
   const i32x4_t rsrc4 = {(int)(unsigned)srcA, (int)((unsigned)(srcA >> 32) & 0xffffu),
                          (int)(total < 0xffffffffull ? (unsigned)total : 0xffffffffu), 0x00020000};
   const int xcd = blockIdx.x & 7, nX = gridDim.x < 8 ? gridDim.x : 8;
@@ -362,10 +366,31 @@ __global__ __launch_bounds__(64 * NCHW_WAVES) void k_conv_dec_nchw(DecParams p) 
     const int r0 = orow * p.stride, c0 = ocol * p.stride;                        // unpadded layers
     const uint32_t img0 = (uint32_t)(p.panel0 + panel) * PANEL + (uint32_t)it * 16u;
     // row li of a product tile: image li & 7 of the tile's eight, position li >> 3 of its two.  Positions past the end of the
-    // output row read columns of the next image row, of the next plane ... finite values or the buffer's zeros, never stored.
+    // output row read columns of the next image row, of the next plane, of the next image ... finite values, never stored.
+    // That stays inside the caller's buffer as long as an image FOLLOWS the tile's sixteen.  An item that holds the batch's
+    // last image or images past it (a ragged last panel launches all eight image tiles) takes the `edge` form of the body:
+    // every image index is clamped to the last image and every position to the last of its output row — in the scalar offset
+    // AND per lane —, so that no address leaves the batch whatever the buffer's range check does with the scalar offset (the
+    // gfx9 raw-buffer check covers the vector offset only), and (last image) x imgBytes cannot wrap 32 bits.  Those lanes'
+    // results are never stored / never read.
+    const bool edge = img0 + 16u >= (uint32_t)p.nImages;
     const int laneOff = (int)((uint32_t)(li & 7) * imgBytes + (uint32_t)((li >> 3) * p.stride) * 4u);
     const uint32_t base0 = img0 * imgBytes + (uint32_t)(r0 * p.W + c0) * 4u;      // tile ti: + 8 (ti & 1) images, + 2 (ti >> 1) positions
     const int* __restrict__ offT = ldsOff + kq;
+   auto body = [&](auto edgeTag) {
+    constexpr bool EDGE = decltype(edgeTag)::value;
+    int laneOffE[IT];
+    uint32_t baseE[IT];
+    if constexpr (EDGE) {
+      const uint32_t lastImg = (uint32_t)p.nImages - 1u, lastPos = (uint32_t)p.Wo - 1u;
+#pragma unroll
+      for (int ti = 0; ti < IT; ++ti) {
+        const uint32_t imgS = min(img0 + 8u * (uint32_t)(ti & 1), lastImg), imgL = min(img0 + 8u * (uint32_t)(ti & 1) + (uint32_t)(li & 7), lastImg);
+        const uint32_t posS = min((uint32_t)ocol + 2u * (uint32_t)(ti >> 1), lastPos), posL = min((uint32_t)ocol + 2u * (uint32_t)(ti >> 1) + (uint32_t)(li >> 3), lastPos);
+        laneOffE[ti] = (int)((imgL - imgS) * imgBytes + (posL - posS) * (uint32_t)p.stride * 4u);
+        baseE[ti] = imgS * imgBytes + ((uint32_t)(r0 * p.W) + posS * (uint32_t)p.stride) * 4u;
+      }
+    }
     // Operand loads as inline assembly with counted waits: the compiler's own vmcnt bookkeeping drains the ring to one
     // step at every loop back edge (s_waitcnt vmcnt(4) in front of the first of four steps).  Loads return in order, so
     // "at most 12 outstanding" = everything but the three newest steps has arrived — whatever else (the previous item's
@@ -373,11 +398,14 @@ __global__ __launch_bounds__(64 * NCHW_WAVES) void k_conv_dec_nchw(DecParams p) 
 #ifndef NCHW_VAR
 #define NCHW_VAR 0                      // timing experiments (scripts/variants_nchw.sh): 1 no operand loads, 2 no products, 4 no stores
 #endif
-    auto issue = [&](int s, float (&bb)[IT]) {                          // the operands of step s
-      const int vo = offT[s * 4] + laneOff;
+    auto issue = [&, rsrc4, base0](int s, float (&bb)[IT]) {             // the operands of step s (explicit captures: asm operands inside a generic lambda)
+      const int ot = offT[s * 4];
+      const int vo = ot + laneOff;
+      (void)base0;
 #pragma unroll
       for (int ti = 0; ti < IT; ++ti)
-        if (NCHW_VAR & 1) asm volatile("v_mov_b32 %0, %1" : "=v"(bb[ti]) : "v"(vo)); else
+        if (NCHW_VAR & 1) asm volatile("v_mov_b32 %0, %1" : "=v"(bb[ti]) : "v"(vo)); else if constexpr (EDGE)
+        asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(bb[ti]) : "v"(ot + laneOffE[ti]), "s"(rsrc4), "s"(baseE[ti])); else
         asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(bb[ti]) : "v"(vo), "s"(rsrc4),
                      "s"(base0 + (uint32_t)(ti & 1) * 8u * imgBytes + (uint32_t)((ti >> 1) * 2 * p.stride) * 4u));
     };
@@ -462,6 +490,8 @@ __global__ __launch_bounds__(64 * NCHW_WAVES) void k_conv_dec_nchw(DecParams p) 
           }
       }
     }
+   };
+    if (edge) body(std::true_type{}); else body(std::false_type{});
   }
 }
 
@@ -685,7 +715,7 @@ hipError_t qk_fc_dec(const FcDecParams& p, int slices, int live, hipStream_t st)
 bool qk_conv_dec_nchw_shape(int Cin, int grp, int M, int Ct, int knl, int pad, int* Kp, int* S) {
   if (grp != 1 || M != 1 || Cin < 1 || Cin > 4 || pad != 0 || Ct % 96) return false;
   const int kp = (Cin * knl * knl + 15) / 16 * 16;            // steps in fours
-  if ((size_t)kp * Ct * sizeof(float) + (kp / 4 + 4) * 16 > 160 * 1024) return false;
+  if ((size_t)(kp + 4) * Ct * sizeof(float) + (kp / 4 + 4) * 16 > 160 * 1024) return false;   // code words + one step of slack + offset table
   *Kp = kp; *S = Ct;
   return true;
 }
@@ -703,7 +733,7 @@ hipError_t qk_conv_dec_nchw(const DecParams& p, hipStream_t st) {
     return hipErrorInvalidValue;
   const long long items = (long long)p.panels * p.Ho * ((p.Wo + 3) / 4) * ((p.live + 15) / 16) * (p.Ct / 96);
   const int blocks = (int)std::min<long long>(256, items);           // (few items: one per workgroup, see `sparse`)
-  const size_t shm = (size_t)p.Kp * p.S * sizeof(float) + (size_t)(p.Kp / 4 + 4) * 16;
+  const size_t shm = (size_t)(p.Kp + 4) * p.S * sizeof(float) + (size_t)(p.Kp / 4 + 4) * 16;
   auto kern = k_conv_dec_nchw<6, 4>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
   if (e != hipSuccess) return e;

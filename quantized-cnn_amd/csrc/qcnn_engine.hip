@@ -28,8 +28,6 @@ struct LayerShape {
   bool dense = false;                                          // precise path: bias + dense weights instead of a quantisation
   size_t offDense = 0, denseFloats = 0;
   size_t offBias = 0, offCtrd = 0, offAsmt = 0, offDmap = 0;   // byte offsets into the arena
-  size_t offCtrd2 = 0;                                         // bf16-pair split of the code book (0 bytes when not applicable)
-  bool hasCtrd2 = false;
   size_t asmtBytes = 0;
   size_t offProg = 0, progBytes = 0;                           // conv with K = 128: offsets in consumption order (QkProgram)
   size_t offProgS = 0, progSBytes = 0;                         // ... and in the order of the sliding variant, where it applies
@@ -123,6 +121,7 @@ struct QcnnCtx {
   float* fcFlat = nullptr;           // first FC layer's input in consumption order
   float* fcPartial = nullptr;        // split-M partial sums of the FC layers
   float* convPartial = nullptr;      // partial sums of split conv tiles (kConvPartialFloats)
+  bool noConvPartial = false;        // ... could not be allocated: split plans launch their tiles whole
   size_t fcPartialElems = 0;
   size_t fcMaxCt = 0;
   int lastN = 0;
@@ -185,9 +184,6 @@ int plan_arena(QcnnCtx* c) {
     if (s.K <= 0) return fail(c, "layer %d: neither a quantisation shape (qcnn_model_set_layer_shape) nor dense weights (qcnn_model_set_layer_dense) declared", l);
     s.offBias = off; off = align_up(off + sizeof(float) * Ct, 256);
     s.offCtrd = off; off = align_up(off + sizeof(float) * (size_t)s.M * s.Cs * s.K, 256);
-    // conv layers with K = 128 and more than 4 dims per sub-space can run the bf16-pair builder (QCNN_OPT_LUT_MODE = 3)
-    s.hasCtrd2 = d.type == QCNN_CONV && s.K == 128 && std::min(c->dims[l].c / d.grpCnt, s.Cs) > 4;
-    if (s.hasCtrd2) { s.offCtrd2 = off; off = align_up(off + qk_ctrd2_bytes(s.M), 256); }
     // assignment table: one-byte row slots in the order the gather waves consume them (QkSlots, qcnn_kernels.h)
     const QkSlots sl = (d.type == QCNN_CONV) ? qk_conv_slots(Ct / d.grpCnt, d.grpCnt) : qk_fc_slots(Ct);
     const size_t taps = (d.type == QCNN_CONV) ? (size_t)d.knlSiz * d.knlSiz : 1;
@@ -276,7 +272,7 @@ void free_model(QcnnCtx* c) {
   }
   if (c->fcPartial) (void)hipFree(c->fcPartial);
   if (c->convPartial) (void)hipFree(c->convPartial);
-  c->convPartial = nullptr;
+  c->convPartial = nullptr; c->noConvPartial = false;
   if (c->fcFlat) (void)hipFree(c->fcFlat);
   c->fcFlat = nullptr;
   c->stageIn = c->stageOut = nullptr; c->stageTop5 = nullptr; c->stageElems = 0;
@@ -323,15 +319,15 @@ int ensure_pipeline(QcnnCtx* c) {
 // live: images every panel of this launch holds (128, or the batch size of a single-panel forward); small: the
 // few-image kernels (qcnn_small.hip) run the conv/FC layers
 // sub / nsub: index and number of the sub-batches (streams) of this forward: each has its own share of the scratch
-// Does conv layer l run through its decoded code words (qcnn_decoded.hip)?  The f32 / bf16-pair MFMA modes only: the exact
+// Does conv layer l run through its decoded code words (qcnn_decoded.hip)?  The f32 MFMA mode only: the exact
 // builder keeps the reference's summation order and the fp16 study is about the tables themselves.
 bool decoded_layer(const QcnnCtx* c, int l) {
   const LayerShape& s = c->shapes[l];
-  return c->decode && s.decKp > 0 && !s.dense && (c->lutMode == 1 || c->lutMode == 3) && c->layers[l].type == QCNN_CONV;
+  return c->decode && s.decKp > 0 && !s.dense && c->lutMode == 1 && c->layers[l].type == QCNN_CONV;
 }
 bool decoded_fc(const QcnnCtx* c, int l) {
   const LayerShape& s = c->shapes[l];
-  return c->decode && s.decKp < 0 && !s.dense && (c->lutMode == 1 || c->lutMode == 3) && c->layers[l].type == QCNN_FCNT;
+  return c->decode && s.decKp < 0 && !s.dense && c->lutMode == 1 && c->layers[l].type == QCNN_FCNT;
 }
 
 int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bool fuseRelu, bool flatFcInput,
@@ -381,7 +377,6 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
       if (inNchw) { p.src = inNchw; p.srcNchw = 1; p.nImages = nImages; p.panel0 = p0; }   // network input read in place
       p.bias = reinterpret_cast<const float*>(c->arena + s.offBias);
       p.ctrd = reinterpret_cast<const float*>(c->arena + s.offCtrd);
-      p.ctrd2 = s.hasCtrd2 ? c->arena + s.offCtrd2 : nullptr;
       p.ctrd8 = (s.prog8Bytes || s.prog8SBytes) ? reinterpret_cast<const float*>(c->arena + s.offCtrd8) : nullptr;
       p.rows = reinterpret_cast<const uint8_t*>(c->arena + s.offAsmt);
       p.prog = s.progBytes ? reinterpret_cast<const uint16_t*>(c->arena + s.offProg) : nullptr;
@@ -481,12 +476,17 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
             for (int i = 0; i <= pl.segN; ++i) { p.segBeg[i] = pl.segBeg[i]; s.segBeg[i] = pl.segBeg[i]; }
             s.lastFrom = -2; s.lastZ = pl.segN;      // reported by qcnn_get_layer_split as (-2, segments per column)
           } else if (pl.plan.Z > 1) {
-            if (!c->convPartial) {                    // first split launch of this context: the scratch for partial sums
-              const hipError_t ea = hipMalloc(&c->convPartial, kConvPartialFloats * sizeof(float));
-              if (ea != hipSuccess) return fail(c, "layer %d: no scratch for split tiles: %s", l, hipGetErrorString(ea));
+            if (!c->convPartial && !c->noConvPartial) {   // first split launch of this context: the scratch for partial sums
+              if (hipMalloc(&c->convPartial, kConvPartialFloats * sizeof(float)) != hipSuccess) {
+                (void)hipGetLastError();                   // no memory left for it (large maps at a large batch): the tiles run whole,
+                c->convPartial = nullptr;                  // which needs no scratch — never a failed forward
+                c->noConvPartial = true;
+              }
             }
-            p.splitFrom = pl.plan.splitFrom; p.splitZ = pl.plan.Z; p.partial = c->convPartial + share * sub;
-            s.lastFrom = pl.plan.splitFrom; s.lastZ = pl.plan.Z;
+            if (c->convPartial) {
+              p.splitFrom = pl.plan.splitFrom; p.splitZ = pl.plan.Z; p.partial = c->convPartial + share * sub;
+              s.lastFrom = pl.plan.splitFrom; s.lastZ = pl.plan.Z;
+            }
           }
         }
         e = qk_conv_aprx(p, c->lutMode, st);
@@ -663,26 +663,29 @@ int drain_profile(QcnnCtx* c) {
 // Can the first layer's builders read the NCHW network input in place (no pack kernel, no packed copy of the input)?
 // Fast path only (layer-for-layer mode keeps fm[0] for dumps); a conv layer with <= 4 input channels per group (one
 // sub-space of <= 4 dims: exactly what the operand loads of one stage touch) and K = 128 or the exact builder.
-// workgroups a fused LRN + pool launch must have (QCNN_LRNPOOL_MIN overrides it for experiments)
+// workgroups a fused LRN + pool launch must have
 // (192: one panel of AlexNet's LRN1 + pool1 — 196 workgroups — fuses: 0.091 against 0.104 ms; LRN2 + pool2 at one / two panels —
 // 64 / 128 workgroups — must not: 0.21 against 0.065 ms)
 int lrn_pool_min_blocks() {
+#ifdef QCNN_EXPERIMENT     // variant builds only (scripts/build_variant.sh -DQCNN_EXPERIMENT)
   static const int v = [] { const char* e = getenv("QCNN_LRNPOOL_MIN"); return (e && atoi(e) > 0) ? atoi(e) : 192; }();
   return v;
+#else
+  return 192;
+#endif
 }
 
 bool direct_input(const QcnnCtx* c, int n) {
   if (c->keepAll || c->L == 0 || c->layers[0].type != QCNN_CONV) return false;
-  // a first layer that runs through its decoded code words reads packed panels (the few-image kernels do not take that
-  // path: one or two images in a 128-image panel layout are 64-byte segments with one float each, they read NCHW densely)
-  // path: one or two images in a 128-image panel layout ...) — unless its kernel has the NCHW form (k_conv_dec_nchw)
-  if ((unsigned long long)c->maxBatch * c->inC * c->inH * c->inW * sizeof(float) >= (1ull << 32)) return false;
+  // the images of THIS forward inside 4 GiB: the in-place kernels keep image offsets in 32 bits
+  if ((unsigned long long)n * c->inC * c->inH * c->inW * sizeof(float) >= (1ull << 32)) return false;
+  // a first layer that runs through its decoded code words reads packed panels — unless its kernel has the NCHW form
+  // (k_conv_dec_nchw); batches of one to three images go to the few-image table kernel below, which reads NCHW densely
   if (decoded_layer(c, 0) && !(c->smallBatch && c->lutMode == 1 && n <= kSmallBatchMax)) return c->directDec && c->shapes[0].decNV > 0;
   const QcnnLayerDesc& d = c->layers[0];
-  // ONE sub-space (a second one would be fetched from channel planes past the group's own, for the last image past the
-  // caller's buffer), and the whole batch inside 4 GiB: the builders keep per-lane image offsets in 32 bits
+  // table kernels: ONE sub-space (a second one would be fetched from channel planes past the group's own, for the last
+  // image past the caller's buffer)
   if (c->shapes[0].dense || c->shapes[0].M != 1) return false;
-  if ((unsigned long long)c->maxBatch * c->inC * c->inH * c->inW * sizeof(float) >= (1ull << 32)) return false;
   return c->inC / d.grpCnt <= 4 && (c->lutMode == 0 || c->shapes[0].K == 128);
 }
 
@@ -857,17 +860,17 @@ int qcnn_ctx_destroy(QcnnCtx* c) {
 
 int qcnn_set_option(QcnnCtx* c, int option, int value) {
   switch (option) {
-    case QCNN_OPT_LUT_MODE: if (value < 0 || value > 3) return fail(c, "LUT mode must be 0, 1, 2 or 3"); c->lutMode = value; return 0;   // (part of the plan key)
+    case QCNN_OPT_LUT_MODE: if (value < 0 || value > 2) return fail(c, "LUT mode must be 0 (exact), 1 (f32 MFMA) or 2 (fp16 table storage)"); c->lutMode = value; return 0;   // (part of the plan key)
     case QCNN_OPT_KEEP_ALL: c->keepAll = value ? 1 : 0; return 0;
     case QCNN_OPT_PROFILE: c->profile = value ? 1 : 0; return 0;
     case QCNN_OPT_SMALL_BATCH: c->smallBatch = value ? 1 : 0; return 0;
     case QCNN_OPT_SPLIT: c->split = value ? 1 : 0; return 0;
     case QCNN_OPT_DECODE: c->decode = value ? 1 : 0; return 0;
-    case QCNN_OPT_SYM8: c->sym8 = value < 0 ? 0 : (value > 3 ? 3 : value); return 0;
+    case QCNN_OPT_SYM8: if (value < 0 || value > 3) return fail(c, "QCNN_OPT_SYM8 must be 0 (off), 1 (planner), 2 (forced tile form) or 3 (forced sliding form)"); c->sym8 = value; return 0;
     case QCNN_OPT_PACKED_FC: c->packedFc = value ? 1 : 0; return 0;
     case QCNN_OPT_DIRECT_DEC: c->directDec = value ? 1 : 0; return 0;
-    case QCNN_OPT_SYM: c->sym = value < 0 ? 0 : (value > 2 ? 2 : value); return 0;
-    case QCNN_OPT_SLIDE: c->slide = value < 0 ? 0 : (value > 2 ? 2 : value); return 0;
+    case QCNN_OPT_SYM: if (value < 0 || value > 2) return fail(c, "QCNN_OPT_SYM must be 0 (off), 1 (planner) or 2 (forced)"); c->sym = value; return 0;
+    case QCNN_OPT_SLIDE: if (value < 0 || value > 2) return fail(c, "QCNN_OPT_SLIDE must be 0 (off), 1 (planner) or 2 (forced)"); c->slide = value; return 0;
     case QCNN_OPT_HOST_CHUNK:
       if (value < 0) return fail(c, "host chunk must be >= 0 panels");
       c->hostChunk = value; return 0;
@@ -1042,7 +1045,7 @@ int qcnn_model_commit(QcnnCtx* c, int max_batch, void* dev_arena) {
 }
 
 namespace {
-// bias + code book (PrepCtrdBuf permutation, and the bf16-pair split where the layer can use it) into the arena
+// bias + code book (PrepCtrdBuf permutation; the eight-wave kernels' operand orders) into the arena
 int upload_bias_ctrd(QcnnCtx* c, int layer, const float* bias, const float* ctrd_file) {
   LayerShape& s = c->shapes[layer];
   const int Ct = c->dims[layer + 1].c;
@@ -1052,29 +1055,6 @@ int upload_bias_ctrd(QcnnCtx* c, int layer, const float* bias, const float* ctrd
   for (int m = 0; m < M; ++m)
     for (int k = 0; k < K; ++k)
       for (int dd = 0; dd < Cs; ++dd) ctrd[((size_t)m * Cs + dd) * K + k] = ctrd_file[((size_t)m * K + k) * Cs + dd];
-  // bf16-pair split of the code book in v_mfma_f32_16x16x32_bf16 A-operand order: [m][row tile][k-slice g][row][dim],
-  // slices 0/1 = leading part a1 = bf16(c), slices 2/3 = remainder a2 = bf16(c - a1) (round to nearest even)
-  std::vector<uint16_t> split;
-  if (s.hasCtrd2) {
-    auto toBf16 = [](float f) -> uint16_t {
-      uint32_t u; memcpy(&u, &f, 4);
-      if ((u & 0x7f800000u) == 0x7f800000u) return (uint16_t)(u >> 16);        // inf / nan: truncate
-      return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
-    };
-    auto fromBf16 = [](uint16_t h) -> float { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; };
-    split.assign(qk_ctrd2_bytes(M) / sizeof(uint16_t), 0);
-    for (int m = 0; m < M; ++m)
-      for (int i = 0; i < 8; ++i)
-        for (int g4 = 0; g4 < 4; ++g4)
-          for (int row = 0; row < 16; ++row)
-            for (int dd = 0; dd < 8; ++dd) {
-              const float cv = dd < Cs ? ctrd[((size_t)m * Cs + dd) * K + i * 16 + row] : 0.0f;
-              const uint16_t a1 = toBf16(cv);
-              const uint16_t a2 = toBf16(cv - fromBf16(a1));
-              split[((((size_t)m * 8 + i) * 4 + g4) * 16 + row) * 8 + dd] = (g4 < 2) ? a1 : a2;
-            }
-    HIP_TRY(c, hipMemcpyAsync(c->arena + s.offCtrd2, split.data(), split.size() * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
-  }
   std::vector<float> ctrdF;
   if (s.progF8Bytes) {                // the eight-wave FC kernel's operand order (K = 32, Cs = 4)
     ctrdF.resize((size_t)M * Cs * K);

@@ -169,8 +169,6 @@ struct ConvParams {
   float* dst;            // [panels][Ho*Wo*Ct][128]
   const float* bias;     // [Ct]
   const float* ctrd;     // [M][Cs][K]      (PrepCtrdBuf layout, src/CaffeEva.cc:556-557)
-  const void* ctrd2;     // [M][8 row tiles][4 k-slices][16 rows][8 bf16]: code book split in two bf16 parts (slices 0, 1:
-                         // leading part, 2, 3: remainder) in v_mfma_f32_16x16x32_bf16 operand order; K = 128 layers only, else NULL
   const float* ctrd8;    // eight-wave symmetric kernel: the code book in its operand order [M][2 halves of the row tiles][k-steps][64 lanes]
                          // [4 row tiles] (qk_ctrd8_index): a lane's four code-book operands of a k-step are ONE 16-byte load; else NULL
   const uint8_t* rows;   // [kh][kw][M][rowStride] (PrepAsmtBuf order, src/CaffeEva.cc:585-586): row slots, QkSlots order
@@ -281,10 +279,8 @@ struct DenseParams {
 };
 hipError_t qk_dense(const DenseParams& p, hipStream_t st);
 
-// lutMode: 0 exact VALU, 1 f32 MFMA (2 = f32 MFMA with fp16-rounded table entries, see lutF16), 3 = bf16-pair MFMA for
-// the conv layers with K = 128 and more than 4 dims per sub-space (every other layer as mode 1).  Return hipError_t of the launch.
-// bytes of ConvParams::ctrd2 for M sub-spaces
-static inline size_t qk_ctrd2_bytes(int M) { return (size_t)M * 8 * 4 * 16 * 16; }
+// lutMode: 0 exact VALU, 1 f32 MFMA, 2 = f32 MFMA with fp16-rounded table entries kept in f32 slots (see lutF16: the layers the
+// fp16-storage kernels of qcnn_sym8.hip do not cover).  Return hipError_t of the launch.
 hipError_t qk_conv_aprx(const ConvParams& p, int lutMode, hipStream_t st);
 hipError_t qk_fc_aprx(const FcParams& p, int lutMode, hipStream_t st);
 int qk_fc_channels_per_block(int Ct);   // output channels one k_fc_aprx workgroup covers

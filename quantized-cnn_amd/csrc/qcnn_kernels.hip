@@ -527,85 +527,6 @@ __device__ __forceinline__ void mfma_store(MfmaOps<KT, KS>& o, int Cs, int D, in
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Reduced-precision builder for 8-dim sub-spaces (QCNN_OPT_LUT_MODE = 3, K = 128 only): both operands are split
-// in two bf16 parts (x = x1 + x2 with 16 mantissa bits kept), and ONE v_mfma_f32_16x16x32_bf16 per tile sums the
-// four cross products over the 8 dims — k-slice g = lane >> 4 of the instruction carries (a1,b1), (a1,b2), (a2,b1),
-// (a2,b2) for g = 0..3 — with fp32 accumulation.  An f32 16x16x4 MFMA keeps the other waves of its SIMD at 30 % of
-// their VALU issue rate for 32 cycles and a tile needs two of them; the bf16 instruction is 17 cycles and a tile
-// needs one (profiles/r2_v7/ubench_stage2.log).  Products carry ~2^-17 relative error per operand; the table
-// entries and the accumulation stay fp32.  The split code book (a1, a2) is prepared at upload time
-// (ConvParams::ctrd2: [M][8 row tiles][4 k-slices][16 rows][8 bf16]); activations are split here.
-// ------------------------------------------------------------------------------------------------
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-struct BfSet {
-  bf16x8 a[8];     // code-book operand of the 8 row tiles
-  bf16x8 b[2];     // activation operand of the wave's two image tiles
-};
-// raw fp32 activations of the stage after next: x[it][d] = dim d of image (2*bw + it)*16 + (lane & 15)
-__device__ __forceinline__ void bf_issue_x(float (&x)[2][8], const char* __restrict__ xbase, uint32_t xoff0, int Cs, int m0,
-                                           int bw, int lane) {
-  const char* __restrict__ xbU = xbase + xoff0 + (uint32_t)(m0 * Cs) * (uint32_t)XROWB + bw * 128;   // uniform
-  const uint32_t laneB = (lane & 15) * 4;
-#pragma unroll
-  for (int it = 0; it < 2; ++it)
-#pragma unroll
-    for (int d = 0; d < 8; ++d) x[it][d] = *reinterpret_cast<const float*>(xbU + (d * XROWB + it * 64) + laneB);
-}
-__device__ __forceinline__ void bf_load_a(BfSet& o, const uint4* __restrict__ ctrd2, int m0, int bw, int lane) {
-  const uint32_t laneA = (uint32_t)(lane >> 4) * 16 + ((uint32_t)(lane & 15) ^ ((uint32_t)bw << 2));   // rows pre-swizzled, see mfma_load
-  const uint4* __restrict__ cU = ctrd2 + (size_t)m0 * 512;                                             // 8 KB per sub-space
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const uint4 v = (cU + i * 64)[laneA];
-    o.a[i] = __builtin_bit_cast(bf16x8, v);
-  }
-}
-// split the raw activations: k-slices 0 and 2 take the leading part x1 = bf16(x), slices 1 and 3 the remainder
-// x2 = bf16(x - x1); dims the sub-space does not have (and whole sub-spaces past the end) contribute zero
-__device__ __forceinline__ void bf_convert(BfSet& o, const float (&x)[2][8], int dsel, int lane) {
-  const bool second = (lane >> 4) & 1;
-#pragma unroll
-  for (int it = 0; it < 2; ++it) {
-    bf16x8 r;
-#pragma unroll
-    for (int d = 0; d < 8; ++d) {
-      const float v = (d < dsel) ? x[it][d] : 0.0f;
-      const float lead = (float)(__bf16)v;
-      r[d] = (__bf16)(second ? __fsub_rn(v, lead) : v);
-    }
-    o.b[it] = r;
-  }
-}
-template <int BUF, int N>
-__device__ __forceinline__ void bf_pair(BfSet& o, f32x4& pa, f32x4& pb, int bw) {
-  constexpr int it = (N < 8 ? N : 0) / 4, i = 2 * ((N < 8 ? N : 0) % 4);
-  constexpr int pit = (N > 0 ? N - 1 : 0) / 4, pi = 2 * ((N > 0 ? N - 1 : 0) % 4);
-  const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
-  const uint32_t m0v = (uint32_t)BUF * STAGE_BYTES + (uint32_t)(2 * bw + pit) * TILEB;
-  f32x4 ca = zero, cb = zero;
-  __builtin_amdgcn_sched_barrier(0);
-  if (N < 8) ca = __builtin_amdgcn_mfma_f32_16x16x32_bf16(o.a[i], o.b[it], zero, 0, 0, 0);
-  __builtin_amdgcn_sched_barrier(0);
-  if (N > 0) store_tile_lo<pi>(pa, m0v);
-  __builtin_amdgcn_sched_barrier(0);
-  if (N > 0) store_tile_hi<pi>(pa, m0v);
-  __builtin_amdgcn_sched_barrier(0);
-  if (N < 8) cb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(o.a[i + 1], o.b[it], zero, 0, 0, 0);
-  __builtin_amdgcn_sched_barrier(0);
-  if (N > 0) store_tile_lo<pi + 1>(pb, m0v);
-  __builtin_amdgcn_sched_barrier(0);
-  if (N > 0) store_tile_hi<pi + 1>(pb, m0v);
-  __builtin_amdgcn_sched_barrier(0);
-  pa = ca; pb = cb;
-}
-template <int BUF>
-__device__ __forceinline__ void bf_store(BfSet& o, int bw) {
-  f32x4 pa = {0.0f, 0.0f, 0.0f, 0.0f}, pb = pa;
-  bf_pair<BUF, 0>(o, pa, pb, bw); bf_pair<BUF, 1>(o, pa, pb, bw); bf_pair<BUF, 2>(o, pa, pb, bw);
-  bf_pair<BUF, 3>(o, pa, pb, bw); bf_pair<BUF, 4>(o, pa, pb, bw); bf_pair<BUF, 5>(o, pa, pb, bw);
-  bf_pair<BUF, 6>(o, pa, pb, bw); bf_pair<BUF, 7>(o, pa, pb, bw); bf_pair<BUF, 8>(o, pa, pb, bw);
-}
 
 // ------------------------------------------------------------------------------------------------
 // conv.  Workgroup = 16 waves = one 128-image panel x a TH x TW tile of output positions x 12*CPW output
@@ -732,7 +653,6 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
   constexpr int HC = CPW / 2;
   constexpr int DW = idx_dwords(CPW);
   constexpr int KTT = KT > 0 ? KT : 1;
-  static_assert(KS != 3 || KT == 8, "the bf16-pair builder exists for K = 128");
   const int lane = threadIdx.x & 63;
   const int wave = uni(threadIdx.x >> 6);
   // blockIdx.x = tile rank (heaviest first) * panels + panel for the tiles a single workgroup runs from end to end; the
@@ -802,58 +722,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
     const XAddr xa = p.srcNchw ? xaddr_nchw(bw, lane, (p.panel0 + panel) * PANEL, p.nImages, (uint32_t)p.Cin * p.H * p.W * 4u,
                                             (uint32_t)p.H * p.W * 4u, Cg)
                                : xaddr_panel(bw, lane);
-    if constexpr (KS == 3) {
-      // bf16-pair builder (K = 128, one sub-space of up to 8 dims per stage).  Per stage period: issue the raw
-      // activation loads of the stage after next, multiply the next stage out of one operand set, refill that set's
-      // code-book tiles, split the (long landed) activations into it.
-      const uint4* __restrict__ c2 = reinterpret_cast<const uint4*>(p.ctrd2);
-      BfSet sa, sb;
-      float raw[2][8];
-      StagePos q1 = next_pos(first, g);
-      StagePos q2 = next_pos(q1, g);
-      auto dselOf = [&](const StagePos& q) { return min(Cg - q.mg * Cs, Cs); };
-      auto clampPos = [&](const StagePos& q, int idx) { return (idx < S) ? q : first; };   // stages past the end re-fetch the first
-      bf_load_a(sa, c2, first.mg, bw, lane);
-      bf_issue_x(raw, xbase, pixel_off(first, g), Cs, first.mg, bw, lane);
-      bf_convert(sa, raw, dselOf(first), lane);
-      bf_store<0>(sa, bw);
-      {
-        const StagePos qa = clampPos(q1, 1), qb = clampPos(q2, 2);
-        bf_load_a(sa, c2, qa.mg, bw, lane);
-        bf_issue_x(raw, xbase, pixel_off(qa, g), Cs, qa.mg, bw, lane);
-        bf_convert(sa, raw, dselOf(qa), lane);
-        bf_load_a(sb, c2, qb.mg, bw, lane);
-        bf_issue_x(raw, xbase, pixel_off(qb, g), Cs, qb.mg, bw, lane);
-        bf_convert(sb, raw, dselOf(qb), lane);
-      }
-      StagePos q3 = next_pos(q2, g);
-      barrier_after_lds_writes();
-      for (int s = 0; s < Sp; s += 2) {
-        {                                                // stage s+1 -> buffer 1 from set A; set A then receives stage s+3
-          const StagePos qf = clampPos(q3, s + 3);
-          bf_issue_x(raw, xbase, pixel_off(qf, g), Cs, qf.mg, bw, lane);
-          bf_store<1>(sa, bw);
-          bf_load_a(sa, c2, qf.mg, bw, lane);
-          bf_convert(sa, raw, dselOf(qf), lane);
-        }
-        TR_ARRIVE(s);
-        barrier_after_lds_writes();
-        TR_LEAVE(s);
-        q1 = q2; q2 = q3; q3 = next_pos(q3, g);
-        {                                                // stage s+2 -> buffer 0 from set B; set B then receives stage s+4
-          const StagePos qf = clampPos(q3, s + 4);
-          bf_issue_x(raw, xbase, pixel_off(qf, g), Cs, qf.mg, bw, lane);
-          bf_store<0>(sb, bw);
-          bf_load_a(sb, c2, qf.mg, bw, lane);
-          bf_convert(sb, raw, dselOf(qf), lane);
-        }
-        TR_ARRIVE(s + 1);
-        barrier_after_lds_writes();
-        TR_LEAVE(s + 1);
-        q1 = q2; q2 = q3; q3 = next_pos(q3, g);
-      }
-      return;
-    } else {
+    {
     // Two operand sets: while stage s+1 is multiplied out of one, the other one already holds (or is
     // receiving) stage s+2, and the loads of stage s+3 are issued as soon as the first is consumed, so
     // an operand fetch has a whole stage period to land.
@@ -1547,8 +1416,6 @@ __global__ __launch_bounds__(256) void k_conv_sum(const f32x4* __restrict__ part
 
 template <int TH, int TW, int CPW>
 hipError_t launch_conv(const ConvParams& p, const QkSlots& sl, int lutMode, hipStream_t st) {
-  const bool bf16Pairs = lutMode == 3;
-  if (lutMode == 3) lutMode = 1;
   const int tilesX = (p.Wo + TW - 1) / TW, tilesY = (p.Ho + TH - 1) / TH;
   const int tiles = tilesX * tilesY;
   const bool split = p.splitZ > 1 && p.splitFrom >= 0 && p.splitFrom < tiles && p.partial != nullptr;
@@ -1564,7 +1431,6 @@ hipError_t launch_conv(const ConvParams& p, const QkSlots& sl, int lutMode, hipS
   if (lutMode == 1 && p.K == 64) kern = two ? k_conv_aprx<TH, TW, CPW, 4, 2> : k_conv_aprx<TH, TW, CPW, 4, 1>;
   if (lutMode == 1 && p.K == 32) kern = two ? k_conv_aprx<TH, TW, CPW, 2, 2> : k_conv_aprx<TH, TW, CPW, 2, 1>;
   if (lutMode == 1 && p.K == 16) kern = two ? k_conv_aprx<TH, TW, CPW, 1, 2> : k_conv_aprx<TH, TW, CPW, 1, 1>;
-  if (bf16Pairs && p.K == 128 && two && p.ctrd2 != nullptr) kern = k_conv_aprx<TH, TW, CPW, 8, 3>;
   hipError_t e = allow_big_lds(reinterpret_cast<const void*>(kern), (int)shm);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, grid, dim3(NW * 64), shm, st, q, tilesX, tilesY, sl.chunks, G, sl.rowStride);
@@ -1580,12 +1446,10 @@ hipError_t launch_conv(const ConvParams& p, const QkSlots& sl, int lutMode, hipS
 // sliding variant: grid.x = (segments x output columns, longest segments first) x panels
 template <int NC, int NS, int CPW>
 hipError_t launch_conv_slide(const ConvParams& p, const QkSlots& sl, int lutMode, hipStream_t st) {
-  const bool bf16Pairs = lutMode == 3;
   const dim3 grid((unsigned)(p.nSeg * ((p.Wo + NC - 1) / NC) * p.panels), sl.chunks * p.grp, 1);
   const size_t shm = (size_t)2 * STAGE_BYTES + 2 * IDX_BUF;
   const bool two = min(p.Cin / p.grp, p.Cs) > 4;
   auto kern = two ? k_conv_aprx<NC, NS, CPW, 8, 2, true> : k_conv_aprx<NC, NS, CPW, 8, 1, true>;
-  if (bf16Pairs && two && p.ctrd2 != nullptr) kern = k_conv_aprx<NC, NS, CPW, 8, 3, true>;
   hipError_t e = allow_big_lds(reinterpret_cast<const void*>(kern), (int)shm);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, grid, dim3(NW * 64), shm, st, p, 0, 0, sl.chunks, 1, sl.rowStride);
@@ -1683,7 +1547,6 @@ hipError_t qk_conv_aprx(const ConvParams& pIn, int lutMode, hipStream_t st) {
   ConvParams p = pIn;
   p.lutF16 = (lutMode == 2) ? 1 : 0;
   if (lutMode == 2) lutMode = 1;
-  if (lutMode != 3) p.ctrd2 = nullptr;
   const int Ctg = p.Ct / p.grp;
   if (Ctg % 2 || p.Cs > QCNN_MAX_CS || p.K > QCNN_MAX_K) return hipErrorInvalidValue;
   const QkSlots sl = qk_conv_slots(Ctg, p.grp);
@@ -1868,13 +1731,15 @@ double qk_conv_plan_slide(ConvParams& p, double tileCost) {
   for (int s2 = ns; s2 * 4 < p.Ho; s2 += std::max(1, p.Ho / 12))                      // long + medium + short
     for (int s1 = s2 + std::max(1, p.Ho / 12); s1 + s2 < p.Ho - s1; s1 += std::max(1, p.Ho / 12))
       cands.push_back({0, p.Ho - s1 - s2, p.Ho - s2, p.Ho});
-  if (const char* e = getenv("QCNN_SLIDE_SEGS")) {           // experiments: exactly that many equal segments
+#ifdef QCNN_EXPERIMENT     // variant builds only (scripts/build_variant.sh -DQCNN_EXPERIMENT): exactly that many equal segments
+  if (const char* e = getenv("QCNN_SLIDE_SEGS")) {
     const int n = std::max(1, std::min(atoi(e), std::min(QK_MAX_SEGS, p.Ho / ns)));
     std::vector<int> b(n + 1);
     for (int i = 0; i <= n; ++i) b[i] = (int)(((long long)p.Ho * i + n - 1) / n);
     cands.assign(1, b);
     tileCost = 1e30;
   }
+#endif
   // sliding must beat the (split) tile launch — clearly (8 %) when it needs more channel chunks than the tile kernel: the
   // model does not see the uneven last chunk (VGG-16's 14 x 14 x 512 layers measured 5 % slower where it predicted a tie)
   double best = tileCost * (sc.sl.chunks > qk_conv_slots(Ctg, p.grp).chunks ? 0.92 : 1.0);
@@ -1910,7 +1775,7 @@ int qk_fc_channels_per_block(int Ct) { return NGW * qk_fc_slots(Ct).cpw; }
 hipError_t qk_fc_aprx(const FcParams& pIn, int lutMode, hipStream_t st) {
   FcParams p = pIn;
   p.lutF16 = (lutMode == 2) ? 1 : 0;
-  if (lutMode == 2 || lutMode == 3) lutMode = 1;     // the bf16-pair builder exists for conv layers only
+  if (lutMode == 2) lutMode = 1;
   if (p.Ct % 2 || p.Cs > QCNN_MAX_CS || p.K > QCNN_MAX_K || p.msplit < 1) return hipErrorInvalidValue;
   const QkSlots sl = qk_fc_slots(p.Ct);
   switch (sl.cpw) {

@@ -38,7 +38,8 @@
 #include <vector>
 
 #ifndef S8_VAR
-#define S8_VAR 0      // timing experiments only (scripts/variants_sym8.sh; results wrong): 1 no LUT stores, 2 no matrix instructions, 4 no look-ups
+#define S8_VAR 0      // compile-time, variant builds only (scripts/build_variant.sh -DS8_VAR=n, scripts/variants_sym8.sh; results wrong):
+                      // 1 no LUT stores, 2 no matrix instructions, 4 no look-ups.  0 = the production object: every `#if S8_VAR` below drops out
 #endif
 
 #ifdef S8_TRACE
@@ -774,12 +775,14 @@ double qk_conv_sym8_slide_plan(ConvParams& p, const Qk8Config& cf, double scale)
     cands.push_back(b);
   }
   for (int shortLen = ns; shortLen * 2 < p.Ho; shortLen += std::max(1, p.Ho / 16)) cands.push_back({0, p.Ho - shortLen, p.Ho});
-  if (const char* e = getenv("QCNN_SYM8_SEGS")) {            // experiments: exactly that many equal segments
+#ifdef QCNN_EXPERIMENT     // variant builds only (scripts/build_variant.sh -DQCNN_EXPERIMENT): exactly that many equal segments
+  if (const char* e = getenv("QCNN_SYM8_SEGS")) {
     const int n = std::max(1, std::min(atoi(e), std::min(QK_MAX_SEGS, p.Ho / ns)));
     std::vector<int> b(n + 1);
     for (int i = 0; i <= n; ++i) b[i] = (int)(((long long)p.Ho * i + n - 1) / n);
     cands.assign(1, b);
   }
+#endif
   double best = 0.0;
   std::vector<double> cu(256);
   for (const std::vector<int>& b : cands) {

@@ -661,34 +661,6 @@ def test_fp16_lut_tolerance_study(golden_alex_syn):
     assert agree >= 0.8
 
 
-@pytest.mark.parametrize("model,n_img", [("AlexNet", 2), ("VGG16", 1)])
-def test_bf16_pair_builder_within_tolerance(model, n_img):
-    """QCNN_OPT_LUT_MODE = 3: the conv layers with K = 128 and 8-dim sub-spaces build their tables with one
-    v_mfma_f32_16x16x32_bf16 per tile on operands split in two bf16 parts (opt-in).  Every feature map stays inside
-    the north-star tolerance (1e-4 relative, max-norm and l2) against the oracle; the measured errors are printed.
-    VGG-16 (13 such layers in a row) is the stress case."""
-    in_chw, layers, _, _ = topo.MODELS[model]
-    params = synth.make_params(in_chw, layers, seed=7)
-    imgs = synth.make_images(n_img, in_chw, seed=8)
-    orc = po.COracle(in_chw, layers)
-    orc.set_params(params)
-    orc.forward(imgs)
-    eng = make_engine(in_chw, layers, params, n_img, lut=capi.LUT_MFMA_BF16X2)     # (a study mode: always the panel kernels)
-    prob, top5 = eng.forward_host(imgs)
-    rows = []
-    for l in range(len(layers) + 1):
-        e_inf, e_l2 = rel_err(eng.layer_output(l, n_img), orc.fm(l))
-        rows.append((l, e_inf, e_l2))
-    print("%s, bf16-pair builder, relative error per feature map (max-norm / l2): " % model +
-          " ".join("fm%d=%.1e/%.1e" % r for r in rows if r[1] > 0))
-    assert max(r[1] for r in rows) > 2e-7                                      # the mode is really in use
-    for l, e_inf, e_l2 in rows:
-        assert e_inf <= TOL and e_l2 <= TOL, "%s fm[%d]: %g %g" % (model, l, e_inf, e_l2)
-    L = len(layers)
-    assert np.array_equal(top5, np.stack([orc.top5(orc.fm(L)[i]) for i in range(n_img)]))
-    eng.close()
-
-
 def test_result_does_not_depend_on_the_number_of_streams(golden_tiny):
     """QCNN_OPT_STREAMS cuts a forward into sub-batches of whole panels on concurrent HIP streams: same bits."""
     z = golden_tiny
@@ -845,6 +817,53 @@ def test_decoded_first_layer_geometries(cin, knl, stride, pad, ct):
         assert e_inf <= TOL and e_l2 <= TOL, "fm[%d] vs oracle: %g %g" % (l, e_inf, e_l2)
     eng.close()
 
+
+
+def test_nchw_in_place_input_at_the_very_end_of_an_allocation():
+    """k_conv_dec_nchw reads the caller's device buffer in place.  A batch that ends exactly where its hipMalloc'ed region
+    ends — 5 images (one image tile, eleven of its sixteen images past the batch), 130 (a ragged second panel whose eight
+    image tiles are all launched) and 16 (a full tile whose over-reading positions have no image behind them) — must be
+    classified without touching a byte past the region: every image index and every position of an item that holds the
+    last image is clamped inside the kernel (scalar offset and per lane), not left to the buffer's range check.  Results
+    against the oracle; a read past the region would be a GPU page fault (or garbage in a live lane)."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipFree.argtypes = [C.c_void_p]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    layers = [topo.conv(0, 11, 96, 1, 4), topo.relu(), topo.pool(0, 3, 2), topo.fcnt(40), topo.smax()]
+    in_chw = (3, 67, 71)
+    params = synth.make_params(in_chw, layers, seed=301)
+    rng = np.random.default_rng(302)
+    imgs = (rng.integers(0, 256, size=(130,) + in_chw).astype(np.float32) - 120.0)
+    orc = po.COracle(in_chw, layers)
+    orc.set_params(params)
+    eng = pkg("engine").QcnnEngine(0)
+    eng.set_option(capi.OPT_KEEP_ALL, 0)
+    eng.load_model(in_chw, layers, params, 130)
+    import torch
+    for n in (5, 16, 130):
+        nbytes = n * imgs[0].nbytes
+        region = (nbytes + (2 << 20) - 1) // (2 << 20) * (2 << 20)            # whole 2 MB pages: the batch ends where the region ends
+        base = C.c_void_p()
+        assert hip.hipMalloc(C.byref(base), region) == 0
+        dev = base.value + region - nbytes
+        x = np.ascontiguousarray(imgs[:n])
+        assert hip.hipMemcpy(C.c_void_p(dev), x.ctypes.data_as(C.c_void_p), nbytes, 1) == 0
+        prob_d = torch.empty((n, 40), dtype=torch.float32, device="cuda:0")
+        top5_d = torch.empty((n, 5), dtype=torch.int16, device="cuda:0")
+        eng.forward_dev(dev, n, prob_d.data_ptr(), top5_d.data_ptr())
+        eng.sync()
+        assert eng.layer_split(0) == (-3, 2)                                  # decoded, NCHW in place
+        prob = prob_d.cpu().numpy()
+        m = min(n, 3)
+        orc.forward(imgs[n - m:n])                                            # the batch's last images
+        e_inf, e_l2 = rel_err(prob[n - m:], orc.fm(len(layers)).reshape(m, -1))
+        assert e_inf <= TOL and e_l2 <= TOL, "n = %d: %g %g" % (n, e_inf, e_l2)
+        e_inf, e_l2 = rel_err(eng.layer_output_range(3, n - m, m), orc.fm(3))
+        assert e_inf <= TOL and e_l2 <= TOL, "n = %d pool map: %g %g" % (n, e_inf, e_l2)
+        assert hip.hipFree(base) == 0
+    eng.close()
 
 @pytest.mark.parametrize("cin,knl,stride,ct", [(3, 11, 4, 96), (3, 7, 2, 96), (1, 3, 1, 96), (4, 4, 2, 192), (2, 8, 3, 96), (2, 12, 5, 96)])
 def test_decoded_first_layer_reads_nchw_in_place(cin, knl, stride, ct):
