@@ -43,6 +43,11 @@ struct LayerShape {
                                                                // <= 4 dims (decKp > 0), FC layer with one-dim sub-spaces (decKp = -1); 0: not eligible
   bool hasDmap = false;
   bool loaded = false;
+  // QCNN_OPT_LUT_MODE = 2 (fp16 table storage): the eight-wave kernels' program tables with offsets into the fp16 table layout.
+  // Own allocations, built from the arena's assignment bytes when the mode first runs the layer (every rank of a group builds
+  // its own from the broadcast arena); dropped when the layer's parameters are uploaded again
+  uint16_t* prog8H = nullptr;
+  uint16_t* progF8H = nullptr;
   // conv: launch plans by launch geometry and options (panels, sub-batches, split / slide / sym, LUT mode, input in place):
   // sub-batches of unequal panel counts (3 panels over 2 streams) each keep theirs instead of evicting one another — a plan
   // is dozens of 256-CU list schedules on the host
@@ -255,7 +260,14 @@ int plan_arena(QcnnCtx* c) {
   return 0;
 }
 
+void drop_f16_programs(LayerShape& s) {
+  if (s.prog8H) (void)hipFree(s.prog8H);
+  if (s.progF8H) (void)hipFree(s.progF8H);
+  s.prog8H = nullptr; s.progF8H = nullptr;
+}
+
 void free_model(QcnnCtx* c) {
+  for (LayerShape& s : c->shapes) drop_f16_programs(s);
   for (float* p : c->fmBuf) if (p) (void)hipFree(p);
   c->fmBuf.clear();
   if (c->ownArena && c->arena) (void)hipFree(c->arena);
@@ -330,6 +342,32 @@ bool decoded_fc(const QcnnCtx* c, int l) {
   return c->decode && s.decKp < 0 && !s.dense && c->lutMode == 1 && c->layers[l].type == QCNN_FCNT;
 }
 
+// fp16 table storage: the layer's program table in the fp16 layout's offsets (first use; the build runs on `st`, in front of the
+// launch that reads it)
+int ensure_f16_program(QcnnCtx* c, int l, hipStream_t st) {
+  const QcnnLayerDesc& d = c->layers[l];
+  LayerShape& s = c->shapes[l];
+  const int Ct = c->dims[l + 1].c;
+  bool built = false;
+  if (d.type == QCNN_CONV && s.prog8Bytes && !s.prog8H) {
+    built = true;
+    HIP_TRY(c, hipMalloc(&s.prog8H, s.prog8Bytes + QCNN_ROWS_PAD));
+    HIP_TRY(c, hipMemsetAsync(s.prog8H, 0, s.prog8Bytes + QCNN_ROWS_PAD, st));
+    HIP_TRY(c, qk_build_program8(reinterpret_cast<const uint8_t*>(c->arena + s.offAsmt), s.prog8H, qk_conv_slots(Ct / d.grpCnt, d.grpCnt),
+                                 qk_conv_sym8_config(c->dims[l].c, d.grpCnt, Ct, s.M, s.Cs, s.K), Ct / d.grpCnt, d.grpCnt, d.knlSiz,
+                                 d.stride, s.M, st, 1));
+  }
+  if (d.type == QCNN_FCNT && s.progF8Bytes && !s.progF8H) {
+    HIP_TRY(c, hipMalloc(&s.progF8H, s.progF8Bytes + QCNN_ROWS_PAD));
+    HIP_TRY(c, hipMemsetAsync(s.progF8H, 0, s.progF8Bytes + QCNN_ROWS_PAD, st));
+    HIP_TRY(c, qk_build_program_fc8(reinterpret_cast<const uint8_t*>(c->arena + s.offAsmt), s.progF8H, qk_fc_slots(Ct), Ct, s.M, st, 1));
+  } else if (!built) {
+    return 0;
+  }
+  HIP_TRY(c, hipStreamSynchronize(st));       // once per layer: the other sub-batch streams of this forward read the table too
+  return 0;
+}
+
 int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bool fuseRelu, bool flatFcInput,
                  int p0, hipStream_t st, const float* inNchw = nullptr, int nImages = 0, int live = QCNN_PANEL,
                  bool small = false, int sub = 0, int nsub = 1) {
@@ -389,6 +427,16 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
       p.nSeg = 0; p.progS = s.progSBytes ? reinterpret_cast<const uint16_t*>(c->arena + s.offProgS) : nullptr;
       s.lastFrom = -1; s.lastZ = 1;
       e = small ? qk_conv_small(p, live, st) : hipErrorInvalidValue;
+      // fp16 table storage (QCNN_OPT_LUT_MODE = 2): the eight-wave tile kernel in its fp16 form wherever the layer's shape has one
+      // (K = 128, complete 4- / 8-dim sub-spaces, > 64 channels per group); QCNN_OPT_SYM8 = 0 keeps every layer in the 16-wave
+      // kernels, which round the same entries and keep them in f32 slots (same sums, same bits: the tests compare the two)
+      if (e == hipErrorInvalidValue && c->lutMode == 2 && c->sym8 && s.prog8Bytes && !inNchw) {
+        if (ensure_f16_program(c, l, st)) return 1;
+        p.progS = s.prog8H;
+        s.lastFrom = -7; s.lastZ = 1;                 // reported by qcnn_get_layer_split as (-7, 1)
+        e = qk_conv_sym8(p, st, 1);
+        break;
+      }
       if (e == hipErrorInvalidValue) {
         // A launch of a few hundred workgroups (one GPU's share of a sharded batch) splits the tail of its tiles over
         // several workgroups (qk_conv_plan).  MFMA builders only: the exact builder keeps the reference's summation order.
@@ -560,7 +608,8 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
       // k_fc_sym8: 768 channels per workgroup.  A launch of one or two panels stays with the 12-wave kernel's 384 (measured,
       // AlexNet fc6 / fc7 per 125 images: 0.092 / 0.053 against 0.108 / 0.070 ms; 250: 0.148 / 0.076 against 0.150 / 0.082; 500:
       // 0.304 / 0.135 against 0.259 / 0.129) — under QCNN_OPT_SPLIT only, whose results may depend on the batch size
-      const bool fc8 = s.progF8Bytes && c->sym8 && c->lutMode == 1 && !small && (c->sym8 >= 2 || !c->split || panels >= 3);
+      const bool fc8h = s.progF8Bytes && c->sym8 && c->lutMode == 2 && !small;      // fp16 table storage: always the eight-wave form
+      const bool fc8 = fc8h || (s.progF8Bytes && c->sym8 && c->lutMode == 1 && !small && (c->sym8 >= 2 || !c->split || panels >= 3));
       if (c->lutMode >= 1) {
         const int G = qcnn_stage_group(s.K);
         const int stages = (s.M + G - 1) / G;
@@ -607,8 +656,10 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
         const int stagesF = s.M / 4, per = (stagesF + p.msplit - 1) / p.msplit;
         p.msplit = (stagesF + per - 1) / per;
         if (p.msplit == 1) p.partial = nullptr;
-        s.lastFrom = -5; s.lastZ = p.msplit;            // reported by qcnn_get_layer_split as (-5, splits of the sub-space axis)
-        e = qk_fc_sym8(p, reinterpret_cast<const uint16_t*>(c->arena + s.offProgF8), reinterpret_cast<const float*>(c->arena + s.offCtrdF), st);
+        s.lastFrom = fc8h ? -7 : -5; s.lastZ = p.msplit;   // reported by qcnn_get_layer_split as (-5 / -7 fp16 tables, splits of the sub-space axis)
+        if (fc8h && ensure_f16_program(c, l, st)) return 1;
+        e = qk_fc_sym8(p, fc8h ? s.progF8H : reinterpret_cast<const uint16_t*>(c->arena + s.offProgF8),
+                       reinterpret_cast<const float*>(c->arena + s.offCtrdF), st, fc8h ? 1 : 0);
       } else {
         e = qk_fc_aprx(p, c->lutMode, st);
       }
@@ -1160,6 +1211,8 @@ int qcnn_model_set_layer_params(QcnnCtx* c, int layer, const float* bias, const 
   const QcnnLayerDesc& d = c->layers[layer];
   LayerShape& s = c->shapes[layer];
   if (s.K <= 0) return fail(c, "layer %d carries no quantised parameters", layer);
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  drop_f16_programs(s);
   const int Ct = c->dims[layer + 1].c;
   const int M = s.M, K = s.K;
   // PrepAsmtBuf: conv [Ct][kh][kw][M] -> [kh][kw][M][Ct] (:585-586); FC [Ct][M] -> [M][Ct] (:610-611).  Stored as
@@ -1196,6 +1249,8 @@ int qcnn_model_set_layer_params_cbn(QcnnCtx* c, int layer, const float* bias, co
   const QcnnLayerDesc& d = c->layers[layer];
   LayerShape& s = c->shapes[layer];
   if (s.K <= 0) return fail(c, "layer %d carries no parameters", layer);
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  drop_f16_programs(s);
   if (bits < 1 || bits > 8) return fail(c, "layer %d: %d bits per assignment (1..8 supported)", layer, bits);
   const int Ct = c->dims[layer + 1].c;
   const size_t taps = (d.type == QCNN_CONV) ? (size_t)d.knlSiz * d.knlSiz : 1;

@@ -160,24 +160,89 @@ __device__ __forceinline__ void ops8_store(const Ops8<KS>& o, uint32_t mA, uint3
   __builtin_amdgcn_sched_barrier(0);
 }
 
+// ---- fp16 table storage (QCNN_OPT_LUT_MODE = 2, BASELINE configs[4]).  A stage is 128 rows x 128 images x 2 B = 32 KB: row
+// slot s (the same slot numbering as the f32 table: qcnn_row_slot) starts at byte 256 s of the stage buffer, and the eight
+// bytes of image quad q (images 4q .. 4q + 3) sit at position q ^ (s & 15) of the row.  The product is taken TRANSPOSED
+// (A = the activations, B = the code words: the two operands of a 16x16x4 instruction have the same lane layout, so this
+// is the order of the arguments only — same products, same k order, the same f32 entries): a lane then holds four
+// CONSECUTIVE IMAGES of one code word, rounds them to fp16 (two v_cvt_pk_f16_f32, round to nearest even — the oracle's
+// qo_study_mode(1, 0) rounding) and stores them with ONE ds_write_b64 — the eight bytes a look-up lane reads with one
+// ds_read_b64.  Banks: the 16 lanes of a store group hold 16 different code words of a row tile, whose slots differ in
+// their low four bits, so the XOR spreads them over all 32 banks; the 32 lanes of a read group walk one row.
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+constexpr uint32_t ROW16B = 256u;                   // bytes of a table row of 128 fp16 entries
+// byte offset inside a stage buffer of (row tile 0 of the wave, image tile `it`, this lane's code word and image quad)
+__device__ __forceinline__ uint32_t st16_addr(int rt0, int it, uint32_t li, uint32_t lk, uint32_t sw) {
+  const uint32_t rr = li ^ (sw << 2);                                   // the row of a tile this lane's code-book operand holds
+  const uint32_t slotLow = ((rr & 3u) << 2) | (rr >> 2);                // qcnn_row_slot inside the tile
+  return ((uint32_t)rt0 * 16u + slotLow) * ROW16B + ((((uint32_t)it * 4u + lk) ^ slotLow) << 3);
+}
+template <int I>
+__device__ __forceinline__ void st16(char* lds, const f32x4& v, uint32_t adr) {
+  const f16x2 lo = __builtin_convertvector(f32x2{v[0], v[1]}, f16x2), hi = __builtin_convertvector(f32x2{v[2], v[3]}, f16x2);
+  *reinterpret_cast<uint2*>(lds + adr + I * 16 * (int)ROW16B) = uint2{__builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi)};
+}
+template <int KS>
+__device__ __forceinline__ f32x4 ops8_tile_t(const Ops8<KS>& o, int t, int i) {
+  const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+  f32x4 c = __builtin_amdgcn_mfma_f32_16x16x4f32(o.b[t][0], o.a[i][0], zero, 0, 0, 0);
+  if (KS > 1) c = __builtin_amdgcn_mfma_f32_16x16x4f32(o.b[t][KS - 1], o.a[i][KS - 1], c, 0, 0, 0);
+  return c;
+}
+// the wave's eight tiles -> fp16 stage buffer; aA / aB = st16_addr of its two image tiles (+ the buffer's base)
+template <int KS>
+__device__ __forceinline__ void ops8_store16(char* lds, const Ops8<KS>& o, uint32_t aA, uint32_t aB) {
+  const f32x4 v0 = ops8_tile_t<KS>(o, 0, 0);
+  const f32x4 v1 = ops8_tile_t<KS>(o, 0, 1);
+  __builtin_amdgcn_sched_barrier(0);
+  const f32x4 v2 = ops8_tile_t<KS>(o, 0, 2);
+  st16<0>(lds, v0, aA);
+  __builtin_amdgcn_sched_barrier(0);
+  const f32x4 v3 = ops8_tile_t<KS>(o, 0, 3);
+  st16<1>(lds, v1, aA);
+  __builtin_amdgcn_sched_barrier(0);
+  const f32x4 v4 = ops8_tile_t<KS>(o, 1, 0);
+  st16<2>(lds, v2, aA);
+  __builtin_amdgcn_sched_barrier(0);
+  const f32x4 v5 = ops8_tile_t<KS>(o, 1, 1);
+  st16<3>(lds, v3, aA);
+  __builtin_amdgcn_sched_barrier(0);
+  const f32x4 v6 = ops8_tile_t<KS>(o, 1, 2);
+  st16<0>(lds, v4, aB);
+  __builtin_amdgcn_sched_barrier(0);
+  const f32x4 v7 = ops8_tile_t<KS>(o, 1, 3);
+  st16<1>(lds, v5, aB);
+  __builtin_amdgcn_sched_barrier(0);
+  st16<2>(lds, v6, aB);
+  st16<3>(lds, v7, aB);
+  __builtin_amdgcn_sched_barrier(0);
+}
+
 // the 96 look-ups of this wave in stage `c`: NP positions x CPW channels, one pipelined asm statement per position (a
 // position that does not look at the stage's pixel is skipped inside it); blk = LDS byte address of the wave half's block
 // of the stage's program row ([position][CPW / 2] uint16)
-template <int CPW, int P>
+template <int CPW, int P, bool F16>
 __device__ __forceinline__ void gather8_pos(f32x2* acc, uint32_t blk, uint32_t stage, int ok) {
   constexpr int B = CPW / 8;
   static_assert(B == 2 || B == 3 || B == 4 || B == 6, "blocks per position");
-  if constexpr (B == 6) gpos6<P * CPW>(acc, blk, stage, ok);
-  else if constexpr (B == 4) gpos4<P * CPW>(acc, blk, stage, ok);
-  else if constexpr (B == 3) gpos3<P * CPW>(acc, blk, stage, ok);
-  else gpos2<P * CPW>(acc, blk, stage, ok);
+  if constexpr (F16) {                                   // fp16 table: ds_read_b64 + v_fma_mix_f32 (hpos*, same generator)
+    if constexpr (B == 6) hpos6<P * CPW>(acc, blk, stage, ok);
+    else if constexpr (B == 4) hpos4<P * CPW>(acc, blk, stage, ok);
+    else if constexpr (B == 3) hpos3<P * CPW>(acc, blk, stage, ok);
+    else hpos2<P * CPW>(acc, blk, stage, ok);
+  } else {
+    if constexpr (B == 6) gpos6<P * CPW>(acc, blk, stage, ok);
+    else if constexpr (B == 4) gpos4<P * CPW>(acc, blk, stage, ok);
+    else if constexpr (B == 3) gpos3<P * CPW>(acc, blk, stage, ok);
+    else gpos2<P * CPW>(acc, blk, stage, ok);
+  }
 }
-template <int TH, int TW, int CPW, int... Ps>
+template <int TH, int TW, int CPW, bool F16, int... Ps>
 __device__ __forceinline__ void gather8_all(f32x2 (&acc)[TH * TW][CPW], uint32_t blk, uint32_t stage, const int (&ok)[TH * TW],
                                             std::integer_sequence<int, Ps...>) {
-  (gather8_pos<CPW, Ps>(&acc[Ps][0], blk, stage, ok[Ps]), ...);
+  (gather8_pos<CPW, Ps, F16>(&acc[Ps][0], blk, stage, ok[Ps]), ...);
 }
-template <int TH, int TW, int CPW>
+template <int TH, int TW, int CPW, bool F16 = false>
 __device__ __forceinline__ void gather8(f32x2 (&acc)[TH * TW][CPW], uint32_t blk, const StagePos& c, int knl,
                                         const int (&rowStart)[TH], const int (&colStart)[TW], uint32_t stage, int live) {
   constexpr int NP = TH * TW;
@@ -192,7 +257,7 @@ __device__ __forceinline__ void gather8(f32x2 (&acc)[TH * TW][CPW], uint32_t blk
     for (int dx = 0; dx < TW; ++dx) ok[dy * TW + dx] = uni(rowOk & colOk[dx]);
   }
 #if !(S8_VAR & 4)
-  gather8_all<TH, TW, CPW>(acc, blk, stage, ok, std::make_integer_sequence<int, NP>{});
+  gather8_all<TH, TW, CPW, F16>(acc, blk, stage, ok, std::make_integer_sequence<int, NP>{});
 #endif
 }
 
@@ -203,7 +268,9 @@ __device__ __forceinline__ void gather8(f32x2 (&acc)[TH * TW][CPW], uint32_t blk
 // for a 3x3 / 1 layer with 192 or 256 channels per workgroup (2x2 / 1x3 tiles: 4 and 5), 2 with 128 channels (two columns),
 // 5 for a 5x5 / 1 layer with 128 (2x3 tile: 7).  Positions are [slot][column] — the tile kernel's [row][column] with a
 // slot's first source row (xq) in the place of a tile row's; program rows are indexed by the source row modulo TH * stride.
-template <int CPW, int TH, int TW, int KS, bool SLIDE = false>
+// F16: fp16 table storage (see st16_addr): 32 KB stages of 256-byte rows, ds_read_b64 look-ups, fp32 sums; the program rows then
+// hold (slot << 8) | ((slot & 15) << 3) instead of slot * 64 (k_build_program8 with f16 = 1)
+template <int CPW, int TH, int TW, int KS, bool SLIDE = false, bool F16 = false>
 __global__ __launch_bounds__(NW8 * 64) void k_conv_sym8(ConvParams p, int tilesX, int tilesY, int chunks) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   constexpr int NP = TH * TW, HC = CPW / 2;
@@ -250,7 +317,11 @@ __global__ __launch_bounds__(NW8 * 64) void k_conv_sym8(ConvParams p, int tilesX
   const uint32_t bLane = lk * XROWB + (uint32_t)it0 * 64 + li * 4;
   const char* __restrict__ xbase =
       reinterpret_cast<const char*>(p.src + ((size_t)panel * p.H * p.W * p.Cin + (size_t)grp * Cg) * PANEL);
-  const uint32_t mA0 = (uint32_t)it0 * TILEB + (uint32_t)rt0 * 1024u, mB0 = mA0 + TILEB;
+  const uint32_t mA0 = F16 ? st16_addr(rt0, it0, li, lk, (uint32_t)sw) : (uint32_t)it0 * TILEB + (uint32_t)rt0 * 1024u;
+  const uint32_t mB0 = F16 ? st16_addr(rt0, it0 + 1, li, lk, (uint32_t)sw) : mA0 + TILEB;
+  auto build = [&](const Ops8<KS>& o, uint32_t buf) {       // the wave's eight tiles of a stage -> stage buffer at byte `buf`
+    if constexpr (F16) ops8_store16<KS>(lds, o, mA0 + buf, mB0 + buf); else ops8_store<KS>(o, mA0 + buf, mB0 + buf);
+  };
   const int Cs = p.Cs;
 
   // ---- gather side: channels cw0 .. cw0 + CPW - 1 of the group for every position of the tile
@@ -258,7 +329,7 @@ __global__ __launch_bounds__(NW8 * 64) void k_conv_sym8(ConvParams p, int tilesX
   const int cw0 = (chunk * NW8 + wave) * CPW;
   const int activeI = in_range(cw0, Ctg);
   const int cl0 = cw0 + half * HC;
-  const uint32_t laneLds = (uint32_t)(quad >> 2) * TILEB | (uint32_t)(quad >> 3) * 64 | (uint32_t)(quad & 3) * 16;
+  const uint32_t laneLds = F16 ? (uint32_t)quad * 8u : ((uint32_t)(quad >> 2) * TILEB | (uint32_t)(quad >> 3) * 64 | (uint32_t)(quad & 3) * 16);
   f32x2 acc[NP][CPW];
   {
     const float* __restrict__ bp = p.bias + grp * Ctg + (activeI ? cl0 : 0);
@@ -337,7 +408,7 @@ __global__ __launch_bounds__(NW8 * 64) void k_conv_sym8(ConvParams p, int tilesX
   uint32_t rb0 = 0, rb1 = PROG8_BUF, rb2 = 2 * PROG8_BUF;     // buffers of stages s, s + 1, s + 2
   // prologue: stage 0 -> buffer 0; operands of stage 1; program rows of stages 0 and 1
   ops8_load<KS>(ops, xbase, pixel_off(c0, g), bLane, p.ctrd8, Cs, c0.mg, laneA, rt0);
-  ops8_store<KS>(ops, mA0, mB0);
+  build(ops, 0u);
   {
     const StagePos q = posOf(c1, 1);
     ops8_load<KS>(ops, xbase, pixel_off(q, g), bLane, p.ctrd8, Cs, q.mg, laneA, rt0);
@@ -350,7 +421,7 @@ __global__ __launch_bounds__(NW8 * 64) void k_conv_sym8(ConvParams p, int tilesX
     int liveEnd = 0;
     for (int s = 0; s < Sp; s += 2) {
       // ---- period s: stage s + 1 -> buffer 1, gather stage s out of buffer 0
-      ops8_store<KS>(ops, mA0 + STAGE_BYTES, mB0 + STAGE_BYTES);
+      build(ops, (uint32_t)STAGE_BYTES);
       S8_T(4, s);
       // program row of stage s + 2, AFTER the build (whose counted vmcnt waits would otherwise wait for this fresh transfer)
       // and BEFORE the operand loads (whose wait, a period later, then covers it)
@@ -363,7 +434,7 @@ __global__ __launch_bounds__(NW8 * 64) void k_conv_sym8(ConvParams p, int tilesX
       __builtin_amdgcn_sched_barrier(0);
       S8_T(1, s);
       if constexpr (SLIDE) column_end(cEnd, liveEnd);       // what the previous stage finished (its stores have this period to drain)
-      gather8<TH, TW, CPW>(acc, my_blk(wave, BLKB) + rb0, c0, p.knl, rowStart, colStart, laneLds, activeI);
+      gather8<TH, TW, CPW, F16>(acc, my_blk(wave, BLKB) + rb0, c0, p.knl, rowStart, colStart, laneLds, activeI);
       if constexpr (SLIDE) { cEnd = c0; liveEnd = activeI; }
       S8_T(2, s);
       c0 = c1; c1 = c2; c2 = next_pos(c2, g);
@@ -371,7 +442,7 @@ __global__ __launch_bounds__(NW8 * 64) void k_conv_sym8(ConvParams p, int tilesX
       barrier_after_lds_writes();
       S8_T(3, s);
       // ---- period s + 1: stage s + 2 -> buffer 0, gather stage s + 1 out of buffer 1
-      ops8_store<KS>(ops, mA0, mB0);
+      build(ops, 0u);
       S8_T(4, s + 1);
       if (is_wave0(wave)) idx_row_to_lds<ROWB>(rowOf(c2, s + 3), PROG8_LDS + rb2, lane_now());
       __builtin_amdgcn_sched_barrier(0);
@@ -382,7 +453,7 @@ __global__ __launch_bounds__(NW8 * 64) void k_conv_sym8(ConvParams p, int tilesX
       __builtin_amdgcn_sched_barrier(0);
       S8_T(1, s + 1);
       if constexpr (SLIDE) column_end(cEnd, liveEnd);
-      gather8<TH, TW, CPW>(acc, my_blk(wave, BLKB) + rb0, c0, p.knl, rowStart, colStart, laneLds | STAGE_BYTES, activeI & in_range(s + 1, S));
+      gather8<TH, TW, CPW, F16>(acc, my_blk(wave, BLKB) + rb0, c0, p.knl, rowStart, colStart, laneLds | STAGE_BYTES, activeI & in_range(s + 1, S));
       if constexpr (SLIDE) { cEnd = c0; liveEnd = activeI & in_range(s + 1, S); }
       S8_T(2, s + 1);
       c0 = c1; c1 = c2; c2 = next_pos(c2, g);
@@ -472,20 +543,60 @@ __device__ __forceinline__ void fc8_store(const FcOps8& o, uint32_t mA, uint32_t
   __builtin_amdgcn_sched_barrier(0);
 }
 
-// the look-ups of a stage: four sub-spaces x two halves of the wave's 96 channels, each the 24-read position statement of
-// k_conv_sym8 accumulating into the same registers
-__device__ __forceinline__ void fc8_gather(f32x2 (&acc)[FC8_CPW], uint32_t blk, uint32_t stageBase, int live) {
-  const int ok = uni(live);
-  gpos6<0 * FC8_SUBB>(&acc[0], blk, stageBase, ok);
-  gpos6<0 * FC8_SUBB + 48>(&acc[48], blk, stageBase, ok);
-  gpos6<1 * FC8_SUBB>(&acc[0], blk, stageBase, ok);
-  gpos6<1 * FC8_SUBB + 48>(&acc[48], blk, stageBase, ok);
-  gpos6<2 * FC8_SUBB>(&acc[0], blk, stageBase, ok);
-  gpos6<2 * FC8_SUBB + 48>(&acc[48], blk, stageBase, ok);
-  gpos6<3 * FC8_SUBB>(&acc[0], blk, stageBase, ok);
-  gpos6<3 * FC8_SUBB + 48>(&acc[48], blk, stageBase, ok);
+// fp16 table storage (see st16_addr): the same eight tiles, product transposed, one ds_write_b64 per tile
+__device__ __forceinline__ void fc8_store16(char* lds, const FcOps8& o, uint32_t aA, uint32_t aB) {
+  const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+  auto tile = [&](int t, int i) { return __builtin_amdgcn_mfma_f32_16x16x4f32(o.b[t][i >> 1], o.a[i], zero, 0, 0, 0); };
+  const f32x4 v0 = tile(0, 0), v1 = tile(0, 1), v2 = tile(0, 2);
+  __builtin_amdgcn_sched_barrier(0);
+  const f32x4 v3 = tile(0, 3);
+  st16<0>(lds, v0, aA);
+  __builtin_amdgcn_sched_barrier(0);
+  const f32x4 v4 = tile(1, 0);
+  st16<1>(lds, v1, aA);
+  __builtin_amdgcn_sched_barrier(0);
+  const f32x4 v5 = tile(1, 1);
+  st16<2>(lds, v2, aA);
+  __builtin_amdgcn_sched_barrier(0);
+  const f32x4 v6 = tile(1, 2);
+  st16<3>(lds, v3, aA);
+  __builtin_amdgcn_sched_barrier(0);
+  const f32x4 v7 = tile(1, 3);
+  st16<0>(lds, v4, aB);
+  __builtin_amdgcn_sched_barrier(0);
+  st16<1>(lds, v5, aB);
+  st16<2>(lds, v6, aB);
+  st16<3>(lds, v7, aB);
+  __builtin_amdgcn_sched_barrier(0);
 }
 
+// the look-ups of a stage: four sub-spaces x two halves of the wave's 96 channels, each the 24-read position statement of
+// k_conv_sym8 accumulating into the same registers
+template <bool F16>
+__device__ __forceinline__ void fc8_gather(f32x2 (&acc)[FC8_CPW], uint32_t blk, uint32_t stageBase, int live) {
+  const int ok = uni(live);
+  if constexpr (F16) {
+    hpos6<0 * FC8_SUBB>(&acc[0], blk, stageBase, ok);
+    hpos6<0 * FC8_SUBB + 48>(&acc[48], blk, stageBase, ok);
+    hpos6<1 * FC8_SUBB>(&acc[0], blk, stageBase, ok);
+    hpos6<1 * FC8_SUBB + 48>(&acc[48], blk, stageBase, ok);
+    hpos6<2 * FC8_SUBB>(&acc[0], blk, stageBase, ok);
+    hpos6<2 * FC8_SUBB + 48>(&acc[48], blk, stageBase, ok);
+    hpos6<3 * FC8_SUBB>(&acc[0], blk, stageBase, ok);
+    hpos6<3 * FC8_SUBB + 48>(&acc[48], blk, stageBase, ok);
+  } else {
+    gpos6<0 * FC8_SUBB>(&acc[0], blk, stageBase, ok);
+    gpos6<0 * FC8_SUBB + 48>(&acc[48], blk, stageBase, ok);
+    gpos6<1 * FC8_SUBB>(&acc[0], blk, stageBase, ok);
+    gpos6<1 * FC8_SUBB + 48>(&acc[48], blk, stageBase, ok);
+    gpos6<2 * FC8_SUBB>(&acc[0], blk, stageBase, ok);
+    gpos6<2 * FC8_SUBB + 48>(&acc[48], blk, stageBase, ok);
+    gpos6<3 * FC8_SUBB>(&acc[0], blk, stageBase, ok);
+    gpos6<3 * FC8_SUBB + 48>(&acc[48], blk, stageBase, ok);
+  }
+}
+
+template <bool F16>
 __global__ __launch_bounds__(NW8 * 64) void k_fc_sym8(FcParams p, const uint16_t* __restrict__ prog, const float* __restrict__ ctrdF,
                                                        int chunks, int stagesPerSplit) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -505,14 +616,18 @@ __global__ __launch_bounds__(NW8 * 64) void k_fc_sym8(FcParams p, const uint16_t
   const uint32_t laneA16 = (lk * 16 + (li ^ ((uint32_t)sw << 2))) * 16;
   const uint32_t bLane = lk * XROWB + (uint32_t)it0 * 64 + li * 4;
   const char* __restrict__ xbase = reinterpret_cast<const char*>(p.src + (size_t)panel * p.D * PANEL);
-  const uint32_t mA0 = (uint32_t)it0 * TILEB + (uint32_t)(h * 4) * 1024u, mB0 = mA0 + TILEB;
+  const uint32_t mA0 = F16 ? st16_addr(h * 4, it0, li, lk, (uint32_t)sw) : (uint32_t)it0 * TILEB + (uint32_t)(h * 4) * 1024u;
+  const uint32_t mB0 = F16 ? st16_addr(h * 4, it0 + 1, li, lk, (uint32_t)sw) : mA0 + TILEB;
+  auto build = [&](const FcOps8& o, uint32_t buf) {
+    if constexpr (F16) fc8_store16(lds, o, mA0 + buf, mB0 + buf); else fc8_store(o, mA0 + buf, mB0 + buf);
+  };
 
   // ---- gather side
   const int half = lane >> 5, quad = lane & 31;
   const int cw0 = (chunk * NW8 + wave) * FC8_CPW;
   const int activeI = in_range(cw0, p.Ct);
   const int cl0 = cw0 + half * HC;
-  const uint32_t laneLds = (uint32_t)(quad >> 2) * TILEB | (uint32_t)(quad >> 3) * 64 | (uint32_t)(quad & 3) * 16;
+  const uint32_t laneLds = F16 ? (uint32_t)quad * 8u : ((uint32_t)(quad >> 2) * TILEB | (uint32_t)(quad >> 3) * 64 | (uint32_t)(quad & 3) * 16);
   f32x2 acc[FC8_CPW];
 #pragma unroll
   for (int c = 0; c < FC8_CPW; ++c) acc[c] = f32x2{0.0f, 0.0f};
@@ -537,28 +652,28 @@ __global__ __launch_bounds__(NW8 * 64) void k_fc_sym8(FcParams p, const uint16_t
   FcOps8 ops;
   uint32_t rb0 = 0, rb1 = FC8_ROWBUF, rb2 = 2 * FC8_ROWBUF;
   fc8_load(ops, xbase, ctrdF, stageOf(0), stageOf(0) * 4 + 2 * h, bLane, laneA16, h);
-  fc8_store(ops, mA0, mB0);
+  build(ops, 0u);
   fc8_load(ops, xbase, ctrdF, stageOf(1), stageOf(1) * 4 + 2 * h, bLane, laneA16, h);
   dma_rows(stageOf(0), rb0);
   dma_rows(stageOf(1), rb1);
   barrier_after_lds_dma();
   for (int s = 0; s < Sp; s += 2) {
     // ---- period s: stage s + 1 -> buffer 1, gather stage s out of buffer 0
-    fc8_store(ops, mA0 + STAGE_BYTES, mB0 + STAGE_BYTES);
+    build(ops, (uint32_t)STAGE_BYTES);
     dma_rows(stageOf(s + 2), rb2);
     __builtin_amdgcn_sched_barrier(0);
     fc8_load(ops, xbase, ctrdF, stageOf(s + 2), stageOf(s + 2) * 4 + 2 * h, bLane, laneA16, h);
     __builtin_amdgcn_sched_barrier(0);
-    fc8_gather(acc, myBlk + rb0, laneLds, activeI);
+    fc8_gather<F16>(acc, myBlk + rb0, laneLds, activeI);
     { const uint32_t t = rb0; rb0 = rb1; rb1 = rb2; rb2 = t; }
     barrier_after_lds_writes();
     // ---- period s + 1: stage s + 2 -> buffer 0, gather stage s + 1 out of buffer 1
-    fc8_store(ops, mA0, mB0);
+    build(ops, 0u);
     dma_rows(stageOf(s + 3), rb2);
     __builtin_amdgcn_sched_barrier(0);
     fc8_load(ops, xbase, ctrdF, stageOf(s + 3), stageOf(s + 3) * 4 + 2 * h, bLane, laneA16, h);
     __builtin_amdgcn_sched_barrier(0);
-    fc8_gather(acc, myBlk + rb0, laneLds | STAGE_BYTES, activeI & in_range(s + 1, S));
+    fc8_gather<F16>(acc, myBlk + rb0, laneLds | STAGE_BYTES, activeI & in_range(s + 1, S));
     { const uint32_t t = rb0; rb0 = rb1; rb1 = rb2; rb2 = t; }
     barrier_after_lds_writes();
   }
@@ -580,8 +695,13 @@ __global__ __launch_bounds__(NW8 * 64) void k_fc_sym8(FcParams p, const uint16_t
 }
 
 // rows ([M][rowStride] slot bytes, FC QkSlots order) -> [M][chunks][8 waves][2 halves][48] pre-scaled uint16 offsets
+// offset of row slot `slot` as the look-up statements consume it: f32 table slot * 64 (inside an image tile), fp16 table the
+// row's byte offset with its XOR key in bits 3..6 (st16_addr)
+__device__ __forceinline__ uint16_t prog_entry(int slot, int f16) {
+  return f16 ? (uint16_t)((slot << 8) | ((slot & 15) << 3)) : (uint16_t)(slot * 64);
+}
 __global__ __launch_bounds__(256) void k_build_program_fc8(const uint8_t* __restrict__ rows, uint16_t* __restrict__ prog, QkSlots src,
-                                                           int Ct, int chunks, size_t n) {
+                                                           int Ct, int chunks, size_t n, int f16) {
   const int hc = FC8_CPW / 2, subU16 = chunks * NW8 * 2 * hc;
   for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
     const int r = (int)(e % (size_t)subU16), m = (int)(e / (size_t)subU16);
@@ -589,7 +709,7 @@ __global__ __launch_bounds__(256) void k_build_program_fc8(const uint8_t* __rest
     const int half = wh & 1, wave = (wh >> 1) % NW8, chunk = (wh >> 1) / NW8;
     const int ch = (chunk * NW8 + wave) * FC8_CPW + half * hc + j;
     const int at = ch < Ct ? qk_slot_entry(src, 0, ch) : -1;
-    prog[e] = at >= 0 ? (uint16_t)(rows[(size_t)m * src.rowStride + at] * 64) : (uint16_t)0;
+    prog[e] = at >= 0 ? prog_entry(rows[(size_t)m * src.rowStride + at], f16) : (uint16_t)0;
   }
 }
 
@@ -597,7 +717,7 @@ __global__ __launch_bounds__(256) void k_build_program_fc8(const uint8_t* __rest
 // holds per (group, channel chunk), wave and wave half ONE block [position][CPW / 2] of pre-scaled uint16 offsets (0 where
 // the position has no tap at that pixel or the channel does not exist).  One thread per uint16.
 __global__ __launch_bounds__(256) void k_build_program8(const uint8_t* __restrict__ rows, uint16_t* __restrict__ prog, QkSlots src,
-                                                        Qk8Config cf, int Ctg, int groups, int knl, int stride, int M, size_t n) {
+                                                        Qk8Config cf, int Ctg, int groups, int knl, int stride, int M, size_t n, int f16) {
   const int hc = cf.cpw / 2, np = cf.th * cf.tw;
   const int blkU16 = np * hc, rowU16 = groups * cf.chunks * NW8 * 2 * blkU16;
   const int rfW = (cf.tw - 1) * stride + knl;
@@ -620,20 +740,20 @@ __global__ __launch_bounds__(256) void k_build_program8(const uint8_t* __restric
     uint16_t v = 0;
     if (ch < Ctg && (unsigned)kh < (unsigned)knl && (unsigned)kw < (unsigned)knl) {
       const int at = qk_slot_entry(src, g, ch);
-      if (at >= 0) v = (uint16_t)(rows[(size_t)((kh * knl + kw) * M + m) * src.rowStride + at] * 64);
+      if (at >= 0) v = prog_entry(rows[(size_t)((kh * knl + kw) * M + m) * src.rowStride + at], f16);
     }
     prog[e] = v;
   }
 }
 
-template <int CPW, int TH, int TW, bool SLIDE = false>
+template <int CPW, int TH, int TW, bool SLIDE = false, bool F16 = false>
 hipError_t launch_sym8(const ConvParams& p, const Qk8Config& cf, hipStream_t st) {
   const int tilesX = (p.Wo + TW - 1) / TW, tilesY = (p.Ho + TH - 1) / TH;
   // SLIDE: grid.x = (segments x strips of TW output columns, longest segments first) x panels
   const dim3 grid((unsigned)((SLIDE ? p.nSeg * tilesX : tilesX * tilesY) * p.panels), (unsigned)(p.grp * cf.chunks), 1);
   const size_t shm = (size_t)2 * STAGE_BYTES + 3 * PROG8_BUF;
   const bool two = std::min(p.Cin / p.grp, p.Cs) > 4;
-  auto kern = two ? k_conv_sym8<CPW, TH, TW, 2, SLIDE> : k_conv_sym8<CPW, TH, TW, 1, SLIDE>;
+  auto kern = two ? k_conv_sym8<CPW, TH, TW, 2, SLIDE, F16> : k_conv_sym8<CPW, TH, TW, 1, SLIDE, F16>;
   hipError_t e = allow_big_lds(reinterpret_cast<const void*>(kern), (int)shm);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, grid, dim3(NW8 * 64), shm, st, p, tilesX, tilesY, cf.chunks);
@@ -669,11 +789,11 @@ size_t qk_conv_sym8_program_bytes(const Qk8Config& cf, int groups, int knl, int 
 }
 
 hipError_t qk_build_program8(const uint8_t* rows, uint16_t* prog, const QkSlots& src, const Qk8Config& cf, int Ctg, int groups,
-                             int knl, int stride, int M, hipStream_t st) {
+                             int knl, int stride, int M, hipStream_t st, int f16) {
   const size_t n = qk_conv_sym8_program_bytes(cf, groups, knl, stride, M) / sizeof(uint16_t);
   if (!n) return hipErrorInvalidValue;
   const int grid = (int)std::min<size_t>((n + 255) / 256, 8192);
-  hipLaunchKernelGGL(k_build_program8, dim3(grid), dim3(256), 0, st, rows, prog, src, cf, Ctg, groups, knl, stride, M, n);
+  hipLaunchKernelGGL(k_build_program8, dim3(grid), dim3(256), 0, st, rows, prog, src, cf, Ctg, groups, knl, stride, M, n, f16);
   return hipGetLastError();
 }
 
@@ -832,9 +952,19 @@ hipError_t qk_conv_sym8_slide(const ConvParams& p, hipStream_t st) {
   return hipErrorInvalidValue;
 }
 
-hipError_t qk_conv_sym8(const ConvParams& p, hipStream_t st) {
+// f16: the fp16-storage form (QCNN_OPT_LUT_MODE = 2); p.progS then is the program built with f16 = 1
+hipError_t qk_conv_sym8(const ConvParams& p, hipStream_t st, int f16) {
   const Qk8Config cf = qk_conv_sym8_config(p.Cin, p.grp, p.Ct, p.M, p.Cs, p.K);
   if (!cf.cpw || p.progS == nullptr || p.ctrd8 == nullptr || p.srcNchw) return hipErrorInvalidValue;
+  if (f16) {
+    switch (cf.cpw) {
+      case 48: return launch_sym8<48, 1, 2, false, true>(p, cf, st);
+      case 32: return launch_sym8<32, 1, 3, false, true>(p, cf, st);
+      case 24: return launch_sym8<24, 2, 2, false, true>(p, cf, st);
+      case 16: return launch_sym8<16, 2, 3, false, true>(p, cf, st);
+      default: return hipErrorInvalidValue;
+    }
+  }
   switch (cf.cpw) {
     case 48: return launch_sym8<48, 1, 2>(p, cf, st);
     case 32: return launch_sym8<32, 1, 3>(p, cf, st);
@@ -850,24 +980,25 @@ bool qk_fc_sym8_shape(int D, int Ct, int M, int Cs, int K) {
 int qk_fc_sym8_chunks(int Ct) { return (Ct + NW8 * FC8_CPW - 1) / (NW8 * FC8_CPW); }
 size_t qk_fc_sym8_program_bytes(int Ct, int M) { return (size_t)M * qk_fc_sym8_chunks(Ct) * FC8_SUBB; }
 
-hipError_t qk_build_program_fc8(const uint8_t* rows, uint16_t* prog, const QkSlots& src, int Ct, int M, hipStream_t st) {
+hipError_t qk_build_program_fc8(const uint8_t* rows, uint16_t* prog, const QkSlots& src, int Ct, int M, hipStream_t st, int f16) {
   const size_t n = qk_fc_sym8_program_bytes(Ct, M) / sizeof(uint16_t);
   const int grid = (int)std::min<size_t>((n + 255) / 256, 8192);
-  hipLaunchKernelGGL(k_build_program_fc8, dim3(grid), dim3(256), 0, st, rows, prog, src, Ct, qk_fc_sym8_chunks(Ct), n);
+  hipLaunchKernelGGL(k_build_program_fc8, dim3(grid), dim3(256), 0, st, rows, prog, src, Ct, qk_fc_sym8_chunks(Ct), n, f16);
   return hipGetLastError();
 }
 
 // p.msplit = workgroups along the sub-space axis (partial sums in p.partial when > 1, reduced by qk_sum_partials)
-hipError_t qk_fc_sym8(const FcParams& p, const uint16_t* prog, const float* ctrdF, hipStream_t st) {
+hipError_t qk_fc_sym8(const FcParams& p, const uint16_t* prog, const float* ctrdF, hipStream_t st, int f16) {
   if (!qk_fc_sym8_shape(p.D, p.Ct, p.M, p.Cs, p.K) || prog == nullptr || ctrdF == nullptr || p.msplit < 1) return hipErrorInvalidValue;
   const int stages = p.M / 4;
   const int per = (stages + p.msplit - 1) / p.msplit;
   const int splits = (stages + per - 1) / per;                 // every workgroup along z has at least one stage
   if (splits != p.msplit) return hipErrorInvalidValue;
   const size_t shm = (size_t)2 * STAGE_BYTES + 3 * FC8_ROWBUF;
-  hipError_t e = allow_big_lds(reinterpret_cast<const void*>(k_fc_sym8), (int)shm);
+  auto kern = f16 ? k_fc_sym8<true> : k_fc_sym8<false>;
+  hipError_t e = allow_big_lds(reinterpret_cast<const void*>(kern), (int)shm);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_fc_sym8, dim3((unsigned)qk_fc_sym8_chunks(p.Ct), (unsigned)p.panels, (unsigned)p.msplit), dim3(NW8 * 64), shm, st,
+  hipLaunchKernelGGL(kern, dim3((unsigned)qk_fc_sym8_chunks(p.Ct), (unsigned)p.panels, (unsigned)p.msplit), dim3(NW8 * 64), shm, st,
                      p, prog, ctrdF, qk_fc_sym8_chunks(p.Ct), per);
   return hipGetLastError();
 }

@@ -86,6 +86,78 @@ def emit(reads, RB, NSETS):
                                                    text, outs, imms, clob))
 
 
+def emit_f16(reads, RB, NSETS):
+    """The same position statement over an fp16 table (QCNN_OPT_LUT_MODE = 2, BASELINE configs[4]): a row is 256 bytes, a lane's
+    four images of a row are ONE ds_read_b64 (half the LDS cycles of the ds_read_b128 of the f32 table), and every half is
+    added to its fp32 sum by one v_fma_mix_f32 (sum + half * 1.0, rounded once: exactly the fp32 addition of the converted
+    value) — four per read where the f32 table takes two v_pk_add_f32.  Same pipeline: RB reads per block, NSETS sets of
+    two-register temporaries, counted waits from the simulated LDS queue."""
+    NB = reads // RB
+    NG = reads // 4
+    top = 256
+    set_base = [top - (NSETS - s) * RB * 2 for s in range(NSETS)]
+    slot_base = set_base[0] - 4
+    slots = [(slot_base, slot_base + 1), (slot_base + 2, slot_base + 3)]
+    L, issued = [], []
+    a = L.append
+
+    def wait_for(name):
+        n = len(issued) - 1 - issued.index(name)
+        a('s_waitcnt lgkmcnt(%d)' % n)
+
+    def fetch(g):
+        lo, hi = slots[g & 1]
+        a('ds_read_b64 v[%d:%d], %%[blk] offset:%%[i%d]' % (lo, hi, g))
+        issued.append('F%d' % g)
+
+    def accumulate(k):
+        base = set_base[k % NSETS]
+        for r in range(RB):
+            wait_for('R%d_%d' % (k, r))
+            c = 4 * (k * RB + r)
+            for e in range(4):
+                a('v_fma_mix_f32 %%[c%d], v%d, 1.0, %%[c%d] op_sel:[%d,0,0] op_sel_hi:[1,0,0]' % (c + e, base + 2 * r + (e >> 1), c + e, e & 1))
+
+    a('s_cmp_eq_u32 %[ok], 0')
+    a('s_cbranch_scc1 .Lhskip%=')
+    fetch(0)
+    if NG > 1:
+        fetch(1)
+    for k in range(NB):
+        base = set_base[k % NSETS]
+        first_read = k * RB
+        g = first_read // 4
+        if first_read % 4 == 0:
+            wait_for('F%d' % g)
+        for r in range(RB):
+            q = (first_read + r) % 4
+            src = slots[g & 1][q >> 1]
+            a('v_xor_b32_sdwa v%d, v%d, %%[b] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_%d src1_sel:DWORD'
+              % (base + 2 * r, src, q & 1))
+        for r in range(RB):
+            a('ds_read_b64 v[%d:%d], v%d' % (base + 2 * r, base + 2 * r + 1, base + 2 * r))
+            issued.append('R%d_%d' % (k, r))
+        if (first_read + RB) % 4 == 0 and g + 2 < NG:
+            fetch(g + 2)
+        if k >= NSETS - 1:
+            accumulate(k - (NSETS - 1))
+    for k in range(max(0, NB - (NSETS - 1)), NB):
+        accumulate(k)
+    text = "".join('               "%s\\n\\t"\n' % s for s in L) + '               ".Lhskip%=:"\n'
+    outs = ", ".join('[c%d] "+v"(acc[%d].%s)' % (i, i // 2, "xy"[i & 1]) for i in range(4 * reads))
+    imms = ", ".join('[i%d] "n"(IMM0 + %d)' % (g, 8 * g) for g in range(NG))
+    clob = ", ".join('"v%d"' % r for r in range(slot_base, 256))
+    return ('// fp16 table: %d reads = %d look-ups of one position (blocks of %d ds_read_b64, %d sets of temporaries v[%d:255], offset\n'
+            '// slots v[%d:%d]); acc[2j], acc[2j+1] = the four images of channel j of the lane half (fp32 sums)\n'
+            'template <int IMM0>\n'
+            '__device__ __forceinline__ void hpos%d(f32x2* acc, uint32_t blk, uint32_t base, int valid) {\n'
+            '  asm volatile(\n%s'
+            '               : %s\n'
+            '               : [blk] "v"(blk), [b] "v"(base), [ok] "s"(valid), %s\n'
+            '               : "scc", %s);\n}\n' % (reads, 2 * reads, RB, NSETS, set_base[0], slot_base, slot_base + 3, reads // 4,
+                                                   text, outs, imms, clob))
+
+
 def main():
     RB = int(sys.argv[1]) if len(sys.argv) > 1 else 2
     NSETS = int(sys.argv[2]) if len(sys.argv) > 2 else 3
@@ -93,6 +165,8 @@ def main():
     print('#ifndef QCNN_SYM8_GATHER_H_\n#define QCNN_SYM8_GATHER_H_\n')
     for reads in (8, 12, 16, 24):        # CPW = 16, 24, 32, 48 -> gpos2, gpos3, gpos4, gpos6 (named by CPW / 8)
         print(emit(reads, RB, NSETS))
+    for reads in (8, 12, 16, 24):        # the same positions over an fp16 table -> hpos2, hpos3, hpos4, hpos6
+        print(emit_f16(reads, RB, NSETS))
     print('#endif  // QCNN_SYM8_GATHER_H_')
 
 

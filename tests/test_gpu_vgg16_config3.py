@@ -55,9 +55,19 @@ def test_vgg16_batch_1000_library_defaults_against_oracle_and_tile_kernels():
     imgs = synth.make_images(N, in_chw, seed=54)
     conv = [i for i, l in enumerate(layers) if l["type"] == topo.CONV]
 
+    import torch
+    x = torch.from_numpy(imgs).to("cuda:0")                     # device-resident like bench.py's batch: ONE launch per layer over
+    prob_d = torch.empty((N, 1000), dtype=torch.float32, device="cuda:0")   # all eight panels (a host batch would go through in
+    top5_d = torch.empty((N, 5), dtype=torch.int16, device="cuda:0")        # two-panel chunks, which the planner cuts differently)
+
+    def run(eng):
+        eng.forward_dev(x.data_ptr(), N, prob_d.data_ptr(), top5_d.data_ptr())
+        eng.sync()
+        return prob_d.cpu().numpy(), top5_d.cpu().numpy().view(np.uint16)
+
     # (a) library defaults at the measured batch size
     eng = _engine(in_chw, layers, params)
-    prob, top5 = eng.forward_host(imgs)
+    prob, top5 = run(eng)
     codes = {l: eng.layer_split(l)[0] for l in conv}
     # the kernels profiles/r5_vgg16 (and bench.py's vgg16 block) are made of: decoded first layer, the eight-wave sliding
     # form on every layer with >= 128 channels (-6); the 64-channel conv1_2 slides too (16-wave strips -2, or eight-wave -6)
@@ -87,7 +97,7 @@ def test_vgg16_batch_1000_library_defaults_against_oracle_and_tile_kernels():
     # (b) the families' contract: 16-wave tile kernels only (no eight-wave / sliding / symmetric / split kernels; the first
     # layer stays decoded, the FC layers keep their kernels) — same table entries in the same (kh, kw, m) order per output
     eng = _engine(in_chw, layers, params, OPT_SYM8=0, OPT_SLIDE=0, OPT_SYM=0, OPT_SPLIT=0)
-    eng.forward_host(imgs, want_prob=False, want_top5=False)
+    run(eng)
     assert all(eng.layer_split(l)[0] == -1 for l in conv[1:])
     tile = _maps(eng, L)
     eng.close()
