@@ -446,6 +446,7 @@ def main():
 
     extras = {}
     bf_prob = None
+    acc_prob = None
     dt_tab, snap_tab = None, None
     if args.extras and rank == 0 and world == 1:
         eng.set_option(capi.OPT_PROFILE, 0)
@@ -483,7 +484,21 @@ def main():
                                                 for i, m in enumerate(f16_ms) if m > 0 and layers[i]["type"] in (topo.CONV, topo.FCNT)},
                                       kernels=f16_split,
                                       note="fp16 table entries (round to nearest even), fp32 sums; kernels: qcnn_get_layer_split codes "
-                                           "(-7: fp16-storage form of the eight-wave kernels; others: entries rounded, f32 slots)")
+                                           "(-7: fp16-storage form of the eight-wave kernels, -8: with packed fp16 running sums and twice "
+                                           "the tile; others: entries rounded, f32 slots, fp32 sums)")
+            # ... and with the running sums in packed fp16 as well (QCNN_OPT_LUT_MODE = 3: twice the tile per wave)
+            eng.set_option(capi.OPT_LUT_MODE, capi.LUT_MFMA_F16ACC)
+            step()
+            extras["value_fp16_lut_fp16_sums"] = round(B * 3 / timed(torch, dev, step, 3), 2)
+            acc_prob = prob[: args.parity_images].cpu().numpy() if args.parity_images > 0 else None
+            eng.set_option(capi.OPT_PROFILE, 1)
+            eng.reset_layer_ms()
+            step(); step()
+            a_ms, _ = eng.layer_ms()
+            eng.set_option(capi.OPT_PROFILE, 0)
+            extras["fp16_lut"]["fp16_sums_layer_ms"] = {"%02d_%s" % (i, topo.TYPE_NAMES[layers[i]["type"]]): round(float(m), 4)
+                                                        for i, m in enumerate(a_ms) if m > 0 and layers[i]["type"] in (topo.CONV, topo.FCNT)}
+            extras["fp16_lut"]["fp16_sums_kernels"] = {str(i): list(eng.layer_split(i)) for i, l in enumerate(layers) if l["type"] in (topo.CONV, topo.FCNT)}
             eng.set_option(capi.OPT_LUT_MODE, capi.LUT_MFMA)
             step()
         # small batches: one image (the reference's own regime) and one 128-image panel (an 8-GPU shard of the batch)
@@ -622,6 +637,9 @@ def main():
                 ref = prob[lo:lo + bf_prob.shape[0]].cpu().numpy()
                 extras["fp16_lut"]["max_rel_diff_prob_vs_f32_tables"] = float(
                     max(np.abs(bf_prob[i] - ref[i]).max() / np.abs(ref[i]).max() for i in range(bf_prob.shape[0])))
+                if acc_prob is not None:
+                    extras["fp16_lut"]["fp16_sums_max_rel_diff_prob_vs_f32_tables"] = float(
+                        max(np.abs(acc_prob[i] - ref[i]).max() / np.abs(ref[i]).max() for i in range(acc_prob.shape[0])))
         if args.cpu_sample > 0 and world == 1:
             cb = cpu_baseline(kind, cpu, imgs[: args.cpu_sample].cpu().numpy(), params)
 

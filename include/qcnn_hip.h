@@ -69,7 +69,10 @@ enum {
                               rounded to fp16 when it is stored, sums stay fp32 — conv layers with K = 128 and complete
                               4- / 8-dim sub-spaces and FC layers with 32 code words of 4 dims keep half-size tables in
                               LDS (256-byte rows, ds_read_b64 look-ups: k_conv_sym8 / k_fc_sym8 in their fp16 form),
-                              every other layer rounds the entries and keeps them in f32 slots (same values) */
+                              every other layer rounds the entries and keeps them in f32 slots (same values); 3 = as 2 with the
+                              RUNNING SUMS of those layers in packed fp16 too (rounded after every addition; the accumulate
+                              half of the configs[4] study, 1e-2 territory): half the accumulator registers, so a
+                              workgroup's tile is twice as large and every source pixel's table is built a third less often */
   QCNN_OPT_KEEP_ALL = 1,   /* 1 = every layer writes its own feature map (layer-for-layer dumps, default);
                               0 = fast path: ReLU fused into the producing conv/FC epilogue, the first conv layer
                               reads the NCHW input in place, and an LRN layer followed by a 3x3 / stride 2 / pad 0

@@ -148,9 +148,10 @@ __device__ __forceinline__ void glds16(const char* row, uint32_t off, uint32_t l
 }
 template <int BYTES>
 __device__ __forceinline__ void idx_row_to_lds(const char* __restrict__ row, uint32_t ldsDst, int lane) {
-  static_assert(BYTES <= (int)IDX_BUF && BYTES % 16 == 0, "a workgroup row fits one buffer");
+  static_assert(BYTES <= 3072 && BYTES % 16 == 0, "a workgroup row fits one buffer (2 KB; 3 KB for the fp16-sum tiles of k_conv_sym8)");
   if (lane * 16 < BYTES) glds16(row, (uint32_t)lane * 16u, ldsDst);
   if (BYTES > 1024 && lane * 16 < BYTES - 1024) glds16(row, (uint32_t)lane * 16u + 1024u, ldsDst + 1024u);
+  if (BYTES > 2048 && lane * 16 < BYTES - 2048) glds16(row, (uint32_t)lane * 16u + 2048u, ldsDst + 2048u);
 }
 __device__ __forceinline__ void barrier_after_lds_dma() {
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");

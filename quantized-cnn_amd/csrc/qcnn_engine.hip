@@ -48,6 +48,7 @@ struct LayerShape {
   // its own from the broadcast arena); dropped when the layer's parameters are uploaded again
   uint16_t* prog8H = nullptr;
   uint16_t* progF8H = nullptr;
+  uint16_t* prog8A = nullptr;        // QCNN_OPT_LUT_MODE = 3 (fp16 sums too): the program of the twice-as-large tiles (qk_conv_sym8_config16)
   // conv: launch plans by launch geometry and options (panels, sub-batches, split / slide / sym, LUT mode, input in place):
   // sub-batches of unequal panel counts (3 panels over 2 streams) each keep theirs instead of evicting one another — a plan
   // is dozens of 256-CU list schedules on the host
@@ -263,7 +264,8 @@ int plan_arena(QcnnCtx* c) {
 void drop_f16_programs(LayerShape& s) {
   if (s.prog8H) (void)hipFree(s.prog8H);
   if (s.progF8H) (void)hipFree(s.progF8H);
-  s.prog8H = nullptr; s.progF8H = nullptr;
+  if (s.prog8A) (void)hipFree(s.prog8A);
+  s.prog8H = nullptr; s.progF8H = nullptr; s.prog8A = nullptr;
 }
 
 void free_model(QcnnCtx* c) {
@@ -349,7 +351,16 @@ int ensure_f16_program(QcnnCtx* c, int l, hipStream_t st) {
   LayerShape& s = c->shapes[l];
   const int Ct = c->dims[l + 1].c;
   bool built = false;
-  if (d.type == QCNN_CONV && s.prog8Bytes && !s.prog8H) {
+  if (d.type == QCNN_CONV && s.prog8Bytes && c->lutMode == 3 && !s.prog8A) {
+    built = true;
+    const Qk8Config cf = qk_conv_sym8_config16(c->dims[l].c, d.grpCnt, Ct, s.M, s.Cs, s.K);
+    const size_t bytes = qk_conv_sym8_program_bytes(cf, d.grpCnt, d.knlSiz, d.stride, s.M);
+    HIP_TRY(c, hipMalloc(&s.prog8A, bytes + QCNN_ROWS_PAD + 4096));
+    HIP_TRY(c, hipMemsetAsync(s.prog8A, 0, bytes + QCNN_ROWS_PAD + 4096, st));
+    HIP_TRY(c, qk_build_program8(reinterpret_cast<const uint8_t*>(c->arena + s.offAsmt), s.prog8A, qk_conv_slots(Ct / d.grpCnt, d.grpCnt),
+                                 cf, Ct / d.grpCnt, d.grpCnt, d.knlSiz, d.stride, s.M, st, 1));
+  }
+  if (d.type == QCNN_CONV && s.prog8Bytes && c->lutMode == 2 && !s.prog8H) {
     built = true;
     HIP_TRY(c, hipMalloc(&s.prog8H, s.prog8Bytes + QCNN_ROWS_PAD));
     HIP_TRY(c, hipMemsetAsync(s.prog8H, 0, s.prog8Bytes + QCNN_ROWS_PAD, st));
@@ -430,11 +441,13 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
       // fp16 table storage (QCNN_OPT_LUT_MODE = 2): the eight-wave tile kernel in its fp16 form wherever the layer's shape has one
       // (K = 128, complete 4- / 8-dim sub-spaces, > 64 channels per group); QCNN_OPT_SYM8 = 0 keeps every layer in the 16-wave
       // kernels, which round the same entries and keep them in f32 slots (same sums, same bits: the tests compare the two)
-      if (e == hipErrorInvalidValue && c->lutMode == 2 && c->sym8 && s.prog8Bytes && !inNchw) {
+      // QCNN_OPT_LUT_MODE = 3 keeps the running sums as packed fp16 as well (twice the tile per wave); layers without an fp16
+      // form round their entries and keep fp32 sums in both modes
+      if (e == hipErrorInvalidValue && c->lutMode >= 2 && c->sym8 && s.prog8Bytes && !inNchw) {
         if (ensure_f16_program(c, l, st)) return 1;
-        p.progS = s.prog8H;
-        s.lastFrom = -7; s.lastZ = 1;                 // reported by qcnn_get_layer_split as (-7, 1)
-        e = qk_conv_sym8(p, st, 1);
+        p.progS = c->lutMode == 3 ? s.prog8A : s.prog8H;
+        s.lastFrom = c->lutMode == 3 ? -8 : -7; s.lastZ = 1;   // reported by qcnn_get_layer_split as (-7 / -8 fp16 sums, 1)
+        e = qk_conv_sym8(p, st, c->lutMode == 3 ? 2 : 1);
         break;
       }
       if (e == hipErrorInvalidValue) {
@@ -608,7 +621,7 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
       // k_fc_sym8: 768 channels per workgroup.  A launch of one or two panels stays with the 12-wave kernel's 384 (measured,
       // AlexNet fc6 / fc7 per 125 images: 0.092 / 0.053 against 0.108 / 0.070 ms; 250: 0.148 / 0.076 against 0.150 / 0.082; 500:
       // 0.304 / 0.135 against 0.259 / 0.129) — under QCNN_OPT_SPLIT only, whose results may depend on the batch size
-      const bool fc8h = s.progF8Bytes && c->sym8 && c->lutMode == 2 && !small;      // fp16 table storage: always the eight-wave form
+      const bool fc8h = s.progF8Bytes && c->sym8 && c->lutMode >= 2 && !small;      // fp16 table storage (3: fp16 sums too): always the eight-wave form
       const bool fc8 = fc8h || (s.progF8Bytes && c->sym8 && c->lutMode == 1 && !small && (c->sym8 >= 2 || !c->split || panels >= 3));
       if (c->lutMode >= 1) {
         const int G = qcnn_stage_group(s.K);
@@ -656,10 +669,10 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
         const int stagesF = s.M / 4, per = (stagesF + p.msplit - 1) / p.msplit;
         p.msplit = (stagesF + per - 1) / per;
         if (p.msplit == 1) p.partial = nullptr;
-        s.lastFrom = fc8h ? -7 : -5; s.lastZ = p.msplit;   // reported by qcnn_get_layer_split as (-5 / -7 fp16 tables, splits of the sub-space axis)
+        s.lastFrom = fc8h ? (c->lutMode == 3 ? -8 : -7) : -5; s.lastZ = p.msplit;   // reported by qcnn_get_layer_split as (-5 / -7 fp16 tables / -8 fp16 sums, splits of the sub-space axis)
         if (fc8h && ensure_f16_program(c, l, st)) return 1;
         e = qk_fc_sym8(p, fc8h ? s.progF8H : reinterpret_cast<const uint16_t*>(c->arena + s.offProgF8),
-                       reinterpret_cast<const float*>(c->arena + s.offCtrdF), st, fc8h ? 1 : 0);
+                       reinterpret_cast<const float*>(c->arena + s.offCtrdF), st, fc8h ? (c->lutMode == 3 ? 2 : 1) : 0);
       } else {
         e = qk_fc_aprx(p, c->lutMode, st);
       }
@@ -911,7 +924,7 @@ int qcnn_ctx_destroy(QcnnCtx* c) {
 
 int qcnn_set_option(QcnnCtx* c, int option, int value) {
   switch (option) {
-    case QCNN_OPT_LUT_MODE: if (value < 0 || value > 2) return fail(c, "LUT mode must be 0 (exact), 1 (f32 MFMA) or 2 (fp16 table storage)"); c->lutMode = value; return 0;   // (part of the plan key)
+    case QCNN_OPT_LUT_MODE: if (value < 0 || value > 3) return fail(c, "LUT mode must be 0 (exact), 1 (f32 MFMA), 2 (fp16 table storage) or 3 (fp16 tables and fp16 sums)"); c->lutMode = value; return 0;   // (part of the plan key)
     case QCNN_OPT_KEEP_ALL: c->keepAll = value ? 1 : 0; return 0;
     case QCNN_OPT_PROFILE: c->profile = value ? 1 : 0; return 0;
     case QCNN_OPT_SMALL_BATCH: c->smallBatch = value ? 1 : 0; return 0;

@@ -229,7 +229,8 @@ size_t qk_conv_sym8_program_bytes(const Qk8Config& cf, int groups, int knl, int 
 hipError_t qk_build_program8(const uint8_t* rows, uint16_t* prog, const QkSlots& src, const Qk8Config& cf, int Ctg, int groups,
                              int knl, int stride, int M, hipStream_t st, int f16 = 0);   // f16: offsets into the fp16 table layout
 double qk_conv_sym8_cost(const ConvParams& p, const Qk8Config& cf, double stageFactor);
-hipError_t qk_conv_sym8(const ConvParams& p, hipStream_t st, int f16 = 0);   // f16: fp16 table storage, p.progS built with f16 = 1
+hipError_t qk_conv_sym8(const ConvParams& p, hipStream_t st, int mode = 0);   // mode 1: fp16 table storage, 2: + fp16 sums (p.progS built with f16 = 1)
+Qk8Config qk_conv_sym8_config16(int Cin, int grp, int Ct, int M, int Cs, int K);   // tiles of mode 2 (twice the positions)
 // The sliding form of the eight-wave kernel (k_conv_sym8<.., SLIDE>): config (cpw = 0: not eligible), segments + predicted
 // duration, launch.  Program table: qk_conv_sym8_program_bytes / qk_build_program8 with this config.
 Qk8Config qk_conv_sym8_slide_config(int Cin, int grp, int Ct, int M, int Cs, int K, int knl, int stride);
@@ -259,7 +260,7 @@ bool qk_fc_sym8_shape(int D, int Ct, int M, int Cs, int K);
 int qk_fc_sym8_chunks(int Ct);
 size_t qk_fc_sym8_program_bytes(int Ct, int M);
 hipError_t qk_build_program_fc8(const uint8_t* rows, uint16_t* prog, const QkSlots& src, int Ct, int M, hipStream_t st, int f16 = 0);
-hipError_t qk_fc_sym8(const FcParams& p, const uint16_t* prog, const float* ctrdF, hipStream_t st, int f16 = 0);
+hipError_t qk_fc_sym8(const FcParams& p, const uint16_t* prog, const float* ctrdF, hipStream_t st, int mode = 0);   // 1: fp16 tables, 2: + fp16 sums
 // position (in floats) inside ctrdF of code word k (0..31), dim d (0..3) of sub-space m: stage m / 4, row tile 2 (m % 4) + k / 16
 __host__ __device__ static inline size_t qk_ctrdf_index(int m, int d, int k) {
   const int stage = m >> 2, rt = 2 * (m & 3) + (k >> 4), h = rt >> 2, i = rt & 3, li = k & 15;

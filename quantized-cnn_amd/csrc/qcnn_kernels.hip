@@ -1545,8 +1545,8 @@ double qk_conv_sym_cost(const ConvParams& p) {
 
 hipError_t qk_conv_aprx(const ConvParams& pIn, int lutMode, hipStream_t st) {
   ConvParams p = pIn;
-  p.lutF16 = (lutMode == 2) ? 1 : 0;
-  if (lutMode == 2) lutMode = 1;
+  p.lutF16 = (lutMode >= 2) ? 1 : 0;        // 2, 3: entries rounded to fp16, kept in f32 slots, fp32 sums (layers without an fp16 form)
+  if (lutMode >= 2) lutMode = 1;
   const int Ctg = p.Ct / p.grp;
   if (Ctg % 2 || p.Cs > QCNN_MAX_CS || p.K > QCNN_MAX_K) return hipErrorInvalidValue;
   const QkSlots sl = qk_conv_slots(Ctg, p.grp);
@@ -1774,8 +1774,8 @@ int qk_fc_channels_per_block(int Ct) { return NGW * qk_fc_slots(Ct).cpw; }
 // p.msplit is chosen by the caller (engine): 1 keeps the reference's summation order.
 hipError_t qk_fc_aprx(const FcParams& pIn, int lutMode, hipStream_t st) {
   FcParams p = pIn;
-  p.lutF16 = (lutMode == 2) ? 1 : 0;
-  if (lutMode == 2) lutMode = 1;
+  p.lutF16 = (lutMode >= 2) ? 1 : 0;
+  if (lutMode >= 2) lutMode = 1;
   if (p.Ct % 2 || p.Cs > QCNN_MAX_CS || p.K > QCNN_MAX_K || p.msplit < 1) return hipErrorInvalidValue;
   const QkSlots sl = qk_fc_slots(p.Ct);
   switch (sl.cpw) {

@@ -221,11 +221,17 @@ __device__ __forceinline__ void ops8_store16(char* lds, const Ops8<KS>& o, uint3
 // the 96 look-ups of this wave in stage `c`: NP positions x CPW channels, one pipelined asm statement per position (a
 // position that does not look at the stage's pixel is skipped inside it); blk = LDS byte address of the wave half's block
 // of the stage's program row ([position][CPW / 2] uint16)
-template <int CPW, int P, bool F16>
-__device__ __forceinline__ void gather8_pos(f32x2* acc, uint32_t blk, uint32_t stage, int ok) {
+// MODE: 0 = f32 table, f32 sums (gpos*); 1 = fp16 table, f32 sums (hpos*); 2 = fp16 table, packed fp16 sums (apos*: AccT = uint32_t)
+template <int CPW, int P, int MODE, typename AccT>
+__device__ __forceinline__ void gather8_pos(AccT* acc, uint32_t blk, uint32_t stage, int ok) {
   constexpr int B = CPW / 8;
   static_assert(B == 2 || B == 3 || B == 4 || B == 6, "blocks per position");
-  if constexpr (F16) {                                   // fp16 table: ds_read_b64 + v_fma_mix_f32 (hpos*, same generator)
+  if constexpr (MODE == 2) {                             // fp16 table, fp16 sums: ds_read_b64 + two v_pk_add_f16
+    if constexpr (B == 6) apos6<P * CPW>(acc, blk, stage, ok);
+    else if constexpr (B == 4) apos4<P * CPW>(acc, blk, stage, ok);
+    else if constexpr (B == 3) apos3<P * CPW>(acc, blk, stage, ok);
+    else apos2<P * CPW>(acc, blk, stage, ok);
+  } else if constexpr (MODE == 1) {                      // fp16 table: ds_read_b64 + v_fma_mix_f32 (hpos*, same generator)
     if constexpr (B == 6) hpos6<P * CPW>(acc, blk, stage, ok);
     else if constexpr (B == 4) hpos4<P * CPW>(acc, blk, stage, ok);
     else if constexpr (B == 3) hpos3<P * CPW>(acc, blk, stage, ok);
@@ -237,13 +243,13 @@ __device__ __forceinline__ void gather8_pos(f32x2* acc, uint32_t blk, uint32_t s
     else gpos2<P * CPW>(acc, blk, stage, ok);
   }
 }
-template <int TH, int TW, int CPW, bool F16, int... Ps>
-__device__ __forceinline__ void gather8_all(f32x2 (&acc)[TH * TW][CPW], uint32_t blk, uint32_t stage, const int (&ok)[TH * TW],
+template <int TH, int TW, int CPW, int MODE, typename AccT, int... Ps>
+__device__ __forceinline__ void gather8_all(AccT (&acc)[TH * TW][CPW], uint32_t blk, uint32_t stage, const int (&ok)[TH * TW],
                                             std::integer_sequence<int, Ps...>) {
-  (gather8_pos<CPW, Ps, F16>(&acc[Ps][0], blk, stage, ok[Ps]), ...);
+  (gather8_pos<CPW, Ps, MODE, AccT>(&acc[Ps][0], blk, stage, ok[Ps]), ...);
 }
-template <int TH, int TW, int CPW, bool F16 = false>
-__device__ __forceinline__ void gather8(f32x2 (&acc)[TH * TW][CPW], uint32_t blk, const StagePos& c, int knl,
+template <int TH, int TW, int CPW, int MODE = 0, typename AccT = f32x2>
+__device__ __forceinline__ void gather8(AccT (&acc)[TH * TW][CPW], uint32_t blk, const StagePos& c, int knl,
                                         const int (&rowStart)[TH], const int (&colStart)[TW], uint32_t stage, int live) {
   constexpr int NP = TH * TW;
   int ok[NP];
@@ -257,8 +263,18 @@ __device__ __forceinline__ void gather8(f32x2 (&acc)[TH * TW][CPW], uint32_t blk
     for (int dx = 0; dx < TW; ++dx) ok[dy * TW + dx] = uni(rowOk & colOk[dx]);
   }
 #if !(S8_VAR & 4)
-  gather8_all<TH, TW, CPW, F16>(acc, blk, stage, ok, std::make_integer_sequence<int, NP>{});
+  gather8_all<TH, TW, CPW, MODE, AccT>(acc, blk, stage, ok, std::make_integer_sequence<int, NP>{});
 #endif
+}
+
+// packed fp16 sums: two copies of fp16(b) / the two halves back as floats
+__device__ __forceinline__ uint32_t pk16(float b) {
+  const f16x2 h = {(_Float16)b, (_Float16)b};
+  return __builtin_bit_cast(uint32_t, h);
+}
+__device__ __forceinline__ f32x2 unpk16(uint32_t w) {
+  const f16x2 h = __builtin_bit_cast(f16x2, w);
+  return f32x2{(float)h[0], (float)h[1]};
 }
 
 // SLIDE (the eight-wave form of k_conv_aprx<.., SLIDE>): the workgroup owns a SEGMENT of output rows of a strip of TW output
@@ -268,16 +284,22 @@ __device__ __forceinline__ void gather8(f32x2 (&acc)[TH * TW][CPW], uint32_t blk
 // for a 3x3 / 1 layer with 192 or 256 channels per workgroup (2x2 / 1x3 tiles: 4 and 5), 2 with 128 channels (two columns),
 // 5 for a 5x5 / 1 layer with 128 (2x3 tile: 7).  Positions are [slot][column] — the tile kernel's [row][column] with a
 // slot's first source row (xq) in the place of a tile row's; program rows are indexed by the source row modulo TH * stride.
-// F16: fp16 table storage (see st16_addr): 32 KB stages of 256-byte rows, ds_read_b64 look-ups, fp32 sums; the program rows then
-// hold (slot << 8) | ((slot & 15) << 3) instead of slot * 64 (k_build_program8 with f16 = 1)
-template <int CPW, int TH, int TW, int KS, bool SLIDE = false, bool F16 = false>
+// MODE 1, 2: fp16 table storage (see st16_addr): 32 KB stages of 256-byte rows, ds_read_b64 look-ups; the program rows then hold
+// (slot << 8) | ((slot & 15) << 3) instead of slot * 64 (k_build_program8 with f16 = 1).  MODE 1 keeps fp32 sums; MODE 2 keeps the
+// running sums as packed fp16 too (the accumulate half of the configs[4] study): half the accumulator registers, so a wave owns
+// 192 (position, channel) pairs — twice the tile, a third fewer table builds per output position
+template <int CPW, int TH, int TW, int KS, bool SLIDE = false, int MODE = 0>
 __global__ __launch_bounds__(NW8 * 64) void k_conv_sym8(ConvParams p, int tilesX, int tilesY, int chunks) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
+  constexpr bool F16 = MODE >= 1, ACC16 = MODE == 2;
+  using AccT = std::conditional_t<ACC16, uint32_t, f32x2>;
   constexpr int NP = TH * TW, HC = CPW / 2;
-  static_assert(CPW % 8 == 0 && NP * CPW <= 96 && (SLIDE || NP * CPW == 96),
-                "96 (position, channel) pairs of four images per lane = 192 accumulator registers");
+  constexpr int PAIRS = ACC16 ? 192 : 96;
+  static_assert(CPW % 8 == 0 && NP * CPW <= PAIRS && (SLIDE || NP * CPW == PAIRS) && !(SLIDE && ACC16),
+                "96 (position, channel) pairs of four images per lane (192 with packed fp16 sums) = 192 accumulator registers");
   constexpr int BLKB = NP * CPW;                       // bytes of a wave half's block of a program row ([NP][HC] uint16)
-  constexpr int ROWB = NW8 * 2 * BLKB;                 // bytes of the workgroup's program row of one entry (<= 1536)
+  constexpr int ROWB = NW8 * 2 * BLKB;                 // bytes of the workgroup's program row of one entry (<= 1536; 3072 with fp16 sums)
+  constexpr uint32_t PBUF = ROWB > (int)PROG8_BUF ? 3072u : PROG8_BUF;   // bytes of one of the three program-row buffers
   const int lane = threadIdx.x & 63;
   const int wave = uni(threadIdx.x >> 6);
   const int rank = (int)(blockIdx.x / (unsigned)p.panels), panel = (int)(blockIdx.x % (unsigned)p.panels);
@@ -330,14 +352,17 @@ __global__ __launch_bounds__(NW8 * 64) void k_conv_sym8(ConvParams p, int tilesX
   const int activeI = in_range(cw0, Ctg);
   const int cl0 = cw0 + half * HC;
   const uint32_t laneLds = F16 ? (uint32_t)quad * 8u : ((uint32_t)(quad >> 2) * TILEB | (uint32_t)(quad >> 3) * 64 | (uint32_t)(quad & 3) * 16);
-  f32x2 acc[NP][CPW];
+  AccT acc[NP][CPW];
   {
     const float* __restrict__ bp = p.bias + grp * Ctg + (activeI ? cl0 : 0);
 #pragma unroll
     for (int j = 0; j < HC; ++j) {
       const float b = bp[j];
 #pragma unroll
-      for (int q = 0; q < NP; ++q) { acc[q][2 * j] = f32x2{b, b}; acc[q][2 * j + 1] = f32x2{b, b}; }
+      for (int q = 0; q < NP; ++q) {
+        if constexpr (ACC16) { acc[q][2 * j] = pk16(b); acc[q][2 * j + 1] = pk16(b); }     // the start value rounded to fp16 too
+        else { acc[q][2 * j] = f32x2{b, b}; acc[q][2 * j + 1] = f32x2{b, b}; }
+      }
     }
   }
   // first source row of every tile row's (SLIDE: every slot's current) window, first source column of every tile column's;
@@ -363,6 +388,7 @@ __global__ __launch_bounds__(NW8 * 64) void k_conv_sym8(ConvParams p, int tilesX
   // SLIDE: after the last stage of a source row the positions whose window ends with this row (or with the strip) are stored
   // and their slot restarts from the bias for the output row TH further down
   auto column_end = [&](const StagePos& c, int live) {
+   if constexpr (!ACC16) {
     if (!(live && c.wi == g.wiU && c.mg == g.MG - 1)) return;
     // everything lane-dependent is re-derived HERE from an opaque copy of the lane index: hoisted out of the stage loop these
     // values cost the 96-pair instantiations ten spilled registers, reloaded in every stage period (measured +20 % per stage)
@@ -397,6 +423,7 @@ __global__ __launch_bounds__(NW8 * 64) void k_conv_sym8(ConvParams p, int tilesX
         rowStart[q] = (woq[q] <= hoL) ? rowStart[q] + TH * p.stride : -(1 << 28);
       }
     }
+   }
   };
   auto posOf = [&](const StagePos& q, int idx) { return (idx < S) ? q : first; };
   Ops8<KS> ops;
@@ -405,7 +432,7 @@ __global__ __launch_bounds__(NW8 * 64) void k_conv_sym8(ConvParams p, int tilesX
   StagePos c2 = next_pos(c1, g);
   // program rows: three LDS buffers, the row of stage t in buffer t % 3, fetched by LDS-DMA two periods before it is read —
   // wave 0 never waits for it at a barrier: it has landed when the operands loaded after it are consumed a period later
-  uint32_t rb0 = 0, rb1 = PROG8_BUF, rb2 = 2 * PROG8_BUF;     // buffers of stages s, s + 1, s + 2
+  uint32_t rb0 = 0, rb1 = PBUF, rb2 = 2 * PBUF;               // buffers of stages s, s + 1, s + 2
   // prologue: stage 0 -> buffer 0; operands of stage 1; program rows of stages 0 and 1
   ops8_load<KS>(ops, xbase, pixel_off(c0, g), bLane, p.ctrd8, Cs, c0.mg, laneA, rt0);
   build(ops, 0u);
@@ -434,7 +461,7 @@ __global__ __launch_bounds__(NW8 * 64) void k_conv_sym8(ConvParams p, int tilesX
       __builtin_amdgcn_sched_barrier(0);
       S8_T(1, s);
       if constexpr (SLIDE) column_end(cEnd, liveEnd);       // what the previous stage finished (its stores have this period to drain)
-      gather8<TH, TW, CPW, F16>(acc, my_blk(wave, BLKB) + rb0, c0, p.knl, rowStart, colStart, laneLds, activeI);
+      gather8<TH, TW, CPW, MODE, AccT>(acc, my_blk(wave, BLKB) + rb0, c0, p.knl, rowStart, colStart, laneLds, activeI);
       if constexpr (SLIDE) { cEnd = c0; liveEnd = activeI; }
       S8_T(2, s);
       c0 = c1; c1 = c2; c2 = next_pos(c2, g);
@@ -453,7 +480,7 @@ __global__ __launch_bounds__(NW8 * 64) void k_conv_sym8(ConvParams p, int tilesX
       __builtin_amdgcn_sched_barrier(0);
       S8_T(1, s + 1);
       if constexpr (SLIDE) column_end(cEnd, liveEnd);
-      gather8<TH, TW, CPW, F16>(acc, my_blk(wave, BLKB) + rb0, c0, p.knl, rowStart, colStart, laneLds | STAGE_BYTES, activeI & in_range(s + 1, S));
+      gather8<TH, TW, CPW, MODE, AccT>(acc, my_blk(wave, BLKB) + rb0, c0, p.knl, rowStart, colStart, laneLds | STAGE_BYTES, activeI & in_range(s + 1, S));
       if constexpr (SLIDE) { cEnd = c0; liveEnd = activeI & in_range(s + 1, S); }
       S8_T(2, s + 1);
       c0 = c1; c1 = c2; c2 = next_pos(c2, g);
@@ -473,7 +500,13 @@ __global__ __launch_bounds__(NW8 * 64) void k_conv_sym8(ConvParams p, int tilesX
           float* o = dst + ((size_t)(ho * p.Wo + wo) * p.Ct + grp * Ctg + cl0) * PANEL + 4 * quad;
 #pragma unroll
           for (int j = 0; j < HC; ++j) {
-            f32x4 v = {acc[q][2 * j].x, acc[q][2 * j].y, acc[q][2 * j + 1].x, acc[q][2 * j + 1].y};
+            f32x4 v;
+            if constexpr (ACC16) {
+              const f32x2 lo = unpk16(acc[q][2 * j]), hi = unpk16(acc[q][2 * j + 1]);
+              v = f32x4{lo.x, lo.y, hi.x, hi.y};
+            } else {
+              v = f32x4{acc[q][2 * j].x, acc[q][2 * j].y, acc[q][2 * j + 1].x, acc[q][2 * j + 1].y};
+            }
             if (p.relu) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[e] = (0.0f < v[e]) ? v[e] : 0.0f;
@@ -572,10 +605,19 @@ __device__ __forceinline__ void fc8_store16(char* lds, const FcOps8& o, uint32_t
 
 // the look-ups of a stage: four sub-spaces x two halves of the wave's 96 channels, each the 24-read position statement of
 // k_conv_sym8 accumulating into the same registers
-template <bool F16>
-__device__ __forceinline__ void fc8_gather(f32x2 (&acc)[FC8_CPW], uint32_t blk, uint32_t stageBase, int live) {
+template <int MODE, typename AccT>
+__device__ __forceinline__ void fc8_gather(AccT (&acc)[FC8_CPW], uint32_t blk, uint32_t stageBase, int live) {
   const int ok = uni(live);
-  if constexpr (F16) {
+  if constexpr (MODE == 2) {
+    apos6<0 * FC8_SUBB>(&acc[0], blk, stageBase, ok);
+    apos6<0 * FC8_SUBB + 48>(&acc[48], blk, stageBase, ok);
+    apos6<1 * FC8_SUBB>(&acc[0], blk, stageBase, ok);
+    apos6<1 * FC8_SUBB + 48>(&acc[48], blk, stageBase, ok);
+    apos6<2 * FC8_SUBB>(&acc[0], blk, stageBase, ok);
+    apos6<2 * FC8_SUBB + 48>(&acc[48], blk, stageBase, ok);
+    apos6<3 * FC8_SUBB>(&acc[0], blk, stageBase, ok);
+    apos6<3 * FC8_SUBB + 48>(&acc[48], blk, stageBase, ok);
+  } else if constexpr (MODE == 1) {
     hpos6<0 * FC8_SUBB>(&acc[0], blk, stageBase, ok);
     hpos6<0 * FC8_SUBB + 48>(&acc[48], blk, stageBase, ok);
     hpos6<1 * FC8_SUBB>(&acc[0], blk, stageBase, ok);
@@ -596,10 +638,12 @@ __device__ __forceinline__ void fc8_gather(f32x2 (&acc)[FC8_CPW], uint32_t blk, 
   }
 }
 
-template <bool F16>
+template <int MODE>
 __global__ __launch_bounds__(NW8 * 64) void k_fc_sym8(FcParams p, const uint16_t* __restrict__ prog, const float* __restrict__ ctrdF,
                                                        int chunks, int stagesPerSplit) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
+  constexpr bool F16 = MODE >= 1, ACC16 = MODE == 2;     // fp16 table storage; packed fp16 running sums (per workgroup: the slices of
+  using AccT = std::conditional_t<ACC16, uint32_t, f32x2>;   // a split sub-space axis are still added in fp32 by k_sum_partials)
   constexpr int HC = FC8_CPW / 2;
   const int lane = threadIdx.x & 63;
   const int wave = uni(threadIdx.x >> 6);
@@ -628,15 +672,18 @@ __global__ __launch_bounds__(NW8 * 64) void k_fc_sym8(FcParams p, const uint16_t
   const int activeI = in_range(cw0, p.Ct);
   const int cl0 = cw0 + half * HC;
   const uint32_t laneLds = F16 ? (uint32_t)quad * 8u : ((uint32_t)(quad >> 2) * TILEB | (uint32_t)(quad >> 3) * 64 | (uint32_t)(quad & 3) * 16);
-  f32x2 acc[FC8_CPW];
+  AccT acc[FC8_CPW];
 #pragma unroll
-  for (int c = 0; c < FC8_CPW; ++c) acc[c] = f32x2{0.0f, 0.0f};
+  for (int c = 0; c < FC8_CPW; ++c) {
+    if constexpr (ACC16) acc[c] = 0u; else acc[c] = f32x2{0.0f, 0.0f};
+  }
   if (split == 0) {
     const float* __restrict__ bp = p.bias + (activeI ? cl0 : 0);
 #pragma unroll
     for (int j = 0; j < HC; ++j) {
       const float b = (cl0 + j < p.Ct) ? bp[j] : 0.0f;
-      acc[2 * j] = f32x2{b, b}; acc[2 * j + 1] = f32x2{b, b};
+      if constexpr (ACC16) { acc[2 * j] = pk16(b); acc[2 * j + 1] = pk16(b); }
+      else { acc[2 * j] = f32x2{b, b}; acc[2 * j + 1] = f32x2{b, b}; }
     }
   }
   // program: [M][chunks][16 wave halves][48] uint16; a stage = four consecutive sub-spaces
@@ -664,7 +711,7 @@ __global__ __launch_bounds__(NW8 * 64) void k_fc_sym8(FcParams p, const uint16_t
     __builtin_amdgcn_sched_barrier(0);
     fc8_load(ops, xbase, ctrdF, stageOf(s + 2), stageOf(s + 2) * 4 + 2 * h, bLane, laneA16, h);
     __builtin_amdgcn_sched_barrier(0);
-    fc8_gather<F16>(acc, myBlk + rb0, laneLds, activeI);
+    fc8_gather<MODE, AccT>(acc, myBlk + rb0, laneLds, activeI);
     { const uint32_t t = rb0; rb0 = rb1; rb1 = rb2; rb2 = t; }
     barrier_after_lds_writes();
     // ---- period s + 1: stage s + 2 -> buffer 0, gather stage s + 1 out of buffer 1
@@ -673,7 +720,7 @@ __global__ __launch_bounds__(NW8 * 64) void k_fc_sym8(FcParams p, const uint16_t
     __builtin_amdgcn_sched_barrier(0);
     fc8_load(ops, xbase, ctrdF, stageOf(s + 3), stageOf(s + 3) * 4 + 2 * h, bLane, laneA16, h);
     __builtin_amdgcn_sched_barrier(0);
-    fc8_gather<F16>(acc, myBlk + rb0, laneLds | STAGE_BYTES, activeI & in_range(s + 1, S));
+    fc8_gather<MODE, AccT>(acc, myBlk + rb0, laneLds | STAGE_BYTES, activeI & in_range(s + 1, S));
     { const uint32_t t = rb0; rb0 = rb1; rb1 = rb2; rb2 = t; }
     barrier_after_lds_writes();
   }
@@ -683,7 +730,13 @@ __global__ __launch_bounds__(NW8 * 64) void k_fc_sym8(FcParams p, const uint16_t
 #pragma unroll
     for (int j = 0; j < HC; ++j) {
       if (cl0 + j < p.Ct) {
-        f32x4 v = {acc[2 * j].x, acc[2 * j].y, acc[2 * j + 1].x, acc[2 * j + 1].y};
+        f32x4 v;
+        if constexpr (ACC16) {
+          const f32x2 lo = unpk16(acc[2 * j]), hi = unpk16(acc[2 * j + 1]);
+          v = f32x4{lo.x, lo.y, hi.x, hi.y};
+        } else {
+          v = f32x4{acc[2 * j].x, acc[2 * j].y, acc[2 * j + 1].x, acc[2 * j + 1].y};
+        }
         if (p.relu && p.msplit == 1) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = (0.0f < v[e]) ? v[e] : 0.0f;
@@ -746,14 +799,14 @@ __global__ __launch_bounds__(256) void k_build_program8(const uint8_t* __restric
   }
 }
 
-template <int CPW, int TH, int TW, bool SLIDE = false, bool F16 = false>
+template <int CPW, int TH, int TW, bool SLIDE = false, int MODE = 0>
 hipError_t launch_sym8(const ConvParams& p, const Qk8Config& cf, hipStream_t st) {
   const int tilesX = (p.Wo + TW - 1) / TW, tilesY = (p.Ho + TH - 1) / TH;
   // SLIDE: grid.x = (segments x strips of TW output columns, longest segments first) x panels
   const dim3 grid((unsigned)((SLIDE ? p.nSeg * tilesX : tilesX * tilesY) * p.panels), (unsigned)(p.grp * cf.chunks), 1);
-  const size_t shm = (size_t)2 * STAGE_BYTES + 3 * PROG8_BUF;
+  const size_t shm = (size_t)2 * STAGE_BYTES + 3 * (size_t)(NW8 * 2 * TH * TW * CPW > (int)PROG8_BUF ? 3072 : PROG8_BUF);
   const bool two = std::min(p.Cin / p.grp, p.Cs) > 4;
-  auto kern = two ? k_conv_sym8<CPW, TH, TW, 2, SLIDE, F16> : k_conv_sym8<CPW, TH, TW, 1, SLIDE, F16>;
+  auto kern = two ? k_conv_sym8<CPW, TH, TW, 2, SLIDE, MODE> : k_conv_sym8<CPW, TH, TW, 1, SLIDE, MODE>;
   hipError_t e = allow_big_lds(reinterpret_cast<const void*>(kern), (int)shm);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, grid, dim3(NW8 * 64), shm, st, p, tilesX, tilesY, cf.chunks);
@@ -952,16 +1005,39 @@ hipError_t qk_conv_sym8_slide(const ConvParams& p, hipStream_t st) {
   return hipErrorInvalidValue;
 }
 
-// f16: the fp16-storage form (QCNN_OPT_LUT_MODE = 2); p.progS then is the program built with f16 = 1
-hipError_t qk_conv_sym8(const ConvParams& p, hipStream_t st, int f16) {
+// Tiles of the fp16-sum form (QCNN_OPT_LUT_MODE = 3): the same channels per wave, twice the positions (192 pairs per wave)
+Qk8Config qk_conv_sym8_config16(int Cin, int grp, int Ct, int M, int Cs, int K) {
+  Qk8Config cf = qk_conv_sym8_config(Cin, grp, Ct, M, Cs, K);
+  switch (cf.cpw) {
+    case 48: cf.th = 2; cf.tw = 2; break;      // 384 channels: 2x2 (1x2 with fp32 sums)
+    case 32: cf.th = 2; cf.tw = 3; break;      // 256: 2x3 (1x3)
+    case 24: cf.th = 2; cf.tw = 4; break;      // 192: 2x4 (2x2)
+    case 16: cf.th = 3; cf.tw = 4; break;      // 128: 3x4 (2x3)
+    default: break;
+  }
+  return cf;
+}
+
+// mode 1: the fp16-storage form (QCNN_OPT_LUT_MODE = 2), mode 2: fp16 storage + fp16 sums (QCNN_OPT_LUT_MODE = 3, the tiles of
+// qk_conv_sym8_config16); p.progS then is the program of that configuration built with f16 = 1
+hipError_t qk_conv_sym8(const ConvParams& p, hipStream_t st, int mode) {
   const Qk8Config cf = qk_conv_sym8_config(p.Cin, p.grp, p.Ct, p.M, p.Cs, p.K);
   if (!cf.cpw || p.progS == nullptr || p.ctrd8 == nullptr || p.srcNchw) return hipErrorInvalidValue;
-  if (f16) {
+  if (mode == 2) {
     switch (cf.cpw) {
-      case 48: return launch_sym8<48, 1, 2, false, true>(p, cf, st);
-      case 32: return launch_sym8<32, 1, 3, false, true>(p, cf, st);
-      case 24: return launch_sym8<24, 2, 2, false, true>(p, cf, st);
-      case 16: return launch_sym8<16, 2, 3, false, true>(p, cf, st);
+      case 48: return launch_sym8<48, 2, 2, false, 2>(p, cf, st);
+      case 32: return launch_sym8<32, 2, 3, false, 2>(p, cf, st);
+      case 24: return launch_sym8<24, 2, 4, false, 2>(p, cf, st);
+      case 16: return launch_sym8<16, 3, 4, false, 2>(p, cf, st);
+      default: return hipErrorInvalidValue;
+    }
+  }
+  if (mode == 1) {
+    switch (cf.cpw) {
+      case 48: return launch_sym8<48, 1, 2, false, 1>(p, cf, st);
+      case 32: return launch_sym8<32, 1, 3, false, 1>(p, cf, st);
+      case 24: return launch_sym8<24, 2, 2, false, 1>(p, cf, st);
+      case 16: return launch_sym8<16, 2, 3, false, 1>(p, cf, st);
       default: return hipErrorInvalidValue;
     }
   }
@@ -988,14 +1064,14 @@ hipError_t qk_build_program_fc8(const uint8_t* rows, uint16_t* prog, const QkSlo
 }
 
 // p.msplit = workgroups along the sub-space axis (partial sums in p.partial when > 1, reduced by qk_sum_partials)
-hipError_t qk_fc_sym8(const FcParams& p, const uint16_t* prog, const float* ctrdF, hipStream_t st, int f16) {
+hipError_t qk_fc_sym8(const FcParams& p, const uint16_t* prog, const float* ctrdF, hipStream_t st, int mode) {
   if (!qk_fc_sym8_shape(p.D, p.Ct, p.M, p.Cs, p.K) || prog == nullptr || ctrdF == nullptr || p.msplit < 1) return hipErrorInvalidValue;
   const int stages = p.M / 4;
   const int per = (stages + p.msplit - 1) / p.msplit;
   const int splits = (stages + per - 1) / per;                 // every workgroup along z has at least one stage
   if (splits != p.msplit) return hipErrorInvalidValue;
   const size_t shm = (size_t)2 * STAGE_BYTES + 3 * FC8_ROWBUF;
-  auto kern = f16 ? k_fc_sym8<true> : k_fc_sym8<false>;
+  auto kern = mode == 2 ? k_fc_sym8<2> : (mode == 1 ? k_fc_sym8<1> : k_fc_sym8<0>);
   hipError_t e = allow_big_lds(reinterpret_cast<const void*>(kern), (int)shm);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3((unsigned)qk_fc_sym8_chunks(p.Ct), (unsigned)p.panels, (unsigned)p.msplit), dim3(NW8 * 64), shm, st,

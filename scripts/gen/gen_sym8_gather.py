@@ -158,6 +158,77 @@ def emit_f16(reads, RB, NSETS):
                                                    text, outs, imms, clob))
 
 
+def emit_f16acc(reads, RB, NSETS):
+    """fp16 table AND fp16 running sums (QCNN_OPT_LUT_MODE = 3, the second column of the configs[4] study): the four images of a
+    channel are two packed registers, a read is followed by two v_pk_add_f16 (round to nearest even after every addition, like
+    the oracle's qo_study_mode(1, 1)).  Half the accumulator registers of the fp32 sums: the kernel gives a wave twice the
+    (position, channel) pairs."""
+    NB = reads // RB
+    NG = reads // 4
+    top = 256
+    set_base = [top - (NSETS - s) * RB * 2 for s in range(NSETS)]
+    slot_base = set_base[0] - 4
+    slots = [(slot_base, slot_base + 1), (slot_base + 2, slot_base + 3)]
+    L, issued = [], []
+    a = L.append
+
+    def wait_for(name):
+        n = len(issued) - 1 - issued.index(name)
+        a('s_waitcnt lgkmcnt(%d)' % n)
+
+    def fetch(g):
+        lo, hi = slots[g & 1]
+        a('ds_read_b64 v[%d:%d], %%[blk] offset:%%[i%d]' % (lo, hi, g))
+        issued.append('F%d' % g)
+
+    def accumulate(k):
+        base = set_base[k % NSETS]
+        for r in range(RB):
+            wait_for('R%d_%d' % (k, r))
+            c = 2 * (k * RB + r)
+            a('v_pk_add_f16 %%[c%d], %%[c%d], v%d' % (c, c, base + 2 * r))
+            a('v_pk_add_f16 %%[c%d], %%[c%d], v%d' % (c + 1, c + 1, base + 2 * r + 1))
+
+    a('s_cmp_eq_u32 %[ok], 0')
+    a('s_cbranch_scc1 .Laskip%=')
+    fetch(0)
+    if NG > 1:
+        fetch(1)
+    for k in range(NB):
+        base = set_base[k % NSETS]
+        first_read = k * RB
+        g = first_read // 4
+        if first_read % 4 == 0:
+            wait_for('F%d' % g)
+        for r in range(RB):
+            q = (first_read + r) % 4
+            src = slots[g & 1][q >> 1]
+            a('v_xor_b32_sdwa v%d, v%d, %%[b] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_%d src1_sel:DWORD'
+              % (base + 2 * r, src, q & 1))
+        for r in range(RB):
+            a('ds_read_b64 v[%d:%d], v%d' % (base + 2 * r, base + 2 * r + 1, base + 2 * r))
+            issued.append('R%d_%d' % (k, r))
+        if (first_read + RB) % 4 == 0 and g + 2 < NG:
+            fetch(g + 2)
+        if k >= NSETS - 1:
+            accumulate(k - (NSETS - 1))
+    for k in range(max(0, NB - (NSETS - 1)), NB):
+        accumulate(k)
+    text = "".join('               "%s\\n\\t"\n' % s for s in L) + '               ".Laskip%=:"\n'
+    outs = ", ".join('[c%d] "+v"(acc[%d])' % (i, i) for i in range(2 * reads))
+    imms = ", ".join('[i%d] "n"(IMM0 + %d)' % (g, 8 * g) for g in range(NG))
+    clob = ", ".join('"v%d"' % r for r in range(slot_base, 256))
+    return ('// fp16 table, fp16 sums: %d reads = %d look-ups of one position (blocks of %d ds_read_b64, %d sets of temporaries v[%d:255],\n'
+            '// offset slots v[%d:%d]); acc[2j] = images 0, 1 and acc[2j+1] = images 2, 3 of channel j of the lane half, packed fp16\n'
+            'template <int IMM0>\n'
+            '__device__ __forceinline__ void apos%d(uint32_t* acc, uint32_t blk, uint32_t base, int valid) {\n'
+            '  asm volatile(\n%s'
+            '               : %s\n'
+            '               : [blk] "v"(blk), [b] "v"(base), [ok] "s"(valid), %s\n'
+            '               : "scc", %s);\n}\n' % (reads, 2 * reads, RB, NSETS, set_base[0], slot_base, slot_base + 3, reads // 4,
+                                                   text, outs, imms, clob))
+
+
 def main():
     RB = int(sys.argv[1]) if len(sys.argv) > 1 else 2
     NSETS = int(sys.argv[2]) if len(sys.argv) > 2 else 3
@@ -167,6 +238,8 @@ def main():
         print(emit(reads, RB, NSETS))
     for reads in (8, 12, 16, 24):        # the same positions over an fp16 table -> hpos2, hpos3, hpos4, hpos6
         print(emit_f16(reads, RB, NSETS))
+    for reads in (8, 12, 16, 24):        # ... with fp16 running sums -> apos2, apos3, apos4, apos6
+        print(emit_f16acc(reads, RB, NSETS))
     print('#endif  // QCNN_SYM8_GATHER_H_')
 
 
