@@ -58,6 +58,7 @@ struct LayerShape {
     double slideCost = 0.0;                                    // ... and its predicted duration
     double symCost = 0.0;                                      // predicted duration of the symmetric kernel (0: not eligible)
     double sym8Cost = 0.0;                                     // ... of the eight-wave symmetric kernel
+    int sym8Z = 1;                                             // ... with every tile cut into this many slices (QCNN_OPT_SPLIT; 1: whole tiles)
     double sym8sCost = 0.0;                                    // ... of its sliding form, with the segments it would run
     int seg8N = 0, seg8Beg[9] = {0};
   };
@@ -467,6 +468,19 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
             pl.symCost = (c->sym && s.progYBytes && c->lutMode == 1 && !inNchw) ? qk_conv_sym_cost(p) : 0.0;
             pl.sym8Cost = (c->sym8 && s.prog8Bytes && c->lutMode == 1 && !inNchw)
                               ? qk_conv_sym8_cost(p, qk_conv_sym8_config(p.Cin, p.grp, p.Ct, p.M, p.Cs, p.K), kSym8StageFactor) : 0.0;
+            if (pl.sym8Cost > 0.0 && c->split) {
+              // a launch of a few hundred tiles (one GPU's share of a sharded batch): every tile in Z slices of its stage sequence,
+              // partial sums reduced by k_conv_sum — taken when predicted 3 % cheaper than the whole tiles
+              const Qk8Config c8 = qk_conv_sym8_config(p.Cin, p.grp, p.Ct, p.M, p.Cs, p.K);
+              const int tiles8 = ((p.Wo + c8.tw - 1) / c8.tw) * ((p.Ho + c8.th - 1) / c8.th);
+              const long long wgs8 = (long long)tiles8 * panels * p.grp * c8.chunks;
+              for (int Z = 2; Z <= 6 && wgs8 < 2 * 256; ++Z) {
+                if ((size_t)tiles8 * Z * panels * c8.th * c8.tw * p.Ct * QCNN_PANEL > share) break;
+                if ((long long)p.M * p.knl * p.knl < 6LL * Z) break;       // a slice keeps a few stages
+                const double cz = qk_conv_sym8_cost(p, c8, kSym8StageFactor, Z);
+                if (cz < 0.97 * pl.sym8Cost) { pl.sym8Cost = cz; pl.sym8Z = Z; }
+              }
+            }
             if (c->sym8 && s.prog8SBytes && c->lutMode == 1 && !inNchw) {
               ConvParams t = p;
               pl.sym8sCost = qk_conv_sym8_slide_plan(t, qk_conv_sym8_slide_config(p.Cin, p.grp, p.Ct, p.M, p.Cs, p.K, p.knl, p.stride),
@@ -481,8 +495,8 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
               for (int i = 0; i <= t.nSeg && i < 9; ++i) pl.segBeg[i] = t.segBeg[i];
             }
             if (const char* dbg = getenv("QCNN_DEBUG_PLAN"); dbg && atoi(dbg))
-              fprintf(stderr, "[qcnn plan] layer %d panels %d: tile %.0f (Z %d) | slide %.0f (%d segments) | sym %.0f | sym8 %.0f | sym8 sliding %.0f (%d segments) stage-times\n",
-                      l, panels, pl.plan.cost, pl.plan.Z, pl.slideCost, pl.segN, pl.symCost, pl.sym8Cost, pl.sym8sCost, pl.seg8N);
+              fprintf(stderr, "[qcnn plan] layer %d panels %d: tile %.0f (Z %d) | slide %.0f (%d segments) | sym %.0f | sym8 %.0f (Z %d) | sym8 sliding %.0f (%d segments) stage-times\n",
+                      l, panels, pl.plan.cost, pl.plan.Z, pl.slideCost, pl.segN, pl.symCost, pl.sym8Cost, pl.sym8Z, pl.sym8sCost, pl.seg8N);
             it = s.plans.emplace(key, pl).first;
           }
           const LayerShape::Plan& pl = it->second;
@@ -518,7 +532,14 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
             if (pl.segN > 0 && pl.slideCost > 0.0) other = std::min(other, 1.15 * pl.slideCost);
             if (c->sym8 >= 2 || pl.sym8Cost < 0.97 * other) {
               p.progS = reinterpret_cast<const uint16_t*>(c->arena + s.offProg8);
-              s.lastFrom = -5; s.lastZ = 1;             // reported by qcnn_get_layer_split as (-5, 1)
+              s.lastFrom = -5; s.lastZ = 1;             // reported by qcnn_get_layer_split as (-5, slices per tile)
+              if (pl.sym8Z > 1) {
+                if (!c->convPartial && !c->noConvPartial && hipMalloc(&c->convPartial, kConvPartialFloats * sizeof(float)) != hipSuccess) {
+                  (void)hipGetLastError();
+                  c->convPartial = nullptr; c->noConvPartial = true;          // no scratch: whole tiles
+                }
+                if (c->convPartial) { p.splitFrom = 0; p.splitZ = pl.sym8Z; p.partial = c->convPartial + share * sub; s.lastZ = pl.sym8Z; }
+              }
               e = qk_conv_sym8(p, st);
               break;
             }

@@ -228,7 +228,10 @@ Qk8Config qk_conv_sym8_config(int Cin, int grp, int Ct, int M, int Cs, int K);
 size_t qk_conv_sym8_program_bytes(const Qk8Config& cf, int groups, int knl, int stride, int M);
 hipError_t qk_build_program8(const uint8_t* rows, uint16_t* prog, const QkSlots& src, const Qk8Config& cf, int Ctg, int groups,
                              int knl, int stride, int M, hipStream_t st, int f16 = 0);   // f16: offsets into the fp16 table layout
-double qk_conv_sym8_cost(const ConvParams& p, const Qk8Config& cf, double stageFactor);
+double qk_conv_sym8_cost(const ConvParams& p, const Qk8Config& cf, double stageFactor, int Z = 1);   // Z: slices per tile (ConvParams::splitZ)
+// dst = sum over the Z slices (in slice order) of the partial sums of the tiles from rank splitFrom on; optional ReLU (k_conv_sum)
+hipError_t qk_conv_sum(const float* partial, float* dst, int splitFrom, int Z, int panels, int tilesX, int tilesY, int TH, int TW, int Ho,
+                       int Wo, int Ct, int relu, hipStream_t st);
 hipError_t qk_conv_sym8(const ConvParams& p, hipStream_t st, int mode = 0);   // mode 1: fp16 table storage, 2: + fp16 sums (p.progS built with f16 = 1)
 Qk8Config qk_conv_sym8_config16(int Cin, int grp, int Ct, int M, int Cs, int K);   // tiles of mode 2 (twice the positions)
 // The sliding form of the eight-wave kernel (k_conv_sym8<.., SLIDE>): config (cpw = 0: not eligible), segments + predicted

@@ -1436,11 +1436,7 @@ hipError_t launch_conv(const ConvParams& p, const QkSlots& sl, int lutMode, hipS
   hipLaunchKernelGGL(kern, grid, dim3(NW * 64), shm, st, q, tilesX, tilesY, sl.chunks, G, sl.rowStride);
   e = hipGetLastError();
   if (e != hipSuccess || !split) return e;
-  const int rowQuads = p.Ct * (PANEL / 4);
-  hipLaunchKernelGGL(k_conv_sum, dim3(tailTiles * TH * TW, p.panels, (rowQuads + 1023) / 1024), dim3(256), 0, st,
-                     reinterpret_cast<const f32x4*>(q.partial), reinterpret_cast<f32x4*>(p.dst), q.splitFrom, q.splitZ,
-                     p.panels, tilesX, tilesY, TH, TW, p.Ho, p.Wo, p.Ct, p.relu);
-  return hipGetLastError();
+  return qk_conv_sum(q.partial, p.dst, q.splitFrom, q.splitZ, p.panels, tilesX, tilesY, TH, TW, p.Ho, p.Wo, p.Ct, p.relu, st);
 }
 
 // sliding variant: grid.x = (segments x output columns, longest segments first) x panels
@@ -1799,5 +1795,15 @@ hipError_t qk_build_program(const uint8_t* rows, uint16_t* prog, QkSlots src, Qk
   const size_t n = (size_t)pg.rfH * pg.rfW * M * pg.rowU16;
   const int grid = (int)std::min<size_t>((n + 255) / 256, 8192);
   hipLaunchKernelGGL(k_build_program, dim3(grid ? grid : 1), dim3(256), 0, st, rows, prog, src, dst, pg, knl, stride, M, n, slide);
+  return hipGetLastError();
+}
+
+hipError_t qk_conv_sum(const float* partial, float* dst, int splitFrom, int Z, int panels, int tilesX, int tilesY, int TH, int TW, int Ho,
+                       int Wo, int Ct, int relu, hipStream_t st) {
+  const int tailTiles = tilesX * tilesY - splitFrom;
+  const int rowQuads = Ct * (PANEL / 4);
+  hipLaunchKernelGGL(k_conv_sum, dim3(tailTiles * TH * TW, panels, (rowQuads + 1023) / 1024), dim3(256), 0, st,
+                     reinterpret_cast<const f32x4*>(partial), reinterpret_cast<f32x4*>(dst), splitFrom, Z, panels, tilesX, tilesY, TH, TW,
+                     Ho, Wo, Ct, relu);
   return hipGetLastError();
 }

@@ -302,7 +302,17 @@ __global__ __launch_bounds__(NW8 * 64) void k_conv_sym8(ConvParams p, int tilesX
   constexpr uint32_t PBUF = ROWB > (int)PROG8_BUF ? 3072u : PROG8_BUF;   // bytes of one of the three program-row buffers
   const int lane = threadIdx.x & 63;
   const int wave = uni(threadIdx.x >> 6);
-  const int rank = (int)(blockIdx.x / (unsigned)p.panels), panel = (int)(blockIdx.x % (unsigned)p.panels);
+  // blockIdx.x = tile rank (heaviest first) * panels + panel; a launch that cannot fill the chip with whole tiles (one GPU's share
+  // of a sharded batch: ConvParams::splitZ > 1, tile form) cuts EVERY tile into splitZ workgroups that take consecutive slices of
+  // its stage sequence and write partial sums, which k_conv_sum adds in slice order (as k_conv_aprx does)
+  int rank = (int)(blockIdx.x / (unsigned)p.panels);
+  const int panel = (int)(blockIdx.x % (unsigned)p.panels);
+  int slice = 0, slices = 1;
+  if (!SLIDE && p.splitZ > 1) {
+    slices = p.splitZ;
+    slice = rank % slices;
+    rank = rank / slices;
+  }
   int ty = 0, tx = 0, segBeg = 0, segEnd = 0;
   if constexpr (SLIDE) {
     // rank = segment-major unit (longest segments first): segment x strip of TW output columns
@@ -327,9 +337,12 @@ __global__ __launch_bounds__(NW8 * 64) void k_conv_sym8(ConvParams p, int tilesX
   g.wiU = min(p.W - 1, woL * p.stride - p.pad + p.knl - 1);
   g.slide = SLIDE ? 1 : 0; g.hiL = hiL; g.hiU = hiU; g.period = SLIDE ? TH * p.stride : 1;
   const int cols = g.wiU - g.wiL + 1;
-  const int S = (hiU - hiL + 1) * cols * g.MG;
+  const int Stot = (hiU - hiL + 1) * cols * g.MG;      // stages of the whole tile; this workgroup runs [sBeg, sBeg + S)
+  const int sBeg = (int)((long long)Stot * slice / slices);
+  const int S = (int)((long long)Stot * (slice + 1) / slices) - sBeg;
   const int Sp = (S + 1) & ~1;
-  const StagePos first = {hiL, g.wiL, 0, SLIDE ? (int)((unsigned)(hiL - (ho0 * p.stride - p.pad)) % (unsigned)(TH * p.stride)) : 0};
+  const StagePos first = {hiL + (sBeg / g.MG) / cols, g.wiL + (sBeg / g.MG) % cols, sBeg % g.MG,
+                          SLIDE ? (int)((unsigned)(hiL - (ho0 * p.stride - p.pad)) % (unsigned)(TH * p.stride)) : 0};
   if ((uint32_t)(uintptr_t)lds != 0u) __builtin_trap();   // the stage addressing assumes the dynamic segment starts at LDS byte 0
 
   // ---- builder side of this wave: image tiles 2 (wave >> 1), + 1 (both with slot swizzle wave >> 1), row tiles 4 (wave & 1) ..
@@ -357,7 +370,7 @@ __global__ __launch_bounds__(NW8 * 64) void k_conv_sym8(ConvParams p, int tilesX
     const float* __restrict__ bp = p.bias + grp * Ctg + (activeI ? cl0 : 0);
 #pragma unroll
     for (int j = 0; j < HC; ++j) {
-      const float b = bp[j];
+      const float b = (slice == 0) ? bp[j] : 0.0f;       // the bias enters the first slice's partial sum only
 #pragma unroll
       for (int q = 0; q < NP; ++q) {
         if constexpr (ACC16) { acc[q][2 * j] = pk16(b); acc[q][2 * j + 1] = pk16(b); }     // the start value rounded to fp16 too
@@ -492,12 +505,15 @@ __global__ __launch_bounds__(NW8 * 64) void k_conv_sym8(ConvParams p, int tilesX
     if constexpr (SLIDE) column_end(cEnd, liveEnd);           // the strip's last source row
     // ---- results (SLIDE: every position was stored when its window closed)
     if (activeI && !SLIDE) {
-      float* __restrict__ dst = p.dst + (size_t)panel * p.Ho * p.Wo * p.Ct * PANEL;
+      // final map, or — a slice of a split tile — this slice's slab of partial sums [tile][slice][panel][position][Ct][128]
+      const bool part = slices > 1;
+      float* __restrict__ dst = part ? p.partial + ((size_t)(rank * slices + slice) * p.panels + panel) * NP * p.Ct * PANEL
+                                     : p.dst + (size_t)panel * p.Ho * p.Wo * p.Ct * PANEL;
 #pragma unroll
       for (int q = 0; q < NP; ++q) {
         const int ho = ho0 + q / TW, wo = wo0 + q % TW;
         if (ho < p.Ho && wo < p.Wo) {
-          float* o = dst + ((size_t)(ho * p.Wo + wo) * p.Ct + grp * Ctg + cl0) * PANEL + 4 * quad;
+          float* o = dst + ((size_t)(part ? q : ho * p.Wo + wo) * p.Ct + grp * Ctg + cl0) * PANEL + 4 * quad;
 #pragma unroll
           for (int j = 0; j < HC; ++j) {
             f32x4 v;
@@ -507,7 +523,7 @@ __global__ __launch_bounds__(NW8 * 64) void k_conv_sym8(ConvParams p, int tilesX
             } else {
               v = f32x4{acc[q][2 * j].x, acc[q][2 * j].y, acc[q][2 * j + 1].x, acc[q][2 * j + 1].y};
             }
-            if (p.relu) {
+            if (p.relu && !part) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[e] = (0.0f < v[e]) ? v[e] : 0.0f;
             }
@@ -803,14 +819,19 @@ template <int CPW, int TH, int TW, bool SLIDE = false, int MODE = 0>
 hipError_t launch_sym8(const ConvParams& p, const Qk8Config& cf, hipStream_t st) {
   const int tilesX = (p.Wo + TW - 1) / TW, tilesY = (p.Ho + TH - 1) / TH;
   // SLIDE: grid.x = (segments x strips of TW output columns, longest segments first) x panels
-  const dim3 grid((unsigned)((SLIDE ? p.nSeg * tilesX : tilesX * tilesY) * p.panels), (unsigned)(p.grp * cf.chunks), 1);
+  const bool split = !SLIDE && MODE == 0 && p.splitZ > 1 && p.partial != nullptr;     // every tile in p.splitZ slices (splitFrom = 0)
+  ConvParams q = p;
+  if (!split) { q.splitZ = 1; q.partial = nullptr; }
+  const dim3 grid((unsigned)((SLIDE ? p.nSeg * tilesX : tilesX * tilesY * q.splitZ) * p.panels), (unsigned)(p.grp * cf.chunks), 1);
   const size_t shm = (size_t)2 * STAGE_BYTES + 3 * (size_t)(NW8 * 2 * TH * TW * CPW > (int)PROG8_BUF ? 3072 : PROG8_BUF);
   const bool two = std::min(p.Cin / p.grp, p.Cs) > 4;
   auto kern = two ? k_conv_sym8<CPW, TH, TW, 2, SLIDE, MODE> : k_conv_sym8<CPW, TH, TW, 1, SLIDE, MODE>;
   hipError_t e = allow_big_lds(reinterpret_cast<const void*>(kern), (int)shm);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, grid, dim3(NW8 * 64), shm, st, p, tilesX, tilesY, cf.chunks);
-  return hipGetLastError();
+  hipLaunchKernelGGL(kern, grid, dim3(NW8 * 64), shm, st, q, tilesX, tilesY, cf.chunks);
+  e = hipGetLastError();
+  if (e != hipSuccess || !split) return e;
+  return qk_conv_sum(q.partial, p.dst, 0, q.splitZ, p.panels, tilesX, tilesY, TH, TW, p.Ho, p.Wo, p.Ct, p.relu, st);
 }
 
 }  // namespace
@@ -854,7 +875,9 @@ hipError_t qk_build_program8(const uint8_t* rows, uint16_t* prog, const QkSlots&
 // list-scheduled heaviest first on 256 CUs.  A stage of this kernel is priced by its look-ups: measured (AlexNet conv2 - 5,
 // 1000 images, profiles/r4_*) 2540 + 1.97 x (row look-ups per stage) cycles against ~2500 for a stage of the tile kernel,
 // whose look-ups run beside its builder waves; `scale` corrects the whole (1.0 = that calibration)
-double qk_conv_sym8_cost(const ConvParams& p, const Qk8Config& cf, double scale) {
+// Z > 1: every tile cut into Z slices of its stage sequence (ConvParams::splitZ) + the reduction of the partial sums (priced as
+// qk_conv_plan prices k_conv_sum: Z slabs read, one written at ~4 TB/s behind a launch)
+double qk_conv_sym8_cost(const ConvParams& p, const Qk8Config& cf, double scale, int Z) {
   if (!cf.cpw) return 0.0;
   const int TH = cf.th, TW = cf.tw;
   const int tilesX = (p.Wo + TW - 1) / TW, tilesY = (p.Ho + TH - 1) / TH, tiles = tilesX * tilesY;
@@ -880,17 +903,23 @@ double qk_conv_sym8_cost(const ConvParams& p, const Qk8Config& cf, double scale)
   const double factor = scale * (2540.0 + 1.97 * perStage) / 2500.0;
   const int ny = p.grp * cf.chunks;
   const long long wgs = (long long)tiles * p.panels * ny;
-  if (wgs >= 8 * 256) return (factor * total + 10.0 * tiles) * p.panels * ny / 256.0;
+  if (wgs >= 8 * 256 && Z <= 1) return (factor * total + 10.0 * tiles) * p.panels * ny / 256.0;
   std::priority_queue<double, std::vector<double>, std::greater<double>> q;
   for (int i = 0; i < 256; ++i) q.push(0.0);
   double end = 0.0;
+  const int zz = std::max(Z, 1);
   for (int y = 0; y < ny; ++y)
     for (int r = 0; r < tiles; ++r)
-      for (int k = 0; k < p.panels; ++k) {
-        const double t = q.top() + factor * stages[r] + 10.0;
-        q.pop(); q.push(t);
-        end = std::max(end, t);
-      }
+      for (int z = 0; z < zz; ++z)
+        for (int k = 0; k < p.panels; ++k) {
+          const double t = q.top() + factor * stages[r] / zz + 10.0;
+          q.pop(); q.push(t);
+          end = std::max(end, t);
+        }
+  if (zz > 1) {
+    const double slab = (double)tiles * p.panels * TH * TW * p.Ct * PANEL * 4.0;
+    end += (slab * (zz + 1.0) / 4.0e6 + slab * zz / 10.0e6 + 5.0) / 1.1;
+  }
   return end;
 }
 

@@ -824,6 +824,58 @@ def test_split_tiles_of_a_sharded_batch(n_img):
     eng.close()
 
 
+@pytest.mark.parametrize("n_img", [125, 250])
+def test_split_tiles_of_the_eight_wave_kernel(n_img):
+    """The same split for k_conv_sym8 (QCNN_OPT_SPLIT with the eight-wave tile form): at one or two panels its 2x3 / 1x2 / 2x2
+    tiles are 90 - 250 workgroups on 256 CUs, so every tile is cut into Z slices of its (pixel, sub-space) stage sequence, the
+    bias enters slice 0, k_conv_sum adds the slices in order.  Forced eight-wave kernels (QCNN_OPT_SYM8 = 2) with and without
+    the split: every conv map within 1e-5 (summation order only), same top-5; the last images against the oracle (1e-4); other
+    geometries (padded 3x3, 5x5 / 2 in two groups, 192 / 256 / 384 channels) the same way."""
+    in_chw, layers, _, _ = topo.MODELS["AlexNet"]
+    params = synth.make_params(in_chw, layers, seed=0)
+    imgs = synth.make_images(n_img, in_chw, seed=78)
+    base = make_engine(in_chw, layers, params, n_img, lut=capi.LUT_MFMA, keep_all=1, split=0, sym8=2)
+    p0, t0 = base.forward_host(imgs)
+    assert [base.layer_split(l) for l in (4, 8, 10, 12)] == [(-5, 1)] * 4
+    fm0 = {l: base.layer_output(l, n_img) for l in (5, 9, 11, 13)}
+    base.close()
+    eng = make_engine(in_chw, layers, params, n_img, lut=capi.LUT_MFMA, keep_all=1, split=1, sym8=2)
+    eng.set_option(capi.OPT_STREAMS, 1)
+    p1, t1 = eng.forward_host(imgs)
+    cut = {l: eng.layer_split(l) for l in (4, 8, 10, 12)}
+    assert all(c[0] == -5 for c in cut.values()) and any(c[1] > 1 for c in cut.values()), cut
+    if n_img <= 128:
+        assert all(cut[l][1] > 1 for l in (8, 10, 12)), cut                 # one panel of a 13x13 layer: 91 / 98 tiles
+    for l, want in fm0.items():
+        e_inf, _ = rel_err(eng.layer_output(l, n_img), want)
+        assert e_inf <= 1e-5, "fm[%d]: %g (split %r)" % (l, e_inf, cut)
+    assert np.array_equal(t0, t1) and np.abs(p1 - p0).max() <= 1e-5 * np.abs(p0).max()
+    orc = po.COracle(in_chw, layers)
+    orc.set_params(params)
+    for i in (0, n_img - 1):
+        orc.forward(imgs[i:i + 1])
+        for l in (5, 9, 11, 13):
+            e_inf, e_l2 = rel_err(eng.layer_output_range(l, i, 1), orc.fm(l))
+            assert e_inf <= TOL and e_l2 <= TOL, "fm[%d] image %d" % (l, i)
+    eng.close()
+    if n_img > 128:
+        return
+    geo = ((3, 21, 17), [topo.conv(1, 3, 128, 1, 1), topo.relu(), topo.conv(2, 5, 256, 2, 2), topo.relu(),
+                         topo.conv(1, 3, 384, 1, 1), topo.relu(), topo.conv(1, 3, 384, 2, 1), topo.relu(), topo.conv(1, 3, 256, 1, 1),
+                         topo.relu(), topo.fcnt(48), topo.smax()])
+    g_chw, g_layers = geo
+    g_params = synth.make_params(g_chw, g_layers, seed=93)
+    g_imgs = synth.make_images(70, g_chw, seed=94)
+    outs = []
+    for split in (0, 1):
+        e = make_engine(g_chw, g_layers, g_params, 70, lut=capi.LUT_MFMA, keep_all=0, split=split, sym8=2)
+        outs.append(e.forward_host(g_imgs) + ([e.layer_split(l) for l, ly in enumerate(g_layers) if ly["type"] == topo.CONV],))
+        e.close()
+    assert any(z > 1 for f, z in outs[1][2] if f == -5), outs[1][2]
+    assert np.array_equal(outs[0][1], outs[1][1])
+    assert np.abs(outs[0][0] - outs[1][0]).max() <= 1e-5 * np.abs(outs[0][0]).max()
+
+
 def test_split_tiles_small_geometries():
     """The split on small maps and odd shapes (tiny model, conv geometries with borders, K < 128 program-less kernels):
     every slice boundary falls somewhere inside a tile's (pixel, sub-space) sequence; results within 1e-5 of the unsplit run."""
