@@ -44,7 +44,8 @@
 extern "C" {
 #endif
 
-#define QCNN_ABI_VERSION 3
+#define QCNN_ABI_VERSION 4   /* 4 (round 5): QCNN_OPT_LUT_MODE 2 = fp16 table storage, 3 = fp16 tables + fp16 sums (the bf16-pair builder
+                              * of version 3 is gone); qcnn_set_option rejects out-of-range values of QCNN_OPT_SYM / _SLIDE / _SYM8 */
 
 #define QCNN_SMALL_BATCH_MAX 3   /* batches up to this size can take the few-image kernels (QCNN_OPT_SMALL_BATCH) */
 
@@ -103,7 +104,7 @@ enum {
                               pipe (a look-up there stands for <= 4 multiply-adds and the table of a pixel costs more than
                               the look-ups it serves).  Same parameters, same function, results within the MFMA modes'
                               tolerance; the network input is then packed into panels first.  MFMA modes only
-                              (QCNN_OPT_LUT_MODE 1, 3), batches above QCNN_SMALL_BATCH_MAX.  0 = table kernels for every layer */
+                              (QCNN_OPT_LUT_MODE 1), batches above QCNN_SMALL_BATCH_MAX.  0 = table kernels for every layer */
   QCNN_OPT_SYM = 9,        /* 1 (default): a conv layer with exactly 128 channels per group and K = 128 (AlexNet conv2) that neither
                               slides nor splits may run SYMMETRIC workgroups — all 16 waves build and gather, 8 channels x a
                               2x2 tile per wave: fewer table builds per output position and no idle gather lane — when the
@@ -118,8 +119,9 @@ enum {
                               columns with 3 or 5 accumulator slots: 3x3 / 1 and 5x5 / 1 layers of up to 256 channels per workgroup build
                               every source pixel of a strip once: 3 or 2 table builds per output position instead of 4 - 5) where the
                               planner predicts that faster: VGG-16's 256- / 512-channel layers.  0 = never; 2 = tile form whenever
-                              eligible, 3 = sliding form whenever eligible (tests).  qcnn_get_layer_split reports (-5, 1) for the tile
-                              form, (-6, segments per column) for the sliding form.  FC layers with 32 code words of 4 dims
+                              eligible, 3 = sliding form whenever eligible (tests); other values are refused.  qcnn_get_layer_split reports
+                              (-5, slices per tile: QCNN_OPT_SPLIT cuts its tiles too) for the tile form, (-6, segments per column) for the
+                              sliding form.  FC layers with 32 code words of 4 dims
                               (AlexNet / VGG-16 fc6, fc7) run the same eight waves (k_fc_sym8: 96 channels per wave, offsets through
                               LDS-DMA, software-pipelined look-ups) unless the option is 0 */
   QCNN_OPT_PACKED_FC = 11, /* 1: for batches of up to QCNN_SMALL_BATCH_MAX images the FC layers read their assignments from the
@@ -233,8 +235,10 @@ int qcnn_run_layer(QcnnCtx* ctx, int layer, const float* in_host, int n, float* 
  * kernel (QCNN_OPT_SLIDE): *tiles_unsplit = -2, *slices = segments per output column; a conv or FC layer that ran through
  * its decoded code words (QCNN_OPT_DECODE): *tiles_unsplit = -3, *slices = 1 (FC: slices of the input axis over workgroups);
  * (a conv layer that read the NCHW batch in place: *slices = 2); symmetric workgroups (QCNN_OPT_SYM): *tiles_unsplit = -4;
- * eight-wave symmetric workgroups (QCNN_OPT_SYM8): -5 (conv tile form, *slices = 1; FC: *slices = splits of the sub-space axis),
- * -6 in their sliding form (*slices = segments per output column; qcnn_get_layer_segments reports the boundaries). */
+ * eight-wave symmetric workgroups (QCNN_OPT_SYM8): -5 (conv tile form, *slices = slices per tile under QCNN_OPT_SPLIT, else 1; FC:
+ * *slices = splits of the sub-space axis), -6 in their sliding form (*slices = segments per output column;
+ * qcnn_get_layer_segments reports the boundaries); their fp16-storage form (QCNN_OPT_LUT_MODE = 2): -7, with fp16 sums too
+ * (QCNN_OPT_LUT_MODE = 3): -8. */
 int qcnn_get_layer_split(QcnnCtx* ctx, int layer, int* tiles_unsplit, int* slices);
 /* Sliding kernel: the row segments [seg_beg9[i], seg_beg9[i + 1]) every output column of the last launch of `layer` was
  * cut into (*n_seg of them; 0 when the layer ran the tile kernel). */

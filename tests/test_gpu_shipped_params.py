@@ -3,7 +3,8 @@
 north_star: "outputs match the reference CPU CaffeEva layer-for-layer within 1e-4 relative on the same 227x227
 inputs".  The ten shipped Bmp.Files/*.BMP (decoded by the reference's own BmpImgIO) are tiled to 1000 images = 7 full
 panels + a ragged one of 104, and every feature map the configuration materialises is compared with what the COMPILED
-reference produced for that image (tests/golden/alexnet_real10_ref.npz, oracle/make_golden.py) — for images of the
+reference produced for that image (tests/golden/alexnet_real10_ref.npz, oracle/make_golden.py: samples + l2 norm; and every
+element of every map against the oracle, which is pinned bit for bit to the compiled reference) — for images of the
 first panel, of a middle one and of the ragged last one.  Configurations: the library defaults (decoded conv1 / fc8,
 split, sliding, symmetric and eight-wave symmetric kernels as the planner picks them), layer-for-layer and fast path (fused ReLU, fused
 LRN + pool, one stream = what bench.py times), every eligible layer forced through the symmetric / sliding kernels, and
@@ -66,6 +67,28 @@ def _check_maps(eng, z, fx, maps, tag):
     return checked
 
 
+def _check_full_tensors(eng, orc, L, tag):
+    """Every materialised map of the images of BLOCKS, EVERY element, against the oracle's maps of the ten source images (the
+    oracle is pinned bit for bit to the compiled reference: tests/test_oracle_vs_reference.py) — max-norm and l2, 1e-4."""
+    checked = 0
+    for l in range(L + 1):
+        want = orc.fm(l)                                  # [10, ...]: image i of the batch is source image i % 10
+        for first, cnt in BLOCKS:
+            try:
+                fm = eng.layer_output_range(l, first, cnt)
+            except pkg("engine").QcnnError:
+                checked -= 1
+                break
+            for j in range(cnt):
+                ref = want[(first + j) % 10]
+                d = np.abs(fm[j].astype(np.float64) - ref)
+                assert d.max() <= TOL * max(np.abs(ref).max(), 1e-30), "%s: fm[%d] image %d, full tensor max-norm" % (tag, l, first + j)
+                assert np.sqrt((d * d).sum()) <= TOL * max(np.sqrt((ref.astype(np.float64) ** 2).sum()), 1e-30), \
+                    "%s: fm[%d] image %d, full tensor l2" % (tag, l, first + j)
+        checked += 1
+    return checked
+
+
 def _check_outputs(prob, top5, z, fx, tag):
     want = z["prob%d" % fx]
     for i in list(range(0, 20)) + list(range(500, 520)) + list(range(N - 20, N)):
@@ -107,6 +130,10 @@ def test_shipped_parameters_headline_kernels_match_reference(golden_alex_real10,
     prob, top5 = eng.forward_host(imgs)
     n_maps = _check_maps(eng, z, 1, range(0, L + 1), name)
     _check_outputs(prob, top5, z, 1, name)
+    orc = po.COracle(in_chw, layers)
+    orc.set_params(p1)
+    orc.forward(imgs[:10])
+    assert _check_full_tensors(eng, orc, L, name) == n_maps
     if name == "headline_fast_path":
         # which kernels ran (qcnn_get_layer_split: -3 decoded, -5 eight-wave symmetric, -2 sliding): the ones the headline is made of
         assert eng.layer_split(0) == (-3, 2) and eng.layer_split(21)[0] == -3        # conv1 decoded, NCHW in place; fc8 decoded
