@@ -285,6 +285,11 @@ int qcnn_group_forward_host(QcnnGroup* grp, const float* in_nchw_host, int n, fl
  * rank's uploads overlap its layers as in qcnn_forward_host_batches. */
 int qcnn_group_forward_host_batches(QcnnGroup* grp, const float* const* in_host, const int* n, int nb,
                                     float* const* prob_host, uint16_t* const* top5_host);
+/* Asynchronous, device-resident: in_dev[r] / prob_dev[r] / top5_dev[r] are pointers ON RANK r's DEVICE to that rank's block of the
+ * batch (qcnn_group_shard_bounds; NULL entries for ranks whose block is empty, prob_dev / top5_dev may be NULL altogether).  Every
+ * rank's layers are enqueued on its own stream — no host thread, no PCIe: what a caller that already holds the images on the
+ * GPUs uses, and what times the sharded batch without the uploads.  qcnn_group_sync waits for all ranks. */
+int qcnn_group_forward(QcnnGroup* grp, const float* const* in_dev, int n, float* const* prob_dev, uint16_t* const* top5_dev);
 int qcnn_group_sync(QcnnGroup* grp);
 
 #ifdef __cplusplus

@@ -107,6 +107,7 @@ def load():
     lib.qcnn_group_model_broadcast.argtypes = [vp, C.POINTER(C.c_float)]
     lib.qcnn_group_forward_host.argtypes = [vp, f32p, i, f32p, u16p]
     lib.qcnn_group_forward_host_batches.argtypes = [vp, C.POINTER(vp), C.POINTER(i), i, C.POINTER(vp), C.POINTER(vp)]
+    lib.qcnn_group_forward.argtypes = [vp, C.POINTER(vp), i, C.POINTER(vp), C.POINTER(vp)]
     lib.qcnn_group_sync.argtypes = [vp]
     _lib = lib
     return lib

@@ -280,6 +280,24 @@ int qcnn_group_forward_host(QcnnGroup* g, const float* in_nchw_host, int n, floa
   return qcnn_group_forward_host_batches(g, &in_nchw_host, &n, 1, &prob_host, &top5_host);
 }
 
+// Device-resident form: rank r's block of the batch (qcnn_group_shard_bounds) already lies on rank r's device; every rank's
+// layers are ENQUEUED on its own stream (no host thread, no PCIe), qcnn_group_sync waits for all of them.
+int qcnn_group_forward(QcnnGroup* g, const float* const* in_dev, int n, float* const* prob_dev, uint16_t* const* top5_dev) {
+  const int G = (int)g->ctx.size();
+  if (n <= 0 || !in_dev) return gfail(g, "batch %d must be positive", n);
+  if (G > 1 && !g->broadcastDone) return gfail(g, "qcnn_group_model_broadcast must follow the parameter upload");
+  for (int r = 0; r < G; ++r) {
+    int first = 0, count = 0;
+    shard(n, r, G, &first, &count);
+    if (count == 0) continue;
+    if (!in_dev[r]) return gfail(g, "rank %d: no input pointer for its %d images", r, count);
+    if (qcnn_set_option(g->ctx[r], QCNN_OPT_SMALL_BATCH, (g->smallBatch && n <= QCNN_SMALL_BATCH_MAX) ? 1 : 0) ||
+        qcnn_forward(g->ctx[r], in_dev[r], count, prob_dev ? prob_dev[r] : nullptr, top5_dev ? top5_dev[r] : nullptr))
+      return gfail(g, "rank %d (device %d): %s", r, g->devs[r], qcnn_last_error(g->ctx[r]));
+  }
+  return 0;
+}
+
 int qcnn_group_sync(QcnnGroup* g) {
   FOR_ALL(g, qcnn_sync(c));
   return 0;

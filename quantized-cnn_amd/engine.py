@@ -304,6 +304,15 @@ class QcnnDeviceGroup:
         self._chk(self.lib.qcnn_group_forward_host(self.h, imgs.ctypes.data, n, prob.ctypes.data, top5.ctypes.data))
         return prob, top5
 
+    def forward_dev(self, in_ptrs, n, prob_ptrs=None, top5_ptrs=None):
+        """Asynchronous, device-resident (qcnn_group_forward): per-rank device pointers to each rank's block; sync() waits."""
+        vp = C.c_void_p
+        arr = lambda ptrs: (vp * self.size)(*[vp(p) if p else None for p in ptrs]) if ptrs is not None else None
+        self._chk(self.lib.qcnn_group_forward(self.h, arr(in_ptrs), n, arr(prob_ptrs), arr(top5_ptrs)))
+
+    def sync(self):
+        self._chk(self.lib.qcnn_group_sync(self.h))
+
     def forward_host_batches(self, batches, want_prob=True, want_top5=True):
         d = (C.c_int * 3)()
         self.lib.qcnn_fm_dims(self.lib.qcnn_group_ctx(self.h, 0), self.L, d)

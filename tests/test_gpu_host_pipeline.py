@@ -105,6 +105,17 @@ def test_two_ranks_on_one_device(monkeypatch):
     assert np.array_equal(pb[0], want[0]) and np.array_equal(pb[1], want[0][:7]) and np.array_equal(tb[2], want[1][10:141])
     one, _ = grp.forward_host(imgs[:1])                                  # fewer images than ranks: rank 1 idles
     assert np.array_equal(one, want[0][:1])
+    # device-resident form (qcnn_group_forward): every rank's block already on its device, layers enqueued, one sync
+    import torch
+    x = torch.from_numpy(imgs).to("cuda:0")
+    prob_d = torch.zeros((300, want[0].shape[1]), dtype=torch.float32, device="cuda:0")
+    top5_d = torch.zeros((300, 5), dtype=torch.int16, device="cuda:0")
+    torch.cuda.synchronize()
+    b = [grp.shard_bounds(300, r) for r in range(2)]
+    grp.forward_dev([x[lo:hi].data_ptr() for lo, hi in b], 300, [prob_d[lo:hi].data_ptr() for lo, hi in b],
+                    [top5_d[lo:hi].data_ptr() for lo, hi in b])
+    grp.sync()
+    assert np.array_equal(prob_d.cpu().numpy(), want[0]) and np.array_equal(top5_d.cpu().numpy().view(np.uint16), want[1])
     grp.close()
 
 
