@@ -56,15 +56,24 @@ def main():
             return "k_conv_aprx<%s.%s.%d.8." % (m.group(1), m.group(2), int(m.group(3)) // 12)
         return None
 
+    # rocprofv3 --kernel-trace --stats: average duration per kernel, names normalised like the counter tables' ("k_x<1.2.false>")
+    import re as _re
+    stats = {}
+    for r in rows[1:]:
+        m = _re.search(r"(k_[a-z0-9_]+)(<[^>]*>)?", r[0])
+        if m:
+            stats[(m.group(1) + (m.group(2) or "")).replace(", ", ".")] = (float(r[3]) / 1e6, int(r[1]))   # (average ms, calls)
     kernels = {}
     for key, rep in bench["roofline"]["layers"].items():
         pre = kernel_prefix(rep.get("tile", ""))
-        rows = [r for r in table if pre and r["kernel"].startswith(pre) and r.get("FETCH_SIZE") and r.get("WRITE_SIZE")]
-        if key.endswith("_conv") and len(rows) >= 1:
-            r = max(rows, key=lambda r: float(r["SQ_WAVE_CYCLES"] or 0))
+        rows_ = [r for r in table if pre and r["kernel"].startswith(pre) and r.get("FETCH_SIZE") and r.get("WRITE_SIZE")]
+        if key.endswith("_conv") and len(rows_) >= 1:
+            r = max(rows_, key=lambda r: float(r["SQ_WAVE_CYCLES"] or 0))
             f, w = float(r["FETCH_SIZE"]), float(r["WRITE_SIZE"])
+            avg = stats.get(r["kernel"])
             kernels[str(int(key[:2]))] = dict(kernel=r["kernel"], bytes=int((2.0 * f + w) * 1024), fetch_bytes=int(2.0 * f * 1024),
-                                              write_bytes=int(w * 1024))
+                                              write_bytes=int(w * 1024), rocprof_avg_ms=round(avg[0], 4) if avg else None,
+                                              rocprof_calls=avg[1] if avg else None, hip_event_ms_under_rocprof=rep.get("ms"))
     dom = kernels[str(dom_layer)]
     fetch_kib, write_kib = dom["fetch_bytes"] / 2048.0, dom["write_bytes"] / 1024.0
     dom = dict(kernel=dom["kernel"])
