@@ -45,7 +45,8 @@ extern "C" {
 #endif
 
 #define QCNN_ABI_VERSION 4   /* 4 (round 5): QCNN_OPT_LUT_MODE 2 = fp16 table storage, 3 = fp16 tables + fp16 sums (the bf16-pair builder
-                              * of version 3 is gone); qcnn_set_option rejects out-of-range values of QCNN_OPT_SYM / _SLIDE / _SYM8 */
+                              * of version 3 is gone); qcnn_set_option rejects out-of-range values of QCNN_OPT_SYM / _SLIDE / _SYM8;
+                              * qcnn_model_set_layer_shape accepts up to 256 code words per sub-space; qcnn_group_forward */
 
 #define QCNN_SMALL_BATCH_MAX 3   /* batches up to this size can take the few-image kernels (QCNN_OPT_SMALL_BATCH) */
 
@@ -160,7 +161,11 @@ void* qcnn_ctx_stream(const QcnnCtx* ctx);        /* the hipStream_t the context
 /* ---- model ---- */
 int qcnn_model_begin(QcnnCtx* ctx, int layer_cnt, const QcnnLayerDesc* layers, int in_c, int in_h, int in_w);
 /* Declare the quantisation shape of conv/FC layer `layer` (M sub-spaces, K codewords, Cs dims each).
- * Must precede qcnn_model_commit for every conv/FC layer. */
+ * Must precede qcnn_model_commit for every conv/FC layer.  K <= 256 — everything the reference's uint8 assignments can
+ * name (include/FileIO.h:128-166); Cs <= 8.  No shipped model has more than 128 code words, and a LUT stage in LDS holds 128
+ * rows: a layer with 128 < K <= 256 is cut into ceil(K / 127) pseudo sub-spaces of <= 127 code words + one all-zero row over the
+ * same dims (an assignment names its code word in one of them and the zero row in the others: the same sums in the same order)
+ * and runs the exact-builder kernels whatever QCNN_OPT_LUT_MODE says — correct, about half the speed of a K <= 128 layer. */
 int qcnn_model_set_layer_shape(QcnnCtx* ctx, int layer, int M, int K, int Cs);
 /* The reference's PRECISE path (CaffeEva::Init(false): CalcFeatMap_ConvPrec src/CaffeEva.cc:681-758, _FCntPrec :932-966) as
  * an on-device exact baseline: declare conv/FC layer `layer` dense (instead of qcnn_model_set_layer_shape, before commit)

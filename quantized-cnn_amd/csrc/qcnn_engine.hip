@@ -24,7 +24,9 @@ namespace {
 std::string g_createError = "";
 
 struct LayerShape {
-  int M = 0, K = 0, Cs = 0;
+  int M = 0, K = 0, Cs = 0;                                    // as the kernels see the layer (K <= 128)
+  int P = 1, Mfile = 0, Kfile = 0;                             // a parameter set with 128 < K <= 256 code words per sub-space: every sub-space is P =
+                                                               // ceil(K / 127) pseudo sub-spaces of <= 127 code words + a zero row (M = P * Mfile, K = 128)
   bool dense = false;                                          // precise path: bias + dense weights instead of a quantisation
   size_t offDense = 0, denseFloats = 0;
   size_t offBias = 0, offCtrd = 0, offAsmt = 0, offDmap = 0;   // byte offsets into the arena
@@ -222,7 +224,7 @@ int plan_arena(QcnnCtx* c) {
       s.offCtrdF = off; off = align_up(off + sizeof(float) * (size_t)s.M * s.Cs * s.K, 256);
     }
     s.cbnBytes = 0;
-    if (d.type == QCNN_FCNT) {           // bits = the reference's CalcBitCntPerEle for K code words (src/CaffePara.cc:360-380)
+    if (d.type == QCNN_FCNT && s.P == 1) {           // bits = the reference's CalcBitCntPerEle for K code words (src/CaffePara.cc:360-380)
       s.cbnBits = 1;
       while ((1 << s.cbnBits) < s.K) ++s.cbnBits;
       const size_t per = 4096 * 8 / (size_t)s.cbnBits;
@@ -432,12 +434,16 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
       p.prog = s.progBytes ? reinterpret_cast<const uint16_t*>(c->arena + s.offProg) : nullptr;
       p.H = a.h; p.W = a.w; p.Cin = a.c; p.Ho = b.h; p.Wo = b.w; p.Ct = b.c;
       p.knl = d.knlSiz; p.stride = d.stride; p.pad = d.padSiz; p.grp = d.grpCnt;
-      p.M = s.M; p.Cs = s.Cs; p.K = s.K; p.relu = fuseRelu ? 1 : 0; p.panels = panels;
+      p.M = s.M; p.Cs = s.Cs; p.K = s.K; p.pd = s.P; p.relu = fuseRelu ? 1 : 0; p.panels = panels;
       // few-image kernel unless the layer's shape is outside what it covers (a tap window x K that does not fit its LDS
       // table): the panel kernel handles every shape set_layer_shape accepts
       p.splitFrom = 0; p.splitZ = 1; p.partial = nullptr;
       p.nSeg = 0; p.progS = s.progSBytes ? reinterpret_cast<const uint16_t*>(c->arena + s.offProgS) : nullptr;
       s.lastFrom = -1; s.lastZ = 1;
+      if (s.P > 1) {                       // more than 128 code words per sub-space: pseudo sub-spaces, exact-builder kernel in every mode
+        e = qk_conv_aprx(p, 0, st);
+        break;
+      }
       e = small ? qk_conv_small(p, live, st) : hipErrorInvalidValue;
       // fp16 table storage (QCNN_OPT_LUT_MODE = 2): the eight-wave tile kernel in its fp16 form wherever the layer's shape has one
       // (K = 128, complete 4- / 8-dim sub-spaces, > 64 channels per group); QCNN_OPT_SYM8 = 0 keeps every layer in the 16-wave
@@ -628,11 +634,15 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
         if (e != hipSuccess) break;
         p.src = flat;
       }
-      p.D = a.h * a.w * a.c; p.Ct = b.c; p.M = s.M; p.Cs = s.Cs; p.K = s.K;
+      p.D = a.h * a.w * a.c; p.Ct = b.c; p.M = s.M; p.Cs = s.Cs; p.K = s.K; p.pd = s.P;
       p.relu = fuseRelu ? 1 : 0; p.panels = panels;
       // Split the sub-space axis over workgroups when the (channel chunk x panel) grid cannot fill the
       // chip; the exact builder keeps one pass so that the summation order stays the reference's.
       p.msplit = 1; p.partial = nullptr;
+      if (s.P > 1) {                       // pseudo sub-spaces: one pass of the exact-builder kernel
+        e = qk_fc_aprx(p, 0, st);
+        break;
+      }
       if (small && s.K % 4 == 0 && (size_t)live * s.M * s.K <= c->fcPartialElems) {
         p.partial = c->fcPartial;          // few images: the tables are materialised in the partial-sum scratch
         e = qk_fc_small(p, live, st);      // (K not a multiple of 4: the panel kernel below)
@@ -1014,16 +1024,23 @@ int qcnn_model_set_layer_shape(QcnnCtx* c, int layer, int M, int K, int Cs) {
   if (layer < 0 || layer >= c->L) return fail(c, "layer %d out of range", layer);
   const QcnnLayerDesc& d = c->layers[layer];
   if (d.type != QCNN_CONV && d.type != QCNN_FCNT) return fail(c, "layer %d carries no parameters", layer);
-  if (M <= 0 || K <= 0 || K > QCNN_MAX_K || Cs <= 0 || Cs > QCNN_MAX_CS)
+  if (M <= 0 || K <= 0 || K > QCNN_MAX_K_FILE || Cs <= 0 || Cs > QCNN_MAX_CS)
     return fail(c, "layer %d: unsupported quantisation shape M=%d K=%d Cs=%d (K <= %d, Cs <= %d)", layer, M, K, Cs,
-                QCNN_MAX_K, QCNN_MAX_CS);
+                QCNN_MAX_K_FILE, QCNN_MAX_CS);
   const int D = (d.type == QCNN_CONV) ? c->dims[layer].c / d.grpCnt : (int)fm_elems(c, layer);
   if ((size_t)M * Cs < (size_t)D) return fail(c, "layer %d: M*Cs = %d does not cover %d input dims", layer, M * Cs, D);
   if ((M - 1) * Cs >= D) return fail(c, "layer %d: sub-space %d starts beyond the %d input dims", layer, M - 1, D);
   const int Ct = c->dims[layer + 1].c;
   const int Ctg = (d.type == QCNN_CONV) ? Ct / d.grpCnt : Ct;
   if (Ctg % 2) return fail(c, "layer %d: %d output channels per group is not even", layer, Ctg);
-  c->shapes[layer].M = M; c->shapes[layer].K = K; c->shapes[layer].Cs = Cs;
+  LayerShape& s = c->shapes[layer];
+  s.Mfile = M; s.Kfile = K; s.Cs = Cs;
+  // more code words than a 128-row LDS stage holds (the reference's uint8 assignments allow 256, include/FileIO.h:128-166): P pseudo
+  // sub-spaces of <= 127 code words + one all-zero row each over the SAME dims; an assignment names its code word in one of them and
+  // the zero row in the others — the same sums (x + 0 = x), through the exact-builder kernels (ConvParams::pd)
+  s.P = K > QCNN_MAX_K ? (K + 126) / 127 : 1;
+  s.M = M * s.P;
+  s.K = s.P > 1 ? QCNN_MAX_K : K;
   return 0;
 }
 
@@ -1248,6 +1265,27 @@ int qcnn_model_set_layer_params(QcnnCtx* c, int layer, const float* bias, const 
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   drop_f16_programs(s);
   const int Ct = c->dims[layer + 1].c;
+  std::vector<float> ctrdX;
+  std::vector<uint8_t> asmtX;
+  if (s.P > 1) {
+    // file layout (Mfile, Kfile) -> pseudo sub-spaces (M = P * Mfile, K = 128): pseudo sub-space j of m holds code words 127 j .. 127 j +
+    // 126 in its rows 0 .. 126 and zeros in row 127; an assignment v becomes row v % 127 of pseudo sub-space v / 127, row 127 elsewhere
+    const size_t tapsX = (d.type == QCNN_CONV) ? (size_t)d.knlSiz * d.knlSiz : 1;
+    const int P = s.P, Mf = s.Mfile, Kf = s.Kfile, Cs = s.Cs;
+    ctrdX.assign((size_t)s.M * 128 * Cs, 0.0f);
+    for (int m = 0; m < Mf; ++m)
+      for (int k = 0; k < Kf; ++k)
+        for (int dd = 0; dd < Cs; ++dd)
+          ctrdX[(((size_t)m * P + k / 127) * 128 + k % 127) * Cs + dd] = ctrd_file[((size_t)m * Kf + k) * Cs + dd];
+    asmtX.resize((size_t)Ct * tapsX * s.M);
+    for (size_t e = 0; e < (size_t)Ct * tapsX * Mf; ++e) {
+      const unsigned v = asmt_file[e];
+      if ((int)v >= Kf) return fail(c, "layer %d: assignment %u >= K = %d", layer, v, Kf);
+      for (int j = 0; j < P; ++j) asmtX[e * P + j] = (uint8_t)((int)(v / 127) == j ? v % 127 : 127);
+    }
+    ctrd_file = ctrdX.data();
+    asmt_file = asmtX.data();
+  }
   const int M = s.M, K = s.K;
   // PrepAsmtBuf: conv [Ct][kh][kw][M] -> [kh][kw][M][Ct] (:585-586); FC [Ct][M] -> [M][Ct] (:610-611).  Stored as
   // the one-byte SLOT of the code word's row inside a LUT stage (row = (m % G) * K + index < 128; LDS offset = slot * 64),
@@ -1288,6 +1326,18 @@ int qcnn_model_set_layer_params_cbn(QcnnCtx* c, int layer, const float* bias, co
   if (bits < 1 || bits > 8) return fail(c, "layer %d: %d bits per assignment (1..8 supported)", layer, bits);
   const int Ct = c->dims[layer + 1].c;
   const size_t taps = (d.type == QCNN_CONV) ? (size_t)d.knlSiz * d.knlSiz : 1;
+  if (s.P > 1) {                        // more than 128 code words: unpacked here, expanded into pseudo sub-spaces by the byte path
+    const size_t nF = (size_t)Ct * taps * s.Mfile, perF = 4096 * 8 / (size_t)bits;
+    if (cbn_bytes < (nF + perF - 1) / perF * 4096) return fail(c, "layer %d: %zu bytes of packed assignments, %zu needed", layer, cbn_bytes, (nF + perF - 1) / perF * 4096);
+    std::vector<uint8_t> vals(nF);
+    for (size_t e = 0; e < nF; ++e) {
+      const size_t bit0 = (e % perF) * bits;
+      const uint8_t* b = cbn_blocks + (e / perF) * 4096 + (bit0 >> 3);
+      const unsigned w = ((unsigned)b[0] << 8) | (unsigned)b[(bit0 & 7) + bits > 8 ? 1 : 0];
+      vals[e] = (uint8_t)((w >> (16 - (bit0 & 7) - bits)) & ((1u << bits) - 1u));
+    }
+    return qcnn_model_set_layer_params(c, layer, bias, ctrd_file, vals.data());
+  }
   const int groups = (d.type == QCNN_CONV) ? d.grpCnt : 1;
   const QkSlots sl = (d.type == QCNN_CONV) ? qk_conv_slots(Ct / groups, groups) : qk_fc_slots(Ct);
   const size_t n = (size_t)Ct * taps * s.M;

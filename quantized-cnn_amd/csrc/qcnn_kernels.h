@@ -22,7 +22,9 @@
 
 #define QCNN_PANEL 128
 #define QCNN_MAX_CS 8          // dims per sub-space supported by the LUT builders
-#define QCNN_MAX_K 128         // code words per sub-space supported (a LUT stage holds 128 rows)
+#define QCNN_MAX_K 128         // code words per (pseudo) sub-space a kernel handles (a LUT stage holds 128 rows)
+#define QCNN_MAX_K_FILE 256    // code words per sub-space a parameter set may have (uint8 assignments): above 128 the engine cuts the
+                               // sub-space into pseudo sub-spaces of <= 127 code words + a zero row (ConvParams::pd)
 #define QCNN_ROWS_PAD 256      // bytes of slack after every row-offset table (over-read of the last groups)
 #define QCNN_STAGE_ROWS 128    // code-word rows of one LUT stage in LDS
 #define QCNN_TILE_BYTES 8192   // one image tile of a stage: 128 rows x 16 images x 4 B
@@ -176,6 +178,10 @@ struct ConvParams {
   int H, W, Cin, Ho, Wo, Ct;
   int knl, stride, pad, grp;
   int M, Cs, K;
+  int pd;                // sub-spaces per group of input dims: sub-space m covers dims (m / pd) * Cs ...  1 everywhere except layers with
+                         // MORE THAN 128 code words per sub-space (the reference's uint8 allows 256): such a sub-space is pd = ceil(K / 127)
+                         // pseudo sub-spaces of <= 127 code words + one all-zero row each; an assignment names its code word in one of them
+                         // and the zero row in the others (x + 0 = x: same sums).  Exact-builder kernels only (qk_conv_aprx with lutMode 0)
   int relu;              // fuse max(0, x) into the store
   int panels;
   int lutF16;            // tolerance study (BASELINE configs[4]): table entries rounded to fp16 before they are stored
@@ -252,6 +258,7 @@ struct FcParams {
                          // order [Ct][M], 4096-byte blocks of floor(32768 / bits) values, MSB first, 0-based code words), or NULL;
   int cbnBits;           // read in place by the few-image kernel (qk_fc_small): 4 / 5 bits per assignment instead of a byte
   int D, Ct, M, Cs, K;
+  int pd;                // as ConvParams::pd
   int relu;
   int panels;
   int lutF16;            // as ConvParams::lutF16

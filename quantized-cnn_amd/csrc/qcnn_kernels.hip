@@ -339,7 +339,7 @@ __device__ __forceinline__ XAddr xaddr_nchw(int bw, int lane, int img0, int n, u
 // Builder wave bw computes rows bw*ceil(K/4) .. of every sub-space; a lane carries an image pair.
 __device__ __forceinline__ void build_stage_exact(char* stage, const char* __restrict__ xbase, uint32_t xoff0, const XAddr& xa,
                                                   const float* __restrict__ ctrd, int K, int Cs, int D, int G, int m0,
-                                                  int mEnd, int bw, int lane) {
+                                                  int mEnd, int bw, int lane, int pd = 1) {
   const int kpw = (K + NBW - 1) / NBW;
   const int k0 = bw * kpw;
   const int k1 = min(K, k0 + kpw);
@@ -348,8 +348,9 @@ __device__ __forceinline__ void build_stage_exact(char* stage, const char* __res
   for (int g = 0; g < G; ++g) {
     const int m = m0 + g;
     if (m >= mEnd) break;
-    const int dsel = min(D - m * Cs, Cs);
-    const char* __restrict__ xm = xbase + xoff0 + (uint32_t)(m * Cs) * xa.dimStride;
+    const int md = pd > 1 ? m / pd : m;                          // pseudo sub-spaces (K > 128, ConvParams::pd) share their dims
+    const int dsel = min(D - md * Cs, Cs);
+    const char* __restrict__ xm = xbase + xoff0 + (uint32_t)(md * Cs) * xa.dimStride;
     f32x2 xv[QCNN_MAX_CS];
 #pragma unroll
     for (int d = 0; d < QCNN_MAX_CS; ++d) {
@@ -748,7 +749,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
         }
       }
     } else {
-      build_stage_exact(lds, xbase, pixel_off(first, g), xa, p.ctrd, K, Cs, Cg, G, first.mg * G, M, bw, lane);
+      build_stage_exact(lds, xbase, pixel_off(first, g), xa, p.ctrd, K, Cs, Cg, G, first.mg * G, M, bw, lane, p.pd);
     }
     barrier_after_lds_writes();
     // Straight-line body (no VMEM operation under a condition), so that the compiler's vmcnt waits are
@@ -761,7 +762,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
         const StagePos qf = (s + 3 < S) ? q3 : first;
         mfma_load<KTT, KS>(opsA, xbase, pixel_off(qf, g), xa, p.ctrd, Cs, qf.mg * G, bw, lane, reloadA);
       } else if (s + 1 < S) {
-        build_stage_exact(lds + STAGE_BYTES, xbase, pixel_off(q1, g), xa, p.ctrd, K, Cs, Cg, G, q1.mg * G, M, bw, lane);
+        build_stage_exact(lds + STAGE_BYTES, xbase, pixel_off(q1, g), xa, p.ctrd, K, Cs, Cg, G, q1.mg * G, M, bw, lane, p.pd);
       }
       TR_ARRIVE(s);
       barrier_after_lds_writes();
@@ -773,7 +774,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv_aprx(ConvParams p, int tilesX,
         const StagePos qf = (s + 4 < S) ? q3 : first;
         mfma_load<KTT, KS>(opsB, xbase, pixel_off(qf, g), xa, p.ctrd, Cs, qf.mg * G, bw, lane, reloadA);
       } else if (s + 2 < S) {
-        build_stage_exact(lds, xbase, pixel_off(q1, g), xa, p.ctrd, K, Cs, Cg, G, q1.mg * G, M, bw, lane);
+        build_stage_exact(lds, xbase, pixel_off(q1, g), xa, p.ctrd, K, Cs, Cg, G, q1.mg * G, M, bw, lane, p.pd);
       }
       TR_ARRIVE(s + 1);
       barrier_after_lds_writes();
@@ -1227,7 +1228,7 @@ __global__ __launch_bounds__(NW * 64) void k_fc_aprx(FcParams p, int G, int stag
         __builtin_amdgcn_sched_barrier(0);
         mfma_load<KTT, KS>(opsB, xbase, 0u, xa, p.ctrd, Cs, min(mBeg + 2 * G, mLastStage), bw, lane);
       } else {
-        build_stage_exact(lds, xbase, 0u, xa, p.ctrd, K, Cs, p.D, G, mBeg, mEnd, bw, lane);
+        build_stage_exact(lds, xbase, 0u, xa, p.ctrd, K, Cs, p.D, G, mBeg, mEnd, bw, lane, p.pd);
       }
     }
     barrier_after_lds_writes();
@@ -1237,14 +1238,14 @@ __global__ __launch_bounds__(NW * 64) void k_fc_aprx(FcParams p, int G, int stag
         mfma_store<KTT, KS, 1>(opsA, Cs, p.D, min(m0 + G, mLastStage), mEnd, bw, lane, p.lutF16);
         mfma_load<KTT, KS>(opsA, xbase, 0u, xa, p.ctrd, Cs, min(m0 + 3 * G, mLastStage), bw, lane);
       } else if (s + 1 < S) {
-        build_stage_exact(lds + STAGE_BYTES, xbase, 0u, xa, p.ctrd, K, Cs, p.D, G, m0 + G, mEnd, bw, lane);
+        build_stage_exact(lds + STAGE_BYTES, xbase, 0u, xa, p.ctrd, K, Cs, p.D, G, m0 + G, mEnd, bw, lane, p.pd);
       }
       barrier_after_lds_writes();
       if (KT > 0) {
         mfma_store<KTT, KS, 0>(opsB, Cs, p.D, min(m0 + 2 * G, mLastStage), mEnd, bw, lane, p.lutF16);
         mfma_load<KTT, KS>(opsB, xbase, 0u, xa, p.ctrd, Cs, min(m0 + 4 * G, mLastStage), bw, lane);
       } else if (s + 2 < S) {
-        build_stage_exact(lds, xbase, 0u, xa, p.ctrd, K, Cs, p.D, G, m0 + 2 * G, mEnd, bw, lane);
+        build_stage_exact(lds, xbase, 0u, xa, p.ctrd, K, Cs, p.D, G, m0 + 2 * G, mEnd, bw, lane, p.pd);
       }
       barrier_after_lds_writes();
     }
@@ -1543,6 +1544,7 @@ hipError_t qk_conv_aprx(const ConvParams& pIn, int lutMode, hipStream_t st) {
   ConvParams p = pIn;
   p.lutF16 = (lutMode >= 2) ? 1 : 0;        // 2, 3: entries rounded to fp16, kept in f32 slots, fp32 sums (layers without an fp16 form)
   if (lutMode >= 2) lutMode = 1;
+  if (p.pd < 1 || (p.pd > 1 && lutMode != 0)) return hipErrorInvalidValue;   // pseudo sub-spaces: the exact-builder kernels only
   const int Ctg = p.Ct / p.grp;
   if (Ctg % 2 || p.Cs > QCNN_MAX_CS || p.K > QCNN_MAX_K) return hipErrorInvalidValue;
   const QkSlots sl = qk_conv_slots(Ctg, p.grp);
@@ -1772,6 +1774,7 @@ hipError_t qk_fc_aprx(const FcParams& pIn, int lutMode, hipStream_t st) {
   FcParams p = pIn;
   p.lutF16 = (lutMode >= 2) ? 1 : 0;
   if (lutMode >= 2) lutMode = 1;
+  if (p.pd < 1 || (p.pd > 1 && lutMode != 0)) return hipErrorInvalidValue;
   if (p.Ct % 2 || p.Cs > QCNN_MAX_CS || p.K > QCNN_MAX_K || p.msplit < 1) return hipErrorInvalidValue;
   const QkSlots sl = qk_fc_slots(p.Ct);
   switch (sl.cpw) {

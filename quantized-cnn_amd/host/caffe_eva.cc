@@ -131,21 +131,15 @@ bool CaffeEva::LoadCaffePara(void) {
     return false;
   }
   if (!caffeParaObj.LoadLayerPara(enblAprx, ENUM_AsmtEnc::Compact)) return false;
-  // Limits of the MI355X build, reported HERE in the reference's convention ([ERROR] + false from LoadCaffePara) instead of
-  // surfacing later from the device library: the reference's uint8 assignments allow up to 256 code words per sub-space
-  // (include/FileIO.h:128-166; no shipped model has more than 128) — a sub-space's table is ONE 128-row LDS stage here —, and
-  // output channels are handled in pairs (the reference itself needs multiples of 8 per group: the unrolled loops of
-  // src/CaffeEva.cc:849-858, 1008-1017 over-run otherwise)
+  // A limit of the MI355X build, reported HERE in the reference's convention ([ERROR] + false from LoadCaffePara) instead of
+  // surfacing later from the device library: output channels are handled in pairs (the reference itself needs multiples of 8 per
+  // group: the unrolled loops of src/CaffeEva.cc:849-858, 1008-1017 over-run otherwise).  (Up to 256 code words per sub-space — all
+  // the reference's uint8 assignments can name, include/FileIO.h:128-166 — are supported: above 128 the device library cuts a
+  // sub-space into pseudo sub-spaces, qcnn_model_set_layer_shape.)
   if (enblAprx) {
     for (int l = 0; l < caffeParaObj.layerCnt; ++l) {
       const LayerInfo& li = caffeParaObj.layerInfoLst[l];
       if (li.type != ENUM_LyrType::Conv && li.type != ENUM_LyrType::FCnt) continue;
-      const Matrix<float>& ctrd = caffeParaObj.layerParaLst[l].ctrdLst;
-      if (ctrd.GetDimCnt() == 3 && ctrd.GetDimLen(1) > 128) {
-        printf("[ERROR] layer #%d: %d code words per sub-space; this build supports at most 128 (one LDS stage per sub-space)\n",
-               l + 1, ctrd.GetDimLen(1));
-        return false;
-      }
       const int perGrp = (li.type == ENUM_LyrType::Conv) ? li.knlCnt / (li.grpCnt > 0 ? li.grpCnt : 1) : li.nodCnt;
       if (perGrp % 2 != 0) {
         printf("[ERROR] layer #%d: %d output channels per group; this build needs an even count\n", l + 1, perGrp);
@@ -153,7 +147,6 @@ bool CaffeEva::LoadCaffePara(void) {
       }
     }
   }
-
   batchSize_ = envInt("QCNN_BATCH", 1);
   batchCnt_ = envInt("QCNN_BATCHES", 100);
   // images handed to the devices at once: all of them up to QCNN_MAX_INFLIGHT (QCNN_COALESCE=0: one logical batch at a time)

@@ -462,6 +462,56 @@ def test_odd_channel_count_is_rejected():
         eng.configure(in_chw, layers, {0: (1, 16, 3), 2: (63, 16, 4)})
 
 
+def test_option_values_out_of_range_are_refused():
+    """qcnn_set_option never clamps: a value a kernel family does not define (QCNN_OPT_SYM8 = 6 was once silently run as 3) is an
+    error with a message, and the option keeps its value.  More than 128 code words per sub-space are refused at
+    qcnn_model_set_layer_shape (the host mirror reports the same at LoadCaffePara: tests/test_host_mirror.py)."""
+    eng = pkg("engine").QcnnEngine(0)
+    for opt, bad in ((capi.OPT_SYM8, 4), (capi.OPT_SYM8, 6), (capi.OPT_SYM8, -1), (capi.OPT_SYM, 3), (capi.OPT_SLIDE, 3),
+                     (capi.OPT_LUT_MODE, 4), (capi.OPT_LUT_MODE, -1), (capi.OPT_STREAMS, 0), (capi.OPT_STREAMS, 9)):
+        with pytest.raises(pkg("engine").QcnnError):
+            eng.set_option(opt, bad)
+    for opt, ok in ((capi.OPT_SYM8, 3), (capi.OPT_SYM, 2), (capi.OPT_SLIDE, 2), (capi.OPT_LUT_MODE, 3), (capi.OPT_LUT_MODE, 1)):
+        eng.set_option(opt, ok)
+    layers = [topo.conv(0, 3, 8, 1, 1), topo.relu(), topo.fcnt(10), topo.smax()]
+    with pytest.raises(pkg("engine").QcnnError) as ei:
+        eng.configure((3, 8, 8), layers, {0: (1, 257, 3), 2: (72, 16, 4)})      # more than a uint8 assignment can name
+    assert "K" in str(ei.value)
+    eng.close()
+
+
+def test_more_than_128_code_words_per_sub_space():
+    """The reference's uint8 assignments allow up to 256 code words per sub-space (include/FileIO.h:128-166; GetInPdMat has no
+    K limit, src/CaffeEva.cc:1261-1296); a LUT stage here holds 128 rows.  Layers with 128 < K <= 256 are cut into pseudo
+    sub-spaces of <= 127 code words + one all-zero row over the same dims (an assignment names its code word in one of them, the
+    zero row in the others: x + 0 = x, the same sums in the same order) and run the exact-builder kernels in every LUT mode.
+    K = 200 (two pseudo sub-spaces), 256 (three), 130; conv with incomplete last sub-space, FC with 2-dim sub-spaces, a 1-dim
+    classifier; 5 and 131 images; device-side .cbn decode of 8-bit streams: every conv / FC layer BIT-IDENTICAL to the oracle in
+    isolation, every feature map within 1e-4 (LRN / soft-max: libm)."""
+    in_chw, layers = topo.tiny_model()
+    for spec_kw in (dict(conv_k=200, conv_cs=8, fc_k=256, fc_cs=4, last_k=130, last_cs=1),
+                    dict(conv_k=256, conv_cs=4, fc_k=129, fc_cs=2, last_k=255, last_cs=2)):
+        _run_vs_oracle(in_chw, layers, spec_kw, 5, seed=141)
+    spec = synth.quant_spec(in_chw, layers, conv_k=200, conv_cs=8, fc_k=256, fc_cs=4, last_k=130, last_cs=1)
+    params = synth.make_params(in_chw, layers, seed=143, spec=spec)
+    imgs = synth.make_images(131, in_chw, seed=144)
+    orc = po.COracle(in_chw, layers)
+    orc.set_params(params)
+    orc.forward(imgs[128:131])
+    L = len(layers)
+    for cbn in (False, True):
+        eng = pkg("engine").QcnnEngine(0)
+        eng.set_option(capi.OPT_KEEP_ALL, 0)                                  # library defaults otherwise (f32 MFMA mode, fast path)
+        eng.load_model(in_chw, layers, params, 131, upload=not cbn)
+        if cbn:
+            eng.upload_cbn(params)
+        prob, top5 = eng.forward_host(imgs)
+        e_inf, e_l2 = rel_err(prob[128:131], orc.fm(L).reshape(3, -1))
+        assert e_inf <= TOL_LIBM and e_l2 <= TOL_LIBM, "cbn %r: %g %g" % (cbn, e_inf, e_l2)
+        assert np.array_equal(top5[128:131], np.stack([orc.top5(orc.fm(L)[i]) for i in range(3)]))
+        eng.close()
+
+
 # ---------------------------------------------------------------- batches of a few images ----
 @pytest.mark.parametrize("model,n_img", [("AlexNet", 1), ("AlexNet", 2), ("CaffeNetFGB", 2), ("VggCnnS", 2), ("VGG16", 1)])
 def test_small_batch_kernels_vs_oracle(model, n_img):

@@ -91,30 +91,6 @@ def test_parameter_loading_and_encoding_conversion(tmp_path):
     assert sums[0, 2] == params[0]["asmt"].astype(np.float64).sum()
 
 
-def test_more_than_128_code_words_rejected_at_load_time(tmp_path, capfd):
-    """The reference's uint8 assignments allow up to 256 code words per sub-space (include/FileIO.h:128-166); this build
-    keeps a sub-space's table in one 128-row LDS stage.  A parameter set with K = 200 must be refused by LoadCaffePara in
-    the reference's convention — `[ERROR] ...` on stdout, false — before any device is touched (runs without a GPU)."""
-    lib = host()
-    if not hasattr(lib, "qh_eva_prob"):
-        pytest.skip("host mirror built without the device entry points")
-    f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
-    lib.qh_eva_prob.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, f32p, C.c_int, C.c_int, C.c_int, f32p, C.c_int]
-    in_chw, layers, _, _ = topo.MODELS["AlexNet"]
-    spec = synth.quant_spec(in_chw, layers, fc_k=200)
-    params = synth.make_params(in_chw, layers, seed=3, spec=spec)
-    d = tmp_path / "AlexNet" / "Bin.Files"
-    d.mkdir(parents=True)
-    synth.write_param_dir(str(d), "p", params)
-    img = np.zeros((3, 227, 227), np.float32)
-    prob = np.zeros(1000, np.float32)
-    rc = lib.qh_eva_prob(str(tmp_path).encode(), b"AlexNet", b"AlexNet/Bin.Files", b"p", 1, img.reshape(-1), 3, 227, 227, prob, 1000)
-    assert rc == 3                                                        # LoadCaffePara returned false
-    C.CDLL(None).fflush(None)                                             # the C side's stdio buffer
-    out = capfd.readouterr().out
-    assert "[ERROR]" in out and "200 code words" in out
-
-
 @pytest.mark.skipif(not (po.have_ref() and os.path.isdir(po.REF_DATA)), reason="needs oracle/_ref (+ data)")
 def test_bmp_preprocessing_matches_reference_bitwise():
     lib = host()
