@@ -10,7 +10,7 @@ sys.path.insert(0, ROOT)
 pkg = lambda n: importlib.import_module("quantized-cnn_amd." + n)
 
 
-def run(model, n, reps, modes):
+def run(model, n, reps, modes, compare=True):
     import torch
     capi, topo, synth = pkg("capi"), pkg("topology"), pkg("synth")
     in_chw, layers, _, _ = topo.MODELS[model]
@@ -46,8 +46,8 @@ def run(model, n, reps, modes):
         # (the eight-wave FC kernel groups the partial sums differently: conv families are compared through fc-free bits only
         # when it is off; with it on, equality to rounding)
         close = np.abs(first - ref).max() <= 1e-5 * np.abs(ref).max()
-        print("%-8s %-22s %d forwards reproducible; equal to the tile kernels: %s  [%s]" % (model, name, reps, "bitwise" if same else ("to rounding" if close else "NO"), cuts), flush=True)
-        assert close
+        print("%-8s %-22s %d forwards reproducible; equal to the tile kernels: %s  [%s]" % (model, name, reps, "bitwise" if same else ("to rounding" if close else ("not compared" if not compare else "NO")), cuts), flush=True)
+        assert close or not compare
 
 
 def main():
@@ -58,6 +58,11 @@ def main():
              ("planner", [(capi.OPT_SLIDE, 1), (capi.OPT_SYM, 1), (capi.OPT_SYM8, 1)])]
     run("AlexNet", 300, reps, modes)
     run("VGG16", 140, max(4, reps // 8), modes)
+    # round 5: the fp16 study kernels (reproducible run to run; their values are another function) and the split eight-wave tiles
+    study = [("fp16 tables", [(capi.OPT_LUT_MODE, capi.LUT_MFMA_F16), (capi.OPT_SYM8, 1)]),
+             ("fp16 tables + sums", [(capi.OPT_LUT_MODE, capi.LUT_MFMA_F16ACC), (capi.OPT_SYM8, 1)])]
+    run("AlexNet", 300, reps, study, compare=False)
+    run("AlexNet", 125, reps, [("tile", []), ("sym8 tile, split", [(capi.OPT_SYM8, 2), (capi.OPT_SPLIT, 1)])])
     print("soak_modes OK")
 
 
