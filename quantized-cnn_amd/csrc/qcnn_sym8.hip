@@ -42,6 +42,11 @@
                       // 1 no LUT stores, 2 no matrix instructions, 4 no look-ups.  0 = the production object: every `#if S8_VAR` below drops out
 #endif
 
+#ifndef S8_ANTI
+#define S8_ANTI 0     // compile-time, variant builds only: 1 = the two waves of a SIMD in OPPOSITE phases (waves 4 .. 7 gather while waves 0 .. 3
+                      // build and vice versa: the same loop body, the stage barrier moved between build and look-ups for the second set)
+#endif
+
 #ifdef S8_TRACE
 // Debug build only (scripts/trace_sym8.py): every wave of workgroup `s8_trace_block` sums, in scalar registers, the cycles
 // between its phase marks — period start / build done (matrix instructions + stores issued, next operand loads issued) /
@@ -455,6 +460,14 @@ __global__ __launch_bounds__(NW8 * 64) void k_conv_sym8(ConvParams p, int tilesX
   }
   if (wave == 0) { idx_row_to_lds<ROWB>(rowOf(c0, 0), PROG8_LDS + rb0, lane); idx_row_to_lds<ROWB>(rowOf(c1, 1), PROG8_LDS + rb1, lane); }
   barrier_after_lds_dma();
+  // S8_ANTI: waves 4 .. 7 (the second wave of every SIMD) run half a period ahead in the look-ups: they gather stage t + 1 where
+  // waves 0 .. 3 gather stage t, and wait at the stage barrier BETWEEN build and look-ups instead of behind the look-ups — so
+  // that one wave of a SIMD multiplies while the other one gathers.  Same buffers, same hazards: within a barrier period set A
+  // builds stage s + 1 and gathers stage s, set B gathers stage s and builds stage s + 1.
+  constexpr bool ANTI = S8_ANTI != 0 && !SLIDE && MODE == 0;
+  const int isB = ANTI ? (wave >= 4 ? 1 : 0) : 0;
+  if (ANTI && isB) gather8<TH, TW, CPW, MODE, AccT>(acc, my_blk(wave, BLKB) + rb0, c0, p.knl, rowStart, colStart, laneLds, activeI);
+  auto pick = [&](const StagePos& a, const StagePos& b) { StagePos r; r.hi = isB ? b.hi : a.hi; r.wi = isB ? b.wi : a.wi; r.mg = isB ? b.mg : a.mg; r.ph = isB ? b.ph : a.ph; return r; };
   {
     S8_DECL;
     StagePos cEnd = first;                              // SLIDE: the stage gathered last (its source row may have ended)
@@ -474,12 +487,18 @@ __global__ __launch_bounds__(NW8 * 64) void k_conv_sym8(ConvParams p, int tilesX
       __builtin_amdgcn_sched_barrier(0);
       S8_T(1, s);
       if constexpr (SLIDE) column_end(cEnd, liveEnd);       // what the previous stage finished (its stores have this period to drain)
-      gather8<TH, TW, CPW, MODE, AccT>(acc, my_blk(wave, BLKB) + rb0, c0, p.knl, rowStart, colStart, laneLds, activeI);
+      if constexpr (ANTI) {
+        if (isB) barrier_after_lds_writes();
+        gather8<TH, TW, CPW, MODE, AccT>(acc, my_blk(wave, BLKB) + (isB ? rb1 : rb0), pick(c0, c1), p.knl, rowStart, colStart,
+                                         laneLds | (uint32_t)(isB ? STAGE_BYTES : 0), activeI & (isB ? in_range(s + 1, S) : 1));
+      } else {
+        gather8<TH, TW, CPW, MODE, AccT>(acc, my_blk(wave, BLKB) + rb0, c0, p.knl, rowStart, colStart, laneLds, activeI);
+      }
       if constexpr (SLIDE) { cEnd = c0; liveEnd = activeI; }
       S8_T(2, s);
       c0 = c1; c1 = c2; c2 = next_pos(c2, g);
       { const uint32_t t = rb0; rb0 = rb1; rb1 = rb2; rb2 = t; }
-      barrier_after_lds_writes();
+      if (!ANTI || !isB) barrier_after_lds_writes();
       S8_T(3, s);
       // ---- period s + 1: stage s + 2 -> buffer 0, gather stage s + 1 out of buffer 1
       build(ops, 0u);
@@ -493,12 +512,18 @@ __global__ __launch_bounds__(NW8 * 64) void k_conv_sym8(ConvParams p, int tilesX
       __builtin_amdgcn_sched_barrier(0);
       S8_T(1, s + 1);
       if constexpr (SLIDE) column_end(cEnd, liveEnd);
-      gather8<TH, TW, CPW, MODE, AccT>(acc, my_blk(wave, BLKB) + rb0, c0, p.knl, rowStart, colStart, laneLds | STAGE_BYTES, activeI & in_range(s + 1, S));
+      if constexpr (ANTI) {
+        if (isB) barrier_after_lds_writes();
+        gather8<TH, TW, CPW, MODE, AccT>(acc, my_blk(wave, BLKB) + (isB ? rb1 : rb0), pick(c0, c1), p.knl, rowStart, colStart,
+                                         laneLds | (uint32_t)(isB ? 0 : STAGE_BYTES), activeI & in_range(s + 1 + isB, S));
+      } else {
+        gather8<TH, TW, CPW, MODE, AccT>(acc, my_blk(wave, BLKB) + rb0, c0, p.knl, rowStart, colStart, laneLds | STAGE_BYTES, activeI & in_range(s + 1, S));
+      }
       if constexpr (SLIDE) { cEnd = c0; liveEnd = activeI & in_range(s + 1, S); }
       S8_T(2, s + 1);
       c0 = c1; c1 = c2; c2 = next_pos(c2, g);
       { const uint32_t t = rb0; rb0 = rb1; rb1 = rb2; rb2 = t; }
-      barrier_after_lds_writes();
+      if (!ANTI || !isB) barrier_after_lds_writes();
       S8_T(3, s + 1);
     }
     S8_DUMP;
