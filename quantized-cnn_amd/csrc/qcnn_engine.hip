@@ -301,14 +301,24 @@ void free_model(QcnnCtx* c) {
   c->committed = false;
 }
 
-int ensure_stage(QcnnCtx* c) {
-  if (c->stageIn) return 0;
-  size_t maxE = 0;
-  for (int l = 0; l <= c->L; ++l) maxE = fm_elems(c, l) > maxE ? fm_elems(c, l) : maxE;
-  c->stageElems = maxE * c->maxBatch;
-  HIP_TRY(c, hipMalloc(&c->stageIn, c->stageElems * sizeof(float)));
-  HIP_TRY(c, hipMalloc(&c->stageOut, c->stageElems * sizeof(float)));
-  HIP_TRY(c, hipMalloc(&c->stageTop5, (size_t)c->maxBatch * 5 * sizeof(uint16_t)));
+// Linear staging for host <-> device conversions.  Sized for what the forward paths need — a batch of network inputs, a batch of
+// class scores — and grown on demand when a larger feature map is dumped (qcnn_get_layer_output / qcnn_run_layer): sizing it for the
+// LARGEST map of the model up front made the first qcnn_forward_host of VGG-16 at batch 1000 allocate 2 x 12.8 GB (0.75 s; AlexNet: 2 x
+// 1.2 GB)
+int ensure_stage(QcnnCtx* c, size_t elems = 0) {
+  const size_t base = std::max(fm_elems(c, 0), fm_elems(c, c->L)) * (size_t)c->maxBatch;
+  const size_t need = std::max(base, elems);
+  if (c->stageIn && c->stageElems >= need) return 0;
+  if (c->stageIn) {                                     // grow: nothing may still be using the old buffers
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->copyStream) HIP_TRY(c, hipStreamSynchronize(c->copyStream));
+    (void)hipFree(c->stageIn); (void)hipFree(c->stageOut);
+    c->stageIn = c->stageOut = nullptr;
+  }
+  c->stageElems = need;
+  HIP_TRY(c, hipMalloc(&c->stageIn, c->stageElems * sizeof(float) + kSlack));
+  HIP_TRY(c, hipMalloc(&c->stageOut, c->stageElems * sizeof(float) + kSlack));
+  if (!c->stageTop5) HIP_TRY(c, hipMalloc(&c->stageTop5, (size_t)c->maxBatch * 5 * sizeof(uint16_t)));
   return 0;
 }
 
@@ -1615,7 +1625,7 @@ int qcnn_get_layer_output(QcnnCtx* c, int l, int n, float* host_out) {
   if (!c->keepAll && l > 0 && (c->layers[l - 1].type == QCNN_CONV || c->layers[l - 1].type == QCNN_FCNT) &&
       l < c->L && c->layers[l].type == QCNN_RELU)
     return fail(c, "feature map %d was fused away (QCNN_OPT_KEEP_ALL = 0)", l);
-  if (ensure_stage(c)) return 1;
+  if (ensure_stage(c, (size_t)n * fm_elems(c, l))) return 1;
   const int E = (int)fm_elems(c, l);
   hipError_t e = qk_unpack_rows(c->lastFm[l], c->stageOut, n, E, c->stream);
   if (e != hipSuccess) return fail(c, "unpack launch failed: %s", hipGetErrorString(e));
@@ -1633,7 +1643,7 @@ int qcnn_get_layer_output_range(QcnnCtx* c, int l, int first, int n, float* host
   if (!c->keepAll && l > 0 && (c->layers[l - 1].type == QCNN_CONV || c->layers[l - 1].type == QCNN_FCNT) &&
       l < c->L && c->layers[l].type == QCNN_RELU)
     return fail(c, "feature map %d was fused away (QCNN_OPT_KEEP_ALL = 0)", l);
-  if (ensure_stage(c)) return 1;
+  if (ensure_stage(c, (size_t)(n + QCNN_PANEL) * fm_elems(c, l))) return 1;
   const size_t E = fm_elems(c, l);
   const int p0 = first / QCNN_PANEL;                       // whole panels from the one that holds `first`
   const int cnt = first + n - p0 * QCNN_PANEL;
@@ -1650,7 +1660,7 @@ int qcnn_run_layer(QcnnCtx* c, int layer, const float* in_host, int n, float* ou
   if (!c->committed) return fail(c, "model not committed");
   if (layer < 0 || layer >= c->L) return fail(c, "layer %d out of range", layer);
   if (n <= 0 || n > c->maxBatch) return fail(c, "batch %d outside (0, %d]", n, c->maxBatch);
-  if (ensure_stage(c)) return 1;
+  if (ensure_stage(c, (size_t)n * std::max(fm_elems(c, layer), fm_elems(c, layer + 1)))) return 1;
   const int Ein = (int)fm_elems(c, layer), Eout = (int)fm_elems(c, layer + 1);
   const int panels = (n + QCNN_PANEL - 1) / QCNN_PANEL;
   // scratch: reuse the layer's own input/output maps (sized for maxBatch)

@@ -47,6 +47,11 @@
                       // build and vice versa: the same loop body, the stage barrier moved between build and look-ups for the second set)
 #endif
 
+#ifndef S8_ROWMAJOR
+#define S8_ROWMAJOR 0 // compile-time, variant builds only: 1 = the f32 table ROW-MAJOR like the fp16 table (512-byte rows, image quads XOR-swizzled
+                      // by the row's index in its tile), product transposed, ONE ds_write_b128 per result tile instead of four add-TID stores
+#endif
+
 #ifdef S8_TRACE
 // Debug build only (scripts/trace_sym8.py): every wave of workgroup `s8_trace_block` sums, in scalar registers, the cycles
 // between its phase marks — period start / build done (matrix instructions + stores issued, next operand loads issued) /
@@ -187,6 +192,17 @@ __device__ __forceinline__ void st16(char* lds, const f32x4& v, uint32_t adr) {
   const f16x2 lo = __builtin_convertvector(f32x2{v[0], v[1]}, f16x2), hi = __builtin_convertvector(f32x2{v[2], v[3]}, f16x2);
   *reinterpret_cast<uint2*>(lds + adr + I * 16 * (int)ROW16B) = uint2{__builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi)};
 }
+// row-major f32 table (S8_ROWMAJOR): row slot s at byte 512 s, the 16 bytes of image quad q at position q ^ key(s), key = the row's
+// index inside its tile (its low three bits differ over the eight lanes of a ds_write_b128 group: conflict-free)
+__device__ __forceinline__ uint32_t st32_addr(int rt0, int it, uint32_t li, uint32_t lk, uint32_t sw) {
+  const uint32_t rr = li ^ (sw << 2);
+  const uint32_t slotLow = ((rr & 3u) << 2) | (rr >> 2);
+  return ((uint32_t)rt0 * 16u + slotLow) * 512u + ((((uint32_t)it * 4u + lk) ^ rr) << 4);
+}
+template <int I>
+__device__ __forceinline__ void st32(char* lds, const f32x4& v, uint32_t adr) {
+  *reinterpret_cast<f32x4*>(lds + adr + I * 16 * 512) = v;
+}
 template <int KS>
 __device__ __forceinline__ f32x4 ops8_tile_t(const Ops8<KS>& o, int t, int i) {
   const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -220,6 +236,34 @@ __device__ __forceinline__ void ops8_store16(char* lds, const Ops8<KS>& o, uint3
   __builtin_amdgcn_sched_barrier(0);
   st16<2>(lds, v6, aB);
   st16<3>(lds, v7, aB);
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int KS>
+__device__ __forceinline__ void ops8_store32(char* lds, const Ops8<KS>& o, uint32_t aA, uint32_t aB) {
+  const f32x4 v0 = ops8_tile_t<KS>(o, 0, 0);
+  const f32x4 v1 = ops8_tile_t<KS>(o, 0, 1);
+  __builtin_amdgcn_sched_barrier(0);
+  const f32x4 v2 = ops8_tile_t<KS>(o, 0, 2);
+  st32<0>(lds, v0, aA);
+  __builtin_amdgcn_sched_barrier(0);
+  const f32x4 v3 = ops8_tile_t<KS>(o, 0, 3);
+  st32<1>(lds, v1, aA);
+  __builtin_amdgcn_sched_barrier(0);
+  const f32x4 v4 = ops8_tile_t<KS>(o, 1, 0);
+  st32<2>(lds, v2, aA);
+  __builtin_amdgcn_sched_barrier(0);
+  const f32x4 v5 = ops8_tile_t<KS>(o, 1, 1);
+  st32<3>(lds, v3, aA);
+  __builtin_amdgcn_sched_barrier(0);
+  const f32x4 v6 = ops8_tile_t<KS>(o, 1, 2);
+  st32<0>(lds, v4, aB);
+  __builtin_amdgcn_sched_barrier(0);
+  const f32x4 v7 = ops8_tile_t<KS>(o, 1, 3);
+  st32<1>(lds, v5, aB);
+  __builtin_amdgcn_sched_barrier(0);
+  st32<2>(lds, v6, aB);
+  st32<3>(lds, v7, aB);
   __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -357,10 +401,13 @@ __global__ __launch_bounds__(NW8 * 64) void k_conv_sym8(ConvParams p, int tilesX
   const uint32_t bLane = lk * XROWB + (uint32_t)it0 * 64 + li * 4;
   const char* __restrict__ xbase =
       reinterpret_cast<const char*>(p.src + ((size_t)panel * p.H * p.W * p.Cin + (size_t)grp * Cg) * PANEL);
-  const uint32_t mA0 = F16 ? st16_addr(rt0, it0, li, lk, (uint32_t)sw) : (uint32_t)it0 * TILEB + (uint32_t)rt0 * 1024u;
-  const uint32_t mB0 = F16 ? st16_addr(rt0, it0 + 1, li, lk, (uint32_t)sw) : mA0 + TILEB;
+  constexpr bool RM = S8_ROWMAJOR != 0 && MODE == 0;
+  const uint32_t mA0 = F16 ? st16_addr(rt0, it0, li, lk, (uint32_t)sw) : RM ? st32_addr(rt0, it0, li, lk, (uint32_t)sw) : (uint32_t)it0 * TILEB + (uint32_t)rt0 * 1024u;
+  const uint32_t mB0 = F16 ? st16_addr(rt0, it0 + 1, li, lk, (uint32_t)sw) : RM ? st32_addr(rt0, it0 + 1, li, lk, (uint32_t)sw) : mA0 + TILEB;
   auto build = [&](const Ops8<KS>& o, uint32_t buf) {       // the wave's eight tiles of a stage -> stage buffer at byte `buf`
-    if constexpr (F16) ops8_store16<KS>(lds, o, mA0 + buf, mB0 + buf); else ops8_store<KS>(o, mA0 + buf, mB0 + buf);
+    if constexpr (F16) ops8_store16<KS>(lds, o, mA0 + buf, mB0 + buf);
+    else if constexpr (RM) ops8_store32<KS>(lds, o, mA0 + buf, mB0 + buf);
+    else ops8_store<KS>(o, mA0 + buf, mB0 + buf);
   };
   const int Cs = p.Cs;
 
@@ -369,7 +416,7 @@ __global__ __launch_bounds__(NW8 * 64) void k_conv_sym8(ConvParams p, int tilesX
   const int cw0 = (chunk * NW8 + wave) * CPW;
   const int activeI = in_range(cw0, Ctg);
   const int cl0 = cw0 + half * HC;
-  const uint32_t laneLds = F16 ? (uint32_t)quad * 8u : ((uint32_t)(quad >> 2) * TILEB | (uint32_t)(quad >> 3) * 64 | (uint32_t)(quad & 3) * 16);
+  const uint32_t laneLds = F16 ? (uint32_t)quad * 8u : RM ? (uint32_t)quad * 16u : ((uint32_t)(quad >> 2) * TILEB | (uint32_t)(quad >> 3) * 64 | (uint32_t)(quad & 3) * 16);
   AccT acc[NP][CPW];
   {
     const float* __restrict__ bp = p.bias + grp * Ctg + (activeI ? cl0 : 0);
@@ -644,6 +691,32 @@ __device__ __forceinline__ void fc8_store16(char* lds, const FcOps8& o, uint32_t
   __builtin_amdgcn_sched_barrier(0);
 }
 
+__device__ __forceinline__ void fc8_store32(char* lds, const FcOps8& o, uint32_t aA, uint32_t aB) {
+  const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+  auto tile = [&](int t, int i) { return __builtin_amdgcn_mfma_f32_16x16x4f32(o.b[t][i >> 1], o.a[i], zero, 0, 0, 0); };
+  const f32x4 v0 = tile(0, 0), v1 = tile(0, 1), v2 = tile(0, 2);
+  __builtin_amdgcn_sched_barrier(0);
+  const f32x4 v3 = tile(0, 3);
+  st32<0>(lds, v0, aA);
+  __builtin_amdgcn_sched_barrier(0);
+  const f32x4 v4 = tile(1, 0);
+  st32<1>(lds, v1, aA);
+  __builtin_amdgcn_sched_barrier(0);
+  const f32x4 v5 = tile(1, 1);
+  st32<2>(lds, v2, aA);
+  __builtin_amdgcn_sched_barrier(0);
+  const f32x4 v6 = tile(1, 2);
+  st32<3>(lds, v3, aA);
+  __builtin_amdgcn_sched_barrier(0);
+  const f32x4 v7 = tile(1, 3);
+  st32<0>(lds, v4, aB);
+  __builtin_amdgcn_sched_barrier(0);
+  st32<1>(lds, v5, aB);
+  st32<2>(lds, v6, aB);
+  st32<3>(lds, v7, aB);
+  __builtin_amdgcn_sched_barrier(0);
+}
+
 // the look-ups of a stage: four sub-spaces x two halves of the wave's 96 channels, each the 24-read position statement of
 // k_conv_sym8 accumulating into the same registers
 template <int MODE, typename AccT>
@@ -701,10 +774,13 @@ __global__ __launch_bounds__(NW8 * 64) void k_fc_sym8(FcParams p, const uint16_t
   const uint32_t laneA16 = (lk * 16 + (li ^ ((uint32_t)sw << 2))) * 16;
   const uint32_t bLane = lk * XROWB + (uint32_t)it0 * 64 + li * 4;
   const char* __restrict__ xbase = reinterpret_cast<const char*>(p.src + (size_t)panel * p.D * PANEL);
-  const uint32_t mA0 = F16 ? st16_addr(h * 4, it0, li, lk, (uint32_t)sw) : (uint32_t)it0 * TILEB + (uint32_t)(h * 4) * 1024u;
-  const uint32_t mB0 = F16 ? st16_addr(h * 4, it0 + 1, li, lk, (uint32_t)sw) : mA0 + TILEB;
+  constexpr bool RM = S8_ROWMAJOR != 0 && MODE == 0;
+  const uint32_t mA0 = F16 ? st16_addr(h * 4, it0, li, lk, (uint32_t)sw) : RM ? st32_addr(h * 4, it0, li, lk, (uint32_t)sw) : (uint32_t)it0 * TILEB + (uint32_t)(h * 4) * 1024u;
+  const uint32_t mB0 = F16 ? st16_addr(h * 4, it0 + 1, li, lk, (uint32_t)sw) : RM ? st32_addr(h * 4, it0 + 1, li, lk, (uint32_t)sw) : mA0 + TILEB;
   auto build = [&](const FcOps8& o, uint32_t buf) {
-    if constexpr (F16) fc8_store16(lds, o, mA0 + buf, mB0 + buf); else fc8_store(o, mA0 + buf, mB0 + buf);
+    if constexpr (F16) fc8_store16(lds, o, mA0 + buf, mB0 + buf);
+    else if constexpr (RM) fc8_store32(lds, o, mA0 + buf, mB0 + buf);
+    else fc8_store(o, mA0 + buf, mB0 + buf);
   };
 
   // ---- gather side
@@ -712,7 +788,7 @@ __global__ __launch_bounds__(NW8 * 64) void k_fc_sym8(FcParams p, const uint16_t
   const int cw0 = (chunk * NW8 + wave) * FC8_CPW;
   const int activeI = in_range(cw0, p.Ct);
   const int cl0 = cw0 + half * HC;
-  const uint32_t laneLds = F16 ? (uint32_t)quad * 8u : ((uint32_t)(quad >> 2) * TILEB | (uint32_t)(quad >> 3) * 64 | (uint32_t)(quad & 3) * 16);
+  const uint32_t laneLds = F16 ? (uint32_t)quad * 8u : RM ? (uint32_t)quad * 16u : ((uint32_t)(quad >> 2) * TILEB | (uint32_t)(quad >> 3) * 64 | (uint32_t)(quad & 3) * 16);
   AccT acc[FC8_CPW];
 #pragma unroll
   for (int c = 0; c < FC8_CPW; ++c) {
@@ -792,6 +868,9 @@ __global__ __launch_bounds__(NW8 * 64) void k_fc_sym8(FcParams p, const uint16_t
 // offset of row slot `slot` as the look-up statements consume it: f32 table slot * 64 (inside an image tile), fp16 table the
 // row's byte offset with its XOR key in bits 3..6 (st16_addr)
 __device__ __forceinline__ uint16_t prog_entry(int slot, int f16) {
+#if S8_ROWMAJOR
+  if (!f16) return (uint16_t)((slot << 9) | (((((slot & 3) << 2) | ((slot >> 2) & 3))) << 4));   // row-major f32 table: row + XOR key (st32_addr)
+#endif
   return f16 ? (uint16_t)((slot << 8) | ((slot & 15) << 3)) : (uint16_t)(slot * 64);
 }
 __global__ __launch_bounds__(256) void k_build_program_fc8(const uint8_t* __restrict__ rows, uint16_t* __restrict__ prog, QkSlots src,
