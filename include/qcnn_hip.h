@@ -135,6 +135,14 @@ enum {
                               decoded code words (QCNN_OPT_DECODE) reads the caller's NCHW batch in place (k_conv_dec_nchw: k over the
                               columns of a kernel row) — no pack pass into panels (AlexNet: 1.24 GB of HBM traffic per 1000 images).
                               0 = pack, then the panel kernel.  qcnn_get_layer_split reports (-3, 2) against (-3, 1) */
+  QCNN_OPT_HALF8 = 13,     /* 1 (default): a conv layer with K = 128, complete 4- or 8-dim sub-spaces and 128 / 192 / 256 / 384 / 512
+                              output channels per group (or chunks of 512) may run in eight-wave workgroups of HALF a panel (64 images:
+                              twice the output tile per workgroup, half the table build per stage — qcnn_half8.hip) where the launch
+                              planner predicts them faster than every other form — in their tile form or, for windows that overlap in
+                              three output rows, their SLIDING form (segments of strips of output columns, every source pixel built once
+                              per segment); 2 = the tile form whenever eligible, 3 = the sliding form whenever eligible (tests); 0 = never.
+                              Same table entries in the same order: bit-identical to the other f32 table kernels.
+                              qcnn_get_layer_split reports (-9, 1) / (-10, segments per column) */
   QCNN_OPT_HOST_CHUNK = 6, /* panels per chunk (default 2) of a qcnn_forward_host batch of at least two chunks: every chunk is
                               uploaded on a copy stream and its layers start when it has arrived, so the upload of chunk
                               k + 1 runs under the layers of chunk k; all chunks fill the same whole-batch feature maps.

@@ -25,7 +25,7 @@ BIN_DIR = os.path.join(ROOT, "build", "bin")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
-HIP_SOURCES = ["qcnn_kernels.hip", "qcnn_sym8.hip", "qcnn_glue.hip", "qcnn_small.hip", "qcnn_dense.hip", "qcnn_decoded.hip", "qcnn_engine.hip", "qcnn_group.hip"]
+HIP_SOURCES = ["qcnn_kernels.hip", "qcnn_sym8.hip", "qcnn_half8.hip", "qcnn_glue.hip", "qcnn_small.hip", "qcnn_dense.hip", "qcnn_decoded.hip", "qcnn_engine.hip", "qcnn_group.hip"]
 HIP_FLAGS = ["-O3", "-std=c++17", "--offload-arch=" + ARCH, "-fPIC", "-ffp-contract=off", "-Wall",
              "-Wno-unused-function"]
 

@@ -36,6 +36,8 @@ struct LayerShape {
   size_t offProgY = 0, progYBytes = 0;                         // ... and of the symmetric kernel's (8 channels per wave, 2x2 tile) layout
   size_t offProg8 = 0, prog8Bytes = 0;                         // ... and of the eight-wave symmetric kernel's layout (Qk8Config)
   size_t offProg8S = 0, prog8SBytes = 0;                       // ... and of its sliding form (qk_conv_sym8_slide_config)
+  size_t offProgH8 = 0, progH8Bytes = 0;                       // ... and of the half-panel eight-wave kernel (QkH8Config, qcnn_half8.hip)
+  size_t offProgH8S = 0, progH8SBytes = 0;                     // ... and of its sliding form (qk_conv_half8_slide_config)
   size_t offCtrd8 = 0;                                         // ... with the code book in that kernel's operand order (qk_ctrd8_index)
   size_t offProgF8 = 0, progF8Bytes = 0, offCtrdF = 0;         // FC with 32 code words of 4 dims: program + code book of the eight-wave kernel (k_fc_sym8)
   size_t offCbn = 0, cbnBytes = 0; int cbnBits = 0;            // FC: the assignments bit-packed as the .cbn payload holds them (file order
@@ -63,6 +65,9 @@ struct LayerShape {
     int sym8Z = 1;                                             // ... with every tile cut into this many slices (QCNN_OPT_SPLIT; 1: whole tiles)
     double sym8sCost = 0.0;                                    // ... of its sliding form, with the segments it would run
     int seg8N = 0, seg8Beg[9] = {0};
+    double half8Cost = 0.0;                                    // ... of the half-panel eight-wave kernel (0: not eligible / off)
+    double half8sCost = 0.0;                                   // ... of its sliding form, with the segments it would run
+    int segHN = 0, segHBeg[9] = {0};
   };
   std::map<long long, Plan> plans;
   int segN = 0, segBeg[9] = {0};                               // segments of the last launch when it slid (qcnn_get_layer_segments)
@@ -77,6 +82,7 @@ constexpr int kSmallBatchMax = QCNN_SMALL_BATCH_MAX;  // batches up to this size
                                    // 128-image panel is cheaper (measured: 1 / 2 / 3 / 4 images 0.58 / 0.85 / 1.15 / 1.47 ms, a panel 1.50 ms)
 constexpr int kMaxFcSplit = 32;  // workgroups along the sub-space axis of an FC layer (partial sums reduced in fixed order)
 constexpr size_t kConvPartialFloats = (size_t)64 << 20;   // 256 MB of partial sums for split conv tiles (all sub-batches), allocated when a plan first splits
+constexpr double kHalf8SlideFactor = 1.25;   // a planner unit of the half-panel sliding form against one of its tile form
 constexpr double kSym8StageFactor = 0.97;   // scale of qk_conv_sym8_cost's stage price (its list schedule over-prices the last round by ~3 %)
 constexpr size_t kSlack = 64 * 1024;   // bytes of slack behind every device buffer: the MFMA operand loads are
                                         // unconditional and may read a few rows past the last dim / sub-space
@@ -94,6 +100,7 @@ struct QcnnCtx {
   int hostChunk = 2;                 // QCNN_OPT_HOST_CHUNK: panels per chunk of a large qcnn_forward_host batch (0: one launch)
   int directDec = 1;                 // QCNN_OPT_DIRECT_DEC: a decoded first layer reads the NCHW input in place (k_conv_dec_nchw) on the fast path
   int packedFc = 0;                  // QCNN_OPT_PACKED_FC (default off: measured 0.056 against 0.035 ms for AlexNet fc6 at one image): the few-image FC kernel reads the bit-packed assignment stream in place
+  int half8 = 1;                     // QCNN_OPT_HALF8: half-panel eight-wave workgroups where predicted faster (2: whenever eligible)
   int sym8 = 1;                      // QCNN_OPT_SYM8: eight-wave symmetric workgroups where predicted faster (2: whenever eligible)
   int sym = 1;                       // QCNN_OPT_SYM: symmetric workgroups for 128-channel layers where predicted faster (2: whenever eligible)
   int decode = 1;                    // QCNN_OPT_DECODE: one-sub-space conv layers through their decoded code words (MFMA builders only)
@@ -231,15 +238,21 @@ int plan_arena(QcnnCtx* c) {
       s.cbnBytes = ((size_t)Ct * s.M + per - 1) / per * 4096;
       s.offCbn = off; off = align_up(off + s.cbnBytes + 256, 256);
     }
-    s.prog8Bytes = 0; s.prog8SBytes = 0;
+    s.prog8Bytes = 0; s.prog8SBytes = 0; s.progH8Bytes = 0; s.progH8SBytes = 0;
     if (d.type == QCNN_CONV) {
       const Qk8Config c8 = qk_conv_sym8_config(c->dims[l].c, d.grpCnt, Ct, s.M, s.Cs, s.K);
       s.prog8Bytes = qk_conv_sym8_program_bytes(c8, d.grpCnt, d.knlSiz, d.stride, s.M);
       const Qk8Config c8s = qk_conv_sym8_slide_config(c->dims[l].c, d.grpCnt, Ct, s.M, s.Cs, s.K, d.knlSiz, d.stride);
       s.prog8SBytes = qk_conv_sym8_program_bytes(c8s, d.grpCnt, d.knlSiz, d.stride, s.M);
+      const QkH8Config ch8 = qk_conv_half8_config(c->dims[l].c, d.grpCnt, Ct, s.M, s.Cs, s.K);
+      s.progH8Bytes = qk_conv_half8_program_bytes(ch8, d.grpCnt, d.knlSiz, d.stride, s.M);
+      if (s.progH8Bytes) { s.offProgH8 = off; off = align_up(off + s.progH8Bytes + QCNN_ROWS_PAD, 256); }
+      const QkH8Config ch8s = qk_conv_half8_slide_config(c->dims[l].c, d.grpCnt, Ct, s.M, s.Cs, s.K, d.knlSiz, d.stride);
+      s.progH8SBytes = qk_conv_half8_program_bytes(ch8s, d.grpCnt, d.knlSiz, d.stride, s.M);
+      if (s.progH8SBytes) { s.offProgH8S = off; off = align_up(off + s.progH8SBytes + QCNN_ROWS_PAD, 256); }
       if (s.prog8Bytes) { s.offProg8 = off; off = align_up(off + s.prog8Bytes + QCNN_ROWS_PAD, 256); }
       if (s.prog8SBytes) { s.offProg8S = off; off = align_up(off + s.prog8SBytes + QCNN_ROWS_PAD, 256); }
-      if (s.prog8Bytes || s.prog8SBytes) { s.offCtrd8 = off; off = align_up(off + sizeof(float) * (size_t)s.M * s.Cs * s.K, 256); }
+      if (s.prog8Bytes || s.prog8SBytes || s.progH8Bytes) { s.offCtrd8 = off; off = align_up(off + sizeof(float) * (size_t)s.M * s.Cs * s.K, 256); }
     }
     s.decKp = 0;
     s.hasDmap = (d.type == QCNN_FCNT && l == c->firstFc && c->dims[l].h * c->dims[l].w > 1);
@@ -439,7 +452,7 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
       if (inNchw) { p.src = inNchw; p.srcNchw = 1; p.nImages = nImages; p.panel0 = p0; }   // network input read in place
       p.bias = reinterpret_cast<const float*>(c->arena + s.offBias);
       p.ctrd = reinterpret_cast<const float*>(c->arena + s.offCtrd);
-      p.ctrd8 = (s.prog8Bytes || s.prog8SBytes) ? reinterpret_cast<const float*>(c->arena + s.offCtrd8) : nullptr;
+      p.ctrd8 = (s.prog8Bytes || s.prog8SBytes || s.progH8Bytes) ? reinterpret_cast<const float*>(c->arena + s.offCtrd8) : nullptr;
       p.rows = reinterpret_cast<const uint8_t*>(c->arena + s.offAsmt);
       p.prog = s.progBytes ? reinterpret_cast<const uint16_t*>(c->arena + s.offProg) : nullptr;
       p.H = a.h; p.W = a.w; p.Cin = a.c; p.Ho = b.h; p.Wo = b.w; p.Ct = b.c;
@@ -470,12 +483,12 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
       if (e == hipErrorInvalidValue) {
         // A launch of a few hundred workgroups (one GPU's share of a sharded batch) splits the tail of its tiles over
         // several workgroups (qk_conv_plan).  MFMA builders only: the exact builder keeps the reference's summation order.
-        if (c->lutMode >= 1 && (c->split || c->slide || c->sym || c->sym8)) {
+        if (c->lutMode >= 1 && (c->split || c->slide || c->sym || c->sym8 || c->half8)) {
           // Plan of this launch geometry (cached): tile kernel whole / with a split tail (QCNN_OPT_SPLIT; changes a cut
           // tile's summation order) / sliding kernel (QCNN_OPT_SLIDE; same order and bits as the tile kernel).
           const size_t share = kConvPartialFloats / (size_t)nsub;
-          const long long key = (((((((long long)panels * 8 + nsub) * 2 + (c->split ? 1 : 0)) * 4 + c->slide) * 4 + c->sym) * 4 +
-                                  c->lutMode) * 2 + (inNchw ? 1 : 0)) * 8 + c->sym8;
+          const long long key = ((((((((long long)panels * 8 + nsub) * 2 + (c->split ? 1 : 0)) * 4 + c->slide) * 4 + c->sym) * 4 +
+                                  c->lutMode) * 2 + (inNchw ? 1 : 0)) * 8 + c->sym8) * 4 + c->half8;
           auto it = s.plans.find(key);
           if (it == s.plans.end()) {
             LayerShape::Plan pl;
@@ -504,6 +517,15 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
               pl.seg8N = t.nSeg;
               for (int i = 0; i <= t.nSeg && i < 9; ++i) pl.seg8Beg[i] = t.segBeg[i];
             }
+            pl.half8Cost = (c->half8 && s.progH8Bytes && c->lutMode == 1 && !inNchw)
+                               ? qk_conv_half8_cost(p, qk_conv_half8_config(p.Cin, p.grp, p.Ct, p.M, p.Cs, p.K), kSym8StageFactor) : 0.0;
+            if (c->half8 && s.progH8SBytes && c->lutMode == 1 && !inNchw) {
+              ConvParams t = p;
+              pl.half8sCost = qk_conv_half8_slide_plan(t, qk_conv_half8_slide_config(p.Cin, p.grp, p.Ct, p.M, p.Cs, p.K, p.knl, p.stride),
+                                                       kSym8StageFactor);
+              pl.segHN = t.nSeg;
+              for (int i = 0; i <= t.nSeg && i < 9; ++i) pl.segHBeg[i] = t.segBeg[i];
+            }
             if (c->slide && p.progS) {                // sliding variant where it is predicted to beat the (split) tile kernel
               ConvParams t = p;
               pl.slideCost = qk_conv_plan_slide(t, c->slide >= 2 ? 1e30 : pl.plan.cost);   // 2: whenever the layer is eligible (tests)
@@ -512,13 +534,48 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
             }
             if (const char* dbg = getenv("QCNN_DEBUG_PLAN"); dbg && atoi(dbg))
               fprintf(stderr, "[qcnn plan] layer %d panels %d: tile %.0f (Z %d) | slide %.0f (%d segments) | sym %.0f | sym8 %.0f (Z %d) | sym8 sliding %.0f (%d segments) stage-times\n",
-                      l, panels, pl.plan.cost, pl.plan.Z, pl.slideCost, pl.segN, pl.symCost, pl.sym8Cost, pl.sym8Z, pl.sym8sCost, pl.seg8N);
+                      l, panels, pl.plan.cost, pl.plan.Z, pl.slideCost, pl.segN, pl.symCost, pl.sym8Cost, pl.sym8Z, pl.sym8sCost, pl.seg8N),
+              fprintf(stderr, "[qcnn plan] layer %d panels %d: half-panel eight-wave %.0f | sliding %.0f (%d segments) stage-times\n", l, panels, pl.half8Cost, pl.half8sCost, pl.segHN);
             it = s.plans.emplace(key, pl).first;
           }
           const LayerShape::Plan& pl = it->second;
           // eight-wave symmetric workgroups, tile or sliding form: when forced (QCNN_OPT_SYM8 = 2: tile form, 3: sliding form where
           // eligible), or predicted at least 3 % faster than every other plan of the launch
-          const bool may8 = c->lutMode == 1 && !inNchw && (c->sym8 >= 2 || (c->sym < 2 && c->slide < 2));
+          const bool may8 = c->lutMode == 1 && !inNchw && (c->sym8 >= 2 || (c->sym < 2 && c->slide < 2)) && c->half8 < 2;
+          // half-panel eight-wave workgroups: forced (QCNN_OPT_HALF8 = 2), or predicted at least 3 % faster than every other plan
+          // ... in the sliding form: forced (3), or predicted at least 3 % faster than every other plan INCLUDING the half-panel tile
+          // form (a strip is a coarser work item: x kHalf8SlideFactor like the full-panel sliding form's x 1.15)
+          if (pl.half8sCost > 0.0 && pl.segHN > 0 && c->lutMode == 1 && !inNchw && c->half8 != 2 &&
+              (c->half8 >= 3 || (c->sym8 < 2 && c->sym < 2 && c->slide < 2))) {
+            double other = pl.plan.cost;
+            if (pl.symCost > 0.0 && 1.08 * pl.symCost < other) other = 1.08 * pl.symCost;
+            if (pl.segN > 0 && pl.slideCost > 0.0) other = std::min(other, 1.15 * pl.slideCost);
+            if (pl.sym8Cost > 0.0) other = std::min(other, pl.sym8Cost);
+            if (pl.sym8sCost > 0.0 && pl.seg8N > 0) other = std::min(other, 1.15 * pl.sym8sCost);
+            if (pl.half8Cost > 0.0) other = std::min(other, pl.half8Cost);
+            if (c->half8 >= 3 || kHalf8SlideFactor * pl.half8sCost < 0.97 * other) {
+              p.progS = reinterpret_cast<const uint16_t*>(c->arena + s.offProgH8S);
+              p.nSeg = pl.segHN;
+              s.segN = pl.segHN;
+              for (int i = 0; i <= pl.segHN; ++i) { p.segBeg[i] = pl.segHBeg[i]; s.segBeg[i] = pl.segHBeg[i]; }
+              s.lastFrom = -10; s.lastZ = pl.segHN;     // reported by qcnn_get_layer_split as (-10, segments per column)
+              e = qk_conv_half8_slide(p, st);
+              break;
+            }
+          }
+          if (pl.half8Cost > 0.0 && c->lutMode == 1 && !inNchw && (c->half8 >= 2 || (c->sym8 < 2 && c->sym < 2 && c->slide < 2))) {
+            double other = pl.plan.cost;
+            if (pl.symCost > 0.0 && 1.08 * pl.symCost < other) other = 1.08 * pl.symCost;
+            if (pl.segN > 0 && pl.slideCost > 0.0) other = std::min(other, 1.15 * pl.slideCost);
+            if (pl.sym8Cost > 0.0) other = std::min(other, pl.sym8Cost);
+            if (pl.sym8sCost > 0.0 && pl.seg8N > 0) other = std::min(other, 1.15 * pl.sym8sCost);
+            if (c->half8 >= 2 || pl.half8Cost < 0.97 * other) {
+              p.progS = reinterpret_cast<const uint16_t*>(c->arena + s.offProgH8);
+              s.lastFrom = -9; s.lastZ = 1;             // reported by qcnn_get_layer_split as (-9, 1)
+              e = qk_conv_half8(p, st);
+              break;
+            }
+          }
           if (may8 && pl.sym8sCost > 0.0 && pl.seg8N > 0 && c->sym8 != 2) {
             double other = pl.plan.cost;
             if (pl.symCost > 0.0 && 1.08 * pl.symCost < other) other = 1.08 * pl.symCost;
@@ -971,6 +1028,7 @@ int qcnn_set_option(QcnnCtx* c, int option, int value) {
     case QCNN_OPT_SMALL_BATCH: c->smallBatch = value ? 1 : 0; return 0;
     case QCNN_OPT_SPLIT: c->split = value ? 1 : 0; return 0;
     case QCNN_OPT_DECODE: c->decode = value ? 1 : 0; return 0;
+    case QCNN_OPT_HALF8: if (value < 0 || value > 3) return fail(c, "QCNN_OPT_HALF8 must be 0 (off), 1 (planner), 2 (forced tile form) or 3 (forced sliding form)"); c->half8 = value; return 0;
     case QCNN_OPT_SYM8: if (value < 0 || value > 3) return fail(c, "QCNN_OPT_SYM8 must be 0 (off), 1 (planner), 2 (forced tile form) or 3 (forced sliding form)"); c->sym8 = value; return 0;
     case QCNN_OPT_PACKED_FC: c->packedFc = value ? 1 : 0; return 0;
     case QCNN_OPT_DIRECT_DEC: c->directDec = value ? 1 : 0; return 0;
@@ -1176,7 +1234,7 @@ int upload_bias_ctrd(QcnnCtx* c, int layer, const float* bias, const float* ctrd
     HIP_TRY(c, hipMemcpyAsync(c->arena + s.offCtrdF, ctrdF.data(), ctrdF.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
   }
   std::vector<float> ctrd8;
-  if (s.prog8Bytes || s.prog8SBytes) {  // the eight-wave symmetric kernel's operand order (K = 128, Cs = 4 or 8)
+  if (s.prog8Bytes || s.prog8SBytes || s.progH8Bytes) {  // the eight-wave symmetric kernel's operand order (K = 128, Cs = 4 or 8)
     ctrd8.resize((size_t)M * Cs * K);
     for (int m = 0; m < M; ++m)
       for (int dd = 0; dd < Cs; ++dd)
@@ -1238,6 +1296,18 @@ hipError_t build_program(QcnnCtx* c, int layer, const QkSlots& sl) {
     e = qk_build_program8(reinterpret_cast<const uint8_t*>(c->arena + s.offAsmt), reinterpret_cast<uint16_t*>(c->arena + s.offProg8), sl,
                           qk_conv_sym8_config(c->dims[layer].c, d.grpCnt, Ct, s.M, s.Cs, s.K), Ct / d.grpCnt, d.grpCnt, d.knlSiz,
                           d.stride, s.M, c->stream);
+  }
+  if (e == hipSuccess && s.progH8Bytes) {      // half-panel eight-wave kernel
+    const int Ct = c->dims[layer + 1].c;
+    e = qk_build_program_h8(reinterpret_cast<const uint8_t*>(c->arena + s.offAsmt), reinterpret_cast<uint16_t*>(c->arena + s.offProgH8), sl,
+                            qk_conv_half8_config(c->dims[layer].c, d.grpCnt, Ct, s.M, s.Cs, s.K), Ct / d.grpCnt, d.grpCnt, d.knlSiz,
+                            d.stride, s.M, c->stream);
+  }
+  if (e == hipSuccess && s.progH8SBytes) {     // ... and its sliding form
+    const int Ct = c->dims[layer + 1].c;
+    e = qk_build_program_h8(reinterpret_cast<const uint8_t*>(c->arena + s.offAsmt), reinterpret_cast<uint16_t*>(c->arena + s.offProgH8S), sl,
+                            qk_conv_half8_slide_config(c->dims[layer].c, d.grpCnt, Ct, s.M, s.Cs, s.K, d.knlSiz, d.stride), Ct / d.grpCnt,
+                            d.grpCnt, d.knlSiz, d.stride, s.M, c->stream);
   }
   if (e == hipSuccess && s.prog8SBytes) {      // ... and the program of its sliding form
     const int Ct = c->dims[layer + 1].c;
@@ -1693,7 +1763,7 @@ int qcnn_get_layer_split(QcnnCtx* c, int layer, int* tiles_unsplit, int* slices)
 int qcnn_get_layer_segments(QcnnCtx* c, int layer, int* seg_beg9, int* n_seg) {
   if (layer < 0 || layer >= c->L) return fail(c, "layer %d out of range", layer);
   const LayerShape& s = c->shapes[layer];
-  const int n = (s.lastFrom == -2 || s.lastFrom == -6) ? s.segN : 0;
+  const int n = (s.lastFrom == -2 || s.lastFrom == -6 || s.lastFrom == -10) ? s.segN : 0;
   if (n_seg) *n_seg = n;
   if (seg_beg9)
     for (int i = 0; i < 9; ++i) seg_beg9[i] = (i <= n) ? s.segBeg[i] : 0;

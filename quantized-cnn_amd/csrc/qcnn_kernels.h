@@ -246,6 +246,26 @@ Qk8Config qk_conv_sym8_slide_config(int Cin, int grp, int Ct, int M, int Cs, int
 double qk_conv_sym8_slide_plan(ConvParams& p, const Qk8Config& cf, double stageFactor);
 hipError_t qk_conv_sym8_slide(const ConvParams& p, hipStream_t st);
 
+// Half-panel eight-wave kernel (qcnn_half8.hip, k_conv_half8): workgroups of 64 images — twice the (position, channel) sums per
+// workgroup (1536), half the table build per stage.  cpw channels per wave, th x tw tile, ws wave sets that share the channels and
+// interleave the positions (cpw * th * tw / ws = 192); cpw = 0: not eligible.  Program table: [rfH][rfW][M][groups * chunks][8 waves]
+// [4 lane groups][th * tw / ws][cpw / 4] uint16 (ConvParams::progS when the kernel is launched).
+struct QkH8Config { int cpw, th, tw, ws, chunks, slide; };
+// a half-panel stage costs QK_HALF8_FIX + QK_HALF8_PER_ROW x (row look-ups of 64 images it serves) cycles (k_conv_sym8: 2540 + 1.97 x
+// rows of 128 images); measured: LABBOOK.md, round 6
+constexpr double QK_HALF8_FIX = 2040.0, QK_HALF8_PER_ROW = 0.61, QK_HALF8_TWO_SETS = 1.08;
+QkH8Config qk_conv_half8_config(int Cin, int grp, int Ct, int M, int Cs, int K);
+size_t qk_conv_half8_program_bytes(const QkH8Config& cf, int groups, int knl, int stride, int M);
+hipError_t qk_build_program_h8(const uint8_t* rows, uint16_t* prog, const QkSlots& src, const QkH8Config& cf, int Ctg, int groups,
+                               int knl, int stride, int M, hipStream_t st);
+double qk_conv_half8_cost(const ConvParams& p, const QkH8Config& cf, double stageFactor);
+hipError_t qk_conv_half8(const ConvParams& p, hipStream_t st);       // p.progS = the half-panel program, p.ctrd8 as for qk_conv_sym8
+// its sliding form (k_conv_half8<.., SLIDE>): config (cpw = 0: not eligible), segments + predicted duration, launch.  Program table:
+// qk_conv_half8_program_bytes / qk_build_program_h8 with this config.
+QkH8Config qk_conv_half8_slide_config(int Cin, int grp, int Ct, int M, int Cs, int K, int knl, int stride);
+double qk_conv_half8_slide_plan(ConvParams& p, const QkH8Config& cf, double stageFactor);
+hipError_t qk_conv_half8_slide(const ConvParams& p, hipStream_t st);
+
 struct FcParams {
   float* partial;        // [msplit][panels][Ct][128] scratch for split-M partial sums (msplit > 1)
   int msplit;            // blocks along the sub-space axis (1 = single pass, bit-exact summation order)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-layer device time (QCNN_OPT_PROFILE events) of a forward at a given batch size.
-usage: [QCNN_MODEL=AlexNet|VGG16] [QCNN_SPLIT|QCNN_SLIDE|QCNN_SYM|QCNN_SYM8|QCNN_DIRECT_DEC|QCNN_DECODE|QCNN_LUT=..] layer_times.py [batch=128] [steps=20] [streams=1]"""
+usage: [QCNN_MODEL=AlexNet|VGG16] [QCNN_SPLIT|QCNN_SLIDE|QCNN_SYM|QCNN_SYM8|QCNN_HALF8|QCNN_DIRECT_DEC|QCNN_DECODE|QCNN_LUT=..] layer_times.py [batch=128] [steps=20] [streams=1]"""
 import importlib, os, sys
 import numpy as np
 import torch   # before libqcnn_hip.so: both must bind to the HIP runtime torch ships
@@ -24,6 +24,7 @@ def main():
     eng.set_option(capi.OPT_SLIDE, int(os.environ.get("QCNN_SLIDE", "1")))
     eng.set_option(capi.OPT_SYM, int(os.environ.get("QCNN_SYM", "1")))
     eng.set_option(capi.OPT_SYM8, int(os.environ.get("QCNN_SYM8", "1")))
+    eng.set_option(capi.OPT_HALF8, int(os.environ.get("QCNN_HALF8", "1")))
     eng.set_option(capi.OPT_DIRECT_DEC, int(os.environ.get("QCNN_DIRECT_DEC", "1")))
     eng.set_option(capi.OPT_DECODE, int(os.environ.get("QCNN_DECODE", "1")))
     eng.set_option(capi.OPT_LUT_MODE, int(os.environ.get("QCNN_LUT", "1")))

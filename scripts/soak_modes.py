@@ -23,7 +23,7 @@ def run(model, n, reps, modes, compare=True):
         eng.set_option(capi.OPT_KEEP_ALL, 0)
         eng.set_option(capi.OPT_SPLIT, 0)
         eng.set_option(capi.OPT_DECODE, 0)                 # tables everywhere: the families below are bit-identical
-        eng.set_option(capi.OPT_SYM, 0); eng.set_option(capi.OPT_SLIDE, 0); eng.set_option(capi.OPT_SYM8, 0)
+        eng.set_option(capi.OPT_SYM, 0); eng.set_option(capi.OPT_SLIDE, 0); eng.set_option(capi.OPT_SYM8, 0); eng.set_option(capi.OPT_HALF8, 0)
         for o, v in opts:
             eng.set_option(o, v)
         eng.load_model(in_chw, layers, params, n)
@@ -55,7 +55,8 @@ def main():
     capi = pkg("capi")
     modes = [("tile", []), ("slide16", [(capi.OPT_SLIDE, 2)]), ("sym16", [(capi.OPT_SYM, 2)]),
              ("sym8 tile", [(capi.OPT_SYM8, 2)]), ("sym8 slide", [(capi.OPT_SYM8, 3)]),
-             ("planner", [(capi.OPT_SLIDE, 1), (capi.OPT_SYM, 1), (capi.OPT_SYM8, 1)])]
+             ("half8 tile", [(capi.OPT_HALF8, 2)]), ("half8 slide", [(capi.OPT_HALF8, 3)]),
+             ("planner", [(capi.OPT_SLIDE, 1), (capi.OPT_SYM, 1), (capi.OPT_SYM8, 1), (capi.OPT_HALF8, 1)])]
     run("AlexNet", 300, reps, modes)
     run("VGG16", 140, max(4, reps // 8), modes)
     # round 5: the fp16 study kernels (reproducible run to run; their values are another function) and the split eight-wave tiles

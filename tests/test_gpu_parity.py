@@ -26,7 +26,7 @@ SAMPLE_STRIDE = 97
 BITWISE_TYPES = (topo.CONV, topo.FCNT, topo.RELU, topo.POOL, topo.DRPT)
 
 
-def make_engine(in_chw, layers, params, max_batch, lut=capi.LUT_EXACT, keep_all=1, split=0, decode=0, sym8=0):
+def make_engine(in_chw, layers, params, max_batch, lut=capi.LUT_EXACT, keep_all=1, split=0, decode=0, sym8=0, half8=0):
     """split = 0: one workgroup per tile whatever the batch size (QCNN_OPT_SPLIT off) — the setting under which an image's
     bits do not depend on its batch, which many tests below rely on; the split itself has its own tests.  decode = 0: the
     table kernels for the first layer too (QCNN_OPT_DECODE off) — what these tests are about; the decoded first layer
@@ -37,6 +37,7 @@ def make_engine(in_chw, layers, params, max_batch, lut=capi.LUT_EXACT, keep_all=
     eng.set_option(capi.OPT_SPLIT, split)
     eng.set_option(capi.OPT_DECODE, decode)
     eng.set_option(capi.OPT_SYM8, sym8)     # eight-wave symmetric workgroups: their own tests below (default on everywhere else)
+    eng.set_option(capi.OPT_HALF8, half8)   # half-panel eight-wave workgroups: tests/test_gpu_half8.py (default: planner)
     eng.load_model(in_chw, layers, params, max_batch)
     return eng
 

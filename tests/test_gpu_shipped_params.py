@@ -32,13 +32,13 @@ N = 1000
 BLOCKS = ((0, 10), (500, 10), (990, 10))       # (first image, count): first panel, a middle one, the ragged last one
 
 
-def _engine(params, keep_all, streams=None, host_chunk=None, sym=None, slide=None, decode=None, split=None, sym8=None):
+def _engine(params, keep_all, streams=None, host_chunk=None, sym=None, slide=None, decode=None, split=None, sym8=None, half8=None):
     in_chw, layers, _, _ = topo.MODELS["AlexNet"]
     eng = pkg("engine").QcnnEngine(0)
     eng.set_option(capi.OPT_LUT_MODE, capi.LUT_MFMA)
     eng.set_option(capi.OPT_KEEP_ALL, keep_all)
     for opt, v in ((capi.OPT_STREAMS, streams), (capi.OPT_HOST_CHUNK, host_chunk), (capi.OPT_SYM, sym),
-                   (capi.OPT_SLIDE, slide), (capi.OPT_DECODE, decode), (capi.OPT_SPLIT, split), (capi.OPT_SYM8, sym8)):
+                   (capi.OPT_SLIDE, slide), (capi.OPT_DECODE, decode), (capi.OPT_SPLIT, split), (capi.OPT_SYM8, sym8), (capi.OPT_HALF8, half8)):
         if v is not None:
             eng.set_option(opt, v)
     eng.load_model(in_chw, layers, params, N)
@@ -91,7 +91,7 @@ def _check_full_tensors(eng, orc, L, tag):
 
 def _check_outputs(prob, top5, z, fx, tag):
     want = z["prob%d" % fx]
-    for i in list(range(0, 20)) + list(range(500, 520)) + list(range(N - 20, N)):
+    for i in range(N):                                  # ALL rows of the batch against the ten reference rows (image i = source image i % 10)
         ref = want[i % 10]
         err = np.abs(prob[i].astype(np.float64) - ref).max() / np.abs(ref).max()
         assert err <= TOL, "%s: fixture %d soft-max of image %d: %g" % (tag, fx, i, err)
@@ -113,6 +113,9 @@ CONFIGS = {
     "forced_sym8": dict(keep_all=1, sym8=2),
     # ... and through its sliding form (segments of column strips)
     "forced_sym8_slide": dict(keep_all=0, streams=1, host_chunk=0, sym8=3),
+    # every eligible layer through half-panel eight-wave workgroups (qcnn_half8.hip): tile form, and sliding form where built
+    "forced_half8": dict(keep_all=1, half8=2),
+    "forced_half8_slide": dict(keep_all=0, streams=1, host_chunk=0, half8=3),
     # the north star's scheme for all eight conv / FC layers (bench key value_tables_only)
     "tables_only_fast_path": dict(keep_all=0, streams=1, host_chunk=0, decode=0),
 }
@@ -141,6 +144,10 @@ def test_shipped_parameters_headline_kernels_match_reference(golden_alex_real10,
         assert eng.layer_split(12)[0] == -2                                      # conv5 sliding
         with pytest.raises(pkg("engine").QcnnError):
             eng.layer_output_range(3, 0, 1)                                      # LRN1 fused into the pool behind it
+    if name == "forced_half8":
+        assert [eng.layer_split(l)[0] for l in (4, 8, 10, 12)] == [-9, -9, -9, -9]
+    if name == "forced_half8_slide":
+        assert [eng.layer_split(l)[0] for l in (4, 8, 10, 12)] == [-9, -10, -10, -10]
     if name == "forced_sym8_slide":
         assert [eng.layer_split(l)[0] for l in (4, 8, 10, 12)] == [-6, -6, -6, -6]
     if CONFIGS[name]["keep_all"]:

@@ -26,5 +26,6 @@ def test_forced_kernel_families_reproducible_and_equal(model, n, reps):
     capi = pkg("capi")
     modes = [("tile", []), ("slide16", [(capi.OPT_SLIDE, 2)]), ("sym16", [(capi.OPT_SYM, 2)]),
              ("sym8 tile", [(capi.OPT_SYM8, 2)]), ("sym8 slide", [(capi.OPT_SYM8, 3)]),
-             ("planner", [(capi.OPT_SLIDE, 1), (capi.OPT_SYM, 1), (capi.OPT_SYM8, 1)])]
+             ("half8 tile", [(capi.OPT_HALF8, 2)]), ("half8 slide", [(capi.OPT_HALF8, 3)]),
+             ("planner", [(capi.OPT_SLIDE, 1), (capi.OPT_SYM, 1), (capi.OPT_SYM8, 1), (capi.OPT_HALF8, 1)])]
     _soak().run(model, n, reps, modes)          # asserts inside
