@@ -301,6 +301,11 @@ def main():
     ap.add_argument("--extras", type=int, default=1, help="0 = only the headline measurement")
     ap.add_argument("--sym8", type=int, default=-1,
                     help="QCNN_OPT_SYM8 (eight-wave symmetric workgroups): -1 = library default (1 = planner), 0 off, 2 forced tile form, 3 forced sliding form")
+    ap.add_argument("--init-timeout", type=int, default=120,
+                    help="N > 1: seconds the RCCL rendezvous + parameter broadcast + checksum exchange may take before the run "
+                         "gives up with a one-line JSON error")
+    ap.add_argument("--half8", type=int, default=-1,
+                    help="QCNN_OPT_HALF8 (half-panel eight-wave workgroups): -1 = library default (1 = planner), 0 off, 2 forced tile form, 3 forced sliding form")
     ap.add_argument("--streams", type=int, default=1,
                     help="sub-batches of whole panels run concurrently on separate HIP streams (QCNN_OPT_STREAMS; the "
                          "library default is 2).  1 keeps one launch per layer, so that the per-kernel HIP-event "
@@ -324,9 +329,25 @@ def main():
         raise SystemExit("rank %d: LOCAL_RANK %d but only %d GPU(s) visible" % (rank, local, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    watchdog = None
     if world > 1:
+        # The first N > 1 run is also the first time RCCL initialises with more than one rank on this code: a hang in the
+        # rendezvous, the communicator set-up or the parameter broadcast must end as ONE JSON error line, not as the
+        # driver's timeout.  The watchdog is disarmed once the broadcast has been verified.
+        import datetime
+        import threading
+
+        def _give_up():
+            print(json.dumps({"metric": "images/sec AlexNet quantized forward", "value": None, "n_gpus": world, "rank": rank,
+                              "error": "RCCL set-up (init_process_group / parameter broadcast / checksum exchange) did not finish "
+                                       "within %d s on rank %d" % (args.init_timeout, rank)}), flush=True)
+            os._exit(3)
+        watchdog = threading.Timer(args.init_timeout, _give_up)
+        watchdog.daemon = True
+        watchdog.start()
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev,
+                                timeout=datetime.timedelta(seconds=args.init_timeout))
 
     topo, synth, capi, dmod, perf = pkg("topology"), pkg("synth"), pkg("capi"), pkg("dist"), pkg("perfmodel")
     in_chw, layers, _, _ = topo.MODELS[args.model]
@@ -359,6 +380,8 @@ def main():
     eng.set_option(capi.OPT_STREAMS, args.streams)
     if args.sym8 >= 0:
         eng.set_option(capi.OPT_SYM8, args.sym8)
+    if args.half8 >= 0:
+        eng.set_option(capi.OPT_HALF8, args.half8)
     shapes = {i: tuple(int(x) for x in p["ctrd"].shape) for i, p in params.items()}
     eng.configure(in_chw, layers, shapes)
     arena = torch.zeros(eng.arena_bytes(), dtype=torch.uint8, device=dev)
@@ -375,6 +398,19 @@ def main():
         bcast_ms = 1000.0 * (time.perf_counter() - t0)
     if rank != 0:
         eng.mark_loaded()
+    rccl_ranks, arena_sums = world, None
+    if world > 1:
+        # every rank hashes ITS arena on the device; all ranks compare before anything is timed: a broadcast that moved nothing
+        # (or the wrong bytes) must not surface as a fast run with wrong class scores on seven shards
+        ok_sum, pairs = dmod.checksums_agree(eng.arena_checksum(), device=dev)
+        rccl_ranks = dmod.verified_world_size(device=dev)        # counted by a real all_reduce over the communicator
+        arena_sums = ["%016x:%016x" % p for p in pairs]
+        if not ok_sum:
+            if rank == 0:
+                print(json.dumps({"metric": "images/sec AlexNet quantized forward", "value": None, "n_gpus": world,
+                                  "error": "parameter broadcast: the ranks' arenas differ", "arena_checksums": arena_sums}), flush=True)
+            raise SystemExit("bench.py: arena checksums differ across ranks after the RCCL broadcast: %r" % (arena_sums,))
+        watchdog.cancel()
 
     # synthetic device-resident input: 8-bit pixels minus the BGR channel means (range of BmpImgIO's output); image i of
     # the global batch is the same whatever the number of ranks
@@ -429,7 +465,8 @@ def main():
                     segments={i: eng.layer_segments(i) for i in cf if layers[i]["type"] == topo.CONV},   # sliding kernel, per layer
                     decoded=dec, dec_nchw={i for i in dec if split[i][1] == 2},                          # k_conv_dec_nchw
                     symmetric={i for i in cf if layers[i]["type"] == topo.CONV and split[i][0] == -4},   # k_conv_sym
-                    sym8={i for i in cf if split[i][0] in (-5, -6)})                                     # k_conv_sym8 (-6: sliding form), k_fc_sym8
+                    sym8={i for i in cf if split[i][0] in (-5, -6)},                                     # k_conv_sym8 (-6: sliding form), k_fc_sym8
+                    half8={i for i in cf if split[i][0] in (-9, -10)})                                   # k_conv_half8 (-10: sliding form)
 
     dt = measure(step, args.steps, args.warmup)
     snap = snapshot()
@@ -483,7 +520,10 @@ def main():
             extras["fp16_lut"] = dict(layer_ms={"%02d_%s" % (i, topo.TYPE_NAMES[layers[i]["type"]]): round(float(m), 4)
                                                 for i, m in enumerate(f16_ms) if m > 0 and layers[i]["type"] in (topo.CONV, topo.FCNT)},
                                       kernels=f16_split,
-                                      note="fp16 table entries (round to nearest even), fp32 sums; kernels: qcnn_get_layer_split codes "
+                                      note="fp16 table entries (round to nearest even), fp32 sums; against the oracle's study mode the kernels agree "
+                                           "to 3 - 4e-5 (conv) / 4 - 8e-6 (FC) per layer, not to rounding: the oracle builds an entry with separately "
+                                           "rounded multiply and add (src/CaffeEva.cc:1284-1289), the matrix pipe with a fused chain, so a few entries "
+                                           "per thousand land on the other side of an fp16 rounding boundary (DESIGN.md, fp16 study); kernels: qcnn_get_layer_split codes "
                                            "(-7: fp16-storage form of the eight-wave kernels, -8: with packed fp16 running sums and twice "
                                            "the tile; others: entries rounded, f32 slots, fp32 sums)")
             # ... and with the running sums in packed fp16 as well (QCNN_OPT_LUT_MODE = 3: twice the tile per wave)
@@ -587,6 +627,43 @@ def main():
                               "qcnn_forward_host call (two-panel chunks pipelined inside the call); u8: 8-bit sources "
                               "uploaded on a copy stream while the previous batch computes (double buffered)")
         del pinned_u8, stg, px
+        # the same batch through the C-ABI's own device group (qcnn_group_*: ONE process, every visible GPU, contiguous image
+        # blocks, rank 0's arena broadcast by RCCL inside the library and verified by checksum): device-resident blocks,
+        # layers enqueued on every rank's stream, one sync — the single-process figure next to the one-process-per-GPU `value`
+        try:
+            ndev = torch.cuda.device_count()
+            grp = pkg("engine").QcnnDeviceGroup(list(range(ndev)))
+            grp.set_option(capi.OPT_KEEP_ALL, 0)
+            grp.set_option(capi.OPT_STREAMS, args.streams)
+            grp.load_model(in_chw, layers, params, B)
+            gb = [grp.shard_bounds(B, r) for r in range(grp.size)]
+            gx = [imgs[a:b_].to("cuda:%d" % r) for r, (a, b_) in enumerate(gb)]
+            gp = [torch.empty((b_ - a, classes), dtype=torch.float32, device="cuda:%d" % r) for r, (a, b_) in enumerate(gb)]
+            gt = [torch.empty((b_ - a, 5), dtype=torch.int16, device="cuda:%d" % r) for r, (a, b_) in enumerate(gb)]
+            for r in range(ndev):
+                torch.cuda.synchronize(r)
+
+            def gstep():
+                grp.forward_dev([t.data_ptr() for t in gx], B, [t.data_ptr() for t in gp], [t.data_ptr() for t in gt])
+            gstep(); gstep()
+            grp.sync()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                gstep()
+            grp.sync()
+            extras["value_group_capi"] = round(B * 5 / (time.perf_counter() - t0), 2)
+            step()                                                   # the single context's results for the same batch
+            torch.cuda.synchronize(dev)
+            same = all(bool(torch.equal(gt[r].cpu(), top5[a:b_].cpu())) for r, (a, b_) in enumerate(gb))
+            extras["group_capi"] = dict(devices=grp.size, param_broadcast_ms=round(float(grp.broadcast_ms), 3),
+                                        arena_checksum="%016x:%016x" % grp.arena_checksum(), top5_equal_to_single_context=same,
+                                        note="qcnn_group_forward over every visible device of this process, 5 steps of one %d-image batch, "
+                                             "inputs resident on their ranks' devices" % B)
+            grp.close()
+            del gx, gp, gt
+        except Exception as e:                                       # never the headline's problem
+            extras["group_capi"] = dict(error=str(e))
+        torch.cuda.set_device(local)
         eng.set_option(capi.OPT_PROFILE, 1)
 
     parity = None
@@ -672,14 +749,14 @@ def main():
         vdt = timed(torch, dev, vf, 2)
         vms, _ = ve.layer_ms()
         vdom = int(np.argmax(vms))
-        rep = perf.layer_report(v_sizes, v_layers, v_params, vdom, vb, float(vms[vdom]), ve.layer_segments(vdom),
-                                8 if ve.layer_split(vdom)[0] in (-5, -6) else ve.layer_split(vdom)[0] == -4)
+        fam = lambda code: 8 if code in (-5, -6) else "h8" if code in (-9, -10) else code == -4
+        rep = perf.layer_report(v_sizes, v_layers, v_params, vdom, vb, float(vms[vdom]), ve.layer_segments(vdom), fam(ve.layer_split(vdom)[0]))
         conv_total = sum(float(vms[i]) for i, l in enumerate(v_layers) if l["type"] == topo.CONV)
         slow = {}
         for i in sorted((i for i, l in enumerate(v_layers) if l["type"] in (topo.CONV, topo.FCNT)), key=lambda i: -vms[i])[:5]:
             split = ve.layer_split(i)[0]
             r = (perf.decoded_report(v_sizes, v_layers, i, vb, float(vms[i]), ve.layer_split(i)[1] == 2) if (split == -3 and v_layers[i]["type"] == topo.CONV) else
-                 perf.layer_report(v_sizes, v_layers, v_params, i, vb, float(vms[i]), ve.layer_segments(i), 8 if split in (-5, -6) else split == -4))
+                 perf.layer_report(v_sizes, v_layers, v_params, i, vb, float(vms[i]), ve.layer_segments(i), fam(split)))
             r["ms"] = round(float(vms[i]), 4)
             r["in_hwc"], r["out_hwc"] = list(v_sizes[i]), list(v_sizes[i + 1])
             slow["%02d_%s" % (i, topo.TYPE_NAMES[v_layers[i]["type"]])] = r
@@ -701,7 +778,7 @@ def main():
             v_parity["image_indices"] = vidx
             v_parity["kernels"] = {str(i): list(ve.layer_split(i)) for i, l in enumerate(v_layers) if l["type"] in (topo.CONV, topo.FCNT)}
             v_parity["kernels_note"] = ("qcnn_get_layer_split codes of the timed forwards: -3 decoded code words, -2 16-wave sliding, "
-                                        "-5 / -6 eight-wave tile / sliding form (second number: segments per column)")
+                                        "-5 / -6 eight-wave tile / sliding form (second number: segments per column), -9 / -10 half-panel eight-wave tile / sliding form")
         vgg = dict(value=round(vb * 2 / vdt, 2), unit="images/s", batch=vb, steps=2, parity=v_parity,
                    outputs_finite=bool(torch.isfinite(vp).all().item()), conv_ms_per_batch=round(conv_total, 3),
                    dominant_layer=vdom, dominant_ms=round(float(vms[vdom]), 4), dominant=rep, slowest_layers=slow,
@@ -714,6 +791,7 @@ def main():
         """The `roofline` object of one measured configuration (snapshot() of its forwards)."""
         layer_ms, recorded = snap_["layer_ms"], snap_["recorded"]
         decoded, dec_nchw, symmetric, sym8, segments = (snap_[k] for k in ("decoded", "dec_nchw", "symmetric", "sym8", "segments"))
+        half8 = snap_["half8"]
         dom = int(np.argmax(layer_ms))
         dom_ms = float(layer_ms[dom])
         # a layer is launched once per sub-batch (QCNN_OPT_STREAMS): layer_ms is the mean duration of ONE launch,
@@ -735,7 +813,7 @@ def main():
                      dict(tile="decoded code words: x @ w on the matrix pipe, 64 channels x 64 images per workgroup",
                           issued_mfma_flop_per_image=2 * sizes[i][0] * sizes[i][1] * sizes[i][2] * ((l["nod"] + 63) // 64 * 64),
                           lookups_replaced_per_image=sizes[i][0] * sizes[i][1] * sizes[i][2] * l["nod"]) if i in decoded else
-                     perf.layer_report(sizes, layers, params, i, launch_images, float(layer_ms[i]), segments.get(i), 8 if i in sym8 else (i in symmetric)))
+                     perf.layer_report(sizes, layers, params, i, launch_images, float(layer_ms[i]), segments.get(i), 8 if i in sym8 else "h8" if i in half8 else (i in symmetric)))
                 r["ms"] = round(float(layer_ms[i]), 4)
                 per_layer["%02d_%s" % (i, topo.TYPE_NAMES[l["type"]])] = r
         total_lk, table_lk = 0, 0                       # all look-ups / those of the layers that really ran as table look-ups
@@ -777,6 +855,7 @@ def main():
         rp_ms = dom_ent.get("rocprof_avg_ms")
         roof = dict(bound, kernel=("k_conv_dec (layer %d, %s)" % (dom, name)) if dom in decoded else
                     ("k_conv_sym8 (layer %d, %s)" % (dom, name)) if dom in sym8 else
+                    ("k_conv_half8 (layer %d, %s)" % (dom, name)) if dom in half8 else
                     ("k_conv_sym (layer %d, %s)" % (dom, name)) if dom in symmetric else
                     "k_%s_aprx (layer %d, %s)" % ("conv" if dom in conv_idx else "fc", dom, name),
                     traffic=traffic, traffic_source=tsrc,
@@ -811,6 +890,10 @@ def main():
         out = {
             "metric": "images/sec AlexNet quantized forward" if args.model == "AlexNet" else "images/sec %s quantized forward" % args.model,
             "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            # the north star's algorithm — look-up tables + uint8-indexed accumulation — on EVERY conv / FC layer (QCNN_OPT_DECODE = 0;
+            # `value` runs conv1 and fc8 through the code words their assignments name): filled in below when measured
+            "alg_north_star_value": None, "alg_north_star_ms_per_step": None, "alg_north_star_roofline_frac": None,
+            "alg_north_star_note": None,
             "ms_per_step": round(ms_step, 4), "higher_is_better": True,
             "scaling": "strong" if (strong or world == 1) else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
@@ -822,7 +905,9 @@ def main():
                                       "fixture 1 (the mount lacks that file); inputs U{0..255} minus the shipped mean image") if shipped
                        else "seeded synthetic (seed 0), shipped AlexNet quantisation shapes",
                        "streams_per_gpu": ns, "parallelism": par},
-            "rccl_ranks": world, "param_broadcast_ms": round(bcast_ms, 3),
+            "rccl_ranks": rccl_ranks, "param_broadcast_ms": round(bcast_ms, 3),
+            "param_broadcast_verified": ("every rank's device arena checksum equals rank 0's: %s" % arena_sums[0]) if arena_sums else
+                                        "one rank: nothing to broadcast",
             "outputs_finite": ok,
             "lookups_per_image": int(total_lk),
             "lookups_per_s": round(table_lk * value, 0),
@@ -836,10 +921,23 @@ def main():
             # the north star's scheme for ALL eight conv / FC layers (QCNN_OPT_DECODE = 0): its own rate and roofline block
             v_tab = images_per_step * args.steps / dt_tab
             r_tab, _, lk_tab, _ = roofline_for(snap_tab, v_tab, 1000.0 * dt_tab / args.steps, profiled=False)
+            out["alg_north_star_value"] = round(v_tab, 2)
+            out["alg_north_star_ms_per_step"] = round(1000.0 * dt_tab / args.steps, 4)
+            out["alg_north_star_roofline_frac"] = r_tab.get("frac")
+            out["alg_north_star_note"] = ("images/s with LUT build + uint8-indexed accumulation on all eight conv / FC layers (= value_tables_only; "
+                                          "its dominant kernel and roofline: roofline_tables_only, bound %s, kernel %s); `value` is the library default, "
+                                          "which evaluates conv1 / fc8 — one 3-dim sub-space / one-dim sub-spaces — as f32 MFMA products of the same "
+                                          "code words" % (r_tab.get("bound"), r_tab.get("kernel")))
             out["value_tables_only"] = round(v_tab, 2)
             out["ms_per_step_tables_only"] = round(1000.0 * dt_tab / args.steps, 4)
             out["lookups_per_s_tables_only"] = round(lk_tab * v_tab, 0)
             out["roofline_tables_only"] = r_tab
+        if out["alg_north_star_value"] is None:
+            if not decoded:
+                out.update(alg_north_star_value=out["value"], alg_north_star_ms_per_step=out["ms_per_step"], alg_north_star_roofline_frac=roof.get("frac"),
+                           alg_north_star_note="`value` itself: no layer of this run was decoded")
+            else:
+                out["alg_north_star_note"] = "not measured in this run (--extras 0 or N > 1): see value_tables_only of the N = 1 line"
         out.update(extras)
         if value_weak is not None:
             out["value_weak"] = round(value_weak, 2)

@@ -44,7 +44,8 @@
 extern "C" {
 #endif
 
-#define QCNN_ABI_VERSION 4   /* 4 (round 5): QCNN_OPT_LUT_MODE 2 = fp16 table storage, 3 = fp16 tables + fp16 sums (the bf16-pair builder
+#define QCNN_ABI_VERSION 5   /* 5 (round 6): QCNN_OPT_HALF8 (half-panel eight-wave workgroups), qcnn_model_arena_checksum / qcnn_group_arena_checksum,
+                              * qcnn_model_mark_loaded drops the lazily built fp16 program tables.  4 (round 5): QCNN_OPT_LUT_MODE 2 = fp16 table storage, 3 = fp16 tables + fp16 sums (the bf16-pair builder
                               * of version 3 is gone); qcnn_set_option rejects out-of-range values of QCNN_OPT_SYM / _SLIDE / _SYM8;
                               * qcnn_model_set_layer_shape accepts up to 256 code words per sub-space; qcnn_group_forward */
 
@@ -189,6 +190,10 @@ int qcnn_model_arena_bytes(QcnnCtx* ctx, size_t* bytes);
 int qcnn_model_commit(QcnnCtx* ctx, int max_batch, void* dev_arena);
 /* Device address and size of the packed parameter arena (after commit): what a communicator broadcasts. */
 int qcnn_model_arena_ptr(QcnnCtx* ctx, void** dev_ptr, size_t* bytes);
+/* Checksum of the packed parameter arena as it lies on the device: sum2[0] = sum of its 32-bit words, sum2[1] = a
+ * position-weighted sum (both modulo 2^64).  Ranks whose arenas hold the same bytes report the same pair: what a sharded run
+ * compares before it trusts a broadcast (qcnn_group_model_broadcast does; bench.py --gpus N does across processes).  Blocking. */
+int qcnn_model_arena_checksum(QcnnCtx* ctx, unsigned long long* sum2);
 /* Upload one conv/FC layer's parameters from host memory in the reference's FILE layout:
  * bias [Ct]; ctrd [M][K][Cs]; asmt 0-based uint8, [Ct][kh][kw][M] (conv) or [Ct][M] (FC).
  * Performs the PrepCtrdBuf / PrepAsmtBuf permutations into the arena.  After commit. */
@@ -291,7 +296,11 @@ int qcnn_group_model_commit(QcnnGroup* grp, int max_batch);
 /* uploads to rank 0 only; qcnn_group_model_broadcast then ships the packed arena to the other ranks */
 int qcnn_group_model_set_layer_params(QcnnGroup* grp, int layer, const float* bias, const float* ctrd_file,
                                       const uint8_t* asmt_file);
+/* Ships rank 0's arena to every other rank (RCCL broadcast over xGMI), then compares a device-side checksum of every rank's
+ * arena with rank 0's (qcnn_model_arena_checksum): a mismatch is an error, no rank is declared loaded. */
 int qcnn_group_model_broadcast(QcnnGroup* grp, float* elapsed_ms);
+/* The checksum pair every rank agreed on at the last broadcast. */
+int qcnn_group_arena_checksum(QcnnGroup* grp, unsigned long long* sum2);
 /* Blocking: host in, host out; one host thread per GPU runs its block on its own context and stream. */
 int qcnn_group_forward_host(QcnnGroup* grp, const float* in_nchw_host, int n, float* prob_host, uint16_t* top5_host);
 /* Blocking: nb global batches of n[b] images each, every one sharded over the ranks like qcnn_group_forward_host; a

@@ -90,6 +90,7 @@ def load():
     lib.qcnn_ctx_stream.argtypes = [vp]
     lib.qcnn_ctx_stream.restype = vp
     lib.qcnn_model_arena_ptr.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    lib.qcnn_model_arena_checksum.argtypes = [vp, C.POINTER(C.c_ulonglong)]
     # device group
     lib.qcnn_group_create.argtypes = [C.POINTER(i), i, C.POINTER(vp)]
     lib.qcnn_group_destroy.argtypes = [vp]
@@ -105,6 +106,7 @@ def load():
     lib.qcnn_group_model_commit.argtypes = [vp, i]
     lib.qcnn_group_model_set_layer_params.argtypes = [vp, i, f32p, f32p, u8p]
     lib.qcnn_group_model_broadcast.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.qcnn_group_arena_checksum.argtypes = [vp, C.POINTER(C.c_ulonglong)]
     lib.qcnn_group_forward_host.argtypes = [vp, f32p, i, f32p, u16p]
     lib.qcnn_group_forward_host_batches.argtypes = [vp, C.POINTER(vp), C.POINTER(i), i, C.POINTER(vp), C.POINTER(vp)]
     lib.qcnn_group_forward.argtypes = [vp, C.POINTER(vp), i, C.POINTER(vp), C.POINTER(vp)]

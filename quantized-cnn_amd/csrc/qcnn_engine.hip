@@ -206,7 +206,9 @@ int plan_arena(QcnnCtx* c) {
     s.asmtBytes = taps * s.M * sl.rowStride;
     s.offAsmt = off; off = align_up(off + s.asmtBytes + QCNN_ROWS_PAD, 256);
     s.progBytes = 0;
-    if (d.type == QCNN_CONV && s.K == 128) {     // the MFMA panel kernel reads its offsets through the program table
+    // (layers of pseudo sub-spaces — more than 128 code words, s.P > 1 — always run the exact-builder kernel, which reads the plain
+    // table: none of the program tables / operand-order code books below is built for them)
+    if (d.type == QCNN_CONV && s.K == 128 && s.P == 1) {     // the MFMA panel kernel reads its offsets through the program table
       const QkProgram pg = qk_conv_program(sl, d.knlSiz, d.stride);
       s.progBytes = (size_t)pg.rfH * pg.rfW * s.M * pg.rowU16 * sizeof(uint16_t);
       s.offProg = off; off = align_up(off + s.progBytes + QCNN_ROWS_PAD, 256);
@@ -219,13 +221,13 @@ int plan_arena(QcnnCtx* c) {
       }
     }
     s.progYBytes = 0;
-    if (d.type == QCNN_CONV && qk_conv_sym_shape(c->dims[l].c, d.grpCnt, Ct, s.M, s.Cs, s.K)) {
+    if (d.type == QCNN_CONV && s.P == 1 && qk_conv_sym_shape(c->dims[l].c, d.grpCnt, Ct, s.M, s.Cs, s.K)) {
       const QkProgram py = qk_conv_program(qk_make_slots(Ct / d.grpCnt, d.grpCnt, 8), d.knlSiz, d.stride);
       s.progYBytes = (size_t)py.rfH * py.rfW * s.M * py.rowU16 * sizeof(uint16_t);
       s.offProgY = off; off = align_up(off + s.progYBytes + QCNN_ROWS_PAD, 256);
     }
     s.progF8Bytes = 0;
-    if (d.type == QCNN_FCNT && qk_fc_sym8_shape((int)fm_elems(c, l), Ct, s.M, s.Cs, s.K)) {
+    if (d.type == QCNN_FCNT && s.P == 1 && qk_fc_sym8_shape((int)fm_elems(c, l), Ct, s.M, s.Cs, s.K)) {
       s.progF8Bytes = qk_fc_sym8_program_bytes(Ct, s.M);
       s.offProgF8 = off; off = align_up(off + s.progF8Bytes + QCNN_ROWS_PAD, 256);
       s.offCtrdF = off; off = align_up(off + sizeof(float) * (size_t)s.M * s.Cs * s.K, 256);
@@ -239,7 +241,7 @@ int plan_arena(QcnnCtx* c) {
       s.offCbn = off; off = align_up(off + s.cbnBytes + 256, 256);
     }
     s.prog8Bytes = 0; s.prog8SBytes = 0; s.progH8Bytes = 0; s.progH8SBytes = 0;
-    if (d.type == QCNN_CONV) {
+    if (d.type == QCNN_CONV && s.P == 1) {
       const Qk8Config c8 = qk_conv_sym8_config(c->dims[l].c, d.grpCnt, Ct, s.M, s.Cs, s.K);
       s.prog8Bytes = qk_conv_sym8_program_bytes(c8, d.grpCnt, d.knlSiz, d.stride, s.M);
       const Qk8Config c8s = qk_conv_sym8_slide_config(c->dims[l].c, d.grpCnt, Ct, s.M, s.Cs, s.K, d.knlSiz, d.stride);
@@ -328,9 +330,15 @@ int ensure_stage(QcnnCtx* c, size_t elems = 0) {
     (void)hipFree(c->stageIn); (void)hipFree(c->stageOut);
     c->stageIn = c->stageOut = nullptr;
   }
-  c->stageElems = need;
-  HIP_TRY(c, hipMalloc(&c->stageIn, c->stageElems * sizeof(float) + kSlack));
-  HIP_TRY(c, hipMalloc(&c->stageOut, c->stageElems * sizeof(float) + kSlack));
+  c->stageElems = 0;                                    // committed only when BOTH buffers exist (a half-grown pair must never be used)
+  float *in = nullptr, *out = nullptr;
+  HIP_TRY(c, hipMalloc(&in, need * sizeof(float) + kSlack));
+  if (hipMalloc(&out, need * sizeof(float) + kSlack) != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipFree(in);
+    return fail(c, "staging buffers: 2 x %zu bytes do not fit the device", need * sizeof(float) + kSlack);
+  }
+  c->stageIn = in; c->stageOut = out; c->stageElems = need;
   if (!c->stageTop5) HIP_TRY(c, hipMalloc(&c->stageTop5, (size_t)c->maxBatch * 5 * sizeof(uint16_t)));
   return 0;
 }
@@ -372,6 +380,16 @@ bool decoded_fc(const QcnnCtx* c, int l) {
 
 // fp16 table storage: the layer's program table in the fp16 layout's offsets (first use; the build runs on `st`, in front of the
 // launch that reads it)
+// a table pointer is published in the LayerShape only once its build has been enqueued without error: on any failure behind the
+// hipMalloc the allocation is released, so that a later forward builds again instead of launching with an unbuilt table
+#define F16_TRY(ptr, expr)                                                              \
+  do {                                                                                  \
+    const hipError_t e_ = (expr);                                                       \
+    if (e_ != hipSuccess) {                                                             \
+      (void)hipFree(ptr);                                                               \
+      return fail(c, "%s -> %s", #expr, hipGetErrorString(e_));                         \
+    }                                                                                   \
+  } while (0)
 int ensure_f16_program(QcnnCtx* c, int l, hipStream_t st) {
   const QcnnLayerDesc& d = c->layers[l];
   LayerShape& s = c->shapes[l];
@@ -381,23 +399,29 @@ int ensure_f16_program(QcnnCtx* c, int l, hipStream_t st) {
     built = true;
     const Qk8Config cf = qk_conv_sym8_config16(c->dims[l].c, d.grpCnt, Ct, s.M, s.Cs, s.K);
     const size_t bytes = qk_conv_sym8_program_bytes(cf, d.grpCnt, d.knlSiz, d.stride, s.M);
-    HIP_TRY(c, hipMalloc(&s.prog8A, bytes + QCNN_ROWS_PAD + 4096));
-    HIP_TRY(c, hipMemsetAsync(s.prog8A, 0, bytes + QCNN_ROWS_PAD + 4096, st));
-    HIP_TRY(c, qk_build_program8(reinterpret_cast<const uint8_t*>(c->arena + s.offAsmt), s.prog8A, qk_conv_slots(Ct / d.grpCnt, d.grpCnt),
+    uint16_t* t = nullptr;
+    HIP_TRY(c, hipMalloc(&t, bytes + QCNN_ROWS_PAD + 4096));
+    F16_TRY(t, hipMemsetAsync(t, 0, bytes + QCNN_ROWS_PAD + 4096, st));
+    F16_TRY(t, qk_build_program8(reinterpret_cast<const uint8_t*>(c->arena + s.offAsmt), t, qk_conv_slots(Ct / d.grpCnt, d.grpCnt),
                                  cf, Ct / d.grpCnt, d.grpCnt, d.knlSiz, d.stride, s.M, st, 1));
+    s.prog8A = t;
   }
   if (d.type == QCNN_CONV && s.prog8Bytes && c->lutMode == 2 && !s.prog8H) {
     built = true;
-    HIP_TRY(c, hipMalloc(&s.prog8H, s.prog8Bytes + QCNN_ROWS_PAD));
-    HIP_TRY(c, hipMemsetAsync(s.prog8H, 0, s.prog8Bytes + QCNN_ROWS_PAD, st));
-    HIP_TRY(c, qk_build_program8(reinterpret_cast<const uint8_t*>(c->arena + s.offAsmt), s.prog8H, qk_conv_slots(Ct / d.grpCnt, d.grpCnt),
+    uint16_t* t = nullptr;
+    HIP_TRY(c, hipMalloc(&t, s.prog8Bytes + QCNN_ROWS_PAD));
+    F16_TRY(t, hipMemsetAsync(t, 0, s.prog8Bytes + QCNN_ROWS_PAD, st));
+    F16_TRY(t, qk_build_program8(reinterpret_cast<const uint8_t*>(c->arena + s.offAsmt), t, qk_conv_slots(Ct / d.grpCnt, d.grpCnt),
                                  qk_conv_sym8_config(c->dims[l].c, d.grpCnt, Ct, s.M, s.Cs, s.K), Ct / d.grpCnt, d.grpCnt, d.knlSiz,
                                  d.stride, s.M, st, 1));
+    s.prog8H = t;
   }
   if (d.type == QCNN_FCNT && s.progF8Bytes && !s.progF8H) {
-    HIP_TRY(c, hipMalloc(&s.progF8H, s.progF8Bytes + QCNN_ROWS_PAD));
-    HIP_TRY(c, hipMemsetAsync(s.progF8H, 0, s.progF8Bytes + QCNN_ROWS_PAD, st));
-    HIP_TRY(c, qk_build_program_fc8(reinterpret_cast<const uint8_t*>(c->arena + s.offAsmt), s.progF8H, qk_fc_slots(Ct), Ct, s.M, st, 1));
+    uint16_t* t = nullptr;
+    HIP_TRY(c, hipMalloc(&t, s.progF8Bytes + QCNN_ROWS_PAD));
+    F16_TRY(t, hipMemsetAsync(t, 0, s.progF8Bytes + QCNN_ROWS_PAD, st));
+    F16_TRY(t, qk_build_program_fc8(reinterpret_cast<const uint8_t*>(c->arena + s.offAsmt), t, qk_fc_slots(Ct), Ct, s.M, st, 1));
+    s.progF8H = t;
   } else if (!built) {
     return 0;
   }
@@ -1161,6 +1185,42 @@ int qcnn_model_arena_ptr(QcnnCtx* c, void** dev_ptr, size_t* bytes) {
   return 0;
 }
 
+namespace {
+// two 64-bit sums over the arena's 32-bit words: the plain sum and a position-weighted one (a permutation of blocks changes it)
+__global__ __launch_bounds__(256) void k_arena_checksum(const uint32_t* __restrict__ w, size_t n, unsigned long long* __restrict__ out) {
+  unsigned long long a = 0, b = 0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const unsigned long long v = w[i];
+    a += v;
+    b += v * (unsigned long long)(i % 65521u + 1u);
+  }
+  for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off); b += __shfl_down(b, off); }
+  if ((threadIdx.x & 63) == 0) { atomicAdd(&out[0], a); atomicAdd(&out[1], b); }
+}
+}  // namespace
+
+/* Checksum of the packed parameter arena as it lies on the device (after uploads / a broadcast): sum2[0] = sum of its 32-bit
+ * words, sum2[1] = position-weighted sum.  Ranks whose arenas hold the same bytes report the same pair — what a sharded run
+ * compares before it trusts a broadcast.  Blocking. */
+int qcnn_model_arena_checksum(QcnnCtx* c, unsigned long long* sum2) {
+  if (!c->committed) return fail(c, "model not committed");
+  if (!sum2) return fail(c, "qcnn_model_arena_checksum: sum2 == NULL");
+  HIP_TRY(c, hipSetDevice(c->device));
+  unsigned long long* d = nullptr;
+  HIP_TRY(c, hipMalloc(&d, 2 * sizeof(unsigned long long)));
+  hipError_t e = hipMemsetAsync(d, 0, 2 * sizeof(unsigned long long), c->stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_arena_checksum, dim3(1024), dim3(256), 0, c->stream, reinterpret_cast<const uint32_t*>(c->arena),
+                       c->arenaBytes / 4, d);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(sum2, d, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(d);
+  if (e != hipSuccess) return fail(c, "arena checksum -> %s", hipGetErrorString(e));
+  return 0;
+}
+
 int qcnn_model_commit(QcnnCtx* c, int max_batch, void* dev_arena) {
   HIP_TRY(c, hipSetDevice(c->device));
   if (c->committed) return fail(c, "model already committed");
@@ -1463,8 +1523,17 @@ int qcnn_model_set_layer_params_cbn(QcnnCtx* c, int layer, const float* bias, co
 /* Mark every conv/FC layer as loaded without uploading: the arena was filled by a broadcast. */
 int qcnn_model_mark_loaded(QcnnCtx* c) {
   if (!c->committed) return fail(c, "model not committed");
-  for (int l = 0; l < c->L; ++l)
+  // The arena may have been REfilled (a re-upload on rank 0 + a second broadcast, or a caller-owned arena written again): the
+  // lazily built fp16 program tables (QCNN_OPT_LUT_MODE = 2 / 3) were derived from the OLD assignment bytes — drop them, they are
+  // rebuilt from the arena on the next forward that needs them.  Nothing may still be reading them.
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  for (int k = 0; k < kMaxStreams - 1; ++k)
+    if (c->aux[k]) HIP_TRY(c, hipStreamSynchronize(c->aux[k]));
+  for (int l = 0; l < c->L; ++l) {
+    drop_f16_programs(c->shapes[l]);
     if (c->shapes[l].K > 0 || c->shapes[l].dense) c->shapes[l].loaded = true;
+  }
   return 0;
 }
 

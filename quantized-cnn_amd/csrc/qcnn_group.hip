@@ -29,6 +29,7 @@ struct QcnnGroup {
   int classes = 0;
   size_t inElems = 0;
   float bcastMs = 0.0f;
+  unsigned long long arenaSum[2] = {0, 0};   // checksum every rank's arena agreed on at the last broadcast (qcnn_group_arena_checksum)
   bool broadcastDone = false;
   bool dupDevices = false;      // QCNN_GROUP_ALLOW_DUP: several ranks on one device, no RCCL communicator
   int smallBatch = 1;           // QCNN_OPT_SMALL_BATCH as the caller set it; applied per forward by the GLOBAL batch size
@@ -221,6 +222,18 @@ int qcnn_group_model_broadcast(QcnnGroup* g, float* elapsed_ms) {
   for (int r = 0; r < G; ++r)
     if (qcnn_sync(g->ctx[r])) return gfail(g, "rank %d: %s", r, qcnn_last_error(g->ctx[r]));
   g->bcastMs = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  // every rank's arena must now hold rank 0's bytes: compare device-side checksums before any rank is declared loaded (a
+  // broadcast that silently moved nothing — or the wrong bytes — would otherwise surface as wrong class scores on some shards)
+  unsigned long long want[2] = {0, 0};
+  for (int r = 0; r < G; ++r) {
+    unsigned long long got[2] = {0, 0};
+    if (qcnn_model_arena_checksum(g->ctx[r], got)) return gfail(g, "rank %d: %s", r, qcnn_last_error(g->ctx[r]));
+    if (r == 0) { want[0] = got[0]; want[1] = got[1]; }
+    else if (got[0] != want[0] || got[1] != want[1])
+      return gfail(g, "parameter broadcast: rank %d (device %d) holds arena checksum %016llx:%016llx, rank 0 %016llx:%016llx", r, g->devs[r],
+                   got[0], got[1], want[0], want[1]);
+  }
+  g->arenaSum[0] = want[0]; g->arenaSum[1] = want[1];
   for (int r = 1; r < G; ++r)
     if (qcnn_model_mark_loaded(g->ctx[r])) return gfail(g, "rank %d: %s", r, qcnn_last_error(g->ctx[r]));
   g->broadcastDone = true;
@@ -284,7 +297,8 @@ int qcnn_group_forward_host(QcnnGroup* g, const float* in_nchw_host, int n, floa
 // layers are ENQUEUED on its own stream (no host thread, no PCIe), qcnn_group_sync waits for all of them.
 int qcnn_group_forward(QcnnGroup* g, const float* const* in_dev, int n, float* const* prob_dev, uint16_t* const* top5_dev) {
   const int G = (int)g->ctx.size();
-  if (n <= 0 || !in_dev) return gfail(g, "batch %d must be positive", n);
+  if (!in_dev) return gfail(g, "qcnn_group_forward: in_dev == NULL (one device pointer per rank)");
+  if (n <= 0) return gfail(g, "batch %d must be positive", n);
   if (G > 1 && !g->broadcastDone) return gfail(g, "qcnn_group_model_broadcast must follow the parameter upload");
   for (int r = 0; r < G; ++r) {
     int first = 0, count = 0;
@@ -304,3 +318,10 @@ int qcnn_group_sync(QcnnGroup* g) {
 }
 
 }  // extern "C"
+
+/* Checksum pair every rank's arena agreed on at the last qcnn_group_model_broadcast (qcnn_model_arena_checksum). */
+int qcnn_group_arena_checksum(QcnnGroup* g, unsigned long long* sum2) {
+  if (!g->broadcastDone) return gfail(g, "qcnn_group_model_broadcast has not run");
+  if (sum2) { sum2[0] = g->arenaSum[0]; sum2[1] = g->arenaSum[1]; }
+  return 0;
+}

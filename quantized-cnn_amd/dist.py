@@ -88,3 +88,34 @@ def gather_rows(local_rows, n_items: int):
         lo, hi = shard_bounds(n_items, r, world)
         out.append(bufs[r][: hi - lo])
     return torch.cat(out, 0).numpy()
+
+
+def checksums_agree(local_pair, device="cpu"):
+    """Every rank passes its (sum, weighted sum) checksum pair of the parameter arena (QcnnEngine.arena_checksum, or any pair of
+    Python ints < 2^64); returns (ok, [pair of rank 0, pair of rank 1, ...]) on every rank — ok iff all ranks hold rank 0's pair.
+    What bench.py --gpus N checks between dist.broadcast(arena) and the timed loop."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size()
+    # 64-bit unsigned values travel as four 16-bit limbs each in int64 slots (no unsigned 64-bit tensors in every backend)
+    limbs = [(int(v) >> (16 * k)) & 0xffff for v in local_pair for k in range(4)]
+    mine = torch.tensor(limbs, dtype=torch.int64, device=device)
+    bufs = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(bufs, mine)
+    pairs = []
+    for b in bufs:
+        v = [int(x) for x in b.cpu().tolist()]
+        pairs.append(tuple(sum(v[4 * j + k] << (16 * k) for k in range(4)) for j in range(2)))
+    return all(p == pairs[0] for p in pairs), pairs
+
+
+def verified_world_size(device="cpu"):
+    """World size as the communicator itself reports it after a REAL collective: all_reduce of ones."""
+    import torch
+    import torch.distributed as dist
+    t = torch.ones(1, dtype=torch.int64, device=device)
+    dist.all_reduce(t)
+    n = int(t.item())
+    if n != dist.get_world_size():
+        raise RuntimeError("all_reduce over the communicator counted %d ranks, get_world_size() says %d" % (n, dist.get_world_size()))
+    return n

@@ -92,6 +92,13 @@ class QcnnEngine:
     def mark_loaded(self):
         self._chk(self.lib.qcnn_model_mark_loaded(self.h))
 
+    def arena_checksum(self):
+        """(sum of the arena's 32-bit words, position-weighted sum) as it lies on the device — equal on ranks that hold the same
+        parameter bytes (qcnn_model_arena_checksum); blocking."""
+        s2 = (C.c_ulonglong * 2)()
+        self._chk(self.lib.qcnn_model_arena_checksum(self.h, s2))
+        return int(s2[0]), int(s2[1])
+
     def load_model(self, in_chw, layers, params, max_batch, arena_ptr=None, upload=True):
         shapes = {i: tuple(int(x) for x in p["ctrd"].shape) for i, p in params.items()}   # (M, K, Cs)
         for i, ly in enumerate(layers):
@@ -288,13 +295,30 @@ class QcnnDeviceGroup:
             asmt = np.ascontiguousarray(p["asmt"], np.uint8)
             self._chk(self.lib.qcnn_group_model_set_layer_params(self.h, i, bias.ctypes.data, ctrd.ctypes.data,
                                                                  asmt.ctypes.data))
-        ms = C.c_float(0.0)
-        self._chk(self.lib.qcnn_group_model_broadcast(self.h, C.byref(ms)))
-        self.broadcast_ms = ms.value
+        self.broadcast()
         self.L = len(layers)
         d = (C.c_int * 3)()
         self.lib.qcnn_fm_dims(self.lib.qcnn_group_ctx(self.h, 0), self.L, d)
         self.classes = int(d[0]) * int(d[1]) * int(d[2])
+
+    def upload(self, params):
+        """Re-upload layers' parameters to rank 0 ({layer: dict(bias, ctrd, asmt)}); broadcast() must follow."""
+        for i, p in params.items():
+            bias = np.ascontiguousarray(p["bias"], np.float32)
+            ctrd = np.ascontiguousarray(p["ctrd"], np.float32)
+            asmt = np.ascontiguousarray(p["asmt"], np.uint8)
+            self._chk(self.lib.qcnn_group_model_set_layer_params(self.h, i, bias.ctypes.data, ctrd.ctypes.data, asmt.ctypes.data))
+
+    def broadcast(self):
+        """Rank 0's arena to every rank (RCCL), verified by a per-rank device checksum (qcnn_group_model_broadcast)."""
+        ms = C.c_float(0.0)
+        self._chk(self.lib.qcnn_group_model_broadcast(self.h, C.byref(ms)))
+        self.broadcast_ms = ms.value
+
+    def arena_checksum(self):
+        s2 = (C.c_ulonglong * 2)()
+        self._chk(self.lib.qcnn_group_arena_checksum(self.h, s2))
+        return int(s2[0]), int(s2[1])
 
     def forward_host(self, imgs_nchw):
         imgs = np.ascontiguousarray(imgs_nchw, np.float32)

@@ -37,14 +37,33 @@ def sym8_tile(ctg: int):
     return th, tw, cpw, (ctg + 8 * cpw - 1) // (8 * cpw)
 
 
+def half8_tile(ctg: int):
+    """(TH, TW, channels per wave, wave sets, channel chunks) of the half-panel eight-wave kernel (qk_conv_half8_config)."""
+    chunks = (ctg + 511) // 512
+    cpw, th, tw, ws = {128: (32, 3, 4, 2), 192: (48, 2, 4, 2), 256: (32, 2, 3, 1), 384: (48, 2, 2, 1), 512: (64, 1, 3, 1)}[ctg // chunks]
+    return th, tw, cpw, ws, chunks
+
+
+def half8_slide_cfg(ctg: int):
+    """(slots, columns per strip, channels per wave, wave sets, channel chunks) of its sliding form (qk_conv_half8_slide_config)."""
+    _, _, cpw, ws, chunks = half8_tile(ctg)
+    return 3, {128: 4, 192: 2, 256: 2, 384: 1, 512: 1}[ctg // chunks], cpw, ws, chunks
+
+
 def conv_work(in_hwc, out_hwc, ly, m: int, k: int, cs: int, sym=False):
     """Per 128-image panel: stages built, look-ups (border clipped), ideal stages (every (pixel, sub-space group)
     once per group), f32 MFMA FLOP issued.  sym: True = the 16-wave symmetric kernel's 2x2 tile of all 128 channels
-    (k_conv_sym), 8 = the eight-wave symmetric kernel's tile (k_conv_sym8)."""
+    (k_conv_sym), 8 = the eight-wave symmetric kernel's tile (k_conv_sym8), "h8" = the half-panel eight-wave kernel
+    (k_conv_half8): its workgroups hold 64 images, so `stages` counts TWO half-panel stages per tile stage and a stage issues half
+    the matrix work ("half_stages": True)."""
     h, w, cin = in_hwc
     ho, wo, ct = out_hwc
     knl, s, p, grp = ly["knl"], ly["stride"], ly["pad"], ly["grp"]
-    th, tw, cpw, chunks = sym8_tile(ct // grp) if sym == 8 else (2, 2, 8, 1) if sym else conv_tile(ct // grp)
+    ws = 1
+    if sym == "h8":
+        th, tw, cpw, ws, chunks = half8_tile(ct // grp)
+    else:
+        th, tw, cpw, chunks = sym8_tile(ct // grp) if sym == 8 else (2, 2, 8, 1) if sym else conv_tile(ct // grp)
     g = stage_group(k)
     mg = (m + g - 1) // g
     stages = 0
@@ -63,6 +82,9 @@ def conv_work(in_hwc, out_hwc, ly, m: int, k: int, cs: int, sym=False):
     ks = 2 if min(cin // grp, cs) > 4 else 1
     # algorithmic LUT build (SURVEY.md §8 table "LUT-MAC/img"): every (pixel, sub-space) table once, over the dims it has
     alg_flop = 2 * h * w * grp * k * sum(min(cs, cin // grp - i * cs) for i in range(m)) * 128
+    if sym == "h8":
+        return dict(stages=2 * stages, lookups=lookups, ideal_stages=ideal, mfma_flop=2 * stages * 128 * 64 * 4 * ks * 2, alg_flop=alg_flop,
+                    half_stages=True, tile="half panels, 8 waves %dx%dx%d (%d wave set%s)" % (th, tw, 8 // ws * cpw, ws, "s" if ws > 1 else ""), ks=ks)
     return dict(stages=stages, lookups=lookups, ideal_stages=ideal, mfma_flop=stages * 128 * 128 * 4 * ks * 2, alg_flop=alg_flop,
                 tile=("symmetric 8 waves %dx%dx%d" % (th, tw, 8 * cpw)) if sym == 8 else
                      ("symmetric %dx%dx%d" % (th, tw, 16 * cpw)) if sym else "%dx%dx%d" % (th, tw, GATHER_WAVES * cpw), ks=ks)
@@ -123,6 +145,25 @@ def conv_work_slide8(in_hwc, out_hwc, ly, m: int, k: int, cs: int, seg_beg):
                 tile="slide 8 waves %d column(s) x %d slots x %d, %d segment(s) per column" % (nc, ns, 8 * cpw, len(seg_beg) - 1))
 
 
+def conv_work_slide_h8(in_hwc, out_hwc, ly, m: int, k: int, cs: int, seg_beg):
+    """conv_work_slide for k_conv_half8<.., SLIDE>: strips of nc output columns, row segments, TWO half-panel stages per strip stage."""
+    h, w, cin = in_hwc
+    ho, wo, ct = out_hwc
+    knl, s, p, grp = ly["knl"], ly["stride"], ly["pad"], ly["grp"]
+    base = conv_work(in_hwc, out_hwc, ly, m, k, cs, "h8")
+    ns, nc, cpw, ws, chunks = half8_slide_cfg(ct // grp)
+    stages = 0
+    for x0 in range(0, wo, nc):
+        x1 = min(wo, x0 + nc) - 1
+        cols = min(w - 1, x1 * s - p + knl - 1) - max(0, x0 * s - p) + 1
+        for a, b in zip(seg_beg[:-1], seg_beg[1:]):
+            rows = min(h - 1, (b - 1) * s - p + knl - 1) - max(0, a * s - p) + 1
+            stages += max(rows, 0) * max(cols, 0) * m
+    stages *= chunks * grp * 2
+    return dict(base, stages=stages, mfma_flop=stages * 128 * 64 * 4 * base["ks"] * 2,
+                tile="half panels, slide 8 waves %d column(s) x %d slots x %d, %d segment(s) per column" % (nc, ns, 8 // ws * cpw, len(seg_beg) - 1))
+
+
 def fc_work(d: int, ct: int, m: int, k: int, cs: int, msplit_chunks: int):
     g = stage_group(k)
     stages = (m + g - 1) // g * msplit_chunks
@@ -164,7 +205,9 @@ def layer_report(sizes, layers, params, l: int, images: float, ms: float, seg_be
     the sliding kernel's row segments when the layer ran it (QcnnEngine.layer_segments)."""
     ly = layers[l]
     mm, kk, cc = (int(x) for x in params[l]["ctrd"].shape)
-    if ly["type"] == CONV and seg_beg and sym == 8:
+    if ly["type"] == CONV and seg_beg and sym == "h8":
+        wk = conv_work_slide_h8(sizes[l], sizes[l + 1], ly, mm, kk, cc, seg_beg)
+    elif ly["type"] == CONV and seg_beg and sym == 8:
         wk = conv_work_slide8(sizes[l], sizes[l + 1], ly, mm, kk, cc, seg_beg)
     elif ly["type"] == CONV and seg_beg:
         wk = conv_work_slide(sizes[l], sizes[l + 1], ly, mm, kk, cc, seg_beg)
@@ -186,8 +229,9 @@ def layer_report(sizes, layers, params, l: int, images: float, ms: float, seg_be
     stages = wk["stages"] * panels
     cycles = t * CLOCK_HZ * CUS / stages if stages else 0.0
     lookups = wk["lookups"] * images
-    return dict(tile=wk["tile"], stages_per_panel=wk["stages"], rebuild_factor=round(wk["stages"] / wk["ideal_stages"], 2),
-                lookups_per_stage=round(wk["lookups"] / wk["stages"], 1),   # row look-ups (128 images each) per built stage
+    half = 2 if wk.get("half_stages") else 1                # half-panel stages: two per panel, each with rows of 64 images
+    return dict(tile=wk["tile"], stages_per_panel=wk["stages"], rebuild_factor=round(wk["stages"] / half / wk["ideal_stages"], 2),
+                lookups_per_stage=round(wk["lookups"] * half / wk["stages"], 1),   # row look-ups (128 images each; half-panel kernel: 64) per built stage
                 stage_cycles=round(cycles, 0),
                 mfma_util=round(wk["mfma_flop"] * panels / t / F32_MFMA_FLOPS, 4) if t > 0 else 0.0,
                 # the LUT build the algorithm asks for (every table once), on the images the launch really holds

@@ -63,7 +63,15 @@ def test_layer_report_for_every_kernel_family():
             variants = [dict()] if l["type"] == topo.FCNT else [dict(), dict(sym=8)]
             if l["type"] == topo.CONV and l["knl"] == 3 and sizes[i][2] // l["grp"] >= 64 and l["cnt"] // l["grp"] >= 128:
                 variants += [dict(seg_beg=[0, sizes[i + 1][0]], sym=8), dict(seg_beg=[0, sizes[i + 1][0] // 2, sizes[i + 1][0]], sym=8)]
+            if l["type"] == topo.CONV and l["cnt"] // l["grp"] in (128, 192, 256, 384, 512) and sizes[i][2] // l["grp"] >= 8:
+                variants += [dict(sym="h8")]                   # half-panel eight-wave kernel (round 6), tile form ...
+                if l["knl"] == 3:                              # ... and sliding form
+                    variants += [dict(seg_beg=[0, sizes[i + 1][0] // 2, sizes[i + 1][0]], sym="h8")]
             for kw in variants:
                 r = perf.layer_report(sizes, layers, params, i, 1000.0, 1.5, **kw)
+                if kw.get("sym") == "h8" and not kw.get("seg_beg"):
+                    # twice the tile: fewer table builds per source pixel than the full-panel eight-wave tile
+                    r8 = perf.layer_report(sizes, layers, params, i, 1000.0, 1.5, sym=8)
+                    assert r["rebuild_factor"] < r8["rebuild_factor"], (model, i, r["rebuild_factor"], r8["rebuild_factor"])
                 for key in ("stages_per_panel", "rebuild_factor", "lookups_per_stage", "stage_cycles", "lds_frac"):
                     assert np.isfinite(r[key]) and r[key] > 0, (model, i, kw, key, r)

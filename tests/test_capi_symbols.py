@@ -15,7 +15,7 @@ def test_exports_every_declared_symbol():
     assert len(names) >= 20
     for n in names:
         assert hasattr(lib, n), "libqcnn_hip.so does not export %s" % n
-    assert lib.qcnn_abi_version() == 4
+    assert lib.qcnn_abi_version() == 5
 
 
 @pytest.mark.skipif(has_gpu(), reason="only meaningful without a GPU")

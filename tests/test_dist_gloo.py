@@ -100,6 +100,59 @@ def test_two_ranks_equal_single_process():
         assert csum == params[0]["ctrd"].sum()
 
 
+def _checksum_worker(rank, world, port, q, corrupt):
+    sys.path.insert(0, ROOT)
+    import importlib
+    import torch.distributed as dist
+    d = importlib.import_module("quantized-cnn_amd.dist")
+    s = importlib.import_module("quantized-cnn_amd.synth")
+    t = importlib.import_module("quantized-cnn_amd.topology")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        in_chw, layers = t.tiny_model()
+        full = s.make_params(in_chw, layers, seed=2)
+        shapes = {i: {k: full[i][k].shape for k in ("bias", "ctrd", "asmt")} for i in full}
+        params = d.broadcast_params(full if rank == 0 else None, shapes, src=0)
+        blob = d.pack_param_blob(params)
+        if corrupt and rank == 1:
+            blob[blob.size // 2] ^= 1                          # one flipped bit on one rank
+        w = np.frombuffer(blob.tobytes() + b"\0" * (-blob.size % 4), dtype="<u4").astype(np.uint64)
+        idx = (np.arange(w.size, dtype=np.uint64) % np.uint64(65521)) + np.uint64(1)
+        pair = (int(w.sum(dtype=np.uint64)), int((w * idx).sum(dtype=np.uint64)))      # the sums k_arena_checksum forms, modulo 2^64
+        ok, pairs = d.checksums_agree(pair)
+        q.put((rank, ok, pairs, d.verified_world_size()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("corrupt", [False, True])
+def test_broadcast_checksums_across_ranks(corrupt):
+    """What bench.py --gpus N does between dist.broadcast(arena) and the timed loop (and qcnn_group_model_broadcast does inside
+    one process): every rank forms the checksum pair of ITS copy of the parameters, all ranks compare — equal after a sound
+    broadcast, unequal (on every rank) when one rank's copy differs in one bit; the world size is the one a real all_reduce counts."""
+    import torch.multiprocessing as mp
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_checksum_worker, args=(r, 2, port, q, corrupt)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in procs], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok, pairs, world in res:
+        assert world == 2 and len(pairs) == 2
+        assert ok == (not corrupt), "rank %d: %r" % (rank, pairs)
+        assert (pairs[0] == pairs[1]) == (not corrupt)
+        assert all(0 <= v < 2 ** 64 for p in pairs for v in p)
+    assert res[0][2] == res[1][2]                               # every rank sees the same table
+
+
 def test_bench_refuses_a_multi_gpu_run_it_cannot_do():
     """`python bench.py --gpus 2` outside torch.distributed.run must either start two ranks or fail loudly — never
     report a one-GPU number as a two-GPU one (there is no GPU in the CPU tier, so it has to fail)."""

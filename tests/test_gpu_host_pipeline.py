@@ -119,6 +119,45 @@ def test_two_ranks_on_one_device(monkeypatch):
     grp.close()
 
 
+def test_reupload_and_second_broadcast_in_the_fp16_table_mode(monkeypatch):
+    """the fp16 program tables (QCNN_OPT_LUT_MODE = 2) are built lazily FROM the arena's assignment bytes; a re-upload
+    on rank 0 + a second broadcast refills the other ranks' arenas behind their backs — qcnn_model_mark_loaded must drop their
+    tables, or ranks >= 1 keep gathering with the OLD assignments.  Two ranks on one device, 300 images (both ranks have work),
+    a 256-channel layer (eligible for the eight-wave fp16 form): parameters A, forward, parameters B, broadcast, forward —
+    against a single context that only ever saw B.  The broadcast's own checksum check is exercised on the way."""
+    monkeypatch.setenv("QCNN_GROUP_ALLOW_DUP", "1")
+    layers = [topo.conv(1, 3, 16, 1, 1), topo.relu(), topo.conv(1, 3, 256, 1, 1), topo.relu(), topo.pool(0, 3, 2), topo.fcnt(40), topo.smax()]
+    in_chw = (3, 13, 11)
+    pa = synth.make_params(in_chw, layers, seed=41)
+    pb = synth.make_params(in_chw, layers, seed=42)
+    imgs = synth.make_images(300, in_chw, seed=43)
+    single = engine.QcnnEngine(0)
+    single.set_option(capi.OPT_LUT_MODE, capi.LUT_MFMA_F16)
+    single.set_option(capi.OPT_KEEP_ALL, 0)
+    single.set_option(capi.OPT_SPLIT, 0)
+    single.load_model(in_chw, layers, pb, 300)
+    want_b = single.forward_host(imgs)
+    assert single.layer_split(2)[0] == -7                                # the eight-wave fp16-table kernel ran
+    sum_b = single.arena_checksum()
+    single.close()
+    grp = engine.QcnnDeviceGroup([0, 0])
+    grp.set_option(capi.OPT_LUT_MODE, capi.LUT_MFMA_F16)
+    grp.set_option(capi.OPT_KEEP_ALL, 0)
+    grp.set_option(capi.OPT_SPLIT, 0)
+    grp.load_model(in_chw, layers, pa, 300)
+    sum_a = grp.arena_checksum()
+    prob_a, _ = grp.forward_host(imgs)                                   # builds every rank's fp16 program tables from A
+    grp.upload(pb)
+    with pytest.raises(engine.QcnnError):
+        grp.forward_host(imgs)                                           # a forward between upload and broadcast is refused
+    grp.broadcast()
+    assert grp.arena_checksum() == sum_b and sum_a != sum_b              # every rank holds B's bytes (a single context's arena of B)
+    prob, top5 = grp.forward_host(imgs)
+    assert np.array_equal(prob, want_b[0]) and np.array_equal(top5, want_b[1])
+    assert not np.array_equal(prob_a, prob)
+    grp.close()
+
+
 def test_group_kernel_family_follows_the_global_batch(monkeypatch):
     """A shard of a few images of a LARGER batch must not take the few-image kernels (bits would then depend on
     the number of GPUs): 4 images (> QCNN_SMALL_BATCH_MAX) over 2 ranks = shards of 2 images, panel kernels on both."""

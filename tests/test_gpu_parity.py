@@ -465,8 +465,9 @@ def test_odd_channel_count_is_rejected():
 
 def test_option_values_out_of_range_are_refused():
     """qcnn_set_option never clamps: a value a kernel family does not define (QCNN_OPT_SYM8 = 6 was once silently run as 3) is an
-    error with a message, and the option keeps its value.  More than 128 code words per sub-space are refused at
-    qcnn_model_set_layer_shape (the host mirror reports the same at LoadCaffePara: tests/test_host_mirror.py)."""
+    error with a message, and the option keeps its value.  (Code-word counts: up to 256 per sub-space are accepted — above 128
+    through pseudo sub-spaces, test_more_than_128_code_words_per_sub_space; more than 256 cannot be named by a uint8 assignment
+    and are refused at qcnn_model_set_layer_shape, as the host mirror does at LoadCaffePara: tests/test_host_mirror.py.)"""
     eng = pkg("engine").QcnnEngine(0)
     for opt, bad in ((capi.OPT_SYM8, 4), (capi.OPT_SYM8, 6), (capi.OPT_SYM8, -1), (capi.OPT_SYM, 3), (capi.OPT_SLIDE, 3),
                      (capi.OPT_LUT_MODE, 4), (capi.OPT_LUT_MODE, -1), (capi.OPT_STREAMS, 0), (capi.OPT_STREAMS, 9)):
