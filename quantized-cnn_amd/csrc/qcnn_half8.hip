@@ -71,10 +71,10 @@ __device__ __forceinline__ void lane_group(int lane, int& g, int& i) {
   i = __popc((isB ? GROUP_B : ~GROUP_B) & below);
 }
 // LDS byte address of the lane's group's block of a program row ([wave][4 groups][local position][CPW / 4] uint16)
-__device__ __forceinline__ uint32_t my_blk_h(int wave, int blkBytes) {
+__device__ __forceinline__ uint32_t my_blk_h(int wave, int blkBytes, uint32_t progLds = PROGH_LDS) {
   int g, i;
   lane_group(lane_now_h(), g, i);
-  return PROGH_LDS + (uint32_t)(wave * 4 + g) * (uint32_t)blkBytes;
+  return progLds + (uint32_t)(wave * 4 + g) * (uint32_t)blkBytes;
 }
 
 // operands of one stage for this wave: code-book tiles of its four row tiles, the activation tile of its image tile
@@ -164,11 +164,18 @@ __device__ __forceinline__ void gatherh(f32x2 (&acc)[TH * TW / WS][CPW / 2], uin
 #pragma unroll
   for (int q = 0; q < NPW; ++q) {
     if constexpr (WS == 1) ok[q] = uni(okAll[q]);
-    else {
+    else if constexpr (WS == 2) {
       // two sets: local position q of set s = tile position 2 q + ((s + row of q) & 1) — a CHECKERBOARD (TW is even), so that any
       // rectangle of valid positions splits over the sets to within one position (column parity alone: to within TH)
       const int odd = (set + (2 * q) / TW) & 1;
       ok[q] = uni(okAll[2 * q] ^ ((okAll[2 * q] ^ okAll[2 * q + 1]) & -odd));
+    } else {
+      // four sets (TW a multiple of four): position 4 q + ((s + row of q) & 3) — every set holds one position of every aligned
+      // group of four columns, shifted by one column from row to row
+      const int r = (set + (4 * q) / TW) & 3;
+      const int lo = okAll[4 * q] ^ ((okAll[4 * q] ^ okAll[4 * q + 1]) & -(r & 1));
+      const int hi = okAll[4 * q + 2] ^ ((okAll[4 * q + 2] ^ okAll[4 * q + 3]) & -(r & 1));
+      ok[q] = uni(lo ^ ((lo ^ hi) & -(r >> 1)));
     }
   }
 #if !(H8_VAR & 4)
@@ -183,11 +190,15 @@ __device__ __forceinline__ void gatherh(f32x2 (&acc)[TH * TW / WS][CPW / 2], uin
 // contain the current source row — when a window closes its sums are stored and the slot restarts from the bias TH rows further
 // down.  Every source pixel of the strip is built once per segment.  Positions are [slot][column]; program rows are indexed by
 // the source row modulo TH * stride.  grid.x = (segment x strip, longest segments first) x half panels.
-template <int CPW, int TH, int TW, int WS, int KS, bool SLIDE = false>
+// NT = 2: a barrier period builds and gathers TWO consecutive stages of the sequence (two 32 KB tables per 64 KB period buffer,
+// two program rows per period): the ~1500 cycles a period costs beside its matrix instructions and look-ups — barrier skew, the
+// build -> gather hand-over, operand and program-row latencies — are paid once per two tables (measured: LABBOOK.md, round 6).
+// LDS: 2 x 64 KB + 3 x 6 KB of program rows = 146 KB.
+template <int CPW, int TH, int TW, int WS, int KS, bool SLIDE = false, int NT = 1>
 __global__ __launch_bounds__(NW8 * 64) void k_conv_half8(ConvParams p, int tilesX, int tilesY, int chunks) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   constexpr int NP = TH * TW, NPW = NP / WS, QC = CPW / 4, WPS = NW8 / WS;
-  static_assert((WS == 1 || (WS == 2 && TW % 2 == 0)) && NP % WS == 0 && CPW % 16 == 0 && NPW * CPW <= 192 && (SLIDE || NPW * CPW == 192),
+  static_assert((WS == 1 || (WS == 2 && TW % 2 == 0) || (WS == 4 && TW % 4 == 0)) && NP % WS == 0 && CPW % 16 == 0 && NPW * CPW <= 192 && (SLIDE || NPW * CPW == 192),
                 "192 (position, channel) sums of four images per lane = 192 accumulator registers");
   constexpr int BLKB = NPW * QC * 2;                   // bytes of a lane group's block of a program row ([NPW][QC] uint16)
   constexpr int ROWB = NW8 * 4 * BLKB;                 // bytes of the workgroup's program row of one entry: 3072
@@ -267,7 +278,7 @@ __global__ __launch_bounds__(NW8 * 64) void k_conv_half8(ConvParams p, int tiles
   const int ry0 = ho0 * p.stride - p.pad, rx0 = wo0 * p.stride - p.pad;
   const uint32_t entryB = (uint32_t)(p.grp * chunks) * ROWB;
   const char* __restrict__ progWg = reinterpret_cast<const char*>(p.progS) + (size_t)(grp * chunks + chunk) * ROWB;
-  auto rowOf = [&](const StagePos& q, int idx) {       // stages past the end: any existing row
+  auto rowOf = [&](const StagePos& q, int idx) __attribute__((always_inline)) {       // stages past the end: any existing row
     const StagePos c = (idx < S) ? q : first;
     const int row = SLIDE ? c.ph : c.hi - ry0;
     return progWg + (size_t)(uint32_t)((row * rfW + (c.wi - rx0)) * M + c.mg) * entryB;
@@ -275,7 +286,7 @@ __global__ __launch_bounds__(NW8 * 64) void k_conv_half8(ConvParams p, int tiles
   // SLIDE: after the last stage of a source row the positions whose window ends with this row (or with the strip) are stored
   // and their slot restarts from the bias for the output row TH further down.  Everything lane-dependent is re-derived here from
   // the execution mask (hoisted out of the stage loop such values cost k_conv_sym8 ten spilled registers)
-  auto column_end = [&](const StagePos& c, int live) {
+  auto column_end = [&](const StagePos& c, int live) __attribute__((always_inline)) {
     if (!(live && c.wi == g.wiU && c.mg == g.MG - 1)) return;
     int gC, iC;
     lane_group(lane_now_h(), gC, iC);
@@ -288,7 +299,7 @@ __global__ __launch_bounds__(NW8 * 64) void k_conv_half8(ConvParams p, int tiles
 #pragma unroll
         for (int k = 0; k < TW / WS; ++k) {
           const int q = dy * (TW / WS) + k;                                   // local position of this wave in slot dy
-          const int dx = WS == 1 ? k : 2 * k + ((set + dy) & 1);
+          const int dx = WS * k + ((set + dy) & (WS - 1));
           const bool colReal = wo0 + dx < p.Wo;
           float* __restrict__ o = dstU + (size_t)(woq[dy] * p.Wo + wo0 + dx) * p.Ct * PANEL;   // uniform
 #pragma unroll
@@ -310,7 +321,69 @@ __global__ __launch_bounds__(NW8 * 64) void k_conv_half8(ConvParams p, int tiles
       }
     }
   };
-  auto posOf = [&](const StagePos& q, int idx) { return (idx < S) ? q : first; };
+  auto posOf = [&](const StagePos& q, int idx) __attribute__((always_inline)) { return (idx < S) ? q : first; };
+  if constexpr (NT == 2) {
+    constexpr uint32_t PSTAGE = 2u * HSTAGE;              // a period's buffer: two tables
+    constexpr uint32_t PROG2_LDS = 2u * PSTAGE;           // program rows behind the two period buffers
+    constexpr uint32_t PBUF2 = 2u * PROGH_BUF;            // a period's two program rows
+    OpsH<KS> opsA, opsB;                                  // operands of the NEXT period's two stages
+    StagePos q0 = first, q1 = next_pos(q0, g), q2 = next_pos(q1, g), q3 = next_pos(q2, g), q4 = next_pos(q3, g), q5 = next_pos(q4, g);
+    uint32_t rb0 = 0, rb1 = PBUF2, rb2 = 2 * PBUF2;
+    opsh_load<KS>(opsA, xbase, pixel_off(q0, g), bLane, p.ctrd8, Cs, q0.mg, laneA, rt0);
+    {
+      const StagePos q = posOf(q1, 1);
+      opsh_load<KS>(opsB, xbase, pixel_off(q, g), bLane, p.ctrd8, Cs, q.mg, laneA, rt0);
+    }
+    opsh_store<KS>(opsA, mA0);
+    opsh_store<KS>(opsB, mA0 + HSTAGE);
+    {
+      const StagePos qa = posOf(q2, 2), qb = posOf(q3, 3);
+      opsh_load<KS>(opsA, xbase, pixel_off(qa, g), bLane, p.ctrd8, Cs, qa.mg, laneA, rt0);
+      opsh_load<KS>(opsB, xbase, pixel_off(qb, g), bLane, p.ctrd8, Cs, qb.mg, laneA, rt0);
+    }
+    if (wave == 0) {
+      idx_row_to_lds<ROWB>(rowOf(q0, 0), PROG2_LDS + rb0, lane); idx_row_to_lds<ROWB>(rowOf(q1, 1), PROG2_LDS + rb0 + PROGH_BUF, lane);
+      idx_row_to_lds<ROWB>(rowOf(q2, 2), PROG2_LDS + rb1, lane); idx_row_to_lds<ROWB>(rowOf(q3, 3), PROG2_LDS + rb1 + PROGH_BUF, lane);
+    }
+    barrier_after_lds_dma();
+    StagePos cEnd = first;
+    int liveEnd = 0;
+    const int P = (S + 1) >> 1;
+    // one period: the next period's two tables -> buffer `bb`, the program rows and operands of the period after that, then the
+    // look-ups of this period's two stages (indices s, s + 1 of the sequence) out of buffer `gb`
+    auto period = [&](int s, uint32_t gb, uint32_t bb) __attribute__((always_inline)) {
+      opsh_store<KS>(opsA, mA0 + bb);
+      opsh_store<KS>(opsB, mA0 + bb + HSTAGE);
+      if (is_wave0_h(wave)) {
+        const int l = lane_now_h();
+        idx_row_to_lds<ROWB>(rowOf(q4, s + 4), PROG2_LDS + rb2, l);
+        idx_row_to_lds<ROWB>(rowOf(q5, s + 5), PROG2_LDS + rb2 + PROGH_BUF, l);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      {
+        const StagePos qa = posOf(q4, s + 4), qb = posOf(q5, s + 5);
+        opsh_load<KS>(opsA, xbase, pixel_off(qa, g), bLane, p.ctrd8, Cs, qa.mg, laneA, rt0);
+        opsh_load<KS>(opsB, xbase, pixel_off(qb, g), bLane, p.ctrd8, Cs, qb.mg, laneA, rt0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const uint32_t blk = my_blk_h(wave, BLKB, PROG2_LDS) + rb0;
+      if constexpr (SLIDE) column_end(cEnd, liveEnd);
+      const int liveA = activeI & in_range(s, S), liveB = activeI & in_range(s + 1, S);
+      gatherh<CPW, TH, TW, WS>(acc, blk, q0, p.knl, rowStart, colStart, laneLds + gb, liveA, set);
+      if constexpr (SLIDE) column_end(q0, liveA);         // a source row that ended with the first stage: before the second one looks at the slots
+      gatherh<CPW, TH, TW, WS>(acc, blk + PROGH_BUF, q1, p.knl, rowStart, colStart, laneLds + gb + HSTAGE, liveB, set);
+      if constexpr (SLIDE) { cEnd = q1; liveEnd = liveB; }
+      q0 = q2; q1 = q3; q2 = q4; q3 = q5; q4 = next_pos(q5, g); q5 = next_pos(q4, g);
+      { const uint32_t t = rb0; rb0 = rb1; rb1 = rb2; rb2 = t; }
+      barrier_after_lds_writes();
+    };
+    uint32_t gb = 0u, bb = PSTAGE;                          // ONE call site: the period body must be inlined (the sums live in registers)
+    for (int j = 0; j < P; ++j) {
+      period(2 * j, gb, bb);
+      { const uint32_t t = gb; gb = bb; bb = t; }
+    }
+    if constexpr (SLIDE) column_end(cEnd, liveEnd);
+  } else {
   OpsH<KS> ops;
   StagePos c0 = first;
   StagePos c1 = next_pos(c0, g);
@@ -364,13 +437,14 @@ __global__ __launch_bounds__(NW8 * 64) void k_conv_half8(ConvParams p, int tiles
     barrier_after_lds_writes();
   }
   if constexpr (SLIDE) column_end(cEnd, liveEnd);         // the strip's last source row
+  }
   // ---- results: lane (g4, i16) holds channels cl0 .. and images 64 hp + 4 i16 .. + 3 of every local position
   // (SLIDE: every position was stored when its window closed)
   if (activeI && !SLIDE) {
     float* __restrict__ dst = p.dst + (size_t)panel * p.Ho * p.Wo * p.Ct * PANEL;
 #pragma unroll
     for (int q = 0; q < NPW; ++q) {
-      const int pos = WS == 1 ? q : 2 * q + ((set + (2 * q) / TW) & 1);     // see gatherh
+      const int pos = WS * q + ((set + (WS * q) / TW) & (WS - 1));     // see gatherh
       const int ho = ho0 + pos / TW, wo = wo0 + pos % TW;
       if (ho < p.Ho && wo < p.Wo) {
         float* o = dst + ((size_t)(ho * p.Wo + wo) * p.Ct + grp * Ctg + cl0) * PANEL + hp * 64 + 4 * i16;
@@ -408,7 +482,7 @@ __global__ __launch_bounds__(256) void k_build_program_h8(const uint8_t* __restr
     const int chunk = gc % cf.chunks, g = gc / cf.chunks;
     const int set = wave / wps, cb = wave % wps;
     const int ch = (chunk * wps + cb) * cf.cpw + g4 * qc + j;
-    const int pos = cf.ws == 1 ? q : 2 * q + ((set + (2 * q) / cf.tw) & 1);     // two sets: a checkerboard of the tile (k_conv_half8)
+    const int pos = cf.ws * q + ((set + (cf.ws * q) / cf.tw) & (cf.ws - 1));     // wave sets: a checkerboard of the tile (k_conv_half8)
     // tile: position (dy, dx) looks at tap (ry - dy * stride, rx - dx * stride); sliding: slot dy at tap row (ry - dy * stride)
     // modulo the period th * stride (ry = source row modulo that period)
     const int period = cf.th * stride;
@@ -427,9 +501,11 @@ template <int CPW, int TH, int TW, int WS, bool SLIDE = false>
 hipError_t launch_half8(const ConvParams& p, const QkH8Config& cf, hipStream_t st) {
   const int tilesX = (p.Wo + TW - 1) / TW, tilesY = (p.Ho + TH - 1) / TH;
   const dim3 grid((unsigned)((SLIDE ? p.nSeg * tilesX : tilesX * tilesY) * 2 * p.panels), (unsigned)(p.grp * cf.chunks), 1);
-  const size_t shm = (size_t)2 * HSTAGE + 3 * (size_t)PROGH_BUF;
+  static const int nt = [] { const char* e = getenv("QCNN_HALF8_NT"); return (e && atoi(e) == 2) ? 2 : 1; }();   // experiment knob: 2 = two tables per barrier period
+  const size_t shm = nt == 2 ? (size_t)4 * HSTAGE + 6 * (size_t)PROGH_BUF : (size_t)2 * HSTAGE + 3 * (size_t)PROGH_BUF;
   const bool two = std::min(p.Cin / p.grp, p.Cs) > 4;
-  auto kern = two ? k_conv_half8<CPW, TH, TW, WS, 2, SLIDE> : k_conv_half8<CPW, TH, TW, WS, 1, SLIDE>;
+  auto kern = nt == 2 ? (two ? k_conv_half8<CPW, TH, TW, WS, 2, SLIDE, 2> : k_conv_half8<CPW, TH, TW, WS, 1, SLIDE, 2>)
+                      : (two ? k_conv_half8<CPW, TH, TW, WS, 2, SLIDE, 1> : k_conv_half8<CPW, TH, TW, WS, 1, SLIDE, 1>);
   hipError_t e = allow_big_lds(reinterpret_cast<const void*>(kern), (int)shm);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, grid, dim3(NW8 * 64), shm, st, p, tilesX, tilesY, cf.chunks);
@@ -437,6 +513,12 @@ hipError_t launch_half8(const ConvParams& p, const QkH8Config& cf, hipStream_t s
 }
 
 }  // namespace
+
+// experiment knob (QCNN_HALF8_WS4 = 1): layers with 128 / 192 channels per group in FOUR wave sets of 2 waves x 64 / 96 channels
+static bool half8_wide_sets() {
+  static const bool on = [] { const char* e = getenv("QCNN_HALF8_WS4"); return e && atoi(e) == 1; }();
+  return on;
+}
 
 QkH8Config qk_conv_half8_config(int Cin, int grp, int Ct, int M, int Cs, int K) {
   QkH8Config cf = {0, 0, 0, 0, 0, 0};
@@ -455,6 +537,7 @@ QkH8Config qk_conv_half8_config(int Cin, int grp, int Ct, int M, int Cs, int K) 
     case 512: cf.cpw = 64; cf.th = 1; cf.tw = 3; cf.ws = 1; break;
     default: return cf;
   }
+  if (half8_wide_sets() && cf.ws == 2) { cf.cpw *= 2; cf.ws = 4; }   // experiment: four wave sets, statements twice as long
   cf.chunks = chunks;
   return cf;
 }
@@ -524,8 +607,8 @@ hipError_t qk_conv_half8(const ConvParams& p, hipStream_t st) {
   const QkH8Config cf = qk_conv_half8_config(p.Cin, p.grp, p.Ct, p.M, p.Cs, p.K);
   if (!cf.cpw || p.progS == nullptr || p.ctrd8 == nullptr || p.srcNchw) return hipErrorInvalidValue;
   switch ((p.Ct / p.grp) / cf.chunks) {
-    case 128: return launch_half8<32, 3, 4, 2>(p, cf, st);
-    case 192: return launch_half8<48, 2, 4, 2>(p, cf, st);
+    case 128: return cf.ws == 4 ? launch_half8<64, 3, 4, 4>(p, cf, st) : launch_half8<32, 3, 4, 2>(p, cf, st);
+    case 192: return cf.ws == 4 ? launch_half8<96, 2, 4, 4>(p, cf, st) : launch_half8<48, 2, 4, 2>(p, cf, st);
     case 256: return launch_half8<32, 2, 3, 1>(p, cf, st);
     case 384: return launch_half8<48, 2, 2, 1>(p, cf, st);
     case 512: return launch_half8<64, 1, 3, 1>(p, cf, st);
@@ -541,6 +624,7 @@ QkH8Config qk_conv_half8_slide_config(int Cin, int grp, int Ct, int M, int Cs, i
   const int ns = (knl + stride - 1) / stride;
   if (ns != 3) { cf.cpw = 0; return cf; }
   cf.th = 3; cf.slide = 1;
+  if (cf.ws == 4) { cf.ws = 2; cf.cpw /= 2; }          // (the wide-set experiment covers the tile form only)
   switch ((Ct / grp) / cf.chunks) {
     case 128: cf.tw = 4; break;
     case 192: cf.tw = 2; break;

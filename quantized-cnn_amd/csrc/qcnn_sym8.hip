@@ -512,7 +512,10 @@ __global__ __launch_bounds__(NW8 * 64) void k_conv_sym8(ConvParams p, int tilesX
   // that one wave of a SIMD multiplies while the other one gathers.  Same buffers, same hazards: within a barrier period set A
   // builds stage s + 1 and gathers stage s, set B gathers stage s and builds stage s + 1.
   constexpr bool ANTI = S8_ANTI != 0 && !SLIDE && MODE == 0;
-  const int isB = ANTI ? (wave >= 4 ? 1 : 0) : 0;
+  // which waves form set B: S8_ANTI = 1 the second wave of every SIMD (waves 4 .. 7: a workgroup's waves go to the SIMDs in cyclic
+  // order, so waves w and w + 4 share one), 2 = the odd waves (two whole SIMDs: 0→2→1→3 puts waves 0, 2 on one pair of SIMDs and
+  // 1, 3 on the other), 3 = waves 2, 3, 6, 7 (the other pairing of whole SIMDs)
+  const int isB = ANTI ? (S8_ANTI == 1 ? (wave >= 4 ? 1 : 0) : S8_ANTI == 2 ? (wave & 1) : ((wave >> 1) & 1)) : 0;
   if (ANTI && isB) gather8<TH, TW, CPW, MODE, AccT>(acc, my_blk(wave, BLKB) + rb0, c0, p.knl, rowStart, colStart, laneLds, activeI);
   auto pick = [&](const StagePos& a, const StagePos& b) { StagePos r; r.hi = isB ? b.hi : a.hi; r.wi = isB ? b.wi : a.wi; r.mg = isB ? b.mg : a.mg; r.ph = isB ? b.ph : a.ph; return r; };
   {
