@@ -25,7 +25,7 @@ BIN_DIR = os.path.join(ROOT, "build", "bin")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
-HIP_SOURCES = ["qcnn_kernels.hip", "qcnn_sym8.hip", "qcnn_half8.hip", "qcnn_glue.hip", "qcnn_small.hip", "qcnn_dense.hip", "qcnn_decoded.hip", "qcnn_engine.hip", "qcnn_group.hip"]
+HIP_SOURCES = ["qcnn_kernels.hip", "qcnn_sym8.hip", "qcnn_half8.hip", "qcnn_planner.hip", "qcnn_glue.hip", "qcnn_small.hip", "qcnn_dense.hip", "qcnn_decoded.hip", "qcnn_engine.hip", "qcnn_group.hip"]
 HIP_FLAGS = ["-O3", "-std=c++17", "--offload-arch=" + ARCH, "-fPIC", "-ffp-contract=off", "-Wall",
              "-Wno-unused-function"]
 
@@ -45,7 +45,7 @@ def _run(cmd, **kw):
 def build_hip(force: bool = False, extra_flags=()) -> str:
     """Compile the HIP extension for gfx950 (hipcc cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
-    deps = srcs + [os.path.join(CSRC, "qcnn_kernels.h"), os.path.join(CSRC, "qcnn_dev.h"), os.path.join(CSRC, "qcnn_sym8_gather.h"), os.path.join(ROOT, "include", "qcnn_hip.h")]
+    deps = srcs + [os.path.join(CSRC, "qcnn_kernels.h"), os.path.join(CSRC, "qcnn_dev.h"), os.path.join(CSRC, "qcnn_sym8_gather.h"), os.path.join(CSRC, "qcnn_planner.h"), os.path.join(ROOT, "include", "qcnn_hip.h")]
     if force or _newer(HIP_SO, deps):
         objs = []
         for s in srcs:
@@ -101,6 +101,19 @@ def build_reference_driver(ref: str = "/root/reference", force: bool = False):
         _run(["g++", "-std=c++11", "-O2", "-w", "-o", exe] + srcs +
              ["-L" + PKG, "-lqcnn_host", "-lqcnn_hip", "-Wl,-rpath," + PKG])
     return exe
+
+
+def build_planner_cpu(force: bool = False) -> str:
+    """The launch planner (csrc/qcnn_planner.hip: host code only) compiled by g++ into build/libqcnn_planner_cpu.so — the CPU
+    test tier exercises the very functions libqcnn_hip.so plans with (tests/test_planner_cpu.py), no GPU, no hipcc."""
+    out = os.path.join(ROOT, "build", "libqcnn_planner_cpu.so")
+    src = os.path.join(CSRC, "qcnn_planner.hip")
+    deps = [src, os.path.join(CSRC, "qcnn_planner.h"), os.path.join(CSRC, "qcnn_kernels.h")]
+    if force or _newer(out, deps):
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        _run(["g++", "-std=c++17", "-O2", "-x", "c++", "-fPIC", "-shared", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+              "-I" + CSRC, src, "-o", out])
+    return out
 
 
 def build_all(force: bool = False):

@@ -91,6 +91,7 @@ def load():
     lib.qcnn_ctx_stream.restype = vp
     lib.qcnn_model_arena_ptr.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
     lib.qcnn_model_arena_checksum.argtypes = [vp, C.POINTER(C.c_ulonglong)]
+    lib.qcnn_plan_conv_query.argtypes = [C.POINTER(i), C.POINTER(i), C.POINTER(C.c_double), C.POINTER(i)]
     # device group
     lib.qcnn_group_create.argtypes = [C.POINTER(i), i, C.POINTER(vp)]
     lib.qcnn_group_destroy.argtypes = [vp]

@@ -85,25 +85,6 @@ struct ConvGeom {
   uint32_t pixStride;   // bytes from one source pixel to the next: Cin * 512 (panels) or 4 (NCHW input read in place)
   uint32_t rowStride;   // bytes of one (tap, sub-space) row of the assignment table
 };
-// Workgroups are dispatched in linear order, so the tiles are numbered heaviest first: interior tiles
-// (full receptive field = most stages), then the four edges, then the corners.  With a few workgroups per
-// CU the last dispatch round is then made of the short border tiles (longest-processing-time-first).
-__host__ __device__ __forceinline__ void tile_of_rank(int r, int tilesY, int tilesX, int& ty, int& tx) {
-  if (tilesY < 3 || tilesX < 3) { ty = r / tilesX; tx = r % tilesX; return; }
-  const int iy = tilesY - 2, ix = tilesX - 2;
-  if (r < iy * ix) { ty = 1 + r / ix; tx = 1 + r % ix; return; }
-  r -= iy * ix;
-  if (r < ix) { ty = 0; tx = 1 + r; return; }
-  r -= ix;
-  if (r < ix) { ty = tilesY - 1; tx = 1 + r; return; }
-  r -= ix;
-  if (r < iy) { ty = 1 + r; tx = 0; return; }
-  r -= iy;
-  if (r < iy) { ty = 1 + r; tx = tilesX - 1; return; }
-  r -= iy;
-  ty = (r >> 1) ? tilesY - 1 : 0;
-  tx = (r & 1) ? tilesX - 1 : 0;
-}
 struct StagePos {
   int hi, wi, mg;
   int ph;               // sliding variant: source row modulo the slot period (ConvGeom::period); else unused

@@ -18,6 +18,7 @@
 
 #include "../../include/qcnn_hip.h"
 #include "qcnn_kernels.h"
+#include "qcnn_planner.h"
 
 namespace {
 
@@ -53,23 +54,10 @@ struct LayerShape {
   uint16_t* prog8H = nullptr;
   uint16_t* progF8H = nullptr;
   uint16_t* prog8A = nullptr;        // QCNN_OPT_LUT_MODE = 3 (fp16 sums too): the program of the twice-as-large tiles (qk_conv_sym8_config16)
-  // conv: launch plans by launch geometry and options (panels, sub-batches, split / slide / sym, LUT mode, input in place):
-  // sub-batches of unequal panel counts (3 panels over 2 streams) each keep theirs instead of evicting one another — a plan
-  // is dozens of 256-CU list schedules on the host
-  struct Plan {
-    QkSplitPlan plan = {0, 1, 0, 0.0};                         // split plan (qk_conv_plan)
-    int segN = 0, segBeg[9] = {0};                             // sliding plan (qk_conv_plan_slide)
-    double slideCost = 0.0;                                    // ... and its predicted duration
-    double symCost = 0.0;                                      // predicted duration of the symmetric kernel (0: not eligible)
-    double sym8Cost = 0.0;                                     // ... of the eight-wave symmetric kernel
-    int sym8Z = 1;                                             // ... with every tile cut into this many slices (QCNN_OPT_SPLIT; 1: whole tiles)
-    double sym8sCost = 0.0;                                    // ... of its sliding form, with the segments it would run
-    int seg8N = 0, seg8Beg[9] = {0};
-    double half8Cost = 0.0;                                    // ... of the half-panel eight-wave kernel (0: not eligible / off)
-    double half8sCost = 0.0;                                   // ... of its sliding form, with the segments it would run
-    int segHN = 0, segHBeg[9] = {0};
-  };
-  std::map<long long, Plan> plans;
+  // conv: launch plans (qcnn_planner.h) by launch geometry and options (panels, sub-batches, split / slide / sym, LUT mode, input
+  // in place): sub-batches of unequal panel counts (3 panels over 2 streams) each keep theirs instead of evicting one another —
+  // a plan is dozens of 256-CU list schedules on the host
+  std::map<long long, QkConvPlan> plans;
   int segN = 0, segBeg[9] = {0};                               // segments of the last launch when it slid (qcnn_get_layer_segments)
   int lastFrom = -1, lastZ = 1;                                // how the last launch was actually cut
 };
@@ -82,8 +70,6 @@ constexpr int kSmallBatchMax = QCNN_SMALL_BATCH_MAX;  // batches up to this size
                                    // 128-image panel is cheaper (measured: 1 / 2 / 3 / 4 images 0.58 / 0.85 / 1.15 / 1.47 ms, a panel 1.50 ms)
 constexpr int kMaxFcSplit = 32;  // workgroups along the sub-space axis of an FC layer (partial sums reduced in fixed order)
 constexpr size_t kConvPartialFloats = (size_t)64 << 20;   // 256 MB of partial sums for split conv tiles (all sub-batches), allocated when a plan first splits
-constexpr double kHalf8SlideFactor = 1.25;   // a planner unit of the half-panel sliding form against one of its tile form
-constexpr double kSym8StageFactor = 0.97;   // scale of qk_conv_sym8_cost's stage price (its list schedule over-prices the last round by ~3 %)
 constexpr size_t kSlack = 64 * 1024;   // bytes of slack behind every device buffer: the MFMA operand loads are
                                         // unconditional and may read a few rows past the last dim / sub-space
 
@@ -505,168 +491,78 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
         break;
       }
       if (e == hipErrorInvalidValue) {
-        // A launch of a few hundred workgroups (one GPU's share of a sharded batch) splits the tail of its tiles over
-        // several workgroups (qk_conv_plan).  MFMA builders only: the exact builder keeps the reference's summation order.
+        // Which kernel family runs this launch, and how it is cut: the planner (qcnn_planner.h) prices every eligible family for
+        // this launch geometry — cached per layer —, its decision rules pick one.  MFMA builders only: the exact builder keeps
+        // the tile kernel and the reference's summation order.
         if (c->lutMode >= 1 && (c->split || c->slide || c->sym || c->sym8 || c->half8)) {
-          // Plan of this launch geometry (cached): tile kernel whole / with a split tail (QCNN_OPT_SPLIT; changes a cut
-          // tile's summation order) / sliding kernel (QCNN_OPT_SLIDE; same order and bits as the tile kernel).
           const size_t share = kConvPartialFloats / (size_t)nsub;
+          QkPlanOptions o = {};
+          o.split = c->split; o.slide = c->slide; o.sym = c->sym; o.sym8 = c->sym8; o.half8 = c->half8;
+          o.lutMode = c->lutMode; o.inNchw = inNchw ? 1 : 0; o.scratchFloats = share;
+          o.hasSlide16 = s.progSBytes != 0; o.hasSym16 = s.progYBytes != 0; o.hasSym8 = s.prog8Bytes != 0;
+          o.hasSym8Slide = s.prog8SBytes != 0; o.hasHalf8 = s.progH8Bytes != 0; o.hasHalf8Slide = s.progH8SBytes != 0;
           const long long key = ((((((((long long)panels * 8 + nsub) * 2 + (c->split ? 1 : 0)) * 4 + c->slide) * 4 + c->sym) * 4 +
                                   c->lutMode) * 2 + (inNchw ? 1 : 0)) * 8 + c->sym8) * 4 + c->half8;
           auto it = s.plans.find(key);
-          if (it == s.plans.end()) {
-            LayerShape::Plan pl;
-            const size_t scratch = c->split ? share : 0;            // no scratch: qk_conv_plan only prices the whole-tile launch
-            pl.plan = qk_conv_plan(p, scratch);
-            pl.symCost = (c->sym && s.progYBytes && c->lutMode == 1 && !inNchw) ? qk_conv_sym_cost(p) : 0.0;
-            pl.sym8Cost = (c->sym8 && s.prog8Bytes && c->lutMode == 1 && !inNchw)
-                              ? qk_conv_sym8_cost(p, qk_conv_sym8_config(p.Cin, p.grp, p.Ct, p.M, p.Cs, p.K), kSym8StageFactor) : 0.0;
-            if (pl.sym8Cost > 0.0 && c->split) {
-              // a launch of a few hundred tiles (one GPU's share of a sharded batch): every tile in Z slices of its stage sequence,
-              // partial sums reduced by k_conv_sum — taken when predicted 3 % cheaper than the whole tiles
-              const Qk8Config c8 = qk_conv_sym8_config(p.Cin, p.grp, p.Ct, p.M, p.Cs, p.K);
-              const int tiles8 = ((p.Wo + c8.tw - 1) / c8.tw) * ((p.Ho + c8.th - 1) / c8.th);
-              const long long wgs8 = (long long)tiles8 * panels * p.grp * c8.chunks;
-              for (int Z = 2; Z <= 6 && wgs8 < 2 * 256; ++Z) {
-                if ((size_t)tiles8 * Z * panels * c8.th * c8.tw * p.Ct * QCNN_PANEL > share) break;
-                if ((long long)p.M * p.knl * p.knl < 6LL * Z) break;       // a slice keeps a few stages
-                const double cz = qk_conv_sym8_cost(p, c8, kSym8StageFactor, Z);
-                if (cz < 0.97 * pl.sym8Cost) { pl.sym8Cost = cz; pl.sym8Z = Z; }
-              }
+          if (it == s.plans.end()) it = s.plans.emplace(key, qk_plan_conv(p, o)).first;
+          const QkConvChoice ch = qk_choose_conv(it->second, o);
+          // partial sums of split tiles: scratch allocated by the first split launch of this context; when the device has no
+          // memory left for it (large maps at a large batch) the tiles run whole, which needs none — never a failed forward
+          auto partial = [&]() -> float* {
+            if (!c->convPartial && !c->noConvPartial && hipMalloc(&c->convPartial, kConvPartialFloats * sizeof(float)) != hipSuccess) {
+              (void)hipGetLastError();
+              c->convPartial = nullptr; c->noConvPartial = true;
             }
-            if (c->sym8 && s.prog8SBytes && c->lutMode == 1 && !inNchw) {
-              ConvParams t = p;
-              pl.sym8sCost = qk_conv_sym8_slide_plan(t, qk_conv_sym8_slide_config(p.Cin, p.grp, p.Ct, p.M, p.Cs, p.K, p.knl, p.stride),
-                                                     kSym8StageFactor);
-              pl.seg8N = t.nSeg;
-              for (int i = 0; i <= t.nSeg && i < 9; ++i) pl.seg8Beg[i] = t.segBeg[i];
-            }
-            pl.half8Cost = (c->half8 && s.progH8Bytes && c->lutMode == 1 && !inNchw)
-                               ? qk_conv_half8_cost(p, qk_conv_half8_config(p.Cin, p.grp, p.Ct, p.M, p.Cs, p.K), kSym8StageFactor) : 0.0;
-            if (c->half8 && s.progH8SBytes && c->lutMode == 1 && !inNchw) {
-              ConvParams t = p;
-              pl.half8sCost = qk_conv_half8_slide_plan(t, qk_conv_half8_slide_config(p.Cin, p.grp, p.Ct, p.M, p.Cs, p.K, p.knl, p.stride),
-                                                       kSym8StageFactor);
-              pl.segHN = t.nSeg;
-              for (int i = 0; i <= t.nSeg && i < 9; ++i) pl.segHBeg[i] = t.segBeg[i];
-            }
-            if (c->slide && p.progS) {                // sliding variant where it is predicted to beat the (split) tile kernel
-              ConvParams t = p;
-              pl.slideCost = qk_conv_plan_slide(t, c->slide >= 2 ? 1e30 : pl.plan.cost);   // 2: whenever the layer is eligible (tests)
-              pl.segN = t.nSeg;
-              for (int i = 0; i <= t.nSeg && i < 9; ++i) pl.segBeg[i] = t.segBeg[i];
-            }
-            if (const char* dbg = getenv("QCNN_DEBUG_PLAN"); dbg && atoi(dbg))
-              fprintf(stderr, "[qcnn plan] layer %d panels %d: tile %.0f (Z %d) | slide %.0f (%d segments) | sym %.0f | sym8 %.0f (Z %d) | sym8 sliding %.0f (%d segments) stage-times\n",
-                      l, panels, pl.plan.cost, pl.plan.Z, pl.slideCost, pl.segN, pl.symCost, pl.sym8Cost, pl.sym8Z, pl.sym8sCost, pl.seg8N),
-              fprintf(stderr, "[qcnn plan] layer %d panels %d: half-panel eight-wave %.0f | sliding %.0f (%d segments) stage-times\n", l, panels, pl.half8Cost, pl.half8sCost, pl.segHN);
-            it = s.plans.emplace(key, pl).first;
-          }
-          const LayerShape::Plan& pl = it->second;
-          // eight-wave symmetric workgroups, tile or sliding form: when forced (QCNN_OPT_SYM8 = 2: tile form, 3: sliding form where
-          // eligible), or predicted at least 3 % faster than every other plan of the launch
-          const bool may8 = c->lutMode == 1 && !inNchw && (c->sym8 >= 2 || (c->sym < 2 && c->slide < 2)) && c->half8 < 2;
-          // half-panel eight-wave workgroups: forced (QCNN_OPT_HALF8 = 2), or predicted at least 3 % faster than every other plan
-          // ... in the sliding form: forced (3), or predicted at least 3 % faster than every other plan INCLUDING the half-panel tile
-          // form (a strip is a coarser work item: x kHalf8SlideFactor like the full-panel sliding form's x 1.15)
-          if (pl.half8sCost > 0.0 && pl.segHN > 0 && c->lutMode == 1 && !inNchw && c->half8 != 2 &&
-              (c->half8 >= 3 || (c->sym8 < 2 && c->sym < 2 && c->slide < 2))) {
-            double other = pl.plan.cost;
-            if (pl.symCost > 0.0 && 1.08 * pl.symCost < other) other = 1.08 * pl.symCost;
-            if (pl.segN > 0 && pl.slideCost > 0.0) other = std::min(other, 1.15 * pl.slideCost);
-            if (pl.sym8Cost > 0.0) other = std::min(other, pl.sym8Cost);
-            if (pl.sym8sCost > 0.0 && pl.seg8N > 0) other = std::min(other, 1.15 * pl.sym8sCost);
-            if (pl.half8Cost > 0.0) other = std::min(other, pl.half8Cost);
-            if (c->half8 >= 3 || kHalf8SlideFactor * pl.half8sCost < 0.97 * other) {
+            return c->convPartial ? c->convPartial + share * sub : nullptr;
+          };
+          auto segments = [&]() {
+            p.nSeg = ch.nSeg; s.segN = ch.nSeg;
+            for (int i = 0; i <= ch.nSeg; ++i) { p.segBeg[i] = ch.segBeg[i]; s.segBeg[i] = ch.segBeg[i]; }
+          };
+          s.lastFrom = ch.family; s.lastZ = 1;         // what qcnn_get_layer_split reports: (family code, slices / segments)
+          bool launched = true;
+          switch (ch.family) {
+            case QK_FAM_HALF8_SLIDE:
               p.progS = reinterpret_cast<const uint16_t*>(c->arena + s.offProgH8S);
-              p.nSeg = pl.segHN;
-              s.segN = pl.segHN;
-              for (int i = 0; i <= pl.segHN; ++i) { p.segBeg[i] = pl.segHBeg[i]; s.segBeg[i] = pl.segHBeg[i]; }
-              s.lastFrom = -10; s.lastZ = pl.segHN;     // reported by qcnn_get_layer_split as (-10, segments per column)
+              segments(); s.lastZ = ch.nSeg;
               e = qk_conv_half8_slide(p, st);
               break;
-            }
-          }
-          if (pl.half8Cost > 0.0 && c->lutMode == 1 && !inNchw && (c->half8 >= 2 || (c->sym8 < 2 && c->sym < 2 && c->slide < 2))) {
-            double other = pl.plan.cost;
-            if (pl.symCost > 0.0 && 1.08 * pl.symCost < other) other = 1.08 * pl.symCost;
-            if (pl.segN > 0 && pl.slideCost > 0.0) other = std::min(other, 1.15 * pl.slideCost);
-            if (pl.sym8Cost > 0.0) other = std::min(other, pl.sym8Cost);
-            if (pl.sym8sCost > 0.0 && pl.seg8N > 0) other = std::min(other, 1.15 * pl.sym8sCost);
-            if (c->half8 >= 2 || pl.half8Cost < 0.97 * other) {
+            case QK_FAM_HALF8:
               p.progS = reinterpret_cast<const uint16_t*>(c->arena + s.offProgH8);
-              s.lastFrom = -9; s.lastZ = 1;             // reported by qcnn_get_layer_split as (-9, 1)
               e = qk_conv_half8(p, st);
               break;
-            }
-          }
-          if (may8 && pl.sym8sCost > 0.0 && pl.seg8N > 0 && c->sym8 != 2) {
-            double other = pl.plan.cost;
-            if (pl.symCost > 0.0 && 1.08 * pl.symCost < other) other = 1.08 * pl.symCost;
-            if (pl.segN > 0 && pl.slideCost > 0.0) other = std::min(other, 1.15 * pl.slideCost);
-            if (pl.sym8Cost > 0.0) other = std::min(other, pl.sym8Cost);
-            // (measured per planner unit, 1000 images: the sliding form 1.04 - 1.11 us — VGG-16's layers, AlexNet conv2 / conv5 —,
-            // the tile form 0.89 - 0.93: x 1.15 - 1.2.  With 1.15 the sliding form takes VGG-16's 128-, 256- and 512-channel layers,
-            // none of AlexNet's: 13 x 13 maps leave too few strips — 208 workgroups for conv4)
-            if (c->sym8 >= 3 || 1.15 * pl.sym8sCost < 0.97 * other) {
+            case QK_FAM_SYM8_SLIDE:
               p.progS = reinterpret_cast<const uint16_t*>(c->arena + s.offProg8S);
-              p.nSeg = pl.seg8N;
-              s.segN = pl.seg8N;
-              for (int i = 0; i <= pl.seg8N; ++i) { p.segBeg[i] = pl.seg8Beg[i]; s.segBeg[i] = pl.seg8Beg[i]; }
-              s.lastFrom = -6; s.lastZ = pl.seg8N;      // reported by qcnn_get_layer_split as (-6, segments per column)
+              segments(); s.lastZ = ch.nSeg;
               e = qk_conv_sym8_slide(p, st);
               break;
-            }
-          }
-          if (pl.sym8Cost > 0.0 && may8) {
-            double other = pl.plan.cost;                           // tile kernel, whole or split (in stage-times)
-            // (qk_conv_sym_cost prices a 16-wave symmetric stage at 1.09 tile stages — enough to rank it against the tile kernel;
-            // measured 1.18: 2952 against 2508 cycles on AlexNet conv2)
-            if (pl.symCost > 0.0 && 1.08 * pl.symCost < other) other = 1.08 * pl.symCost;
-            // (a sliding stage is priced 3 % above a tile stage; measured 3330 against 2500 cycles with 12 channels per wave, i.e.
-            // 1.04 - 1.08 us per planner unit against 0.89 - 0.91 for this kernel on VGG-16's 256 / 512-channel layers: x 1.17;
-            // AlexNet conv5, which must keep sliding — 0.99 against 1.04 ms —, sits at a cost ratio of 1.157)
-            if (pl.segN > 0 && pl.slideCost > 0.0) other = std::min(other, 1.15 * pl.slideCost);
-            if (c->sym8 >= 2 || pl.sym8Cost < 0.97 * other) {
+            case QK_FAM_SYM8:
               p.progS = reinterpret_cast<const uint16_t*>(c->arena + s.offProg8);
-              s.lastFrom = -5; s.lastZ = 1;             // reported by qcnn_get_layer_split as (-5, slices per tile)
-              if (pl.sym8Z > 1) {
-                if (!c->convPartial && !c->noConvPartial && hipMalloc(&c->convPartial, kConvPartialFloats * sizeof(float)) != hipSuccess) {
-                  (void)hipGetLastError();
-                  c->convPartial = nullptr; c->noConvPartial = true;          // no scratch: whole tiles
-                }
-                if (c->convPartial) { p.splitFrom = 0; p.splitZ = pl.sym8Z; p.partial = c->convPartial + share * sub; s.lastZ = pl.sym8Z; }
+              if (ch.Z > 1) {
+                if (float* ps = partial()) { p.splitFrom = 0; p.splitZ = ch.Z; p.partial = ps; s.lastZ = ch.Z; }
               }
               e = qk_conv_sym8(p, st);
               break;
-            }
-          }
-          // symmetric workgroups: 128-channel layers that neither slide nor split, when predicted at least 3 % faster
-          if (pl.symCost > 0.0 && pl.segN == 0 && pl.plan.Z <= 1 && c->lutMode == 1 && !inNchw &&
-              (c->sym >= 2 || pl.symCost < 0.97 * pl.plan.cost)) {
-            p.progS = reinterpret_cast<const uint16_t*>(c->arena + s.offProgY);
-            s.lastFrom = -4; s.lastZ = 1;             // reported by qcnn_get_layer_split as (-4, 1)
-            e = qk_conv_sym(p, st);
-            break;
-          }
-          if (pl.segN > 0) {
-            p.nSeg = pl.segN;
-            s.segN = pl.segN;
-            for (int i = 0; i <= pl.segN; ++i) { p.segBeg[i] = pl.segBeg[i]; s.segBeg[i] = pl.segBeg[i]; }
-            s.lastFrom = -2; s.lastZ = pl.segN;      // reported by qcnn_get_layer_split as (-2, segments per column)
-          } else if (pl.plan.Z > 1) {
-            if (!c->convPartial && !c->noConvPartial) {   // first split launch of this context: the scratch for partial sums
-              if (hipMalloc(&c->convPartial, kConvPartialFloats * sizeof(float)) != hipSuccess) {
-                (void)hipGetLastError();                   // no memory left for it (large maps at a large batch): the tiles run whole,
-                c->convPartial = nullptr;                  // which needs no scratch — never a failed forward
-                c->noConvPartial = true;
+            case QK_FAM_SYM16:
+              p.progS = reinterpret_cast<const uint16_t*>(c->arena + s.offProgY);
+              e = qk_conv_sym(p, st);
+              break;
+            case QK_FAM_SLIDE16:
+              segments(); s.lastZ = ch.nSeg;
+              launched = false;                          // k_conv_aprx<.., SLIDE> below (p.progS = the sliding program)
+              break;
+            default:                                     // tile kernel, whole or with a split tail
+              s.lastFrom = -1;
+              if (ch.Z > 1) {
+                if (float* ps = partial()) {
+                  p.splitFrom = ch.splitFrom; p.splitZ = ch.Z; p.partial = ps;
+                  s.lastFrom = ch.splitFrom; s.lastZ = ch.Z;
+                }
               }
-            }
-            if (c->convPartial) {
-              p.splitFrom = pl.plan.splitFrom; p.splitZ = pl.plan.Z; p.partial = c->convPartial + share * sub;
-              s.lastFrom = pl.plan.splitFrom; s.lastZ = pl.plan.Z;
-            }
+              launched = false;
+              break;
           }
+          if (launched) break;
         }
         e = qk_conv_aprx(p, c->lutMode, st);
       }

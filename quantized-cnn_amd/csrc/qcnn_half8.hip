@@ -71,10 +71,10 @@ __device__ __forceinline__ void lane_group(int lane, int& g, int& i) {
   i = __popc((isB ? GROUP_B : ~GROUP_B) & below);
 }
 // LDS byte address of the lane's group's block of a program row ([wave][4 groups][local position][CPW / 4] uint16)
-__device__ __forceinline__ uint32_t my_blk_h(int wave, int blkBytes, uint32_t progLds = PROGH_LDS) {
+__device__ __forceinline__ uint32_t my_blk_h(int wave, int blkBytes) {
   int g, i;
   lane_group(lane_now_h(), g, i);
-  return progLds + (uint32_t)(wave * 4 + g) * (uint32_t)blkBytes;
+  return PROGH_LDS + (uint32_t)(wave * 4 + g) * (uint32_t)blkBytes;
 }
 
 // operands of one stage for this wave: code-book tiles of its four row tiles, the activation tile of its image tile
@@ -164,18 +164,11 @@ __device__ __forceinline__ void gatherh(f32x2 (&acc)[TH * TW / WS][CPW / 2], uin
 #pragma unroll
   for (int q = 0; q < NPW; ++q) {
     if constexpr (WS == 1) ok[q] = uni(okAll[q]);
-    else if constexpr (WS == 2) {
+    else {
       // two sets: local position q of set s = tile position 2 q + ((s + row of q) & 1) — a CHECKERBOARD (TW is even), so that any
       // rectangle of valid positions splits over the sets to within one position (column parity alone: to within TH)
       const int odd = (set + (2 * q) / TW) & 1;
       ok[q] = uni(okAll[2 * q] ^ ((okAll[2 * q] ^ okAll[2 * q + 1]) & -odd));
-    } else {
-      // four sets (TW a multiple of four): position 4 q + ((s + row of q) & 3) — every set holds one position of every aligned
-      // group of four columns, shifted by one column from row to row
-      const int r = (set + (4 * q) / TW) & 3;
-      const int lo = okAll[4 * q] ^ ((okAll[4 * q] ^ okAll[4 * q + 1]) & -(r & 1));
-      const int hi = okAll[4 * q + 2] ^ ((okAll[4 * q + 2] ^ okAll[4 * q + 3]) & -(r & 1));
-      ok[q] = uni(lo ^ ((lo ^ hi) & -(r >> 1)));
     }
   }
 #if !(H8_VAR & 4)
@@ -190,15 +183,11 @@ __device__ __forceinline__ void gatherh(f32x2 (&acc)[TH * TW / WS][CPW / 2], uin
 // contain the current source row — when a window closes its sums are stored and the slot restarts from the bias TH rows further
 // down.  Every source pixel of the strip is built once per segment.  Positions are [slot][column]; program rows are indexed by
 // the source row modulo TH * stride.  grid.x = (segment x strip, longest segments first) x half panels.
-// NT = 2: a barrier period builds and gathers TWO consecutive stages of the sequence (two 32 KB tables per 64 KB period buffer,
-// two program rows per period): the ~1500 cycles a period costs beside its matrix instructions and look-ups — barrier skew, the
-// build -> gather hand-over, operand and program-row latencies — are paid once per two tables (measured: LABBOOK.md, round 6).
-// LDS: 2 x 64 KB + 3 x 6 KB of program rows = 146 KB.
-template <int CPW, int TH, int TW, int WS, int KS, bool SLIDE = false, int NT = 1>
+template <int CPW, int TH, int TW, int WS, int KS, bool SLIDE = false>
 __global__ __launch_bounds__(NW8 * 64) void k_conv_half8(ConvParams p, int tilesX, int tilesY, int chunks) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   constexpr int NP = TH * TW, NPW = NP / WS, QC = CPW / 4, WPS = NW8 / WS;
-  static_assert((WS == 1 || (WS == 2 && TW % 2 == 0) || (WS == 4 && TW % 4 == 0)) && NP % WS == 0 && CPW % 16 == 0 && NPW * CPW <= 192 && (SLIDE || NPW * CPW == 192),
+  static_assert((WS == 1 || (WS == 2 && TW % 2 == 0)) && NP % WS == 0 && CPW % 16 == 0 && NPW * CPW <= 192 && (SLIDE || NPW * CPW == 192),
                 "192 (position, channel) sums of four images per lane = 192 accumulator registers");
   constexpr int BLKB = NPW * QC * 2;                   // bytes of a lane group's block of a program row ([NPW][QC] uint16)
   constexpr int ROWB = NW8 * 4 * BLKB;                 // bytes of the workgroup's program row of one entry: 3072
@@ -322,68 +311,6 @@ __global__ __launch_bounds__(NW8 * 64) void k_conv_half8(ConvParams p, int tiles
     }
   };
   auto posOf = [&](const StagePos& q, int idx) __attribute__((always_inline)) { return (idx < S) ? q : first; };
-  if constexpr (NT == 2) {
-    constexpr uint32_t PSTAGE = 2u * HSTAGE;              // a period's buffer: two tables
-    constexpr uint32_t PROG2_LDS = 2u * PSTAGE;           // program rows behind the two period buffers
-    constexpr uint32_t PBUF2 = 2u * PROGH_BUF;            // a period's two program rows
-    OpsH<KS> opsA, opsB;                                  // operands of the NEXT period's two stages
-    StagePos q0 = first, q1 = next_pos(q0, g), q2 = next_pos(q1, g), q3 = next_pos(q2, g), q4 = next_pos(q3, g), q5 = next_pos(q4, g);
-    uint32_t rb0 = 0, rb1 = PBUF2, rb2 = 2 * PBUF2;
-    opsh_load<KS>(opsA, xbase, pixel_off(q0, g), bLane, p.ctrd8, Cs, q0.mg, laneA, rt0);
-    {
-      const StagePos q = posOf(q1, 1);
-      opsh_load<KS>(opsB, xbase, pixel_off(q, g), bLane, p.ctrd8, Cs, q.mg, laneA, rt0);
-    }
-    opsh_store<KS>(opsA, mA0);
-    opsh_store<KS>(opsB, mA0 + HSTAGE);
-    {
-      const StagePos qa = posOf(q2, 2), qb = posOf(q3, 3);
-      opsh_load<KS>(opsA, xbase, pixel_off(qa, g), bLane, p.ctrd8, Cs, qa.mg, laneA, rt0);
-      opsh_load<KS>(opsB, xbase, pixel_off(qb, g), bLane, p.ctrd8, Cs, qb.mg, laneA, rt0);
-    }
-    if (wave == 0) {
-      idx_row_to_lds<ROWB>(rowOf(q0, 0), PROG2_LDS + rb0, lane); idx_row_to_lds<ROWB>(rowOf(q1, 1), PROG2_LDS + rb0 + PROGH_BUF, lane);
-      idx_row_to_lds<ROWB>(rowOf(q2, 2), PROG2_LDS + rb1, lane); idx_row_to_lds<ROWB>(rowOf(q3, 3), PROG2_LDS + rb1 + PROGH_BUF, lane);
-    }
-    barrier_after_lds_dma();
-    StagePos cEnd = first;
-    int liveEnd = 0;
-    const int P = (S + 1) >> 1;
-    // one period: the next period's two tables -> buffer `bb`, the program rows and operands of the period after that, then the
-    // look-ups of this period's two stages (indices s, s + 1 of the sequence) out of buffer `gb`
-    auto period = [&](int s, uint32_t gb, uint32_t bb) __attribute__((always_inline)) {
-      opsh_store<KS>(opsA, mA0 + bb);
-      opsh_store<KS>(opsB, mA0 + bb + HSTAGE);
-      if (is_wave0_h(wave)) {
-        const int l = lane_now_h();
-        idx_row_to_lds<ROWB>(rowOf(q4, s + 4), PROG2_LDS + rb2, l);
-        idx_row_to_lds<ROWB>(rowOf(q5, s + 5), PROG2_LDS + rb2 + PROGH_BUF, l);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      {
-        const StagePos qa = posOf(q4, s + 4), qb = posOf(q5, s + 5);
-        opsh_load<KS>(opsA, xbase, pixel_off(qa, g), bLane, p.ctrd8, Cs, qa.mg, laneA, rt0);
-        opsh_load<KS>(opsB, xbase, pixel_off(qb, g), bLane, p.ctrd8, Cs, qb.mg, laneA, rt0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      const uint32_t blk = my_blk_h(wave, BLKB, PROG2_LDS) + rb0;
-      if constexpr (SLIDE) column_end(cEnd, liveEnd);
-      const int liveA = activeI & in_range(s, S), liveB = activeI & in_range(s + 1, S);
-      gatherh<CPW, TH, TW, WS>(acc, blk, q0, p.knl, rowStart, colStart, laneLds + gb, liveA, set);
-      if constexpr (SLIDE) column_end(q0, liveA);         // a source row that ended with the first stage: before the second one looks at the slots
-      gatherh<CPW, TH, TW, WS>(acc, blk + PROGH_BUF, q1, p.knl, rowStart, colStart, laneLds + gb + HSTAGE, liveB, set);
-      if constexpr (SLIDE) { cEnd = q1; liveEnd = liveB; }
-      q0 = q2; q1 = q3; q2 = q4; q3 = q5; q4 = next_pos(q5, g); q5 = next_pos(q4, g);
-      { const uint32_t t = rb0; rb0 = rb1; rb1 = rb2; rb2 = t; }
-      barrier_after_lds_writes();
-    };
-    uint32_t gb = 0u, bb = PSTAGE;                          // ONE call site: the period body must be inlined (the sums live in registers)
-    for (int j = 0; j < P; ++j) {
-      period(2 * j, gb, bb);
-      { const uint32_t t = gb; gb = bb; bb = t; }
-    }
-    if constexpr (SLIDE) column_end(cEnd, liveEnd);
-  } else {
   OpsH<KS> ops;
   StagePos c0 = first;
   StagePos c1 = next_pos(c0, g);
@@ -437,7 +364,6 @@ __global__ __launch_bounds__(NW8 * 64) void k_conv_half8(ConvParams p, int tiles
     barrier_after_lds_writes();
   }
   if constexpr (SLIDE) column_end(cEnd, liveEnd);         // the strip's last source row
-  }
   // ---- results: lane (g4, i16) holds channels cl0 .. and images 64 hp + 4 i16 .. + 3 of every local position
   // (SLIDE: every position was stored when its window closed)
   if (activeI && !SLIDE) {
@@ -501,11 +427,9 @@ template <int CPW, int TH, int TW, int WS, bool SLIDE = false>
 hipError_t launch_half8(const ConvParams& p, const QkH8Config& cf, hipStream_t st) {
   const int tilesX = (p.Wo + TW - 1) / TW, tilesY = (p.Ho + TH - 1) / TH;
   const dim3 grid((unsigned)((SLIDE ? p.nSeg * tilesX : tilesX * tilesY) * 2 * p.panels), (unsigned)(p.grp * cf.chunks), 1);
-  static const int nt = [] { const char* e = getenv("QCNN_HALF8_NT"); return (e && atoi(e) == 2) ? 2 : 1; }();   // experiment knob: 2 = two tables per barrier period
-  const size_t shm = nt == 2 ? (size_t)4 * HSTAGE + 6 * (size_t)PROGH_BUF : (size_t)2 * HSTAGE + 3 * (size_t)PROGH_BUF;
+  const size_t shm = (size_t)2 * HSTAGE + 3 * (size_t)PROGH_BUF;
   const bool two = std::min(p.Cin / p.grp, p.Cs) > 4;
-  auto kern = nt == 2 ? (two ? k_conv_half8<CPW, TH, TW, WS, 2, SLIDE, 2> : k_conv_half8<CPW, TH, TW, WS, 1, SLIDE, 2>)
-                      : (two ? k_conv_half8<CPW, TH, TW, WS, 2, SLIDE, 1> : k_conv_half8<CPW, TH, TW, WS, 1, SLIDE, 1>);
+  auto kern = two ? k_conv_half8<CPW, TH, TW, WS, 2, SLIDE> : k_conv_half8<CPW, TH, TW, WS, 1, SLIDE>;
   hipError_t e = allow_big_lds(reinterpret_cast<const void*>(kern), (int)shm);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, grid, dim3(NW8 * 64), shm, st, p, tilesX, tilesY, cf.chunks);
@@ -513,41 +437,6 @@ hipError_t launch_half8(const ConvParams& p, const QkH8Config& cf, hipStream_t s
 }
 
 }  // namespace
-
-// experiment knob (QCNN_HALF8_WS4 = 1): layers with 128 / 192 channels per group in FOUR wave sets of 2 waves x 64 / 96 channels
-static bool half8_wide_sets() {
-  static const bool on = [] { const char* e = getenv("QCNN_HALF8_WS4"); return e && atoi(e) == 1; }();
-  return on;
-}
-
-QkH8Config qk_conv_half8_config(int Cin, int grp, int Ct, int M, int Cs, int K) {
-  QkH8Config cf = {0, 0, 0, 0, 0, 0};
-  if (grp < 1 || Ct % grp || Cin % grp) return cf;
-  const int Cg = Cin / grp, Ctg = Ct / grp;
-  // K = 128, every sub-space complete with 4 or 8 dims (no operand masks in the kernel)
-  if (K != 128 || !(Cs == 4 || Cs == 8) || Cg % Cs || M != Cg / Cs) return cf;
-  // ONE workgroup holds all channels of a group (up to 512; more: chunks of equal size), the tile that fills 1536 sums
-  const int chunks = (Ctg + 511) / 512;
-  if (Ctg % chunks) return cf;
-  switch (Ctg / chunks) {
-    case 128: cf.cpw = 32; cf.th = 3; cf.tw = 4; cf.ws = 2; break;
-    case 192: cf.cpw = 48; cf.th = 2; cf.tw = 4; cf.ws = 2; break;
-    case 256: cf.cpw = 32; cf.th = 2; cf.tw = 3; cf.ws = 1; break;
-    case 384: cf.cpw = 48; cf.th = 2; cf.tw = 2; cf.ws = 1; break;
-    case 512: cf.cpw = 64; cf.th = 1; cf.tw = 3; cf.ws = 1; break;
-    default: return cf;
-  }
-  if (half8_wide_sets() && cf.ws == 2) { cf.cpw *= 2; cf.ws = 4; }   // experiment: four wave sets, statements twice as long
-  cf.chunks = chunks;
-  return cf;
-}
-
-size_t qk_conv_half8_program_bytes(const QkH8Config& cf, int groups, int knl, int stride, int M) {
-  if (!cf.cpw) return 0;
-  const int rfH = cf.slide ? cf.th * stride : (cf.th - 1) * stride + knl, rfW = (cf.tw - 1) * stride + knl;
-  // per entry: groups x chunks x 8 waves x 4 lane groups x [positions per wave][cpw / 4] uint16
-  return (size_t)rfH * rfW * M * groups * cf.chunks * NW8 * 4 * (cf.th * cf.tw / cf.ws) * (cf.cpw / 4) * sizeof(uint16_t);
-}
 
 hipError_t qk_build_program_h8(const uint8_t* rows, uint16_t* prog, const QkSlots& src, const QkH8Config& cf, int Ctg, int groups,
                                int knl, int stride, int M, hipStream_t st) {
@@ -558,142 +447,17 @@ hipError_t qk_build_program_h8(const uint8_t* rows, uint16_t* prog, const QkSlot
   return hipGetLastError();
 }
 
-// predicted duration (in stage-times of the tile kernel, like qk_conv_sym8_cost) of a launch over p.panels panels = 2 p.panels
-// half panels: tiles list-scheduled heaviest first on 256 CUs; a half-panel stage is priced fixH + perRead x (ds_read_b128 per
-// wave-set stage) cycles against 2500 of a tile stage (calibration: qcnn_half8 notes in LABBOOK.md)
-double qk_conv_half8_cost(const ConvParams& p, const QkH8Config& cf, double scale) {
-  if (!cf.cpw) return 0.0;
-  const int TH = cf.th, TW = cf.tw;
-  const int tilesX = (p.Wo + TW - 1) / TW, tilesY = (p.Ho + TH - 1) / TH, tiles = tilesX * tilesY;
-  std::vector<double> stages((size_t)tiles);
-  double total = 0.0;
-  for (int r = 0; r < tiles; ++r) {
-    int ty, tx;
-    tile_of_rank(r, tilesY, tilesX, ty, tx);
-    const int ho0 = ty * TH, wo0 = tx * TW;
-    const int hoL = std::min(ho0 + TH, p.Ho) - 1, woL = std::min(wo0 + TW, p.Wo) - 1;
-    const int rows = std::min(p.H - 1, hoL * p.stride - p.pad + p.knl - 1) - std::max(0, ho0 * p.stride - p.pad) + 1;
-    const int cols = std::min(p.W - 1, woL * p.stride - p.pad + p.knl - 1) - std::max(0, wo0 * p.stride - p.pad) + 1;
-    stages[r] = (double)std::max(rows, 0) * std::max(cols, 0) * p.M;
-    total += stages[r];
-  }
-  auto taps = [&](int n, int nIn) {
-    long long t = 0;
-    for (int o = 0; o < n; ++o) t += std::min(p.knl - 1, nIn - 1 - (o * p.stride - p.pad)) - std::max(0, -(o * p.stride - p.pad)) + 1;
-    return (double)t;
-  };
-  // row look-ups (of 64 images) of one group and channel chunk per half panel and built stage
-  const double perStage = total > 0.0 ? taps(p.Ho, p.H) * taps(p.Wo, p.W) * p.M * std::min(p.Ct / p.grp, (NW8 / cf.ws) * cf.cpw) / total : 0.0;
-  // (two wave sets: a stage's valid positions rarely split evenly over the sets, and the slower set holds the barrier)
-  const double factor = scale * (cf.ws == 2 ? QK_HALF8_TWO_SETS : 1.0) * (QK_HALF8_FIX + QK_HALF8_PER_ROW * perStage) / 2500.0;
-  const int ny = p.grp * cf.chunks;
-  const int halves = 2 * p.panels;
-  const long long wgs = (long long)tiles * halves * ny;
-  if (wgs >= 8 * 256) return (factor * total + 10.0 * tiles) * halves * ny / 256.0;
-  std::priority_queue<double, std::vector<double>, std::greater<double>> q;
-  for (int i = 0; i < 256; ++i) q.push(0.0);
-  double end = 0.0;
-  for (int y = 0; y < ny; ++y)
-    for (int r = 0; r < tiles; ++r)
-      for (int k = 0; k < halves; ++k) {
-        const double t = q.top() + factor * stages[r] + 10.0;
-        q.pop(); q.push(t);
-        end = std::max(end, t);
-      }
-  return end;
-}
-
 hipError_t qk_conv_half8(const ConvParams& p, hipStream_t st) {
   const QkH8Config cf = qk_conv_half8_config(p.Cin, p.grp, p.Ct, p.M, p.Cs, p.K);
   if (!cf.cpw || p.progS == nullptr || p.ctrd8 == nullptr || p.srcNchw) return hipErrorInvalidValue;
   switch ((p.Ct / p.grp) / cf.chunks) {
-    case 128: return cf.ws == 4 ? launch_half8<64, 3, 4, 4>(p, cf, st) : launch_half8<32, 3, 4, 2>(p, cf, st);
-    case 192: return cf.ws == 4 ? launch_half8<96, 2, 4, 4>(p, cf, st) : launch_half8<48, 2, 4, 2>(p, cf, st);
+    case 128: return launch_half8<32, 3, 4, 2>(p, cf, st);
+    case 192: return launch_half8<48, 2, 4, 2>(p, cf, st);
     case 256: return launch_half8<32, 2, 3, 1>(p, cf, st);
     case 384: return launch_half8<48, 2, 2, 1>(p, cf, st);
     case 512: return launch_half8<64, 1, 3, 1>(p, cf, st);
     default: return hipErrorInvalidValue;
   }
-}
-
-// Sliding form: th = slots = ceil(knl / stride) (3 built), tw = output columns of a strip: 128 channels per group 3 x 4 (two wave
-// sets), 192: 3 x 2 (two sets, 144 of the 192 sums per wave), 256: 3 x 2, 384: 3 x 1 (144 sums), 512: 3 x 1
-QkH8Config qk_conv_half8_slide_config(int Cin, int grp, int Ct, int M, int Cs, int K, int knl, int stride) {
-  QkH8Config cf = qk_conv_half8_config(Cin, grp, Ct, M, Cs, K);
-  if (!cf.cpw) return cf;
-  const int ns = (knl + stride - 1) / stride;
-  if (ns != 3) { cf.cpw = 0; return cf; }
-  cf.th = 3; cf.slide = 1;
-  if (cf.ws == 4) { cf.ws = 2; cf.cpw /= 2; }          // (the wide-set experiment covers the tile form only)
-  switch ((Ct / grp) / cf.chunks) {
-    case 128: cf.tw = 4; break;
-    case 192: cf.tw = 2; break;
-    case 256: cf.tw = 2; break;
-    case 384: cf.tw = 1; break;
-    case 512: cf.tw = 1; break;
-    default: cf.cpw = 0; break;
-  }
-  return cf;
-}
-
-// Segments of the sliding form for a launch over p.panels panels (p.nSeg / p.segBeg are filled) and its predicted duration in
-// stage-times: one to four equal segments per column, or a long and a short one, list-scheduled on 256 CUs with this kernel's
-// stage price.  0: the layer cannot slide.
-double qk_conv_half8_slide_plan(ConvParams& p, const QkH8Config& cf, double scale) {
-  p.nSeg = 0;
-  if (!cf.cpw || !cf.slide || p.Ho < 2 * cf.th) return 0.0;
-  const int ns = cf.th, nc = cf.tw;
-  const int colGroups = (p.Wo + nc - 1) / nc;
-  const int ny = p.grp * cf.chunks;
-  const int halves = 2 * p.panels;
-  auto segStages = [&](int cgi, int a, int b) {        // strip of output columns [cgi * nc, ..), output rows [a, b)
-    const int wA = cgi * nc, wB = std::min(p.Wo, wA + nc) - 1;
-    const int cols = std::min(p.W - 1, wB * p.stride - p.pad + p.knl - 1) - std::max(0, wA * p.stride - p.pad) + 1;
-    const int rows = std::min(p.H - 1, (b - 1) * p.stride - p.pad + p.knl - 1) - std::max(0, a * p.stride - p.pad) + 1;
-    return (double)std::max(rows, 0) * std::max(cols, 0) * p.M;
-  };
-  auto taps = [&](int n, int nIn) {
-    long long t = 0;
-    for (int o = 0; o < n; ++o) t += std::min(p.knl - 1, nIn - 1 - (o * p.stride - p.pad)) - std::max(0, -(o * p.stride - p.pad)) + 1;
-    return (double)t;
-  };
-  const double lookups = taps(p.Ho, p.H) * taps(p.Wo, p.W) * p.M * std::min(p.Ct / p.grp, (NW8 / cf.ws) * cf.cpw);   // per group, chunk and half panel
-  std::vector<std::vector<int> > cands;
-  for (int n = 1; n <= 4 && n * ns <= p.Ho; ++n) {
-    std::vector<int> b(n + 1);
-    for (int i = 0; i <= n; ++i) b[i] = (int)(((long long)p.Ho * i + n - 1) / n);   // the longer ones first
-    cands.push_back(b);
-  }
-  for (int shortLen = ns; shortLen * 2 < p.Ho; shortLen += std::max(1, p.Ho / 16)) cands.push_back({0, p.Ho - shortLen, p.Ho});
-  double best = 0.0;
-  std::vector<double> cu(256);
-  for (const std::vector<int>& b : cands) {
-    const int nSeg = (int)b.size() - 1;
-    if (nSeg > QK_MAX_SEGS) continue;
-    double total = 0.0;
-    for (int sgi = 0; sgi < nSeg; ++sgi)
-      for (int wo = 0; wo < colGroups; ++wo) total += segStages(wo, b[sgi], b[sgi + 1]);
-    if (total <= 0.0) continue;
-    const double factor = scale * (QK_HALF8_FIX + QK_HALF8_PER_ROW * lookups / total) / 2500.0;
-    std::fill(cu.begin(), cu.end(), 0.0);
-    std::make_heap(cu.begin(), cu.end(), std::greater<double>());
-    for (int y = 0; y < ny; ++y)
-      for (int sgi = 0; sgi < nSeg; ++sgi)
-        for (int wo = 0; wo < colGroups; ++wo)
-          for (int pn = 0; pn < halves; ++pn) {
-            std::pop_heap(cu.begin(), cu.end(), std::greater<double>());
-            const int rows = std::min(p.H - 1, (b[sgi + 1] - 1) * p.stride - p.pad + p.knl - 1) - std::max(0, b[sgi] * p.stride - p.pad) + 1;
-            cu.back() += factor * segStages(wo, b[sgi], b[sgi + 1]) + 0.3 * std::max(rows, 0) + 12.0;
-            std::push_heap(cu.begin(), cu.end(), std::greater<double>());
-          }
-    const double c = *std::max_element(cu.begin(), cu.end());
-    if (best == 0.0 || c < best) {
-      best = c;
-      p.nSeg = nSeg;
-      for (size_t i = 0; i < b.size(); ++i) p.segBeg[i] = b[i];
-    }
-  }
-  return best;
 }
 
 // p.nSeg / p.segBeg from qk_conv_half8_slide_plan, p.progS = the sliding program (qk_build_program_h8 with the sliding config)

@@ -163,6 +163,25 @@ __host__ __device__ static inline int qk_slot_entry(const QkSlots& s, int g, int
   const int wave = c / s.cpw, k = c % s.cpw, hc = s.cpw / 2;
   return ((g * s.chunks * QCNN_GATHER_WAVES + wave) * 2 + k / hc) * s.hpB + qk_entry_byte(k % hc);
 }
+// Workgroups are dispatched in linear order, so the tiles are numbered heaviest first: interior tiles
+// (full receptive field = most stages), then the four edges, then the corners.  With a few workgroups per
+// CU the last dispatch round is then made of the short border tiles (longest-processing-time-first).
+__host__ __device__ static inline void tile_of_rank(int r, int tilesY, int tilesX, int& ty, int& tx) {
+  if (tilesY < 3 || tilesX < 3) { ty = r / tilesX; tx = r % tilesX; return; }
+  const int iy = tilesY - 2, ix = tilesX - 2;
+  if (r < iy * ix) { ty = 1 + r / ix; tx = 1 + r % ix; return; }
+  r -= iy * ix;
+  if (r < ix) { ty = 0; tx = 1 + r; return; }
+  r -= ix;
+  if (r < ix) { ty = tilesY - 1; tx = 1 + r; return; }
+  r -= ix;
+  if (r < iy) { ty = 1 + r; tx = 0; return; }
+  r -= iy;
+  if (r < iy) { ty = 1 + r; tx = tilesX - 1; return; }
+  r -= iy;
+  ty = (r >> 1) ? tilesY - 1 : 0;
+  tx = (r & 1) ? tilesX - 1 : 0;
+}
 struct ConvParams {
   int srcNchw;           // 1: src is the network input [nImages][Cin][H][W] read in place by the builders (first layer with
   int nImages;           //    <= 4 channels per group, K = 128 or the exact builder); 0: src is a panel map

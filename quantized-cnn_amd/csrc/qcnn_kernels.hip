@@ -1487,57 +1487,9 @@ hipError_t launch_conv_sym(const ConvParams& p, hipStream_t st) {
 
 }  // namespace
 
-// Tile selection: the 12 gather waves split the channels of one group (qk_conv_slots: the workgroup covers
-// all of them whenever 12 x 32 allow it — every further channel chunk would rebuild the same LUT stages); each
-// wave then owns as many positions as 64-72 accumulator registers leave room for.  The MFMA builder is
-// instantiated for K in {16, 32, 64, 128}; any other K <= 128 runs the exact builder.
-bool qk_conv_sym_shape(int Cin, int grp, int Ct, int M, int Cs, int K) {
-  if (grp < 1 || Ct % grp || Cin % grp) return false;
-  const int Cg = Cin / grp;
-  // exactly 16 waves x 8 channels, K = 128, every sub-space complete with 4 or 8 dims (no operand masks in k_conv_sym)
-  return Ct / grp == 128 && K == 128 && (Cs == 4 || Cs == 8) && Cg % Cs == 0 && M == Cg / Cs;
-}
-
 hipError_t qk_conv_sym(const ConvParams& p, hipStream_t st) {
   if (!qk_conv_sym_shape(p.Cin, p.grp, p.Ct, p.M, p.Cs, p.K) || p.progS == nullptr || p.srcNchw) return hipErrorInvalidValue;
   return launch_conv_sym(p, st);
-}
-
-// predicted duration (in stage-times, like QkSplitPlan::cost) of the symmetric kernel for a launch over p.panels panels:
-// 2x2 tiles, list-scheduled heaviest first on 256 CUs
-double qk_conv_sym_cost(const ConvParams& p) {
-  const int tilesX = (p.Wo + 1) / 2, tilesY = (p.Ho + 1) / 2, tiles = tilesX * tilesY;
-  std::vector<double> cu(256, 0.0);
-  std::vector<double> cost((size_t)tiles);
-  for (int r = 0; r < tiles; ++r) {
-    int ty, tx;
-    tile_of_rank(r, tilesY, tilesX, ty, tx);
-    const int ho0 = ty * 2, wo0 = tx * 2;
-    const int hoL = std::min(ho0 + 2, p.Ho) - 1, woL = std::min(wo0 + 2, p.Wo) - 1;
-    const int rows = std::min(p.H - 1, hoL * p.stride - p.pad + p.knl - 1) - std::max(0, ho0 * p.stride - p.pad) + 1;
-    const int cols = std::min(p.W - 1, woL * p.stride - p.pad + p.knl - 1) - std::max(0, wo0 * p.stride - p.pad) + 1;
-    // a symmetric stage serves a quarter more look-ups than the 1x3 tile's and takes longer; the factor is calibrated on
-    // AlexNet conv2 so that the planner's choice matches the measurements (1000 / 500 / 250 images: symmetric -5.9 / -4.2 /
-    // -2.0 %, 125 images: +17 %)
-    cost[r] = 1.09 * ((double)std::max(rows, 0) * std::max(cols, 0) * p.M) + 10.0;
-  }
-  const long long wgs = (long long)tiles * p.panels * p.grp;
-  if (wgs >= 8 * 256) {
-    double sum = 0.0;
-    for (int r = 0; r < tiles; ++r) sum += cost[r];
-    return sum * p.panels * p.grp / 256.0;
-  }
-  // dispatch order: rank-major, panels and groups inside
-  std::priority_queue<double, std::vector<double>, std::greater<double>> q;
-  for (int i = 0; i < 256; ++i) q.push(0.0);
-  double end = 0.0;
-  for (int r = 0; r < tiles; ++r)
-    for (int k = 0; k < p.panels * p.grp; ++k) {
-      const double t = q.top() + cost[r];
-      q.pop(); q.push(t);
-      end = std::max(end, t);
-    }
-  return end;
 }
 
 hipError_t qk_conv_aprx(const ConvParams& pIn, int lutMode, hipStream_t st) {
@@ -1575,196 +1527,6 @@ hipError_t qk_conv_aprx(const ConvParams& pIn, int lutMode, hipStream_t st) {
     case 6: return launch_conv<2, 3, 6>(p, sl, lutMode, st);     // 6 positions x 12 x 6
     default: return launch_conv<2, 4, 4>(p, sl, lutMode, st);    // 8 positions x 12 x 4
   }
-}
-
-// Split plan of a conv launch (ConvParams::splitZ).  A workgroup occupies a CU for its tile's whole stage sequence
-// (0.1 - 0.4 ms), so a launch of a few hundred workgroups — one GPU's share of a batch sharded over 4 - 8 GPUs — leaves
-// CUs idle for whole tile durations.  List-schedule the launch (dispatch order, 256 CUs, cost = stages + a fixed part)
-// for a few candidate splits — none; the last `r` tiles, r = what exceeds whole rounds of 256 workgroups; all tiles —
-// and slice counts, add the cost of writing and re-reading the partial sums, keep the cheapest.
-QkSplitPlan qk_conv_plan(const ConvParams& p, size_t scratchFloats) {
-  const int Ctg = p.Ct / p.grp;
-  const QkSlots sl = qk_conv_slots(Ctg, p.grp);
-  int TH, TW;
-  qk_conv_tile(sl.cpw, &TH, &TW);
-  const int tilesX = (p.Wo + TW - 1) / TW, tilesY = (p.Ho + TH - 1) / TH, tiles = tilesX * tilesY;
-  const int ny = sl.chunks * p.grp;
-  const int G = qcnn_stage_group(p.K), MG = (p.M + G - 1) / G;
-  QkSplitPlan none = {tiles, 1, 0, 0.0};
-  if ((long long)tiles * p.panels * ny >= 8 * 256) {                     // enough workgroups for the tail not to matter
-    double stages = 0.0;
-    const int G0 = qcnn_stage_group(p.K), MG0 = (p.M + G0 - 1) / G0;
-    for (int r = 0; r < tiles; ++r) {
-      int ty, tx;
-      tile_of_rank(r, tilesY, tilesX, ty, tx);
-      const int ho0 = ty * TH, wo0 = tx * TW;
-      const int hoL = std::min(ho0 + TH, p.Ho) - 1, woL = std::min(wo0 + TW, p.Wo) - 1;
-      const int rows = std::min(p.H - 1, hoL * p.stride - p.pad + p.knl - 1) - std::max(0, ho0 * p.stride - p.pad) + 1;
-      const int cols = std::min(p.W - 1, woL * p.stride - p.pad + p.knl - 1) - std::max(0, wo0 * p.stride - p.pad) + 1;
-      stages += (double)std::max(rows, 0) * std::max(cols, 0) * MG0 + 10.0;
-    }
-    none.cost = stages * p.panels * ny / 256.0;
-    return none;
-  }
-  std::vector<int> S(tiles);
-  for (int r = 0; r < tiles; ++r) {
-    int ty, tx;
-    tile_of_rank(r, tilesY, tilesX, ty, tx);
-    const int ho0 = ty * TH, wo0 = tx * TW;
-    const int hoL = std::min(ho0 + TH, p.Ho) - 1, woL = std::min(wo0 + TW, p.Wo) - 1;
-    const int rows = std::min(p.H - 1, hoL * p.stride - p.pad + p.knl - 1) - std::max(0, ho0 * p.stride - p.pad) + 1;
-    const int cols = std::min(p.W - 1, woL * p.stride - p.pad + p.knl - 1) - std::max(0, wo0 * p.stride - p.pad) + 1;
-    S[r] = std::max(rows, 0) * std::max(cols, 0) * MG;
-  }
-  const double kFixed = 10.0;          // stage-times a workgroup spends outside its stage loop (roles, first stage, stores)
-  const double kStageUs = 1.1;         // ~2700 cycles
-  std::vector<double> cu(256);
-  auto makespan = [&](int splitFrom, int Z) {
-    std::fill(cu.begin(), cu.end(), 0.0);
-    std::make_heap(cu.begin(), cu.end(), std::greater<double>());
-    auto run = [&](double cost) {
-      std::pop_heap(cu.begin(), cu.end(), std::greater<double>());
-      cu.back() += cost;
-      std::push_heap(cu.begin(), cu.end(), std::greater<double>());
-    };
-    for (int y = 0; y < ny; ++y) {               // dispatch order: x fastest
-      for (int r = 0; r < splitFrom; ++r)
-        for (int pn = 0; pn < p.panels; ++pn) run(S[r] + kFixed);
-      for (int r = splitFrom; r < tiles; ++r)
-        for (int z = 0; z < Z; ++z)
-          for (int pn = 0; pn < p.panels; ++pn) run((double)S[r] / Z + kFixed);
-    }
-    return *std::max_element(cu.begin(), cu.end());
-  };
-  // stage-times of the reduction: k_conv_sum reads Z slabs and writes one at ~4 TB/s behind a launch; the Z slab stores of
-  // the conv kernel itself mostly hide under other workgroups' stages (calibrated on conv3 / conv5 of AlexNet, one panel:
-  // predicted 36 / 24 stage-times, measured 35 / 27)
-  auto reduceCost = [&](int splitFrom, int Z) {
-    const double slab = (double)(tiles - splitFrom) * p.panels * TH * TW * p.Ct * PANEL * 4.0;
-    return (slab * (Z + 1.0) / 4.0e6 + slab * Z / 10.0e6 + 5.0) / kStageUs;
-  };
-  QkSplitPlan best = none;
-  double bestCost = makespan(tiles, 1);
-  best.cost = bestCost;
-  const long long wgs = (long long)tiles * p.panels * ny;
-  const int rem = (int)(wgs % 256);                 // workgroups beyond whole rounds
-  // candidate tails: every tile; the tiles beyond whole rounds of 256 workgroups; that tail widened by a quarter, a half
-  // and a whole round (finer slices at the end of the launch balance the last round better)
-  std::vector<int> cand = {0};
-  if (rem > 0 && wgs > 256) {
-    const int perTile = p.panels * ny;
-    for (int extra : {0, 64, 128, 256}) {
-      const int from = tiles - (rem + extra + perTile - 1) / perTile;
-      if (from > 0 && std::find(cand.begin(), cand.end(), from) == cand.end()) cand.push_back(from);
-    }
-  }
-  for (const int from : cand) {
-    if (from >= tiles) continue;
-    int minS = S[from];
-    for (int r = from; r < tiles; ++r) minS = std::min(minS, S[r]);
-    for (int Z = 2; Z <= 8; ++Z) {
-      if (minS < 6 * Z) break;                      // a slice keeps at least six stages
-      const size_t need = (size_t)(tiles - from) * Z * p.panels * TH * TW * p.Ct * PANEL;
-      if (need > scratchFloats) break;
-      const double c = makespan(from, Z) + reduceCost(from, Z);
-      if (c < bestCost * 0.97) { bestCost = c; best.splitFrom = from; best.Z = Z; best.partialFloats = need; best.cost = c; }
-    }
-  }
-  return best;
-}
-
-// Segments of the sliding variant.  A segment of L output rows sweeps (L - 1) * stride + knl source rows (clipped), i.e.
-// it re-builds knl - stride rows of its upper neighbour's strip: few, long segments build the least, but a launch of
-// columns x segments x groups x panels workgroups must also fill 256 CUs evenly.  Candidates: 1 .. 4 equal segments and
-// "one long + one short" cuts; list-scheduled (longest first) like qk_conv_plan; taken when it beats the tile kernel.
-double qk_conv_plan_slide(ConvParams& p, double tileCost) {
-  p.nSeg = 0;
-  const int Ctg = p.Ct / p.grp;
-  const QkSlide sc = qk_slide_config(Ctg, p.grp, p.knl, p.stride);
-  const int ns = sc.ns;
-  if (ns == 0 || p.K != 128 || p.progS == nullptr || p.Ho < 2 * ns) return 0.0;
-  const int ny = sc.sl.chunks * p.grp;               // every channel chunk builds the strip's stages again
-  const int G = qcnn_stage_group(p.K), MG = (p.M + G - 1) / G;
-  const double kFixed = 12.0;
-  const int nc = sc.nc;                                // output columns per strip
-  const int colGroups = (p.Wo + nc - 1) / nc;
-  auto segStages = [&](int cgi, int a, int b) {        // strip of output columns [cgi * nc, ..), output rows [a, b)
-    const int wA = cgi * nc, wB = std::min(p.Wo, wA + nc) - 1;
-    const int cols = std::min(p.W - 1, wB * p.stride - p.pad + p.knl - 1) - std::max(0, wA * p.stride - p.pad) + 1;
-    const int rows = std::min(p.H - 1, (b - 1) * p.stride - p.pad + p.knl - 1) - std::max(0, a * p.stride - p.pad) + 1;
-    return (double)std::max(rows, 0) * std::max(cols, 0) * MG;
-  };
-  // a sliding stage costs about what a tile stage costs (measured 0.68 vs 0.74 us per stage-time of this model on
-  // AlexNet conv1), and every source row ends with the store + restart of a slot.  Measured: AlexNet conv1 (11 stages per column) -10 %, conv5 (72) -15 %,
-  // VGG-16 conv1_2 (24) -12 %, its 128-channel layers (24 / 48) -25 %, but conv1_1 (3 stages per column: one sub-space,
-  // three rows) +47 % — a column must hold enough stages to carry its restart.
-  if (std::min(p.knl + (sc.nc - 1) * p.stride, p.W) * MG < 6 && tileCost < 1e29) return 0.0;      // (forced mode, tests: slides anyway)
-  auto segCost = [&](int wo, int a, int b) {
-    const int rows = std::min(p.H - 1, (b - 1) * p.stride - p.pad + p.knl - 1) - std::max(0, a * p.stride - p.pad) + 1;
-    return segStages(wo, a, b) + 0.3 * std::max(rows, 0);
-  };
-  std::vector<double> cu(256);
-  auto makespan = [&](const std::vector<int>& beg) {        // beg: nSeg + 1 boundaries, segments sorted longest first
-    std::fill(cu.begin(), cu.end(), 0.0);
-    std::make_heap(cu.begin(), cu.end(), std::greater<double>());
-    const int nSeg = (int)beg.size() - 1;
-    for (int y = 0; y < ny; ++y)
-      for (int sgi = 0; sgi < nSeg; ++sgi)
-        for (int wo = 0; wo < colGroups; ++wo)
-          for (int pn = 0; pn < p.panels; ++pn) {
-            std::pop_heap(cu.begin(), cu.end(), std::greater<double>());
-            cu.back() += segCost(wo, beg[sgi], beg[sgi + 1]) + kFixed;
-            std::push_heap(cu.begin(), cu.end(), std::greater<double>());
-          }
-    return *std::max_element(cu.begin(), cu.end());
-  };
-  std::vector<std::vector<int> > cands;
-  for (int n = 1; n <= 4 && n * ns <= p.Ho; ++n) {            // n (nearly) equal segments
-    std::vector<int> b(n + 1);
-    for (int i = 0; i <= n; ++i) b[i] = (int)(((long long)p.Ho * i + n - 1) / n);   // the longer ones first
-    cands.push_back(b);
-  }
-  for (int shortLen = ns; shortLen * 2 < p.Ho; shortLen += std::max(1, p.Ho / 16))   // one long + one short segment
-    cands.push_back({0, p.Ho - shortLen, p.Ho});
-  for (int s2 = ns; s2 * 4 < p.Ho; s2 += std::max(1, p.Ho / 12))                      // long + medium + short
-    for (int s1 = s2 + std::max(1, p.Ho / 12); s1 + s2 < p.Ho - s1; s1 += std::max(1, p.Ho / 12))
-      cands.push_back({0, p.Ho - s1 - s2, p.Ho - s2, p.Ho});
-#ifdef QCNN_EXPERIMENT     // variant builds only (scripts/build_variant.sh -DQCNN_EXPERIMENT): exactly that many equal segments
-  if (const char* e = getenv("QCNN_SLIDE_SEGS")) {
-    const int n = std::max(1, std::min(atoi(e), std::min(QK_MAX_SEGS, p.Ho / ns)));
-    std::vector<int> b(n + 1);
-    for (int i = 0; i <= n; ++i) b[i] = (int)(((long long)p.Ho * i + n - 1) / n);
-    cands.assign(1, b);
-    tileCost = 1e30;
-  }
-#endif
-  // sliding must beat the (split) tile launch — clearly (8 %) when it needs more channel chunks than the tile kernel: the
-  // model does not see the uneven last chunk (VGG-16's 14 x 14 x 512 layers measured 5 % slower where it predicted a tie)
-  double best = tileCost * (sc.sl.chunks > qk_conv_slots(Ctg, p.grp).chunks ? 0.92 : 1.0);
-  for (const std::vector<int>& b : cands) {
-    // order the segments longest first (dispatch order = LPT); boundaries stay contiguous per segment
-    std::vector<std::pair<int, int> > segs;
-    for (size_t i = 0; i + 1 < b.size(); ++i) segs.push_back({b[i], b[i + 1]});
-    std::stable_sort(segs.begin(), segs.end(), [](const std::pair<int, int>& x, const std::pair<int, int>& y) {
-      return x.second - x.first > y.second - y.first; });
-    // the kernel reads segment i as [segBeg[i], segBeg[i + 1]): only orders that keep the boundaries monotone fit that
-    // encoding — equal cuts and "long, short" do (longest first = left to right)
-    bool monotone = true;
-    for (size_t i = 0; i + 1 < segs.size(); ++i) monotone = monotone && segs[i].second == segs[i + 1].first;
-    if (!monotone || (int)segs.size() > QK_MAX_SEGS) continue;
-    const double c = makespan(b);
-    if (const char* dbg = getenv("QCNN_DEBUG_PLAN"); dbg && atoi(dbg)) {
-      fprintf(stderr, "[qcnn plan] slide Ho=%d Wo=%d panels=%d ny=%d: segs", p.Ho, p.Wo, p.panels, ny);
-      for (int v : b) fprintf(stderr, " %d", v);
-      fprintf(stderr, " -> %.0f stage-times (tile kernel %.0f)\n", c, tileCost);
-    }
-    if (c < best) {
-      best = c;
-      p.nSeg = (int)segs.size();
-      for (size_t i = 0; i < b.size(); ++i) p.segBeg[i] = b[i];
-    }
-  }
-  return p.nSeg > 0 ? best : 0.0;
 }
 
 int qk_fc_channels_per_block(int Ct) { return NGW * qk_fc_slots(Ct).cpw; }

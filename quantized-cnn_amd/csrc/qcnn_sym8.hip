@@ -943,32 +943,6 @@ hipError_t launch_sym8(const ConvParams& p, const Qk8Config& cf, hipStream_t st)
 
 }  // namespace
 
-Qk8Config qk_conv_sym8_config(int Cin, int grp, int Ct, int M, int Cs, int K) {
-  Qk8Config cf = {0, 0, 0, 0, 0};
-  if (grp < 1 || Ct % grp || Cin % grp) return cf;
-  const int Cg = Cin / grp, Ctg = Ct / grp;
-  // K = 128, every sub-space complete with 4 or 8 dims (no operand masks in the kernel)
-  if (K != 128 || !(Cs == 4 || Cs == 8) || Cg % Cs || M != Cg / Cs) return cf;
-  // channels per wave x positions = 96: as many channels of the group in ONE workgroup as 8 waves hold (every further
-  // channel chunk builds the same stages again), the tile that goes with it
-  const int chunks = (Ctg + 383) / 384;
-  const int per = (Ctg + chunks - 1) / chunks;
-  if (per <= 64) return cf;                      // narrow layers: the sliding kernels of k_conv_aprx build less
-  if (per <= 128) { cf.cpw = 16; cf.th = 2; cf.tw = 3; }
-  else if (per <= 192) { cf.cpw = 24; cf.th = 2; cf.tw = 2; }
-  else if (per <= 256) { cf.cpw = 32; cf.th = 1; cf.tw = 3; }
-  else { cf.cpw = 48; cf.th = 1; cf.tw = 2; }
-  if (Ctg % cf.cpw) { cf.cpw = 0; return cf; }   // a wave's channels all exist or none does
-  cf.chunks = (Ctg + NW8 * cf.cpw - 1) / (NW8 * cf.cpw);
-  return cf;
-}
-
-size_t qk_conv_sym8_program_bytes(const Qk8Config& cf, int groups, int knl, int stride, int M) {
-  if (!cf.cpw) return 0;
-  const int rfH = cf.slide ? cf.th * stride : (cf.th - 1) * stride + knl, rfW = (cf.tw - 1) * stride + knl;
-  return (size_t)rfH * rfW * M * groups * cf.chunks * NW8 * cf.th * cf.tw * cf.cpw * sizeof(uint16_t);   // 16 half-waves x NP x CPW / 2
-}
-
 hipError_t qk_build_program8(const uint8_t* rows, uint16_t* prog, const QkSlots& src, const Qk8Config& cf, int Ctg, int groups,
                              int knl, int stride, int M, hipStream_t st, int f16) {
   const size_t n = qk_conv_sym8_program_bytes(cf, groups, knl, stride, M) / sizeof(uint16_t);
@@ -976,158 +950,6 @@ hipError_t qk_build_program8(const uint8_t* rows, uint16_t* prog, const QkSlots&
   const int grid = (int)std::min<size_t>((n + 255) / 256, 8192);
   hipLaunchKernelGGL(k_build_program8, dim3(grid), dim3(256), 0, st, rows, prog, src, cf, Ctg, groups, knl, stride, M, n, f16);
   return hipGetLastError();
-}
-
-// predicted duration (in stage-times of the tile kernel, like QkSplitPlan::cost) of a launch over p.panels panels: tiles
-// list-scheduled heaviest first on 256 CUs.  A stage of this kernel is priced by its look-ups: measured (AlexNet conv2 - 5,
-// 1000 images, profiles/r4_*) 2540 + 1.97 x (row look-ups per stage) cycles against ~2500 for a stage of the tile kernel,
-// whose look-ups run beside its builder waves; `scale` corrects the whole (1.0 = that calibration)
-// Z > 1: every tile cut into Z slices of its stage sequence (ConvParams::splitZ) + the reduction of the partial sums (priced as
-// qk_conv_plan prices k_conv_sum: Z slabs read, one written at ~4 TB/s behind a launch)
-double qk_conv_sym8_cost(const ConvParams& p, const Qk8Config& cf, double scale, int Z) {
-  if (!cf.cpw) return 0.0;
-  const int TH = cf.th, TW = cf.tw;
-  const int tilesX = (p.Wo + TW - 1) / TW, tilesY = (p.Ho + TH - 1) / TH, tiles = tilesX * tilesY;
-  std::vector<double> stages((size_t)tiles);
-  double total = 0.0;
-  for (int r = 0; r < tiles; ++r) {
-    int ty, tx;
-    tile_of_rank(r, tilesY, tilesX, ty, tx);
-    const int ho0 = ty * TH, wo0 = tx * TW;
-    const int hoL = std::min(ho0 + TH, p.Ho) - 1, woL = std::min(wo0 + TW, p.Wo) - 1;
-    const int rows = std::min(p.H - 1, hoL * p.stride - p.pad + p.knl - 1) - std::max(0, ho0 * p.stride - p.pad) + 1;
-    const int cols = std::min(p.W - 1, woL * p.stride - p.pad + p.knl - 1) - std::max(0, wo0 * p.stride - p.pad) + 1;
-    stages[r] = (double)std::max(rows, 0) * std::max(cols, 0) * p.M;
-    total += stages[r];
-  }
-  // row look-ups of one group and channel chunk per panel (border-clipped taps x sub-spaces x channels) per built stage
-  auto taps = [&](int n, int nIn) {
-    long long t = 0;
-    for (int o = 0; o < n; ++o) t += std::min(p.knl - 1, nIn - 1 - (o * p.stride - p.pad)) - std::max(0, -(o * p.stride - p.pad)) + 1;
-    return (double)t;
-  };
-  const double perStage = total > 0.0 ? taps(p.Ho, p.H) * taps(p.Wo, p.W) * p.M * std::min(p.Ct / p.grp, NW8 * cf.cpw) / total : 0.0;
-  const double factor = scale * (2540.0 + 1.97 * perStage) / 2500.0;
-  const int ny = p.grp * cf.chunks;
-  const long long wgs = (long long)tiles * p.panels * ny;
-  if (wgs >= 8 * 256 && Z <= 1) return (factor * total + 10.0 * tiles) * p.panels * ny / 256.0;
-  std::priority_queue<double, std::vector<double>, std::greater<double>> q;
-  for (int i = 0; i < 256; ++i) q.push(0.0);
-  double end = 0.0;
-  const int zz = std::max(Z, 1);
-  for (int y = 0; y < ny; ++y)
-    for (int r = 0; r < tiles; ++r)
-      for (int z = 0; z < zz; ++z)
-        for (int k = 0; k < p.panels; ++k) {
-          const double t = q.top() + factor * stages[r] / zz + 10.0;
-          q.pop(); q.push(t);
-          end = std::max(end, t);
-        }
-  if (zz > 1) {
-    const double slab = (double)tiles * p.panels * TH * TW * p.Ct * PANEL * 4.0;
-    end += (slab * (zz + 1.0) / 4.0e6 + slab * zz / 10.0e6 + 5.0) / 1.1;
-  }
-  return end;
-}
-
-// Sliding form: th = slots = ceil(knl / stride) (3 or 5 built), tw = output columns of a strip; channels per wave as above
-// for layers of up to 256 channels per workgroup (48 channels per wave would need 144 pairs for three slots).
-Qk8Config qk_conv_sym8_slide_config(int Cin, int grp, int Ct, int M, int Cs, int K, int knl, int stride) {
-  Qk8Config cf = {0, 0, 0, 0, 0};
-  if (grp < 1 || Ct % grp || Cin % grp) return cf;
-  const int Cg = Cin / grp, Ctg = Ct / grp;
-  if (K != 128 || !(Cs == 4 || Cs == 8) || Cg % Cs || M != Cg / Cs) return cf;
-  const int ns = (knl + stride - 1) / stride;
-  const int chunks = (Ctg + 255) / 256;
-  const int per = (Ctg + chunks - 1) / chunks;
-  int cpw = 0, nc = 0;
-  if (ns == 3) {
-    if (per <= 64) return cf;
-    if (per <= 128) { cpw = 16; nc = 2; } else if (per <= 192) { cpw = 24; nc = 1; } else { cpw = 32; nc = 1; }
-  } else if (ns == 5) {
-    if (per <= 64 || per > 128) return cf;
-    cpw = 16; nc = 1;
-  } else {
-    return cf;
-  }
-  if (Ctg % cpw) return cf;
-  cf.cpw = cpw; cf.th = ns; cf.tw = nc; cf.slide = 1;
-  cf.chunks = (Ctg + NW8 * cpw - 1) / (NW8 * cpw);
-  return cf;
-}
-
-// Segments of the sliding form for a launch over p.panels panels (p.nSeg / p.segBeg are filled) and its predicted duration in
-// stage-times: the candidates of qk_conv_plan_slide — one to four equal segments per column, or a long and a short one —
-// list-scheduled on 256 CUs with this kernel's stage price (qk_conv_sym8_cost).  0: the layer cannot slide.
-double qk_conv_sym8_slide_plan(ConvParams& p, const Qk8Config& cf, double scale) {
-  p.nSeg = 0;
-  if (!cf.cpw || !cf.slide || p.Ho < 2 * cf.th) return 0.0;
-  const int ns = cf.th, nc = cf.tw;
-  const int colGroups = (p.Wo + nc - 1) / nc;
-  const int ny = p.grp * cf.chunks;
-  auto segStages = [&](int cgi, int a, int b) {        // strip of output columns [cgi * nc, ..), output rows [a, b)
-    const int wA = cgi * nc, wB = std::min(p.Wo, wA + nc) - 1;
-    const int cols = std::min(p.W - 1, wB * p.stride - p.pad + p.knl - 1) - std::max(0, wA * p.stride - p.pad) + 1;
-    const int rows = std::min(p.H - 1, (b - 1) * p.stride - p.pad + p.knl - 1) - std::max(0, a * p.stride - p.pad) + 1;
-    return (double)std::max(rows, 0) * std::max(cols, 0) * p.M;
-  };
-  auto taps = [&](int n, int nIn) {
-    long long t = 0;
-    for (int o = 0; o < n; ++o) t += std::min(p.knl - 1, nIn - 1 - (o * p.stride - p.pad)) - std::max(0, -(o * p.stride - p.pad)) + 1;
-    return (double)t;
-  };
-  const double lookups = taps(p.Ho, p.H) * taps(p.Wo, p.W) * p.M * std::min(p.Ct / p.grp, NW8 * cf.cpw);   // per group, chunk and panel
-  std::vector<std::vector<int> > cands;
-  for (int n = 1; n <= 4 && n * ns <= p.Ho; ++n) {
-    std::vector<int> b(n + 1);
-    for (int i = 0; i <= n; ++i) b[i] = (int)(((long long)p.Ho * i + n - 1) / n);   // the longer ones first
-    cands.push_back(b);
-  }
-  for (int shortLen = ns; shortLen * 2 < p.Ho; shortLen += std::max(1, p.Ho / 16)) cands.push_back({0, p.Ho - shortLen, p.Ho});
-#ifdef QCNN_EXPERIMENT     // variant builds only (scripts/build_variant.sh -DQCNN_EXPERIMENT): exactly that many equal segments
-  if (const char* e = getenv("QCNN_SYM8_SEGS")) {
-    const int n = std::max(1, std::min(atoi(e), std::min(QK_MAX_SEGS, p.Ho / ns)));
-    std::vector<int> b(n + 1);
-    for (int i = 0; i <= n; ++i) b[i] = (int)(((long long)p.Ho * i + n - 1) / n);
-    cands.assign(1, b);
-  }
-#endif
-  double best = 0.0;
-  std::vector<double> cu(256);
-  for (const std::vector<int>& b : cands) {
-    const int nSeg = (int)b.size() - 1;
-    if (nSeg > QK_MAX_SEGS) continue;
-    double total = 0.0;
-    for (int sgi = 0; sgi < nSeg; ++sgi)
-      for (int wo = 0; wo < colGroups; ++wo) total += segStages(wo, b[sgi], b[sgi + 1]);
-    if (total <= 0.0) continue;
-    // a stage's price by its look-ups (2540 + 1.97 x look-ups cycles against 2500 of a tile stage) + the store / restart of
-    // the slots at every source row's end
-    const double factor = scale * (2540.0 + 1.97 * lookups / total) / 2500.0;
-    std::fill(cu.begin(), cu.end(), 0.0);
-    std::make_heap(cu.begin(), cu.end(), std::greater<double>());
-    for (int y = 0; y < ny; ++y)
-      for (int sgi = 0; sgi < nSeg; ++sgi)
-        for (int wo = 0; wo < colGroups; ++wo)
-          for (int pn = 0; pn < p.panels; ++pn) {
-            std::pop_heap(cu.begin(), cu.end(), std::greater<double>());
-            const int rows = std::min(p.H - 1, (b[sgi + 1] - 1) * p.stride - p.pad + p.knl - 1) - std::max(0, b[sgi] * p.stride - p.pad) + 1;
-            cu.back() += factor * segStages(wo, b[sgi], b[sgi + 1]) + 0.3 * std::max(rows, 0) + 12.0;
-            std::push_heap(cu.begin(), cu.end(), std::greater<double>());
-          }
-    const double c = *std::max_element(cu.begin(), cu.end());
-    if (const char* dbg = getenv("QCNN_DEBUG_PLAN"); dbg && atoi(dbg) > 1) {
-      fprintf(stderr, "[qcnn plan] sym8 slide Ho=%d Wo=%d panels=%d ny=%d factor %.3f: segs", p.Ho, p.Wo, p.panels, ny, factor);
-      for (int v : b) fprintf(stderr, " %d", v);
-      fprintf(stderr, " -> %.0f stage-times\n", c);
-    }
-    if (best == 0.0 || c < best) {
-      best = c;
-      p.nSeg = nSeg;
-      for (size_t i = 0; i < b.size(); ++i) p.segBeg[i] = b[i];
-    }
-  }
-  return best;
 }
 
 // p.nSeg / p.segBeg from qk_conv_sym8_slide_plan, p.progS = the sliding program (qk_build_program8 with the sliding config)
@@ -1139,19 +961,6 @@ hipError_t qk_conv_sym8_slide(const ConvParams& p, hipStream_t st) {
   if (cf.th == 3 && cf.cpw == 32) return launch_sym8<32, 3, 1, true>(p, cf, st);
   if (cf.th == 5 && cf.cpw == 16) return launch_sym8<16, 5, 1, true>(p, cf, st);
   return hipErrorInvalidValue;
-}
-
-// Tiles of the fp16-sum form (QCNN_OPT_LUT_MODE = 3): the same channels per wave, twice the positions (192 pairs per wave)
-Qk8Config qk_conv_sym8_config16(int Cin, int grp, int Ct, int M, int Cs, int K) {
-  Qk8Config cf = qk_conv_sym8_config(Cin, grp, Ct, M, Cs, K);
-  switch (cf.cpw) {
-    case 48: cf.th = 2; cf.tw = 2; break;      // 384 channels: 2x2 (1x2 with fp32 sums)
-    case 32: cf.th = 2; cf.tw = 3; break;      // 256: 2x3 (1x3)
-    case 24: cf.th = 2; cf.tw = 4; break;      // 192: 2x4 (2x2)
-    case 16: cf.th = 3; cf.tw = 4; break;      // 128: 3x4 (2x3)
-    default: break;
-  }
-  return cf;
 }
 
 // mode 1: the fp16-storage form (QCNN_OPT_LUT_MODE = 2), mode 2: fp16 storage + fp16 sums (QCNN_OPT_LUT_MODE = 3, the tiles of

@@ -7,7 +7,7 @@ sfx=$1; src=$2; shift 2
 C=$R/quantized-cnn_amd/csrc
 /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=off -Wno-unused-function "$@" -c $C/$src -o /tmp/variant$sfx.o
 objs=""
-for o in qcnn_kernels qcnn_sym8 qcnn_half8 qcnn_glue qcnn_small qcnn_dense qcnn_decoded qcnn_engine qcnn_group; do
+for o in qcnn_kernels qcnn_sym8 qcnn_half8 qcnn_planner qcnn_glue qcnn_small qcnn_dense qcnn_decoded qcnn_engine qcnn_group; do
   if [ "$o.hip" == "$src" ]; then objs="$objs /tmp/variant$sfx.o"; else objs="$objs $C/$o.hip.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/quantized-cnn_amd/libqcnn_hip$sfx.so $objs -L/opt/rocm/lib -lrccl -lpthread

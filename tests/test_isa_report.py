@@ -19,7 +19,7 @@ spec.loader.exec_module(isa)
 # conv1 / fc8, symmetric conv2, tile conv3 / conv4, sliding conv5, FC, fused LRN + pool) and at one panel / VGG-16
 HOT = [
     r"k_conv_dec<6,1,false,2,4>", r"k_conv_dec<3,1,false,3,4>", r"k_conv_dec<4,1,true,2,4>", r"k_conv_dec_nchw<6,4>",
-    r"k_conv_sym<2>", r"k_conv_sym8<.*>", r"k_fc_sym8<.*>",
+    r"k_conv_sym<2>", r"k_conv_sym8<.*>", r"k_fc_sym8<.*>", r"k_conv_half8<.*>",
     r"k_conv_aprx<1,1,32,8,2,false>", r"k_conv_aprx<1,1,24,8,2,false>", r"k_conv_aprx<1,2,16,8,2,false>",
     r"k_conv_aprx<1,3,12,8,2,false>", r"k_conv_aprx<2,2,8,8,[12],false>", r"k_conv_aprx<2,3,6,8,2,false>",
     r"k_conv_aprx<1,3,12,8,2,true>", r"k_conv_aprx<1,2,16,8,2,true>", r"k_conv_aprx<1,3,8,8,1,true>",
