@@ -2,7 +2,7 @@
 //
 // For such a layer a table look-up replaces Cin <= 4 multiply-adds and the table of a source pixel (K code words x 128
 // images, 64 KB of LDS stores) serves only knl^2 / stride^2 x Ct look-ups: in k_conv_aprx two thirds of a conv1 stage are
-// the table build (DESIGN.md §3.4).  The same sum
+// the table build (DESIGN.md §3.6).  The same sum
 //
 //     dst[pos][c] = bias[c] + sum_taps  LUT[pixel(pos, tap)][asmt[tap][c]],     LUT[p][k] = sum_d x[p][d] * ctrd[d][k]
 //                                                                   (src/CaffeEva.cc:816-865 over :1261-1296)
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(1024) void k_conv_dec(DecParams p) {
       r0[j] = (q / p.Wo) * p.stride - p.pad;
       c0[j] = (q % p.Wo) * p.stride - p.pad;
     }
-    // Vector ALU work takes matrix-pipe time on a SIMD, so a B load costs no vector instruction besides
+    // Vector ALU work takes matrix-pipe time on a SIMD (LABBOOK.md), so a B load costs no vector instruction besides
     // itself: a buffer load with the lane's part of the address (k row kq, images 4 li ..) in ONE constant VGPR and
     // everything else — position, kernel row, step — in the scalar offset.  A kernel row of Kr = knl * Cin products is
     // padded to Kp = a multiple of four by letting its LAST step start at k = Kr - 4 (qk_dec_krow): it re-reads rows the

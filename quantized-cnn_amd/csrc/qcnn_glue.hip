@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256) void k_pool4(const float4* __restrict__ src, f
 // normalised channels at a time in an LDS slab [N][81 pixels][8 quads]; then thread (pool output, channel of the
 // chunk, quad) takes the maximum of its window out of the slab (k_pool4's order and comparison) and stores it.
 // Every normalised value is evaluated once per block (the one-pixel halo between tiles: 81/64 = 1.27x) instead of
-// once per window that contains it (2.25x: that version lost to the two separate kernels), and the
+// once per window that contains it (2.25x: that version lost to the two separate kernels, LABBOOK.md §3.2), and the
 // map takes one HBM read instead of write + read.
 #ifndef QCNN_LP_PREFETCH
 #define QCNN_LP_PREFETCH 0

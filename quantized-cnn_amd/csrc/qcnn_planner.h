@@ -2,7 +2,7 @@
 // launch of a given geometry and panel count, and how it is cut.
 //
 // Every family has a cost model in the same unit — "stage-times" = LUT stages of the 16-wave tile kernel (~2500 cycles), tiles /
-// strips list-scheduled heaviest first on 256 CUs — calibrated on measurements (DESIGN.md §4, LABBOOK.md):
+// strips list-scheduled heaviest first on 256 CUs — calibrated on measurements (DESIGN.md §3.5, LABBOOK.md):
 //   tile (k_conv_aprx), whole or with a split tail (qk_conv_plan)                      1 stage = 1 unit
 //   16-wave sliding strips (qk_conv_plan_slide)                                         1.03 + 0.3 per source row
 //   16-wave symmetric 2x2 x 128 channels (qk_conv_sym_cost)                             1.09

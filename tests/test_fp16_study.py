@@ -4,7 +4,7 @@ A numerical study on the CPU oracle (no GPU needed: rounding is rounding): the r
 table entry rounded to fp16 when stored, fp32 running sums, and (b) fp16 entries AND fp16 running sums (rounded
 after every addition), each against the plain fp32 forward pass, per feature map, relative to the map's largest
 magnitude.  The GPU tier measures variant (a) on the HIP path itself (QCNN_OPT_LUT_MODE = 2,
-test_fp16_lut_tolerance_study); the two agree.  Outcome: (a) is 1e-4 .. 5e-4 — outside the 1e-4
+test_fp16_lut_tolerance_study); the two agree.  Outcome (LABBOOK.md §5): (a) is 1e-4 .. 5e-4 — outside the 1e-4
 parity bar, (b) is 1e-3 .. 1e-2 with top-5 changes; neither is offered as a fast path."""
 import numpy as np
 

@@ -691,7 +691,7 @@ def test_u8_input_pipeline_is_bit_identical_to_host_preprocessing(golden_tiny, w
 def test_fp16_lut_tolerance_study(golden_alex_syn):
     """BASELINE.json configs[4]: AlexNet with the look-up-table entries rounded to fp16 (accumulation fp32),
     against the reference's fp32 feature maps.  This is a study, not a parity claim: the bar is the fp16
-    rounding itself (2^-11 per entry), the measured per-layer errors are printed."""
+    rounding itself (2^-11 per entry), the measured per-layer errors are printed (LABBOOK.md §5)."""
     z = golden_alex_syn
     in_chw, layers, _, _ = topo.MODELS["AlexNet"]
     params = synth.make_params(in_chw, layers, seed=7)
@@ -724,7 +724,7 @@ def test_fp16_table_storage_kernels():
         stored, fp32 sums — within 5e-5 (not 1e-6: the oracle builds an entry with separately rounded multiply and add,
         src/CaffeEva.cc:1284-1289, the matrix pipe with a fused chain, so a few entries per thousand land on the other side of an
         fp16 rounding boundary: measured 5e-6 ... 1e-5);
-      * against the fp32 oracle: the storage rounding is really there (> 1e-5) and is what DESIGN.md §5 says it costs (< 2e-3)."""
+      * against the fp32 oracle: the storage rounding is really there (> 1e-5) and is what LABBOOK.md §5 says it costs (< 2e-3)."""
     in_chw, layers, _, _ = topo.MODELS["AlexNet"]
     L = len(layers)
     params = synth.make_params(in_chw, layers, seed=7)
@@ -780,7 +780,7 @@ def test_fp16_sums_kernels_layer_by_layer():
     (entries AND running sums rounded to fp16 after every addition, the bias start value too, same (kh, kw, m) order): the conv
     layers within 2e-3 of the map's largest value (an entry that rounds the other way moves a sum by an fp16 ulp of its
     magnitude); the FC layers — whose sub-space axis is cut over workgroups, the slices added in fp32: another grouping of the
-    fp16 roundings, measured 1.7e-2 — and all of them within what DESIGN.md §5 says fp16 sums cost against fp32 (5e-2).  The whole network in that mode keeps its top-1."""
+    fp16 roundings, measured 1.7e-2 — and all of them within what LABBOOK.md §5 says fp16 sums cost against fp32 (5e-2).  The whole network in that mode keeps its top-1."""
     in_chw, layers, _, _ = topo.MODELS["AlexNet"]
     L = len(layers)
     params = synth.make_params(in_chw, layers, seed=7)
