@@ -258,6 +258,8 @@ def self_spawn(args):
     """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks ourselves."""
     import torch
     have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if args.dry_run_shared_gpu and have >= 1:
+        have = args.gpus                 # dry run of the N > 1 code path: every rank on GPU 0, collectives over gloo (never a result)
     if have < args.gpus:
         raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible — refusing to report a %d-GPU number"
                          % (args.gpus, have, args.gpus))
@@ -301,6 +303,10 @@ def main():
     ap.add_argument("--extras", type=int, default=1, help="0 = only the headline measurement")
     ap.add_argument("--sym8", type=int, default=-1,
                     help="QCNN_OPT_SYM8 (eight-wave symmetric workgroups): -1 = library default (1 = planner), 0 off, 2 forced tile form, 3 forced sliding form")
+    ap.add_argument("--dry-run-shared-gpu", type=int, default=0,
+                    help="1 = DRY RUN of the N > 1 code path on a box with fewer GPUs: every rank computes on GPU 0 and the collectives "
+                         "(arena broadcast, checksum exchange, barriers, max-over-ranks) run over gloo through host memory.  The line is "
+                         "labelled dry_run and its value is NOT a multi-GPU measurement; RCCL itself is not exercised")
     ap.add_argument("--init-timeout", type=int, default=120,
                     help="N > 1: seconds the RCCL rendezvous + parameter broadcast + checksum exchange may take before the run "
                          "gives up with a one-line JSON error")
@@ -325,6 +331,9 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    dry = bool(args.dry_run_shared_gpu) and world > 1
+    if dry:
+        local = 0
     if local >= torch.cuda.device_count():
         raise SystemExit("rank %d: LOCAL_RANK %d but only %d GPU(s) visible" % (rank, local, torch.cuda.device_count()))
     torch.cuda.set_device(local)
@@ -346,8 +355,12 @@ def main():
         watchdog.daemon = True
         watchdog.start()
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev,
-                                timeout=datetime.timedelta(seconds=args.init_timeout))
+        if dry:
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=args.init_timeout))
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev,
+                                    timeout=datetime.timedelta(seconds=args.init_timeout))
+    cdev = "cpu" if dry else dev          # where the collectives' tensors live
 
     topo, synth, capi, dmod, perf = pkg("topology"), pkg("synth"), pkg("capi"), pkg("dist"), pkg("perfmodel")
     in_chw, layers, _, _ = topo.MODELS[args.model]
@@ -393,7 +406,13 @@ def main():
         torch.cuda.synchronize(dev)
         dist.barrier()
         t0 = time.perf_counter()
-        dist.broadcast(arena, src=0)                        # RCCL over xGMI: codebooks + row-offset tables + biases
+        if dry:
+            host = arena.cpu()
+            dist.broadcast(host, src=0)
+            arena.copy_(host)
+            del host
+        else:
+            dist.broadcast(arena, src=0)                    # RCCL over xGMI: codebooks + row-offset tables + biases
         torch.cuda.synchronize(dev)
         bcast_ms = 1000.0 * (time.perf_counter() - t0)
     if rank != 0:
@@ -402,8 +421,8 @@ def main():
     if world > 1:
         # every rank hashes ITS arena on the device; all ranks compare before anything is timed: a broadcast that moved nothing
         # (or the wrong bytes) must not surface as a fast run with wrong class scores on seven shards
-        ok_sum, pairs = dmod.checksums_agree(eng.arena_checksum(), device=dev)
-        rccl_ranks = dmod.verified_world_size(device=dev)        # counted by a real all_reduce over the communicator
+        ok_sum, pairs = dmod.checksums_agree(eng.arena_checksum(), device=cdev)
+        rccl_ranks = dmod.verified_world_size(device=cdev)       # counted by a real all_reduce over the communicator
         arena_sums = ["%016x:%016x" % p for p in pairs]
         if not ok_sum:
             if rank == 0:
@@ -450,7 +469,7 @@ def main():
         torch.cuda.synchronize(dev)
         dt = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            t = torch.tensor([dt], dtype=torch.float64, device=cdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt
@@ -905,7 +924,9 @@ def main():
                                       "fixture 1 (the mount lacks that file); inputs U{0..255} minus the shipped mean image") if shipped
                        else "seeded synthetic (seed 0), shipped AlexNet quantisation shapes",
                        "streams_per_gpu": ns, "parallelism": par},
-            "rccl_ranks": rccl_ranks, "param_broadcast_ms": round(bcast_ms, 3),
+            "rccl_ranks": 0 if dry else rccl_ranks, "param_broadcast_ms": round(bcast_ms, 3),
+            **({"dry_run": "N > 1 code path on ONE GPU shared by %d ranks, collectives over gloo through host memory: NOT a multi-GPU "
+                           "measurement (`value` is meaningless); RCCL not exercised" % rccl_ranks} if dry else {}),
             "param_broadcast_verified": ("every rank's device arena checksum equals rank 0's: %s" % arena_sums[0]) if arena_sums else
                                         "one rank: nothing to broadcast",
             "outputs_finite": ok,

@@ -90,3 +90,29 @@ def test_profile_ring_never_drops_forwards():
     conv = [i for i, l in enumerate(layers) if l["type"] == topo.CONV]
     assert all(launches[i] == 70 for i in conv) and all(tot[i] > 0 for i in conv)
     eng.close()
+
+
+def test_bench_multi_rank_code_path_dry_run():
+    """`bench.py --gpus 2 --dry-run-shared-gpu 1`: the WHOLE N > 1 path of the bench — self-spawn under torch.distributed.run, shard
+    bounds, rank 0's arena broadcast to the other rank, per-rank device checksums exchanged and compared, barrier + max-over-ranks
+    timing, parity of rank 0's block against the CPU reference, the JSON line — on one GPU shared by two ranks with the collectives
+    over gloo.  Not a measurement (the line says so); what it proves is that the first real 2 / 4 / 8-GPU run does not die in host
+    code that never executed (only RCCL itself stays unexercised on a one-GPU box)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run-shared-gpu", "1", "--steps", "2",
+                        "--warmup", "1", "--extras", "0", "--cpu-sample", "0", "--parity-images", "4"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                       # ONE line, from rank 0
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and "dry_run" in d and d["rccl_ranks"] == 0
+    assert d["config"]["images_on_rank0"] == 500 and d["config"]["global_batch"] == 1000
+    assert "checksum" in d["param_broadcast_verified"] and d["param_broadcast_ms"] > 0
+    assert d["outputs_finite"] and d["parity"]["ok"]
+    assert d["value"] > 0 and d["alg_north_star_value"] is None and "not measured" in d["alg_north_star_note"]
