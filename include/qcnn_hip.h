@@ -265,7 +265,8 @@ int qcnn_get_layer_segments(QcnnCtx* ctx, int layer, int* seg_beg9, int* n_seg);
 /* ---- launch planner (diagnostic; quantized-cnn_amd/csrc/qcnn_planner.h) ---- */
 /* The plan and the choice for ONE conv launch, from plain numbers (needs no device, no context):
  *   geom[14] = H, W, Cin, Ho, Wo, Ct, knl, stride, pad, grp, M, Cs, K, panels          opts[8] = QCNN_OPT_SPLIT, _SLIDE, _SYM, _SYM8, _HALF8,
- *   QCNN_OPT_LUT_MODE, 1 when the layer reads the NCHW input in place, partial-sum scratch in Mi floats.
+ *   QCNN_OPT_LUT_MODE, flags (1: the layer reads the NCHW input in place, 2: the panels are those of concurrent sub-batches —
+ *   QCNN_OPT_STREAMS > 1), partial-sum scratch in Mi floats.
  *   costs[7] (predicted stage-times; 0 = not eligible) = tile kernel, 16-wave sliding, 16-wave symmetric, eight-wave tile, eight-wave
  *   sliding, half-panel tile, half-panel sliding.     choice[13] = family code (what qcnn_get_layer_split reports: -1 tile, -2, -4, -5,
  *   -6, -9, -10), first split tile, slices, segments per column, nine segment boundaries.  Returns non-zero on a malformed geometry. */

@@ -417,7 +417,9 @@ int ensure_f16_program(QcnnCtx* c, int l, hipStream_t st) {
 
 int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bool fuseRelu, bool flatFcInput,
                  int p0, hipStream_t st, const float* inNchw = nullptr, int nImages = 0, int live = QCNN_PANEL,
-                 bool small = false, int sub = 0, int nsub = 1) {
+                 bool small = false, int sub = 0, int nsub = 1, int panelsAll = 0) {
+  // panelsAll: panels of ALL sub-batches of this forward (they run concurrently on their own streams and share the 256 CUs); 0 = this
+  // launch is alone
   const QcnnLayerDesc& d = c->layers[l];
   const FmDims& a = c->dims[l];
   const FmDims& b = c->dims[l + 1];
@@ -499,12 +501,21 @@ int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bo
           QkPlanOptions o = {};
           o.split = c->split; o.slide = c->slide; o.sym = c->sym; o.sym8 = c->sym8; o.half8 = c->half8;
           o.lutMode = c->lutMode; o.inNchw = inNchw ? 1 : 0; o.scratchFloats = share;
+          o.concurrent = (nsub > 1 && panelsAll > panels) ? 1 : 0;
           o.hasSlide16 = s.progSBytes != 0; o.hasSym16 = s.progYBytes != 0; o.hasSym8 = s.prog8Bytes != 0;
           o.hasSym8Slide = s.prog8SBytes != 0; o.hasHalf8 = s.progH8Bytes != 0; o.hasHalf8Slide = s.progH8SBytes != 0;
-          const long long key = ((((((((long long)panels * 8 + nsub) * 2 + (c->split ? 1 : 0)) * 4 + c->slide) * 4 + c->sym) * 4 +
+          const long long key = (((((((((long long)(nsub > 1 ? panelsAll : 0) * 4096 + panels) * 8 + nsub) * 2 + (c->split ? 1 : 0)) * 4 + c->slide) * 4 + c->sym) * 4 +
                                   c->lutMode) * 2 + (inNchw ? 1 : 0)) * 8 + c->sym8) * 4 + c->half8;
           auto it = s.plans.find(key);
-          if (it == s.plans.end()) it = s.plans.emplace(key, qk_plan_conv(p, o)).first;
+          if (it == s.plans.end()) {
+            // Sub-batches on several streams run CONCURRENTLY: the tail of one sub-batch's launch fills with the other's workgroups
+            // (that is what the streams are for), so the family is chosen for the panels of the whole forward — planned per
+            // sub-batch, a 1000-image forward on two streams took the kernels of a 500-image one (conv3 / conv4 back on the 16-wave
+            // tile kernel) and lost what the overlap gained: 103.8 k images/s against 107 k with the one-stream plan's kernels.
+            ConvParams pp = p;
+            if (o.concurrent) pp.panels = panelsAll;
+            it = s.plans.emplace(key, qk_plan_conv(pp, o)).first;
+          }
           const QkConvChoice ch = qk_choose_conv(it->second, o);
           // partial sums of split tiles: scratch allocated by the first split launch of this context; when the device has no
           // memory left for it (large maps at a large batch) the tiles run whole, which needs none — never a failed forward
@@ -840,7 +851,7 @@ int run_layers(QcnnCtx* c, int n, const float* inNchw = nullptr, int pa = 0, int
         const hipError_t e = qk_lrn_pool(src, dst, p1 - p0, c->dims[l].h, c->dims[l].w, c->dims[l].c, c->dims[l + 2].h,
                                          c->dims[l + 2].w, d.lrnSiz, d.lrnAlp, d.lrnBet, d.lrnIni, live, st);
         if (e != hipSuccess) return fail(c, "layer %d (LRN + pool): %s", l, hipGetErrorString(e));
-      } else if (launch_layer(c, l, src, dst, p1 - p0, fuse, false, p0, st, direct ? inNchw : nullptr, n, live, small, k, ns)) {
+      } else if (launch_layer(c, l, src, dst, p1 - p0, fuse, false, p0, st, direct ? inNchw : nullptr, n, live, small, k, ns, panels)) {
         return 1;
       }
       if (prof) {

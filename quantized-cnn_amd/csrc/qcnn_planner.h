@@ -23,6 +23,8 @@ struct QkPlanOptions {
   int split, slide, sym, sym8, half8;     // QCNN_OPT_SPLIT / _SLIDE / _SYM / _SYM8 / _HALF8 as set
   int lutMode;                            // QCNN_OPT_LUT_MODE (1 = f32 MFMA: the only mode the eight-wave families run in)
   int inNchw;                             // the layer reads the network input in place (tile / 16-wave sliding kernels only)
+  int concurrent;                         // the forward runs several sub-batches on their own streams (QCNN_OPT_STREAMS > 1): the plan covers the
+                                          // panels of all of them, and coarse work items (strips) overlap worse than tiles
   size_t scratchFloats;                   // partial-sum scratch this launch may use (0: no split)
   int hasSlide16, hasSym16, hasSym8, hasSym8Slide, hasHalf8, hasHalf8Slide;   // program tables present
 };
@@ -49,6 +51,7 @@ struct QkConvChoice {
 
 constexpr double QK_SYM8_STAGE_FACTOR = 0.97;   // scale of the eight-wave stage prices (their list schedule over-prices the last round by ~3 %)
 constexpr double QK_SLIDE8_FACTOR = 1.15;       // a planner unit of the 16-wave / eight-wave sliding forms against one of the tile forms (measured 1.04 - 1.11 us against 0.89 - 0.93)
+constexpr double QK_CONCURRENT_STRIP_FACTOR = 1.08;   // sliding forms when sub-batches run concurrently (measured: AlexNet conv5 on two streams, sliding 9.45 against tile form 9.36 ms per step)
 constexpr double QK_HALF8_SLIDE_FACTOR = 1.25;  // ... of the half-panel sliding form against the half-panel tile form (measured 1.21 - 1.28 against 1.01 - 1.07)
 
 QkConvPlan qk_plan_conv(const ConvParams& p, const QkPlanOptions& o);

@@ -675,14 +675,16 @@ QkConvChoice qk_choose_conv(const QkConvPlan& pl, const QkPlanOptions& o) {
   ch.family = QK_FAM_TILE; ch.splitFrom = 0; ch.Z = 1;
   const bool f32 = o.lutMode == 1 && !o.inNchw;
   const bool free16 = o.sym < 2 && o.slide < 2;                       // no 16-wave family is forced
+  const double slideF = QK_SLIDE8_FACTOR * (o.concurrent ? QK_CONCURRENT_STRIP_FACTOR : 1.0);
+  const double halfSlideF = QK_HALF8_SLIDE_FACTOR * (o.concurrent ? QK_CONCURRENT_STRIP_FACTOR : 1.0);
   // the best of the families a candidate is compared with, in stage-times corrected per family (measured us per planner unit):
   // 16-wave symmetric x 1.08, 16-wave and eight-wave sliding forms x QK_SLIDE8_FACTOR
   auto others = [&](bool withSym8s, bool withHalf8) {
     double other = pl.plan.cost;
     if (pl.symCost > 0.0 && 1.08 * pl.symCost < other) other = 1.08 * pl.symCost;
-    if (pl.segN > 0 && pl.slideCost > 0.0) other = std::min(other, QK_SLIDE8_FACTOR * pl.slideCost);
+    if (pl.segN > 0 && pl.slideCost > 0.0) other = std::min(other, slideF * pl.slideCost);
     if (pl.sym8Cost > 0.0) other = std::min(other, pl.sym8Cost);
-    if (withSym8s && pl.sym8sCost > 0.0 && pl.seg8N > 0) other = std::min(other, QK_SLIDE8_FACTOR * pl.sym8sCost);
+    if (withSym8s && pl.sym8sCost > 0.0 && pl.seg8N > 0) other = std::min(other, slideF * pl.sym8sCost);
     if (withHalf8 && pl.half8Cost > 0.0) other = std::min(other, pl.half8Cost);
     return other;
   };
@@ -690,7 +692,7 @@ QkConvChoice qk_choose_conv(const QkConvPlan& pl, const QkPlanOptions& o) {
   // half-panel eight-wave workgroups, sliding form: forced (QCNN_OPT_HALF8 = 3), or predicted at least 3 % faster than every
   // other plan INCLUDING the half-panel tile form (a strip is a coarser work item: x QK_HALF8_SLIDE_FACTOR)
   if (pl.half8sCost > 0.0 && pl.segHN > 0 && f32 && o.half8 != 2 && (o.half8 >= 3 || (o.sym8 < 2 && free16))) {
-    if (o.half8 >= 3 || QK_HALF8_SLIDE_FACTOR * pl.half8sCost < 0.97 * others(true, true)) {
+    if (o.half8 >= 3 || halfSlideF * pl.half8sCost < 0.97 * others(true, true)) {
       ch.family = QK_FAM_HALF8_SLIDE; segs(pl.segHN, pl.segHBeg);
       return ch;
     }
@@ -706,7 +708,7 @@ QkConvChoice qk_choose_conv(const QkConvPlan& pl, const QkPlanOptions& o) {
     // (measured per planner unit, 1000 images: the sliding form 1.04 - 1.11 us — VGG-16's layers, AlexNet conv2 / conv5 —, the tile
     // form 0.89 - 0.93.  With 1.15 the sliding form takes VGG-16's 128- and 256-channel layers, none of AlexNet's: 13 x 13 maps
     // leave too few strips — 208 workgroups for conv4)
-    if (o.sym8 >= 3 || QK_SLIDE8_FACTOR * pl.sym8sCost < 0.97 * others(false, false)) {
+    if (o.sym8 >= 3 || slideF * pl.sym8sCost < 0.97 * others(false, false)) {
       ch.family = QK_FAM_SYM8_SLIDE; segs(pl.seg8N, pl.seg8Beg);
       return ch;
     }
@@ -717,7 +719,7 @@ QkConvChoice qk_choose_conv(const QkConvPlan& pl, const QkPlanOptions& o) {
     // conv2.  A sliding stage is priced 3 % above a tile stage; measured 3330 against 2500 cycles with 12 channels per wave;
     // AlexNet conv5, which must keep sliding — 0.99 against 1.04 ms —, sits at a cost ratio of 1.157)
     if (pl.symCost > 0.0 && 1.08 * pl.symCost < other) other = 1.08 * pl.symCost;
-    if (pl.segN > 0 && pl.slideCost > 0.0) other = std::min(other, QK_SLIDE8_FACTOR * pl.slideCost);
+    if (pl.segN > 0 && pl.slideCost > 0.0) other = std::min(other, slideF * pl.slideCost);
     if (o.sym8 >= 2 || pl.sym8Cost < 0.97 * other) { ch.family = QK_FAM_SYM8; ch.Z = pl.sym8Z; return ch; }
   }
   // 16-wave symmetric workgroups: 128-channel layers that neither slide nor split, when predicted at least 3 % faster
@@ -732,7 +734,7 @@ QkConvChoice qk_choose_conv(const QkConvPlan& pl, const QkPlanOptions& o) {
 
 // Diagnostic / test entry (extern "C", plain ints): the plan and the choice for one conv launch.
 //   geom[14] = H, W, Cin, Ho, Wo, Ct, knl, stride, pad, grp, M, Cs, K, panels
-//   opts[8]  = split, slide, sym, sym8, half8, lutMode, inNchw, scratch (in Mi floats)
+//   opts[8]  = split, slide, sym, sym8, half8, lutMode, flags (1: NCHW input read in place, 2: concurrent sub-batches), scratch (in Mi floats)
 // The program tables a layer would have are derived from its shape exactly as qcnn_model_commit plans them.
 //   costs[7] = tile, 16-wave sliding, 16-wave symmetric, eight-wave tile, eight-wave sliding, half-panel tile, half-panel sliding
 //   choice[13] = family, splitFrom, Z, nSeg, segBeg[0..8]
@@ -744,7 +746,7 @@ extern "C" int qcnn_plan_conv_query(const int* geom, const int* opts, double* co
   p.pd = 1; p.splitZ = 1;
   if (p.grp < 1 || p.Ct % p.grp || p.Cin % p.grp || p.panels < 1 || p.knl < 1 || p.stride < 1) return 1;
   QkPlanOptions o = {};
-  o.split = opts[0]; o.slide = opts[1]; o.sym = opts[2]; o.sym8 = opts[3]; o.half8 = opts[4]; o.lutMode = opts[5]; o.inNchw = opts[6];
+  o.split = opts[0]; o.slide = opts[1]; o.sym = opts[2]; o.sym8 = opts[3]; o.half8 = opts[4]; o.lutMode = opts[5]; o.inNchw = opts[6] & 1; o.concurrent = (opts[6] >> 1) & 1;
   o.scratchFloats = (size_t)opts[7] << 20;
   const int Ctg = p.Ct / p.grp;
   o.hasSlide16 = p.K == 128 && qk_slide_config(Ctg, p.grp, p.knl, p.stride).ns > 0;
