@@ -17,13 +17,13 @@ def main(d):
     print("kernel,waves_per_workgroup,kernel_cycles,cu_time_utilisation,issuing,wait_inst_any,wait_any")
     for r in rows:
         k = r["kernel"]
-        if not k.startswith(("k_conv_aprx", "k_conv_sym", "k_conv_dec", "k_fc_sym8", "k_fc_aprx")):
+        if not k.startswith(("k_conv_aprx", "k_conv_sym", "k_conv_half8", "k_conv_dec", "k_fc_sym8", "k_fc_aprx")):
             continue
         try:
             wc, ga = float(r["SQ_WAVE_CYCLES"]), float(r["GRBM_GUI_ACTIVE"])
         except ValueError:
             continue
-        waves = 8 if (k.startswith(("k_conv_sym8", "k_fc_sym8", "k_conv_dec_nchw"))) else 16
+        waves = 8 if (k.startswith(("k_conv_sym8", "k_conv_half8", "k_fc_sym8", "k_conv_dec_nchw"))) else 16
         cyc = ga / 8.0
         print("%s,%d,%.4g,%.3f,%.2f,%.2f,%.2f" % (k.replace(",", "."), waves, cyc, wc * 4.0 / (cyc * waves * 256.0),
                                                   float(r["SQ_ACTIVE_INST_ANY"]) / wc, float(r["SQ_WAIT_INST_ANY"]) / wc,

@@ -37,6 +37,15 @@ def main():
     def kernel_prefix(tile):
         """bench `roofline.layers[*].tile` -> how the kernel's name starts in the counter tables"""
         import re
+        m = re.match(r"half panels, 8 waves (\d+)x(\d+)x(\d+) \((\d+) wave set", tile)       # k_conv_half8<cpw, th, tw, ws, ..>
+        if m:
+            ws = int(m.group(4))
+            return "k_conv_half8<%d.%s.%s.%d." % (int(m.group(3)) * ws // 8, m.group(1), m.group(2), ws)
+        m = re.match(r"half panels, slide 8 waves (\d+) column\(s\) x (\d+) slots x (\d+)", tile)
+        if m:
+            ch, tw = int(m.group(3)), int(m.group(1))
+            ws = 2 if ch in (128, 192) else 1
+            return "k_conv_half8<%d.%s.%d.%d." % (ch * ws // 8, m.group(2), tw, ws)
         m = re.match(r"symmetric 8 waves (\d+)x(\d+)x(\d+)", tile)
         if m:
             return "k_conv_sym8<%d.%s.%s." % (int(m.group(3)) // 8, m.group(1), m.group(2))
