@@ -282,6 +282,56 @@ def timed(torch, dev, fn, steps):
     return time.perf_counter() - t0
 
 
+def group_capi_child(args):
+    """Child process of the N = 1 bench: one batch through qcnn_group_forward over every visible device (see the call site)."""
+    import torch
+    topo, synth, capi = pkg("topology"), pkg("synth"), pkg("capi")
+    in_chw, layers, _, _ = topo.MODELS[args.model]
+    data_root = os.path.join(ROOT, "oracle", "_ref", "data")
+    have_shipped = args.model == "AlexNet" and os.path.exists(os.path.join(data_root, "AlexNet/Bin.Files/bvlc_alexnet_aCaF.ctrdLst.01.bin"))
+    shipped = have_shipped and args.params != "synthetic"
+    params = synth.load_alexnet_shipped(data_root, layers, fixture=1) if shipped else synth.make_params(in_chw, layers, seed=0)
+    B = args.batch
+    if shipped:
+        imgs = torch.from_numpy(synth.make_images(B, in_chw, seed=1234, mean=synth.shipped_mean_image(data_root)))
+    else:
+        g = torch.Generator(device="cuda:0")
+        g.manual_seed(1234)
+        imgs = torch.randint(0, 256, (B,) + tuple(in_chw), generator=g, device="cuda:0", dtype=torch.int32).to(torch.float32)
+        imgs -= torch.tensor([104.0, 117.0, 123.0], device="cuda:0")[: in_chw[0]].view(1, -1, 1, 1)
+    sizes = topo.fmap_sizes(in_chw, layers)
+    classes = sizes[-1][0] * sizes[-1][1] * sizes[-1][2]
+    ndev = torch.cuda.device_count()
+    grp = pkg("engine").QcnnDeviceGroup(list(range(ndev)))
+    grp.set_option(capi.OPT_KEEP_ALL, 0)
+    grp.set_option(capi.OPT_STREAMS, args.streams)
+    grp.load_model(in_chw, layers, params, B)
+    gb = [grp.shard_bounds(B, r) for r in range(grp.size)]
+    gx = [imgs[a:b_].to("cuda:%d" % r) for r, (a, b_) in enumerate(gb)]
+    gp = [torch.empty((b_ - a, classes), dtype=torch.float32, device="cuda:%d" % r) for r, (a, b_) in enumerate(gb)]
+    gt = [torch.empty((b_ - a, 5), dtype=torch.int16, device="cuda:%d" % r) for r, (a, b_) in enumerate(gb)]
+    for r in range(ndev):
+        torch.cuda.synchronize(r)
+
+    def gstep():
+        grp.forward_dev([t.data_ptr() for t in gx], B, [t.data_ptr() for t in gp], [t.data_ptr() for t in gt])
+    gstep(); gstep()
+    grp.sync()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        gstep()
+    grp.sync()
+    value = round(B * 5 / (time.perf_counter() - t0), 2)
+    want = np.load(args.group_capi_child)
+    same = all(bool(np.array_equal(gt[r].cpu().numpy(), want[a:b_])) for r, (a, b_) in enumerate(gb))
+    out = dict(value=value, devices=grp.size, param_broadcast_ms=round(float(grp.broadcast_ms), 3),
+               arena_checksum="%016x:%016x" % grp.arena_checksum(), top5_equal_to_single_context=same,
+               note="qcnn_group_forward over every visible device of ONE process (a child of the bench, time-limited), 5 steps of one "
+                    "%d-image batch, inputs resident on their ranks' devices" % B)
+    grp.close()
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -307,6 +357,8 @@ def main():
                     help="1 = DRY RUN of the N > 1 code path on a box with fewer GPUs: every rank computes on GPU 0 and the collectives "
                          "(arena broadcast, checksum exchange, barriers, max-over-ranks) run over gloo through host memory.  The line is "
                          "labelled dry_run and its value is NOT a multi-GPU measurement; RCCL itself is not exercised")
+    ap.add_argument("--group-capi-child", default="", help=argparse.SUPPRESS)     # internal: path of the parent's top-5 (see group_capi_child)
+    ap.add_argument("--group-timeout", type=int, default=300, help="seconds the value_group_capi child process may take")
     ap.add_argument("--init-timeout", type=int, default=120,
                     help="N > 1: seconds the RCCL rendezvous + parameter broadcast + checksum exchange may take before the run "
                          "gives up with a one-line JSON error")
@@ -318,6 +370,8 @@ def main():
                          "durations behind `roofline` are those of kernels that own the whole GPU")
     args = ap.parse_args()
 
+    if args.group_capi_child:
+        return group_capi_child(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_spawn(args)
 
@@ -648,40 +702,31 @@ def main():
         del pinned_u8, stg, px
         # the same batch through the C-ABI's own device group (qcnn_group_*: ONE process, every visible GPU, contiguous image
         # blocks, rank 0's arena broadcast by RCCL inside the library and verified by checksum): device-resident blocks,
-        # layers enqueued on every rank's stream, one sync — the single-process figure next to the one-process-per-GPU `value`
+        # layers enqueued on every rank's stream, one sync — the single-process figure next to the one-process-per-GPU `value`.
+        # In a CHILD process with a time limit: on a node with several GPUs this is RCCL's first multi-rank run from this code,
+        # and a hang or crash there must never take the headline measurement down with it.
+        step()
+        torch.cuda.synchronize(dev)
+        ref_top5 = os.path.join(tempfile.gettempdir(), "qcnn_bench_top5_%d.npy" % os.getpid())
+        np.save(ref_top5, top5.cpu().numpy())                       # the single context's top-5 of this batch: the child compares
         try:
-            ndev = torch.cuda.device_count()
-            grp = pkg("engine").QcnnDeviceGroup(list(range(ndev)))
-            grp.set_option(capi.OPT_KEEP_ALL, 0)
-            grp.set_option(capi.OPT_STREAMS, args.streams)
-            grp.load_model(in_chw, layers, params, B)
-            gb = [grp.shard_bounds(B, r) for r in range(grp.size)]
-            gx = [imgs[a:b_].to("cuda:%d" % r) for r, (a, b_) in enumerate(gb)]
-            gp = [torch.empty((b_ - a, classes), dtype=torch.float32, device="cuda:%d" % r) for r, (a, b_) in enumerate(gb)]
-            gt = [torch.empty((b_ - a, 5), dtype=torch.int16, device="cuda:%d" % r) for r, (a, b_) in enumerate(gb)]
-            for r in range(ndev):
-                torch.cuda.synchronize(r)
-
-            def gstep():
-                grp.forward_dev([t.data_ptr() for t in gx], B, [t.data_ptr() for t in gp], [t.data_ptr() for t in gt])
-            gstep(); gstep()
-            grp.sync()
-            t0 = time.perf_counter()
-            for _ in range(5):
-                gstep()
-            grp.sync()
-            extras["value_group_capi"] = round(B * 5 / (time.perf_counter() - t0), 2)
-            step()                                                   # the single context's results for the same batch
-            torch.cuda.synchronize(dev)
-            same = all(bool(torch.equal(gt[r].cpu(), top5[a:b_].cpu())) for r, (a, b_) in enumerate(gb))
-            extras["group_capi"] = dict(devices=grp.size, param_broadcast_ms=round(float(grp.broadcast_ms), 3),
-                                        arena_checksum="%016x:%016x" % grp.arena_checksum(), top5_equal_to_single_context=same,
-                                        note="qcnn_group_forward over every visible device of this process, 5 steps of one %d-image batch, "
-                                             "inputs resident on their ranks' devices" % B)
-            grp.close()
-            del gx, gp, gt
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--group-capi-child", ref_top5, "--batch", str(B),
+                                "--params", args.params, "--streams", str(args.streams), "--model", args.model],
+                               capture_output=True, text=True, timeout=args.group_timeout)
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode == 0 and lines:
+                g = json.loads(lines[-1])
+                extras["value_group_capi"] = g.pop("value")
+                extras["group_capi"] = g
+            else:
+                extras["group_capi"] = dict(error="child exited with %d: %s" % (r.returncode, (r.stderr or r.stdout)[-400:]))
+        except subprocess.TimeoutExpired:
+            extras["group_capi"] = dict(error="no result within %d s (child process killed)" % args.group_timeout)
         except Exception as e:                                       # never the headline's problem
             extras["group_capi"] = dict(error=str(e))
+        finally:
+            if os.path.exists(ref_top5):
+                os.remove(ref_top5)
         torch.cuda.set_device(local)
         eng.set_option(capi.OPT_PROFILE, 1)
 
