@@ -144,13 +144,6 @@ enum {
                               per segment); 2 = the tile form whenever eligible, 3 = the sliding form whenever eligible (tests); 0 = never.
                               Same table entries in the same order: bit-identical to the other f32 table kernels.
                               qcnn_get_layer_split reports (-9, 1) / (-10, segments per column) */
-  QCNN_OPT_CHAIN = 14,     /* 1: on the fast path (QCNN_OPT_KEEP_ALL = 0, f32 MFMA mode, launches of >= 2 panels) runs of two or three conv
-                              layers with only (fused) ReLUs between them whose shapes the eight-wave tile kernel covers — AlexNet conv3 ->
-                              conv4 -> conv5 — go out as ONE persistent launch: a workgroup per CU pulls (layer, tile, panel) items from a
-                              queue, an item of layer l + 1 waits for layer l's items of its panel only, so the idle CUs of a layer's last
-                              round fill with the next layer (k_conv_chain, qcnn_sym8.hip).  Bit-identical.  0 (default) = one launch per
-                              layer.  qcnn_get_layer_split reports (-11, position in the chain); qcnn_get_layer_ms attributes the whole
-                              launch to the first layer of the run */
   QCNN_OPT_HOST_CHUNK = 6, /* panels per chunk (default 2) of a qcnn_forward_host batch of at least two chunks: every chunk is
                               uploaded on a copy stream and its layers start when it has arrived, so the upload of chunk
                               k + 1 runs under the layers of chunk k; all chunks fill the same whole-batch feature maps.

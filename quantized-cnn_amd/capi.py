@@ -13,7 +13,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("QCNN_HIP_LIB") or os.path.join(PKG, "libqcnn_hip.so")   # QCNN_HIP_LIB: an experimental build of the same library
 HEADER_PATH = os.path.join(os.path.dirname(PKG), "include", "qcnn_hip.h")
 
-OPT_LUT_MODE, OPT_KEEP_ALL, OPT_PROFILE, OPT_STREAMS, OPT_SMALL_BATCH, OPT_SPLIT, OPT_HOST_CHUNK, OPT_SLIDE, OPT_DECODE, OPT_SYM, OPT_SYM8, OPT_PACKED_FC, OPT_DIRECT_DEC, OPT_HALF8, OPT_CHAIN = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14
+OPT_LUT_MODE, OPT_KEEP_ALL, OPT_PROFILE, OPT_STREAMS, OPT_SMALL_BATCH, OPT_SPLIT, OPT_HOST_CHUNK, OPT_SLIDE, OPT_DECODE, OPT_SYM, OPT_SYM8, OPT_PACKED_FC, OPT_DIRECT_DEC, OPT_HALF8 = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13
 LUT_EXACT, LUT_MFMA, LUT_MFMA_F16, LUT_MFMA_F16ACC = 0, 1, 2, 3
 SMALL_BATCH_MAX = 3        # QCNN_SMALL_BATCH_MAX (include/qcnn_hip.h)
 

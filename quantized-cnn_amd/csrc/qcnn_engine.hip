@@ -124,9 +124,6 @@ struct QcnnCtx {
   float* fcPartial = nullptr;        // split-M partial sums of the FC layers
   float* convPartial = nullptr;      // partial sums of split conv tiles (kConvPartialFloats)
   bool noConvPartial = false;        // ... could not be allocated: split plans launch their tiles whole
-  int chain = 0;                     // QCNN_OPT_CHAIN: runs of consecutive conv layers as one persistent launch (k_conv_chain)
-  bool chainUsed = false;            // a chain has been launched since the context was created
-  int* chainCounters = nullptr;      // its work-queue / dependency counters: kMaxStreams x (2 + QK_CHAIN_MAX x maxPanels) ints
   size_t fcPartialElems = 0;
   size_t fcMaxCt = 0;
   int lastN = 0;
@@ -281,8 +278,6 @@ void free_model(QcnnCtx* c) {
   c->fmBuf.clear();
   if (c->ownArena && c->arena) (void)hipFree(c->arena);
   c->arena = nullptr; c->ownArena = false;
-  if (c->chainCounters) (void)hipFree(c->chainCounters);
-  c->chainCounters = nullptr;
   if (c->stageIn) (void)hipFree(c->stageIn);
   if (c->stageOut) (void)hipFree(c->stageOut);
   if (c->stageTop5) (void)hipFree(c->stageTop5);
@@ -418,33 +413,6 @@ int ensure_f16_program(QcnnCtx* c, int l, hipStream_t st) {
   }
   HIP_TRY(c, hipStreamSynchronize(st));       // once per layer: the other sub-batch streams of this forward read the table too
   return 0;
-}
-
-// ConvParams of conv layer l on panel maps (the table kernels' view of the layer; program / split fields left for the caller)
-ConvParams conv_params(QcnnCtx* c, int l, const float* src, float* dst, int panels, bool fuseRelu) {
-  const QcnnLayerDesc& d = c->layers[l];
-  const FmDims& a = c->dims[l];
-  const FmDims& b = c->dims[l + 1];
-  const LayerShape& s = c->shapes[l];
-  ConvParams p = {};
-  p.src = src; p.dst = dst;
-  p.bias = reinterpret_cast<const float*>(c->arena + s.offBias);
-  p.ctrd = reinterpret_cast<const float*>(c->arena + s.offCtrd);
-  p.ctrd8 = (s.prog8Bytes || s.prog8SBytes || s.progH8Bytes) ? reinterpret_cast<const float*>(c->arena + s.offCtrd8) : nullptr;
-  p.rows = reinterpret_cast<const uint8_t*>(c->arena + s.offAsmt);
-  p.prog = s.progBytes ? reinterpret_cast<const uint16_t*>(c->arena + s.offProg) : nullptr;
-  p.H = a.h; p.W = a.w; p.Cin = a.c; p.Ho = b.h; p.Wo = b.w; p.Ct = b.c;
-  p.knl = d.knlSiz; p.stride = d.stride; p.pad = d.padSiz; p.grp = d.grpCnt;
-  p.M = s.M; p.Cs = s.Cs; p.K = s.K; p.pd = s.P; p.relu = fuseRelu ? 1 : 0; p.panels = panels;
-  p.splitFrom = 0; p.splitZ = 1; p.partial = nullptr;
-  p.nSeg = 0; p.progS = nullptr;
-  return p;
-}
-
-// Can conv layer l be a member of a persistent chain (k_conv_chain)?  The eight-wave tile form's shapes, f32 MFMA mode, panel input.
-bool chain_member(const QcnnCtx* c, int l) {
-  const LayerShape& s = c->shapes[l];
-  return c->layers[l].type == QCNN_CONV && s.loaded && !s.dense && s.P == 1 && s.prog8Bytes != 0 && c->lutMode == 1 && l > 0;
 }
 
 int launch_layer(QcnnCtx* c, int l, const float* src, float* dst, int panels, bool fuseRelu, bool flatFcInput,
@@ -857,30 +825,8 @@ int run_layers(QcnnCtx* c, int n, const float* inNchw = nullptr, int pa = 0, int
     HIP_TRY(c, hipEventRecord(c->evFork, c->stream));
     for (int k = 1; k < ns; ++k) HIP_TRY(c, hipStreamWaitEvent(c->aux[k - 1], c->evFork, 0));
   }
-  // QCNN_OPT_CHAIN: runs of two or three conv layers with nothing but (fused) ReLUs between them — AlexNet conv3 -> conv4 -> conv5 —
-  // go out as ONE persistent, dependency-queued launch per sub-batch (k_conv_chain): chainLen[l] = layers of the run starting at
-  // conv layer l (0: none), chainDone[l]: layer l ran inside a chain
-  std::vector<int> chainLen(c->L, 0);
-  std::vector<char> chainDone(c->L, 0);
-  if (c->chain && !c->keepAll && !small && c->lutMode == 1 && (panels + ns - 1) / ns >= 2) {
-    for (int l = 1; l < c->L; ++l) {
-      if (chainDone[l] || !chain_member(c, l)) continue;
-      int len = 1, m = l;
-      while (len < QK_CHAIN_MAX && m + 2 < c->L && c->layers[m + 1].type == QCNN_RELU && chain_member(c, m + 2)) { m += 2; ++len; }
-      if (len >= 2) {
-        chainLen[l] = len;
-        for (int k = 1; k < len; ++k) chainDone[l + 2 * k] = 1;
-      }
-    }
-  }
-  if (c->chain && !c->chainCounters) {
-    const size_t ints = (size_t)kMaxStreams * (2 + (size_t)QK_CHAIN_MAX * c->maxPanels);
-    HIP_TRY(c, hipMalloc(&c->chainCounters, ints * sizeof(int)));
-    HIP_TRY(c, hipMemset(c->chainCounters, 0, ints * sizeof(int)));
-  }
   for (int l = 0; l < c->L; ++l) {              // layer-major issue order: the streams advance together
     const int type = c->layers[l].type;
-    if (chainDone[l]) continue;                  // ran inside the chain launched at the head of its run
     if (fm[l + 1] == fm[l] && fm[l] != nullptr) continue;   // alias: copy semantics, no traffic
     if (fm[l] == nullptr && l > 0) continue;                               // the pool of a fused LRN + pool pair
     const bool lrnPool = fm[l + 1] == nullptr;
@@ -900,20 +846,7 @@ int run_layers(QcnnCtx* c, int n, const float* inNchw = nullptr, int pa = 0, int
         e0 = c->ev[slot]; e1 = c->ev[slot + 1];
         HIP_TRY(c, hipEventRecord(e0, st));
       }
-      if (chainLen[l] > 0) {
-        ConvParams cps[QK_CHAIN_MAX];
-        for (int k2 = 0; k2 < chainLen[l]; ++k2) {
-          const int m = l + 2 * k2;
-          const bool fuseM = m + 1 < c->L && c->layers[m + 1].type == QCNN_RELU;       // (fast path: checked above)
-          cps[k2] = conv_params(c, m, fm[m] + (size_t)p0 * fm_elems(c, m) * QCNN_PANEL,
-                                fm[m + 1] + (size_t)p0 * fm_elems(c, m + 1) * QCNN_PANEL, p1 - p0, fuseM);
-          cps[k2].progS = reinterpret_cast<const uint16_t*>(c->arena + c->shapes[m].offProg8);
-          c->shapes[m].lastFrom = -11; c->shapes[m].lastZ = k2 + 1;      // reported by qcnn_get_layer_split as (-11, position in the chain)
-        }
-        c->chainUsed = true;
-        const hipError_t e = qk_conv_chain(cps, chainLen[l], c->chainCounters + (size_t)k * (2 + (size_t)QK_CHAIN_MAX * c->maxPanels), st);
-        if (e != hipSuccess) return fail(c, "layers %d .. %d (conv chain): %s", l, l + 2 * (chainLen[l] - 1), hipGetErrorString(e));
-      } else if (lrnPool) {
+      if (lrnPool) {
         const QcnnLayerDesc& d = c->layers[l];
         const hipError_t e = qk_lrn_pool(src, dst, p1 - p0, c->dims[l].h, c->dims[l].w, c->dims[l].c, c->dims[l + 2].h,
                                          c->dims[l + 2].w, d.lrnSiz, d.lrnAlp, d.lrnBet, d.lrnIni, live, st);
@@ -1026,7 +959,6 @@ int qcnn_set_option(QcnnCtx* c, int option, int value) {
     case QCNN_OPT_SMALL_BATCH: c->smallBatch = value ? 1 : 0; return 0;
     case QCNN_OPT_SPLIT: c->split = value ? 1 : 0; return 0;
     case QCNN_OPT_DECODE: c->decode = value ? 1 : 0; return 0;
-    case QCNN_OPT_CHAIN: if (value < 0 || value > 1) return fail(c, "QCNN_OPT_CHAIN must be 0 (off) or 1 (on)"); c->chain = value; return 0;
     case QCNN_OPT_HALF8: if (value < 0 || value > 3) return fail(c, "QCNN_OPT_HALF8 must be 0 (off), 1 (planner), 2 (forced tile form) or 3 (forced sliding form)"); c->half8 = value; return 0;
     case QCNN_OPT_SYM8: if (value < 0 || value > 3) return fail(c, "QCNN_OPT_SYM8 must be 0 (off), 1 (planner), 2 (forced tile form) or 3 (forced sliding form)"); c->sym8 = value; return 0;
     case QCNN_OPT_PACKED_FC: c->packedFc = value ? 1 : 0; return 0;
@@ -1048,16 +980,6 @@ void* qcnn_ctx_stream(const QcnnCtx* c) { return c->stream; }
 
 int qcnn_sync(QcnnCtx* c) {
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  if (c->chain && c->chainCounters && c->chainUsed) {
-    // the persistent conv chain's dependency waits are bounded: a wait that ran out set its sub-batch's flag (and produced
-    // wrong maps) — a forward must not pass for good then
-    const size_t stride = 2 + (size_t)QK_CHAIN_MAX * c->maxPanels;
-    for (int k = 0; k < kMaxStreams; ++k) {
-      int flag = 0;
-      HIP_TRY(c, hipMemcpy(&flag, c->chainCounters + k * stride + 1, sizeof(int), hipMemcpyDeviceToHost));
-      if (flag) return fail(c, "conv chain (QCNN_OPT_CHAIN): a dependency wait ran out in sub-batch %d; results are invalid", k);
-    }
-  }
   return 0;
 }
 

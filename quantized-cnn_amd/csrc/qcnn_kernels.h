@@ -257,10 +257,6 @@ double qk_conv_sym8_cost(const ConvParams& p, const Qk8Config& cf, double stageF
 // dst = sum over the Z slices (in slice order) of the partial sums of the tiles from rank splitFrom on; optional ReLU (k_conv_sum)
 hipError_t qk_conv_sum(const float* partial, float* dst, int splitFrom, int Z, int panels, int tilesX, int tilesY, int TH, int TW, int Ho,
                        int Wo, int Ct, int relu, hipStream_t st);
-constexpr int QK_CHAIN_MAX = 3;       // conv layers of one persistent chain launch (k_conv_chain, qcnn_sym8.hip)
-// two or three consecutive conv layers (fused ReLU in between) as one persistent, dependency-queued launch of the eight-wave tile kernel;
-// counters: 2 + n * panels ints of device memory (zeroed by the call); counters[1] != 0 afterwards: a dependency wait ran out (bug)
-hipError_t qk_conv_chain(const ConvParams* layers, int n, int* counters, hipStream_t st);
 hipError_t qk_conv_sym8(const ConvParams& p, hipStream_t st, int mode = 0);   // mode 1: fp16 table storage, 2: + fp16 sums (p.progS built with f16 = 1)
 Qk8Config qk_conv_sym8_config16(int Cin, int grp, int Ct, int M, int Cs, int K);   // tiles of mode 2 (twice the positions)
 // The sliding form of the eight-wave kernel (k_conv_sym8<.., SLIDE>): config (cpw = 0: not eligible), segments + predicted

@@ -337,10 +337,9 @@ __device__ __forceinline__ f32x2 unpk16(uint32_t w) {
 // (slot << 8) | ((slot & 15) << 3) instead of slot * 64 (k_build_program8 with f16 = 1).  MODE 1 keeps fp32 sums; MODE 2 keeps the
 // running sums as packed fp16 too (the accumulate half of the configs[4] study): half the accumulator registers, so a wave owns
 // 192 (position, channel) pairs — twice the tile, a third fewer table builds per output position
-// The body is a device function of (bx, by) = what a standalone launch has in (blockIdx.x, blockIdx.y): k_conv_sym8 calls it once,
-// the persistent k_conv_chain (below) once per work item it pulls from its queue.
 template <int CPW, int TH, int TW, int KS, bool SLIDE = false, int MODE = 0>
-__device__ __forceinline__ void conv_sym8_body(const ConvParams p, int tilesX, int tilesY, int chunks, unsigned bx, unsigned by, char* lds) {
+__global__ __launch_bounds__(NW8 * 64) void k_conv_sym8(ConvParams p, int tilesX, int tilesY, int chunks) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
   constexpr bool F16 = MODE >= 1, ACC16 = MODE == 2;
   using AccT = std::conditional_t<ACC16, uint32_t, f32x2>;
   constexpr int NP = TH * TW, HC = CPW / 2;
@@ -355,8 +354,8 @@ __device__ __forceinline__ void conv_sym8_body(const ConvParams p, int tilesX, i
   // blockIdx.x = tile rank (heaviest first) * panels + panel; a launch that cannot fill the chip with whole tiles (one GPU's share
   // of a sharded batch: ConvParams::splitZ > 1, tile form) cuts EVERY tile into splitZ workgroups that take consecutive slices of
   // its stage sequence and write partial sums, which k_conv_sum adds in slice order (as k_conv_aprx does)
-  int rank = (int)(bx / (unsigned)p.panels);
-  const int panel = (int)(bx % (unsigned)p.panels);
+  int rank = (int)(blockIdx.x / (unsigned)p.panels);
+  const int panel = (int)(blockIdx.x % (unsigned)p.panels);
   int slice = 0, slices = 1;
   if (!SLIDE && p.splitZ > 1) {
     slices = p.splitZ;
@@ -373,7 +372,7 @@ __device__ __forceinline__ void conv_sym8_body(const ConvParams p, int tilesX, i
   } else {
     tile_of_rank(rank, tilesY, tilesX, ty, tx);
   }
-  const int grp = (int)by / chunks, chunk = (int)by % chunks;
+  const int grp = (int)blockIdx.y / chunks, chunk = (int)blockIdx.y % chunks;
   const int Cg = p.Cin / p.grp, Ctg = p.Ct / p.grp;
   const int M = p.M;
   const int ho0 = SLIDE ? segBeg : ty * TH, wo0 = tx * TW;
@@ -608,91 +607,6 @@ __device__ __forceinline__ void conv_sym8_body(const ConvParams p, int tilesX, i
         }
       }
     }
-  }
-}
-
-template <int CPW, int TH, int TW, int KS, bool SLIDE = false, int MODE = 0>
-__global__ __launch_bounds__(NW8 * 64) void k_conv_sym8(ConvParams p, int tilesX, int tilesY, int chunks) {
-  extern __shared__ __attribute__((aligned(16))) char lds[];
-  conv_sym8_body<CPW, TH, TW, KS, SLIDE, MODE>(p, tilesX, tilesY, chunks, blockIdx.x, blockIdx.y, lds);
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// k_conv_chain: two or three CONSECUTIVE conv layers (each behind the fused ReLU of the one before: AlexNet conv3 -> conv4 ->
-// conv5, the reference's plain layer loop src/CaffeEva.cc:625-670 — nothing there forbids overlap across images) as ONE
-// persistent launch of the eight-wave tile kernel.  A 13 x 13 layer is 560 - 784 workgroups on 256 CUs: 15 - 25 % of its CU-time is
-// idle CUs waiting for the last round (profiles/r6_v12/cu_time_utilisation.csv).  Here one workgroup per CU walks a list of work
-// items — (layer, panel, group, tile rank): the standalone launches' (blockIdx.x, blockIdx.y), layer after layer, panel after panel
-// —, dealt round-robin; an item of layer l + 1 needs every item of layer l OF ITS PANEL (images are independent), which a per-(layer,
-// panel) counter tells: the tail of a layer fills with the next layer's items of the panels that are complete.
-//   * an item only waits for lower-numbered items and every workgroup takes its items in ascending order, so the lowest unfinished
-//     item never waits: no deadlock; the wait is bounded all the same (QK_CHAIN_SPIN_MAX polls, then the error flag is set and the
-//     item runs: wrong results, never a hang).  (A shared queue — one atomic per item, broadcast to the eight waves through an LDS
-//     word — was the first version: that kernel never left its first iteration, see LABBOOK.md §6.3.)
-//   * release / acquire at agent scope around the counters (the eight XCDs have their own L2s: a finished item's stores are written
-//     back before its count, a waiting workgroup invalidates after the count it waited for);
-//   * same body, same tiles, same order per output: bit-identical to the standalone launches.
-// ------------------------------------------------------------------------------------------------------------------
-constexpr int QK_CHAIN_SPIN_MAX = 1 << 22;            // polls (>= 100 ns each): ~0.5 s
-struct ChainParams {
-  ConvParams layer[QK_CHAIN_MAX];
-  int tilesX[QK_CHAIN_MAX], tilesY[QK_CHAIN_MAX], chunks[QK_CHAIN_MAX], cfg[QK_CHAIN_MAX];   // cfg: channels per wave (16 / 24 / 32 / 48) * 4 + k-steps
-  int gx[QK_CHAIN_MAX];             // items along x of every layer (tiles x panels)
-  int first[QK_CHAIN_MAX + 1];      // first item of every layer (+ total)
-  int perPanel[QK_CHAIN_MAX];       // items of a layer that belong to one panel
-  int n;                            // layers
-  int panels;
-  int* counters;                    // [0] next item, [1] error flag, [2 + l * panels + panel] finished items
-  int spinMax;                      // polls a dependency wait may take
-  int debug;                        // debug runs of the protocol (QCNN_DEBUG_CHAIN_MODE): 1 = work items do nothing, 2 = no fences, 4 = no dependency waits (timing only)
-};
-__device__ __forceinline__ void chain_item(const ChainParams& cp, int li, unsigned bx, unsigned by, char* lds) {
-  const ConvParams& p = cp.layer[li];
-  const int tx = cp.tilesX[li], ty = cp.tilesY[li], ch = cp.chunks[li];
-  switch (cp.cfg[li]) {
-    case 16 * 4 + 2: conv_sym8_body<16, 2, 3, 2>(p, tx, ty, ch, bx, by, lds); break;
-    case 16 * 4 + 1: conv_sym8_body<16, 2, 3, 1>(p, tx, ty, ch, bx, by, lds); break;
-    case 24 * 4 + 2: conv_sym8_body<24, 2, 2, 2>(p, tx, ty, ch, bx, by, lds); break;
-    case 24 * 4 + 1: conv_sym8_body<24, 2, 2, 1>(p, tx, ty, ch, bx, by, lds); break;
-    case 32 * 4 + 2: conv_sym8_body<32, 1, 3, 2>(p, tx, ty, ch, bx, by, lds); break;
-    case 32 * 4 + 1: conv_sym8_body<32, 1, 3, 1>(p, tx, ty, ch, bx, by, lds); break;
-    case 48 * 4 + 2: conv_sym8_body<48, 1, 2, 2>(p, tx, ty, ch, bx, by, lds); break;
-    default: conv_sym8_body<48, 1, 2, 1>(p, tx, ty, ch, bx, by, lds); break;
-  }
-}
-__global__ __launch_bounds__(NW8 * 64) void k_conv_chain(ChainParams cp) {
-  extern __shared__ __attribute__((aligned(16))) char lds[];
-  const int total = cp.first[cp.n];
-  // items are dealt round-robin: workgroup b takes items b, b + G, b + 2 G, .. (G = one workgroup per CU).  Within a layer the items
-  // are ordered heaviest first and cost about the same, so the deal is the list schedule a queue would produce, without a broadcast
-  // of the queue's answer to the eight waves; an item only ever waits for lower-numbered items, and the lowest unfinished item of
-  // the launch never waits: no deadlock as long as all G workgroups are resident (G <= CUs, one workgroup per CU by LDS / registers).
-  for (int item = (int)blockIdx.x; item < total; item += (int)gridDim.x) {
-    int li = 0;
-    while (li + 1 < cp.n && item >= cp.first[li + 1]) ++li;
-    // inside a layer: panel after panel (a panel of layer l is complete — and layer l + 1 may start on it — long before the layer
-    // is), inside a panel group after group, tiles heaviest first
-    const int local = item - cp.first[li];
-    const int panel = local / cp.perPanel[li], rem = local % cp.perPanel[li];
-    const int tiles = cp.gx[li] / cp.panels;
-    const unsigned by = (unsigned)(rem / tiles);
-    const unsigned bx = (unsigned)((rem % tiles) * cp.panels + panel);
-    if (li > 0 && !(cp.debug & 4)) {
-      if (threadIdx.x == 0) {
-        int* const dep = &cp.counters[2 + (li - 1) * cp.panels + panel];
-        int spins = 0;
-        while (__hip_atomic_load(dep, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < cp.perPanel[li - 1]) {
-          __builtin_amdgcn_s_sleep(32);
-          if (++spins > cp.spinMax) { __hip_atomic_store(&cp.counters[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-        }
-      }
-      __syncthreads();
-      if (!(cp.debug & 2)) __atomic_thread_fence(__ATOMIC_ACQUIRE);         // every wave: what the producers wrote is what this item reads (agent scope)
-    }
-    if (!(cp.debug & 1)) chain_item(cp, li, bx, by, lds);
-    if (!(cp.debug & 2)) __atomic_thread_fence(__ATOMIC_RELEASE);           // this wave's output stores, written back
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(&cp.counters[2 + li * cp.panels + panel], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -1108,58 +1022,4 @@ hipError_t qk_fc_sym8(const FcParams& p, const uint16_t* prog, const float* ctrd
   hipLaunchKernelGGL(kern, dim3((unsigned)qk_fc_sym8_chunks(p.Ct), (unsigned)p.panels, (unsigned)p.msplit), dim3(NW8 * 64), shm, st,
                      p, prog, ctrdF, qk_fc_sym8_chunks(p.Ct), per);
   return hipGetLastError();
-}
-
-// ---- the persistent chain (k_conv_chain): layers[0 .. n) consecutive conv layers of one forward, all eligible for the eight-wave
-// tile form (qk_conv_sym8_config), every p.progS = its eight-wave program, p.ctrd8 set, same p.panels; counters: 2 + n * panels ints,
-// zeroed on `st` in front of the launch (done here)
-hipError_t qk_conv_chain(const ConvParams* layers, int n, int* counters, hipStream_t st) {
-  if (n < 2 || n > QK_CHAIN_MAX || counters == nullptr) return hipErrorInvalidValue;
-  ChainParams cp;
-  cp.n = n; cp.panels = layers[0].panels; cp.counters = counters;
-  int total = 0;
-  for (int l = 0; l < n; ++l) {
-    const ConvParams& p = layers[l];
-    const Qk8Config cf = qk_conv_sym8_config(p.Cin, p.grp, p.Ct, p.M, p.Cs, p.K);
-    if (!cf.cpw || p.progS == nullptr || p.ctrd8 == nullptr || p.srcNchw || p.panels != cp.panels) return hipErrorInvalidValue;
-    cp.layer[l] = p;
-    cp.layer[l].splitZ = 1; cp.layer[l].partial = nullptr;
-    cp.tilesX[l] = (p.Wo + cf.tw - 1) / cf.tw; cp.tilesY[l] = (p.Ho + cf.th - 1) / cf.th; cp.chunks[l] = cf.chunks;
-    cp.cfg[l] = cf.cpw * 4 + (std::min(p.Cin / p.grp, p.Cs) > 4 ? 2 : 1);
-    cp.gx[l] = cp.tilesX[l] * cp.tilesY[l] * p.panels;
-    cp.first[l] = total;
-    cp.perPanel[l] = cp.tilesX[l] * cp.tilesY[l] * p.grp * cf.chunks;
-    total += cp.gx[l] * p.grp * cf.chunks;
-  }
-  cp.first[n] = total;
-  hipError_t e = hipMemsetAsync(counters, 0, sizeof(int) * (size_t)(2 + n * cp.panels), st);
-  if (e != hipSuccess) return e;
-  const size_t shm = (size_t)2 * STAGE_BYTES + 3 * 3072 + 16;
-  e = allow_big_lds(reinterpret_cast<const void*>(k_conv_chain), (int)shm);
-  if (e != hipSuccess) return e;
-  int dev = 0, cus = 256;
-  (void)hipGetDevice(&dev);
-  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  cp.spinMax = QK_CHAIN_SPIN_MAX;
-  cp.debug = 0;
-  if (const char* e4 = getenv("QCNN_DEBUG_CHAIN_MODE")) cp.debug = atoi(e4);
-  if (const char* e2 = getenv("QCNN_DEBUG_CHAIN_N")) { cp.n = std::max(1, std::min(cp.n, atoi(e2))); total = cp.first[cp.n]; }   // debug: only the first layers
-  if (const char* e3 = getenv("QCNN_DEBUG_CHAIN_ITEMS")) { total = std::min(total, atoi(e3)); cp.first[cp.n] = total; }          // debug: only the first items
-  const char* dbg = getenv("QCNN_DEBUG_CHAIN");
-  if (dbg && atoi(dbg) > 0) cp.spinMax = atoi(dbg);
-  hipLaunchKernelGGL(k_conv_chain, dim3((unsigned)std::min(total, cus)), dim3(NW8 * 64), shm, st, cp);
-  e = hipGetLastError();
-  if (dbg && e == hipSuccess) {
-    (void)hipStreamSynchronize(st);
-    std::vector<int> h((size_t)(2 + n * cp.panels));
-    (void)hipMemcpy(h.data(), counters, h.size() * sizeof(int), hipMemcpyDeviceToHost);
-    fprintf(stderr, "[qcnn chain] total %d items (first", total);
-    for (int l = 0; l <= n; ++l) fprintf(stderr, " %d", cp.first[l]);
-    fprintf(stderr, "), per panel");
-    for (int l = 0; l < n; ++l) fprintf(stderr, " %d", cp.perPanel[l]);
-    fprintf(stderr, "; next %d, error %d, done", h[0], h[1]);
-    for (size_t i = 2; i < h.size(); ++i) fprintf(stderr, " %d", h[i]);
-    fprintf(stderr, "\n");
-  }
-  return e;
 }

@@ -25,8 +25,6 @@ def main():
     eng.set_option(capi.OPT_SYM, int(os.environ.get("QCNN_SYM", "1")))
     eng.set_option(capi.OPT_SYM8, int(os.environ.get("QCNN_SYM8", "1")))
     eng.set_option(capi.OPT_HALF8, int(os.environ.get("QCNN_HALF8", "1")))
-    if "QCNN_CHAIN" in os.environ:
-        eng.set_option(capi.OPT_CHAIN, int(os.environ["QCNN_CHAIN"]))
     eng.set_option(capi.OPT_DIRECT_DEC, int(os.environ.get("QCNN_DIRECT_DEC", "1")))
     eng.set_option(capi.OPT_DECODE, int(os.environ.get("QCNN_DECODE", "1")))
     eng.set_option(capi.OPT_LUT_MODE, int(os.environ.get("QCNN_LUT", "1")))
