@@ -5,7 +5,8 @@ bench.py's `vgg16` block runs 1000 synthetic 224x224 images with the LIBRARY DEF
 sliding, symmetric and eight-wave symmetric kernels as the planner picks them, fast path, one stream).  Here the same
 configuration — same parameters (seed 0), 7 full panels + a ragged one — is checked against the oracle
 (src/CaffeEva.cc:760-868, 968-1025, 1261-1296 restated in oracle/qcnn_oracle.c): every feature map the fast path
-materialises, the soft-max outputs and the top-5 of images 0, 500 and 999 (first panel, a middle one, the ragged last one).
+materialises, the soft-max outputs and the top-5 of images 0, 500 and 999 (first panel, a middle one, the ragged last one), and the
+soft-max outputs and top-5 of one mid-panel image of every panel.
 Then the kernel FAMILIES' contract: the same batch with the eight-wave, sliding, symmetric and split kernels switched off
 (16-wave tile kernels only) must give the same bits on every conv map of those images.
 """
@@ -95,6 +96,19 @@ def test_vgg16_batch_1000_library_defaults_against_oracle_and_tile_kernels():
         assert e_inf <= TOL and e_l2 <= TOL, "image %d soft-max: %g %g" % (i, e_inf, e_l2)
         want = orc.top5(ref)
         for a, b in zip(top5[i], want):        # a swap is legitimate only between classes the oracle separates by < TOL
+            assert a == b or abs(ref[a] - ref[b]) <= TOL * np.abs(ref).max(), "image %d top-5 %r vs %r" % (i, top5[i], want)
+    # one image of EVERY panel (an image in the middle of its panel: lane 77 — the upper half panel of the half-panel kernels), soft-max
+    # outputs and top-5 (images 0 / 500 / 999 never sit mid-panel on a boundary the planner chose)
+    for pn in range((N + 127) // 128):
+        i = min(pn * 128 + 77, N - 1)
+        if i in IMAGES:
+            continue
+        orc.forward(imgs[i:i + 1])
+        ref = orc.fm(L).reshape(-1)
+        e_inf, e_l2 = rel_err(prob[i], ref)
+        assert e_inf <= TOL and e_l2 <= TOL, "panel %d image %d soft-max: %g %g" % (pn, i, e_inf, e_l2)
+        want = orc.top5(ref)
+        for a, b in zip(top5[i], want):
             assert a == b or abs(ref[a] - ref[b]) <= TOL * np.abs(ref).max(), "image %d top-5 %r vs %r" % (i, top5[i], want)
     orc.close()
 
