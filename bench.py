@@ -11,7 +11,16 @@ top-5) over one batch of synthetic images already resident in HBM.
   N > 1   configs[2]: ONE 1000-image batch sharded over the N GPUs in contiguous blocks (dist.shard_bounds):
           "scaling": "strong".  Images are independent, so there is no data-path collective; the only exchange is
           the one-time RCCL broadcast of rank 0's packed parameter arena, outside the timed region (its time is
-          reported as `param_broadcast_ms`).  `value_weak` additionally reports 1000 images PER GPU.
+          reported as `param_broadcast_ms`).  `value_weak` additionally reports 1000 images PER GPU.  Before anything is timed
+          every rank hashes its arena on the device and the ranks compare the pairs over the communicator
+          (`param_broadcast_verified`); `rccl_ranks` is counted by a real all_reduce; a watchdog (`--init-timeout`) turns a hung
+          rendezvous into one JSON error line.  `--dry-run-shared-gpu 1` runs this whole path with every rank on GPU 0 and the
+          collectives over gloo (labelled `dry_run`, not a measurement): how a one-GPU box exercises it.
+
+`value` runs the library defaults on ONE stream (so that a layer's HIP-event time is that layer's alone): conv1 and fc8 through the
+code words their assignments name (`config.decoded_layers`).  Right behind it: `alg_north_star_value` / `_ms_per_step` /
+`_roofline_frac` — the north star's algorithm, look-up tables + uint8-indexed accumulation, on EVERY conv / FC layer (= value_tables_only).
+`value_two_streams` is the library's default execution mode (two sub-batches on two streams).
 
 Extra objects on the JSON line:
   roofline      dominant kernel (largest mean HIP-event time per launch over the timed steps), algorithmic HBM bytes
